@@ -1,0 +1,202 @@
+/*
+ * scs_hip.h -- C-ABI of libscs_hip.so, the MI355X (gfx950) spectral-clustering
+ * core for Spectral Cluster Supertree.
+ *
+ * The reference (rmcar17/SpectralClusterSupertree) has no FFI seam on this
+ * path: the hot path is private Python called in-process
+ * (src/sc_supertree/scs.py:110-134) and its only delegate is scikit-learn's
+ * estimator call at scs.py:235-252.  Each entry point below names the reference
+ * code it replaces.  All pointers are plain host pointers unless stated, all
+ * sizes are explicit, no C++ or torch types cross the boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SCS_E* code on failure;
+ *     scs_last_error() gives the message of the calling thread's last failure.
+ *   - input arrays are caller-owned, read-only for the duration of the call.
+ *   - handles are owned by the library; free them with the matching *_free.
+ *   - one host thread per context at a time; different contexts are independent.
+ *   - no entry point ever computes on the CPU: without a usable HIP device
+ *     scs_ctx_create fails and nothing else can be called.
+ */
+#ifndef SCS_HIP_H
+#define SCS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCS_OK 0
+#define SCS_EINVAL (-1)   /* bad argument (shape, range, null pointer)          */
+#define SCS_EHIP (-2)     /* a HIP runtime call failed                          */
+#define SCS_ENOMEM (-3)   /* device or host allocation failed                   */
+#define SCS_ECOMM (-4)    /* RCCL / communicator failure                        */
+#define SCS_ENOCONV (-5)  /* eigen-solver hit max_iter before reaching tol      */
+#define SCS_EUNSUP (-6)   /* valid request the library does not support (yet)   */
+
+#define SCS_UNIQUE_ID_BYTES 128
+
+typedef struct scs_ctx scs_ctx;       /* device, stream, communicator, scratch        */
+typedef struct scs_tables scs_tables; /* flattened source trees, resident in HBM      */
+typedef struct scs_graph scs_graph;   /* this rank's row block of the PCG weight matrix */
+
+/* Per-call report of scs_fiedler (all times in milliseconds, device-side
+ * hipEvent measurements on the context's stream). */
+typedef struct scs_stats {
+    int32_t n_vertices;      /* V of the graph the solve ran on                      */
+    int32_t block;           /* LOBPCG block width actually used (0: dense path)     */
+    int32_t iterations;      /* LOBPCG iterations                                    */
+    int32_t n_apply;         /* operator applications (launches of the SYMM kernel)  */
+    int32_t converged;       /* 1 if the wanted pair(s) met tol                      */
+    int32_t used_constraint; /* 1: trivial eigenvector deflated analytically         */
+    double lambda[2];        /* two largest eigenvalues of S = D^-1/2 A D^-1/2       */
+    double resid[2];         /* ||S x - lambda x||_2 of the returned unit vectors    */
+    double lambda_next;      /* next Ritz value below lambda[1] (gap estimate)       */
+    double apply_ms_total;   /* sum of SYMM kernel durations                         */
+    double apply_ms_min;     /* fastest single SYMM launch                           */
+    double solve_ms;         /* whole scs_fiedler call, device time                  */
+    double apply_bytes;      /* algorithmic HBM bytes of ONE SYMM launch on this rank */
+} scs_stats;
+
+/* Per-call report of scs_pcg_build. */
+typedef struct scs_build_stats {
+    int32_t n_taxa;
+    int32_t n_trees;
+    int32_t row_begin, row_end; /* rows of W this rank owns                          */
+    int32_t symmetric;          /* 1: upper tiles computed, lower mirrored           */
+    int32_t n_tiles;            /* workgroups of the accumulate kernel per batch     */
+    int32_t n_batches;          /* tree batches (scratch bounded by ctx workspace)   */
+    int32_t reserved;
+    double cell_trees;          /* (matrix cell, tree) evaluations performed         */
+    double prep_ms;             /* position / sparse-table / block-record kernels    */
+    double accumulate_ms;       /* the tile accumulate kernel(s)                     */
+    double degree_ms;           /* row-sum kernel                                    */
+    double total_ms;            /* whole call, device time                           */
+    double bytes_w;             /* algorithmic bytes: W written once (8 * rows * V)  */
+    double bytes_tables;        /* algorithmic bytes: tables read once               */
+} scs_build_stats;
+
+int scs_version(void);
+const char *scs_last_error(void);
+
+/* Number of HIP devices visible (0 when none); never fails. */
+int scs_device_count(void);
+
+/* ---- context ----------------------------------------------------------- */
+
+/* Rank 0 calls this and ships the 128 bytes to the other ranks by any host
+ * channel before they all call scs_ctx_create (RCCL bootstrap). */
+int scs_comm_unique_id(void *out128);
+
+/* One context per process per GPU.  world == 1: single device, unique_id may be
+ * NULL.  world > 1: row-partitioned solve, one RCCL rank per process
+ * (SURVEY.md 8e); the only collective on the data path is the all-gather of
+ * the Krylov block inside scs_fiedler. */
+int scs_ctx_create(int device, int rank, int world, const void *unique_id128, scs_ctx **out);
+
+/* In-process communicator for `world` contexts that live in ONE process and
+ * are driven by `world` host threads (used to exercise the row-partitioned
+ * code path on a single GPU; the collective is a thread barrier plus device
+ * copies instead of RCCL).  `group` comes from scs_local_group_create. */
+typedef struct scs_local_group scs_local_group;
+int scs_local_group_create(int world, scs_local_group **out);
+int scs_local_group_destroy(scs_local_group *group);
+int scs_ctx_create_local(int device, int rank, scs_local_group *group, scs_ctx **out);
+
+int scs_ctx_destroy(scs_ctx *ctx);
+int scs_ctx_synchronize(scs_ctx *ctx);
+
+/* ---- tables ------------------------------------------------------------ */
+
+/* Host -> HBM copy of the flattened trees (layout: DESIGN.md "Tables").
+ * Replaces the reference's in-memory cogent3 trees as the input of
+ * _proper_cluster_graph_edges (scs.py:495-583); the weighting strategy
+ * (scs.py:555-564) is already folded into adj_val by the host.
+ *   tree_off   int64 [n_trees+1]   leaf offsets, tree_off[0] == 0
+ *   leaf_taxon int32 [L]           taxon id of each leaf in DFS order
+ *   adj_depth  int32 [L]           depth of LCA(leaf p, leaf p+1); last slot of a tree unused
+ *   adj_val    fp64  [L]           strategy value at that LCA
+ *   tree_w     fp64  [n_trees]     tree weights                                  */
+int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, const int64_t *tree_off,
+                      const int32_t *leaf_taxon, const int32_t *adj_depth, const double *adj_val,
+                      const double *tree_w, scs_tables **out);
+int scs_tables_free(scs_ctx *ctx, scs_tables *tables);
+
+/* ---- proper cluster graph ---------------------------------------------- */
+
+/* Build rows [row_begin, row_end) of the N x N fp64 weight matrix W on the
+ * device: W[a][b] = sum over trees, in tree order, of value(LCA(a,b)) * w_t for
+ * every tree in which a and b share a root side.  Bit-identical to the
+ * reference's accumulation (scs.py:655-657): one rounded multiply, then rounded
+ * adds in tree order.  Replaces _proper_cluster_graph_edges/_dfs_pcg_weights
+ * (scs.py:495-663) and the dense fill loop (scs.py:246-250).
+ * row_begin = 0, row_end = n_taxa with world == 1 uses the symmetric schedule.
+ * flags: reserved, pass 0.  stats may be NULL. */
+int scs_pcg_build(scs_ctx *ctx, const scs_tables *tables, int32_t row_begin, int32_t row_end,
+                  int32_t flags, scs_graph **out, scs_build_stats *stats);
+
+/* Contract consecutive index ranges into single vertices: vertex g of the new
+ * graph is rows/columns [group_start[g], group_start[g+1]) of the old one,
+ * W'[g][h] = max over member pairs, diagonal 0 (reference: scs.py:336-387; the
+ * host has already relabelled taxa so that every contraction group is a
+ * consecutive range that does not straddle a rank's row block).
+ * group_start: int32 [n_groups+1], group_start[0] == 0, last == old V.
+ * The input graph is consumed (freed) and *out receives the contracted one. */
+int scs_graph_contract(scs_ctx *ctx, scs_graph *graph, const int32_t *group_start,
+                       int32_t n_groups, scs_graph **out);
+
+/* Shape of this rank's block. */
+int scs_graph_shape(const scs_graph *graph, int32_t *n_vertices, int32_t *row_begin,
+                    int32_t *row_end);
+
+/* Dense copy of this rank's rows to the host: out is (row_end-row_begin) x V,
+ * row-major, caller-owned.  For tests and golden vectors. */
+int scs_graph_download(scs_ctx *ctx, const scs_graph *graph, double *out);
+
+/* Row sums of this rank's rows (the degree vector d of scipy's normalized
+ * Laplacian, scipy/sparse/csgraph/_laplacian.py:550): out has row_end-row_begin
+ * entries. */
+int scs_graph_degrees(scs_ctx *ctx, scs_graph *graph, double *out);
+
+int scs_graph_free(scs_ctx *ctx, scs_graph *graph);
+
+/* ---- Fiedler solve ----------------------------------------------------- */
+
+/* The V x 2 spectral embedding scikit-learn's SpectralClustering clusters
+ * (replaces sklearn/manifold/_spectral_embedding.py:299-467 as reached from
+ * scs.py:252): column 0 <-> eigenvalue 1 of S = D^-1/2 A D^-1/2, column 1 the
+ * Fiedler vector; unit-norm eigenvectors divided elementwise by sqrt(degree)
+ * (1 where the degree is 0), each column sign-flipped so its entry of largest
+ * magnitude is positive.
+ *   x_init   fp64 [V] or NULL   start vector for the first block column (the
+ *                               reference's ARPACK v0 draw, sklearn/utils/_arpack.py:31-33)
+ *   tol      residual target: ||S x - lambda x||_2 <= tol (unit x)
+ *   max_iter LOBPCG iteration cap
+ *   block    LOBPCG block width (<= 16); 0 picks the default
+ *   maps_out fp64 [V*2] row-major, caller-owned; every rank receives all V rows
+ * Collective over the context's communicator when world > 1. */
+int scs_fiedler(scs_ctx *ctx, scs_graph *graph, const double *x_init, double tol,
+                int32_t max_iter, int32_t block, double *maps_out, scs_stats *stats);
+
+/* ---- diagnostics used by the parity tests ------------------------------ */
+
+/* Eigen-decomposition of a dense symmetric n x n matrix (n <= 64) by the
+ * device Jacobi kernel that serves the Rayleigh-Ritz step: eigenvalues
+ * descending in w[n], eigenvectors in the columns of v (n x n row-major). */
+int scs_debug_jacobi(scs_ctx *ctx, const double *a, int32_t n, double *w, double *v);
+
+/* out (ka x kb, row-major) = A^T B for host matrices A (n x ka), B (n x kb),
+ * row-major, through the device Gram kernel; use_mfma selects the
+ * v_mfma_f64_16x16x4_f64 variant. */
+int scs_debug_gram(scs_ctx *ctx, const double *a, const double *b, int32_t n, int32_t ka,
+                   int32_t kb, int32_t use_mfma, double *out);
+
+/* y (rows x b) = S[row block] * x for a host x (V x b): one launch of the
+ * SYMM kernel with the graph's degree scaling. */
+int scs_debug_apply(scs_ctx *ctx, scs_graph *graph, const double *x, int32_t b, double *y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCS_HIP_H */

@@ -1,0 +1,147 @@
+"""ctypes binding of libscs_hip.so (include/scs_hip.h).  No torch, no fallback.
+
+The library is built in-tree by ``__graft_entry__.build()`` (or ``make -C
+spectralclustersupertree_amd/csrc``).  If it is missing, or no HIP device is
+usable, every entry point raises: there is no CPU path behind this module.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libscs_hip.so"
+
+UNIQUE_ID_BYTES = 128
+
+
+class ScsError(RuntimeError):
+    """A libscs_hip call returned a non-zero status."""
+
+    def __init__(self, code: int, message: str) -> None:
+        super().__init__(f"libscs_hip error {code}: {message}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("n_vertices", C.c_int32),
+        ("block", C.c_int32),
+        ("iterations", C.c_int32),
+        ("n_apply", C.c_int32),
+        ("converged", C.c_int32),
+        ("used_constraint", C.c_int32),
+        ("lambda_", C.c_double * 2),
+        ("resid", C.c_double * 2),
+        ("lambda_next", C.c_double),
+        ("apply_ms_total", C.c_double),
+        ("apply_ms_min", C.c_double),
+        ("solve_ms", C.c_double),
+        ("apply_bytes", C.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name.rstrip("_")] = list(v) if hasattr(v, "__len__") else v
+        return out
+
+
+class BuildStats(C.Structure):
+    _fields_ = [
+        ("n_taxa", C.c_int32),
+        ("n_trees", C.c_int32),
+        ("row_begin", C.c_int32),
+        ("row_end", C.c_int32),
+        ("symmetric", C.c_int32),
+        ("n_tiles", C.c_int32),
+        ("n_batches", C.c_int32),
+        ("reserved", C.c_int32),
+        ("cell_trees", C.c_double),
+        ("prep_ms", C.c_double),
+        ("accumulate_ms", C.c_double),
+        ("degree_ms", C.c_double),
+        ("total_ms", C.c_double),
+        ("bytes_w", C.c_double),
+        ("bytes_tables", C.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/scs_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_PP = C.POINTER(C.c_void_p)
+_I32 = C.c_int32
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+_LP = C.POINTER(C.c_int64)
+SIGNATURES = {
+    "scs_version": (C.c_int, []),
+    "scs_last_error": (C.c_char_p, []),
+    "scs_device_count": (C.c_int, []),
+    "scs_comm_unique_id": (C.c_int, [_P]),
+    "scs_ctx_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, _PP]),
+    "scs_local_group_create": (C.c_int, [C.c_int, _PP]),
+    "scs_local_group_destroy": (C.c_int, [_P]),
+    "scs_ctx_create_local": (C.c_int, [C.c_int, C.c_int, _P, _PP]),
+    "scs_ctx_destroy": (C.c_int, [_P]),
+    "scs_ctx_synchronize": (C.c_int, [_P]),
+    "scs_tables_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _PP]),
+    "scs_tables_free": (C.c_int, [_P, _P]),
+    "scs_pcg_build": (C.c_int, [_P, _P, _I32, _I32, _I32, _PP, C.POINTER(BuildStats)]),
+    "scs_graph_contract": (C.c_int, [_P, _P, _IP, _I32, _PP]),
+    "scs_graph_shape": (C.c_int, [_P, _IP, _IP, _IP]),
+    "scs_graph_download": (C.c_int, [_P, _P, _DP]),
+    "scs_graph_degrees": (C.c_int, [_P, _P, _DP]),
+    "scs_graph_free": (C.c_int, [_P, _P]),
+    "scs_fiedler": (C.c_int, [_P, _P, _DP, C.c_double, _I32, _I32, _DP, C.POINTER(Stats)]),
+    "scs_debug_jacobi": (C.c_int, [_P, _DP, _I32, _DP, _DP]),
+    "scs_debug_gram": (C.c_int, [_P, _DP, _DP, _I32, _I32, _I32, _I32, _DP]),
+    "scs_debug_apply": (C.c_int, [_P, _P, _DP, _I32, _DP]),
+}
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libscs_hip.so and bind every declared symbol; raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        msg = (
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C spectralclustersupertree_amd/csrc`.  There is no CPU fallback."
+        )
+        raise ImportError(msg)
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().scs_last_error()
+        raise ScsError(rc, msg.decode() if msg else "unknown error")
+
+
+def dptr(a: np.ndarray):
+    return a.ctypes.data_as(_DP)
+
+
+def iptr(a: np.ndarray):
+    return a.ctypes.data_as(_IP)
+
+
+def lptr(a: np.ndarray):
+    return a.ctypes.data_as(_LP)

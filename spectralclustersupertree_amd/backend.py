@@ -1,0 +1,194 @@
+"""Host-side handles on the device objects of libscs_hip.so.
+
+``Device`` owns one context (one process <-> one MI355X); ``DeviceGraph`` is a
+row block of the proper-cluster-graph weight matrix resident in HBM.  These are
+thin: every number is produced by the HIP kernels behind include/scs_hip.h.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from spectralclustersupertree_amd import _native as nv
+from spectralclustersupertree_amd.flatten import TreeTables
+
+DEFAULT_TOL = 1e-13
+DEFAULT_MAX_ITER = 2000
+
+
+class Device:
+    """One libscs_hip context.  ``Device()`` = GPU 0, single rank."""
+
+    def __init__(self, device: int = 0, rank: int = 0, world: int = 1, unique_id: bytes | None = None,
+                 *, _local_group=None) -> None:
+        self._lib = nv.load_library()
+        self._ctx = C.c_void_p()
+        self.rank, self.world = rank, world
+        if _local_group is not None:
+            nv.check(self._lib.scs_ctx_create_local(device, rank, _local_group, C.byref(self._ctx)))
+        else:
+            uid = None
+            if unique_id is not None:
+                if len(unique_id) != nv.UNIQUE_ID_BYTES:
+                    msg = f"unique_id must be {nv.UNIQUE_ID_BYTES} bytes"
+                    raise ValueError(msg)
+                uid = C.create_string_buffer(bytes(unique_id), nv.UNIQUE_ID_BYTES)
+            nv.check(self._lib.scs_ctx_create(device, rank, world, uid, C.byref(self._ctx)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """RCCL bootstrap id; rank 0 creates it and ships it to the other ranks."""
+        lib = nv.load_library()
+        buf = C.create_string_buffer(nv.UNIQUE_ID_BYTES)
+        nv.check(lib.scs_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self) -> None:
+        if self._ctx:
+            self._lib.scs_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self) -> "Device":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    def __del__(self) -> None:
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def synchronize(self) -> None:
+        nv.check(self._lib.scs_ctx_synchronize(self._ctx))
+
+    # -- tables ------------------------------------------------------------
+    def upload(self, tables: TreeTables) -> "DeviceTables":
+        tables.validate()
+        handle = C.c_void_p()
+        nv.check(
+            self._lib.scs_tables_upload(
+                self._ctx, tables.n_taxa, tables.n_trees, nv.lptr(tables.tree_off),
+                nv.iptr(tables.leaf_taxon), nv.iptr(tables.adj_depth), nv.dptr(tables.adj_val),
+                nv.dptr(tables.tree_w), C.byref(handle),
+            )
+        )
+        return DeviceTables(self, handle, tables.n_taxa, tables.n_trees)
+
+    # -- building blocks exposed for the parity tests -----------------------
+    def debug_jacobi(self, a: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        n = a.shape[0]
+        w = np.empty(n)
+        v = np.empty((n, n))
+        nv.check(self._lib.scs_debug_jacobi(self._ctx, nv.dptr(a), n, nv.dptr(w), nv.dptr(v)))
+        return w, v
+
+    def debug_gram(self, a: np.ndarray, b: np.ndarray, use_mfma: bool):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.empty((a.shape[1], b.shape[1]))
+        nv.check(self._lib.scs_debug_gram(self._ctx, nv.dptr(a), nv.dptr(b), a.shape[0], a.shape[1],
+                                          b.shape[1], int(use_mfma), nv.dptr(out)))
+        return out
+
+
+class DeviceTables:
+    def __init__(self, dev: Device, handle, n_taxa: int, n_trees: int) -> None:
+        self.dev, self._h = dev, handle
+        self.n_taxa, self.n_trees = n_taxa, n_trees
+
+    def free(self) -> None:
+        if self._h:
+            self.dev._lib.scs_tables_free(self.dev._ctx, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def build(self, row_begin: int = 0, row_end: int | None = None) -> "DeviceGraph":
+        """Rows [row_begin, row_end) of W (reference: scs.py:495-663)."""
+        if row_end is None:
+            row_end = self.n_taxa
+        handle = C.c_void_p()
+        stats = nv.BuildStats()
+        nv.check(self.dev._lib.scs_pcg_build(self.dev._ctx, self._h, row_begin, row_end, 0,
+                                             C.byref(handle), C.byref(stats)))
+        return DeviceGraph(self.dev, handle, stats.as_dict())
+
+
+class DeviceGraph:
+    def __init__(self, dev: Device, handle, build_stats: dict | None = None) -> None:
+        self.dev, self._h = dev, handle
+        self.build_stats = build_stats or {}
+
+    def free(self) -> None:
+        if self._h:
+            self.dev._lib.scs_graph_free(self.dev._ctx, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001
+            pass
+
+    @property
+    def shape(self) -> tuple[int, int, int]:
+        """(V, row_begin, row_end)."""
+        n, rb, re_ = C.c_int32(), C.c_int32(), C.c_int32()
+        nv.check(self.dev._lib.scs_graph_shape(self._h, C.byref(n), C.byref(rb), C.byref(re_)))
+        return n.value, rb.value, re_.value
+
+    def contract(self, group_start: np.ndarray) -> "DeviceGraph":
+        """Merge consecutive index ranges (reference: scs.py:336-387); consumes self."""
+        gs = np.ascontiguousarray(group_start, dtype=np.int32)
+        handle = C.c_void_p()
+        nv.check(self.dev._lib.scs_graph_contract(self.dev._ctx, self._h, nv.iptr(gs), len(gs) - 1,
+                                                  C.byref(handle)))
+        self._h = C.c_void_p()
+        return DeviceGraph(self.dev, handle, self.build_stats)
+
+    def download(self) -> np.ndarray:
+        n, rb, re_ = self.shape
+        out = np.empty((re_ - rb, n))
+        nv.check(self.dev._lib.scs_graph_download(self.dev._ctx, self._h, nv.dptr(out)))
+        return out
+
+    def degrees(self) -> np.ndarray:
+        n, rb, re_ = self.shape
+        out = np.empty(re_ - rb)
+        nv.check(self.dev._lib.scs_graph_degrees(self.dev._ctx, self._h, nv.dptr(out)))
+        return out
+
+    def apply(self, x: np.ndarray) -> np.ndarray:
+        """One SYMM launch: rows of S @ x for this rank's row block (x: V x b)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n, rb, re_ = self.shape
+        y = np.empty((re_ - rb, x.shape[1]))
+        nv.check(self.dev._lib.scs_debug_apply(self.dev._ctx, self._h, nv.dptr(x), x.shape[1],
+                                               nv.dptr(y)))
+        return y
+
+    def fiedler(self, x_init: np.ndarray | None = None, tol: float = DEFAULT_TOL,
+                max_iter: int = DEFAULT_MAX_ITER, block: int = 0):
+        """V x 2 spectral embedding + solver report (reference: scs.py:252)."""
+        n = self.shape[0]
+        maps = np.empty((n, 2))
+        stats = nv.Stats()
+        x0 = None
+        if x_init is not None:
+            x_init = np.ascontiguousarray(x_init, dtype=np.float64)
+            if x_init.shape != (n,):
+                msg = f"x_init must have shape ({n},)"
+                raise ValueError(msg)
+            x0 = nv.dptr(x_init)
+        nv.check(self.dev._lib.scs_fiedler(self.dev._ctx, self._h, x0, tol, max_iter, block,
+                                           nv.dptr(maps), C.byref(stats)))
+        return maps, stats.as_dict()

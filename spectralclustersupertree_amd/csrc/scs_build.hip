@@ -1,0 +1,737 @@
+// Proper-cluster-graph build on gfx950: W (fp64, row block x V) from flattened trees.
+//
+// Replaces _proper_cluster_graph_edges / _dfs_pcg_weights and the dense fill of
+// spectral_cluster_graph (reference: src/sc_supertree/scs.py:495-663, 246-250).
+//
+// Formulation (output-stationary, no global atomics, tree order preserved):
+//   W[a][b] = sum_t  vw_t(LCA_t(a,b))      over trees where depth(LCA_t(a,b)) > 0
+// with vw_t(node) = value(node) * w_t rounded once (scs.py:656).  A workgroup
+// owns a 64 x 256 tile of W in registers (thread = column, 64 row accumulators)
+// and walks the trees in order, so every cell sees its addends in the
+// reference's order and the sum is bit-identical.
+//
+// LCA depth is an ultrametric.  For a tile's 64 rows Y and a column c in tree t:
+//   d(i,c) = min( D[i][nb(c)], dn(c) ),  nb(c) = the row nearest to c in DFS
+//   order with the deeper LCA, dn(c) = depth(LCA(nb(c), c)),
+// where D is the 64 x 64 row-row LCA table of the tile in that tree.  D is
+// expanded in LDS from a 1.1 KB per-(row block, tree) record (rows sorted by
+// DFS position + the 63 LCAs between neighbours); nb/dn cost two range-minimum
+// queries per column on the tree's sparse table.  The inner loop is then one
+// LDS gather of (depth, value), a compare/select and one fp64 add per cell.
+
+#include <algorithm>
+
+#include "scs_internal.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int REC_SPOS = 0;       // int32[64] sorted DFS positions (INT_MAX beyond cnt)
+constexpr int REC_GDEPTH = 256;   // u32[64]   depth of LCA(sorted k, sorted k+1)
+constexpr int REC_GVW = 512;      // f64[64]   value*w of that LCA (0 where depth 0)
+constexpr int REC_SORIG = 1024;   // u8[64]    row (0..63) at sorted rank k
+constexpr int REC_RANK = 1088;    // u8[64]    sorted rank of row i (255 = absent)
+constexpr int REC_CNT = 1152;     // int32     rows present in the tree
+constexpr int REC_BYTES = 1168;
+constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
+
+// ---------------------------------------------------------------------------
+// prep kernels
+// ---------------------------------------------------------------------------
+
+// grid (ceil(max_leaves/256), trees in batch)
+__global__ void k_positions(const int64_t *__restrict__ tree_off,
+                            const int32_t *__restrict__ leaf_taxon,
+                            const int32_t *__restrict__ adj_depth,
+                            const double *__restrict__ adj_val,
+                            const double *__restrict__ tree_w, int t0, int64_t leaf_base,
+                            int32_t *__restrict__ pos, int64_t npad, double *__restrict__ vw,
+                            const int64_t *__restrict__ st_off, u64 *__restrict__ st) {
+    const int tl = blockIdx.y;
+    const int t = t0 + tl;
+    const int64_t off = tree_off[t];
+    const int n = (int)(tree_off[t + 1] - off);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    pos[(int64_t)tl * npad + leaf_taxon[off + p]] = p;
+    if (p < n - 1) {
+        const u32 d = (u32)adj_depth[off + p];
+        // one rounded multiply, as the reference's `length * tree_weight`
+        vw[off - leaf_base + p] = d ? adj_val[off + p] * tree_w[t] : 0.0;
+        st[st_off[tl] + p] = ((u64)d << 32) | (u32)p;
+    }
+}
+
+// level k >= 1 of every tree's sparse table; grid as above
+__global__ void k_sparse_level(const int64_t *__restrict__ tree_off, int t0, int k,
+                               const int64_t *__restrict__ st_off, u64 *__restrict__ st) {
+    const int tl = blockIdx.y;
+    const int t = t0 + tl;
+    const int m = (int)(tree_off[t + 1] - tree_off[t]) - 1;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = 1 << (k - 1);
+    if (m < (1 << k) || p > m - (1 << k)) return;
+    u64 *base = st + st_off[tl];
+    const u64 *prev = base + (int64_t)(k - 1) * m;
+    const u64 a = prev[p], b = prev[p + half];
+    base[(int64_t)k * m + p] = a < b ? a : b;
+}
+
+__device__ __forceinline__ u64 rmq_tree(const u64 *__restrict__ st, int m, int a, int b) {
+    // minimum over gaps [a, b), a < b <= m
+    const int len = b - a;
+    const int k = 31 - __clz(len);
+    const u64 *lvl = st + (int64_t)k * m;
+    const u64 x = lvl[a];
+    const u64 y = lvl[b - (1 << k)];
+    return x < y ? x : y;
+}
+
+// one wave per (local row block, tree): grid (n_blocks, trees in batch), 64 threads
+__global__ __launch_bounds__(64) void k_block_records(
+    const int64_t *__restrict__ tree_off, int t0, int n_batch, int64_t leaf_base,
+    const int32_t *__restrict__ pos, int64_t npad, const double *__restrict__ vw,
+    const int64_t *__restrict__ st_off, const u64 *__restrict__ st, int row_begin, int row_end,
+    unsigned char *__restrict__ rec_all) {
+    const int blk = blockIdx.x;
+    const int tl = blockIdx.y;
+    const int t = t0 + tl;
+    const int lane = threadIdx.x;
+    const int64_t off = tree_off[t];
+    const int m = (int)(tree_off[t + 1] - off) - 1;
+    const int row = row_begin + blk * SCS_TR + lane;
+    int p = -1;
+    if (row < row_end) p = pos[(int64_t)tl * npad + row];
+    const u32 pk = p < 0 ? 0x7FFFFFFFu : (u32)p;
+    u64 key = ((u64)pk << 32) | (u32)lane;
+    // bitonic sort of 64 unique keys across the wave
+    for (int k = 2; k <= 64; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const u64 other = __shfl_xor(key, j, 64);
+            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+            const u64 lo = key < other ? key : other;
+            const u64 hi = key < other ? other : key;
+            key = take_min ? lo : hi;
+        }
+    }
+    const int spos = (int)(key >> 32);
+    const int orig = (int)(key & 63);
+    const bool present = spos != 0x7FFFFFFF;
+    const int cnt = __popcll(__ballot(present));
+    const int next_pos = __shfl_down(spos, 1, 64);
+    u32 gdepth = 0;
+    double gvw = 0.0;
+    if (lane < cnt - 1) {
+        const u64 r = rmq_tree(st + st_off[tl], m, spos, next_pos);
+        gdepth = (u32)(r >> 32);
+        gvw = gdepth ? vw[off - leaf_base + (u32)(r & 0xFFFFFFFFu)] : 0.0;
+    }
+    unsigned char *rec = rec_all + ((int64_t)blk * n_batch + tl) * REC_BYTES;
+    ((int *)(rec + REC_SPOS))[lane] = spos;
+    ((u32 *)(rec + REC_GDEPTH))[lane] = gdepth;
+    ((double *)(rec + REC_GVW))[lane] = gvw;
+    rec[REC_SORIG + lane] = (unsigned char)orig;
+    rec[REC_RANK + orig] = present ? (unsigned char)lane : (unsigned char)255;
+    if (lane == 0) *(int *)(rec + REC_CNT) = cnt;
+}
+
+// ---------------------------------------------------------------------------
+// tile accumulate
+// ---------------------------------------------------------------------------
+struct acc_params {
+    const int2 *tiles;  // (local row block, column group index)
+    const unsigned char *rec;
+    const int32_t *pos;
+    int64_t npad;
+    const double *vw;
+    const int64_t *st_off;
+    const u64 *st;
+    const int64_t *tree_off;
+    int t0;
+    int n_batch;
+    int64_t leaf_base;
+    double *w;   // this rank's rows
+    int64_t ld;
+    int n;       // V
+    int row_begin, row_end;
+    int load_w;  // 1: continue a sum started by an earlier batch
+};
+
+template <int CPT, bool SYM>
+__global__ __launch_bounds__(SCS_TCW, (CPT == 1 ? 2 : 1)) void k_accumulate(acc_params p) {
+    __shared__ int s_spos[64];
+    __shared__ double s_gvw[64];
+    __shared__ unsigned char s_sorig[64];
+    __shared__ unsigned char s_rank[64];
+    __shared__ int s_cnt;
+    __shared__ u64 s_sp[6][64];
+    __shared__ u32 s_dd[64][64];
+    __shared__ double s_dv[64][64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int2 tile = p.tiles[blockIdx.x];
+    const int blk = tile.x;
+    const int row0 = p.row_begin + blk * SCS_TR;  // global index of the tile's first row
+    int col[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) col[q] = (tile.y * CPT + q) * SCS_TCW + tid;
+
+    double acc[CPT][SCS_TR];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) {
+            double v = 0.0;
+            if (p.load_w && col[q] < p.n && row0 + i < p.row_end)
+                v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col[q]];
+            acc[q][i] = v;
+        }
+    }
+
+    const unsigned char *rec = p.rec + (int64_t)blk * p.n_batch * REC_BYTES;
+    for (int tl = 0; tl < p.n_batch; ++tl, rec += REC_BYTES) {
+        // ---- record -> LDS; wave 0 also builds the sparse table over the 63 gaps
+        if (tid < 64) {
+            s_spos[tid] = ((const int *)(rec + REC_SPOS))[tid];
+            const int cnt = *(const int *)(rec + REC_CNT);
+            const u32 gd = ((const u32 *)(rec + REC_GDEPTH))[tid];
+            u64 key = tid < cnt - 1 ? (((u64)gd << 32) | (u32)tid) : ~0ull;
+            s_sp[0][tid] = key;
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                const u64 other = __shfl_down(key, 1 << (j - 1), 64);
+                if (tid + (1 << (j - 1)) < 64) key = key < other ? key : other;
+                s_sp[j][tid] = key;
+            }
+            if (tid == 0) s_cnt = cnt;
+        } else if (tid < 128) {
+            s_gvw[tid - 64] = ((const double *)(rec + REC_GVW))[tid - 64];
+        } else if (tid < 192) {
+            s_sorig[tid - 128] = rec[REC_SORIG + tid - 128];
+        } else {
+            s_rank[tid - 192] = rec[REC_RANK + tid - 192];
+        }
+        // column positions (global, independent of LDS)
+        int cpos[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) cpos[q] = p.pos[(int64_t)tl * p.npad + col[q]];
+        __syncthreads();
+
+        // ---- expand the row-row LCA table: wave w fills rows w, w+4, ...
+        {
+            const int rj = s_rank[lane];
+#pragma unroll 4
+            for (int i = wave; i < SCS_TR; i += 4) {
+                const int ri = s_rank[i];
+                u32 d = 0;
+                double v = 0.0;
+                if (i == lane) {
+                    d = DEPTH_INF;
+                } else if (ri != 255 && rj != 255) {
+                    const int a = ri < rj ? ri : rj;
+                    const int b = ri < rj ? rj : ri;
+                    const int k = 31 - __clz(b - a);
+                    const u64 x = s_sp[k][a];
+                    const u64 y = s_sp[k][b - (1 << k)];
+                    const u64 r = x < y ? x : y;
+                    d = (u32)(r >> 32);
+                    v = s_gvw[(u32)r & 63u];
+                }
+                s_dd[i][lane] = d;
+                s_dv[i][lane] = v;
+            }
+        }
+        // ---- per column: nearest tile row in DFS order and the LCA with it
+        int nb[CPT];
+        u32 dn[CPT];
+        double vn[CPT];
+        {
+            const int t = p.t0 + tl;
+            const int64_t off = p.tree_off[t];
+            const int m = (int)(p.tree_off[t + 1] - off) - 1;
+            const u64 *st = p.st + p.st_off[tl];
+            const int cnt = s_cnt;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                nb[q] = 0;
+                dn[q] = 0;
+                vn[q] = 0.0;
+                const int cp = cpos[q];
+                if (cp >= 0 && cnt > 0) {
+                    int lo = 0;
+#pragma unroll
+                    for (int s = 32; s > 0; s >>= 1)
+                        if (s_spos[lo + s - 1] < cp) lo += s;
+                    if (s_spos[lo] < cp) lo += 1;  // only when all 64 rows precede the column
+                    if (lo < cnt && s_spos[lo] == cp) {
+                        nb[q] = s_sorig[lo];  // the column is one of the tile's rows
+                        dn[q] = DEPTH_INF;
+                    } else {
+                        u64 gl = 0, gr = 0;
+                        if (lo > 0) gl = rmq_tree(st, m, s_spos[lo - 1], cp);
+                        if (lo < cnt) gr = rmq_tree(st, m, cp, s_spos[lo]);
+                        const bool left = lo > 0 && (lo >= cnt || (gl >> 32) >= (gr >> 32));
+                        const u64 g = left ? gl : gr;
+                        nb[q] = s_sorig[left ? lo - 1 : lo];
+                        dn[q] = (u32)(g >> 32);
+                        if (dn[q]) vn[q] = p.vw[off - p.leaf_base + (u32)(g & 0xFFFFFFFFu)];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- 64 cells per column: gather, select, add (tree order preserved)
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            const u32 *dd = &s_dd[0][nb[q]];
+            const double *dv = &s_dv[0][nb[q]];
+            const u32 dnq = dn[q];
+            const double vnq = vn[q];
+#pragma unroll
+            for (int i = 0; i < SCS_TR; ++i) {
+                const u32 ed = dd[i * 64];
+                const double ev = dv[i * 64];
+                acc[q][i] += ed < dnq ? ev : vnq;
+            }
+        }
+    }
+
+    // ---- write the tile once (and its mirror image in the symmetric schedule)
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int c = col[q];
+        if (c >= p.n) continue;
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) {
+            const int r = row0 + i;
+            if (r < p.row_end) {
+                p.w[(int64_t)(r - p.row_begin) * p.ld + c] = acc[q][i];
+                // mirror only into cells that no tile of the schedule owns, so
+                // every cell of W has exactly one writer (needed for batches)
+                constexpr int CT = SCS_TCW * CPT;
+                if (SYM && ((r / CT) + 1) * CT <= (c / SCS_TR) * SCS_TR)
+                    p.w[(int64_t)c * p.ld + r] = acc[q][i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// contraction: consecutive index ranges -> one vertex, weight = max over members
+// ---------------------------------------------------------------------------
+__global__ void k_contract(const double *__restrict__ w, int64_t ld, int old_row_begin,
+                           const int32_t *__restrict__ gstart, int g_begin, int g_end, int n_groups,
+                           double *__restrict__ out, int64_t ld_out) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;  // new column
+    const int g = g_begin + blockIdx.y;                    // new row (global)
+    if (h >= n_groups || g >= g_end) return;
+    double best = 0.0;
+    if (h != g) {
+        const int r0 = gstart[g], r1 = gstart[g + 1];
+        const int c0 = gstart[h], c1 = gstart[h + 1];
+        best = w[(int64_t)(r0 - old_row_begin) * ld + c0];
+        for (int r = r0; r < r1; ++r)
+            for (int c = c0; c < c1; ++c) {
+                const double v = w[(int64_t)(r - old_row_begin) * ld + c];
+                best = v > best ? v : best;
+            }
+    }
+    out[(int64_t)(g - g_begin) * ld_out + h] = best;
+}
+
+// ---------------------------------------------------------------------------
+// degrees: one wave per row
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_degrees(const double *__restrict__ w, int64_t ld, int n,
+                                                  int rows, int row_begin,
+                                                  double *__restrict__ deg_full) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const double *row = w + (int64_t)r * ld;
+    double s0 = 0.0, s1 = 0.0;
+    const int n2 = n & ~1;
+    for (int j = lane * 2; j < n2; j += 128) {
+        const double2 v = *(const double2 *)(row + j);
+        s0 += v.x;
+        s1 += v.y;
+    }
+    if ((n & 1) && lane == 0) s0 += row[n - 1];
+    double s = s0 + s1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) deg_full[row_begin + r] = s;
+}
+
+__global__ void k_dinv(const double *__restrict__ deg, int n, double *__restrict__ dinv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = deg[i];
+    dinv[i] = d == 0.0 ? 1.0 : 1.0 / sqrt(d);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+namespace {
+
+struct dev_buf {
+    void *p = nullptr;
+    ~dev_buf() {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        if (p) hipFree(p);
+        p = nullptr;
+        SCS_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        return SCS_OK;
+    }
+};
+
+struct ev_pair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~ev_pair() {
+        if (a) hipEventDestroy(a);
+        if (b) hipEventDestroy(b);
+    }
+    int init() {
+        SCS_HIP_CHECK(hipEventCreate(&a));
+        SCS_HIP_CHECK(hipEventCreate(&b));
+        return SCS_OK;
+    }
+};
+
+int levels_for(int64_t m) {
+    int l = 0;
+    while (((int64_t)1 << l) <= m) ++l;
+    return l;  // number of levels k with 2^k <= m
+}
+
+}  // namespace
+
+static int graph_alloc(int32_t n, int32_t row_begin, int32_t row_end, scs_graph **out) {
+    auto *g = new scs_graph();
+    g->n = n;
+    g->row_begin = row_begin;
+    g->row_end = row_end;
+    g->ld = scs_round_up(n, 8);
+    size_t bytes = (size_t)(row_end - row_begin) * (size_t)g->ld * sizeof(double);
+    hipError_t e = hipMalloc((void **)&g->d_w, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        delete g;
+        scs_set_error("cannot allocate %zu bytes for W: %s", bytes, hipGetErrorString(e));
+        return SCS_ENOMEM;
+    }
+    *out = g;
+    return SCS_OK;
+}
+
+extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
+    if (!g) return SCS_OK;
+    if (ctx) hipSetDevice(ctx->device);
+    hipFree(g->d_w);
+    hipFree(g->d_deg);
+    hipFree(g->d_dinv);
+    delete g;
+    return SCS_OK;
+}
+
+extern "C" int scs_graph_shape(const scs_graph *g, int32_t *n, int32_t *rb, int32_t *re) {
+    SCS_REQUIRE(g != nullptr, "scs_graph_shape: null graph");
+    if (n) *n = g->n;
+    if (rb) *rb = g->row_begin;
+    if (re) *re = g->row_end;
+    return SCS_OK;
+}
+
+extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_begin,
+                             int32_t row_end, int32_t flags, scs_graph **out,
+                             scs_build_stats *stats) {
+    SCS_REQUIRE(ctx && tb && out, "scs_pcg_build: null argument");
+    SCS_REQUIRE(flags == 0, "scs_pcg_build: flags must be 0");
+    const int n = tb->n_taxa;
+    SCS_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= n,
+                "scs_pcg_build: bad row range [%d, %d) for %d taxa", row_begin, row_end, n);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const bool sym = (row_begin == 0 && row_end == n && ctx->comm.world == 1);
+    const int rows = row_end - row_begin;
+    const int n_blocks = (rows + SCS_TR - 1) / SCS_TR;
+    const int cpt = (getenv("SCS_BUILD_CPT") && atoi(getenv("SCS_BUILD_CPT")) == 2) ? 2 : 1;
+    const int cols_per_tile = SCS_TCW * cpt;
+    const int n_cgroups = (n + cols_per_tile - 1) / cols_per_tile;
+    const int64_t npad = scs_round_up(n, SCS_NPAD);
+
+    scs_graph *g = nullptr;
+    SCS_TRY(graph_alloc(n, row_begin, row_end, &g));
+    struct guard {
+        scs_ctx *c;
+        scs_graph *g;
+        ~guard() {
+            if (g) scs_graph_free(c, g);
+        }
+    } gd{ctx, g};
+
+    // ---- tile list
+    std::vector<int2> tiles;
+    tiles.reserve((size_t)n_blocks * n_cgroups);
+    for (int b = 0; b < n_blocks; ++b)
+        for (int c = 0; c < n_cgroups; ++c) {
+            if (sym && (int64_t)(c + 1) * cols_per_tile <= (int64_t)b * SCS_TR) continue;
+            tiles.push_back(make_int2(b, c));
+        }
+    dev_buf d_tiles;
+    SCS_TRY(d_tiles.alloc(tiles.size() * sizeof(int2)));
+    SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
+                                 hipMemcpyHostToDevice, s));
+
+    // ---- batch plan: bound sparse tables + records + positions by the workspace
+    const int M = tb->n_trees;
+    std::vector<int> batch_start{0};
+    {
+        size_t used = 0;
+        for (int t = 0; t < M; ++t) {
+            const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
+            const int64_t m = nt - 1;
+            size_t need = (size_t)levels_for(m) * (size_t)m * 8 + (size_t)nt * 8 +
+                          (size_t)npad * 4 + (size_t)n_blocks * REC_BYTES;
+            if (used + need > ctx->ws_limit && t > batch_start.back()) {
+                batch_start.push_back(t);
+                used = 0;
+            }
+            used += need;
+        }
+        batch_start.push_back(M);
+    }
+    const int n_batches = (int)batch_start.size() - 1;
+
+    ev_pair ev_total, ev_prep, ev_acc;
+    SCS_TRY(ev_total.init());
+    SCS_TRY(ev_prep.init());
+    SCS_TRY(ev_acc.init());
+    float prep_ms = 0.f, acc_ms = 0.f;
+    SCS_HIP_CHECK(hipEventRecord(ev_total.a, s));
+
+    dev_buf d_pos, d_vw, d_st, d_stoff, d_rec;
+    size_t cap_pos = 0, cap_vw = 0, cap_st = 0, cap_stoff = 0, cap_rec = 0;
+    for (int bi = 0; bi < n_batches; ++bi) {
+        const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
+        const int nb = t1 - t0;
+        const int64_t leaf_base = tb->h_tree_off[t0];
+        const int64_t leaves = tb->h_tree_off[t1] - leaf_base;
+        std::vector<int64_t> st_off(nb + 1);
+        int max_levels = 0;
+        int64_t max_n = 0;
+        st_off[0] = 0;
+        for (int t = t0; t < t1; ++t) {
+            const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
+            const int lv = levels_for(nt - 1);
+            st_off[t - t0 + 1] = st_off[t - t0] + (int64_t)lv * (nt - 1);
+            max_levels = std::max(max_levels, lv);
+            max_n = std::max(max_n, nt);
+        }
+        const size_t need_pos = (size_t)nb * npad * 4;
+        const size_t need_vw = (size_t)leaves * 8;
+        const size_t need_st = (size_t)st_off[nb] * 8;
+        const size_t need_stoff = (size_t)(nb + 1) * 8;
+        const size_t need_rec = (size_t)n_blocks * nb * REC_BYTES;
+        if (need_pos > cap_pos) { SCS_TRY(d_pos.alloc(need_pos)); cap_pos = need_pos; }
+        if (need_vw > cap_vw) { SCS_TRY(d_vw.alloc(need_vw)); cap_vw = need_vw; }
+        if (need_st > cap_st) { SCS_TRY(d_st.alloc(need_st)); cap_st = need_st; }
+        if (need_stoff > cap_stoff) { SCS_TRY(d_stoff.alloc(need_stoff)); cap_stoff = need_stoff; }
+        if (need_rec > cap_rec) { SCS_TRY(d_rec.alloc(need_rec)); cap_rec = need_rec; }
+
+        SCS_HIP_CHECK(hipEventRecord(ev_prep.a, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(d_stoff.p, st_off.data(), need_stoff, hipMemcpyHostToDevice, s));
+        SCS_HIP_CHECK(hipMemsetAsync(d_pos.p, 0xFF, need_pos, s));
+        dim3 grid_l((unsigned)((max_n + 255) / 256), (unsigned)nb);
+        k_positions<<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon, tb->d_adj_depth,
+                                           tb->d_adj_val, tb->d_tree_w, t0, leaf_base,
+                                           (int32_t *)d_pos.p, npad, (double *)d_vw.p,
+                                           (const int64_t *)d_stoff.p, (u64 *)d_st.p);
+        for (int k = 1; k < max_levels; ++k)
+            k_sparse_level<<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
+                                                  (const int64_t *)d_stoff.p, (u64 *)d_st.p);
+        k_block_records<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
+            tb->d_tree_off, t0, nb, leaf_base, (const int32_t *)d_pos.p, npad,
+            (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const u64 *)d_st.p, row_begin,
+            row_end, (unsigned char *)d_rec.p);
+        SCS_HIP_CHECK(hipEventRecord(ev_prep.b, s));
+
+        acc_params ap;
+        ap.tiles = (const int2 *)d_tiles.p;
+        ap.rec = (const unsigned char *)d_rec.p;
+        ap.pos = (const int32_t *)d_pos.p;
+        ap.npad = npad;
+        ap.vw = (const double *)d_vw.p;
+        ap.st_off = (const int64_t *)d_stoff.p;
+        ap.st = (const u64 *)d_st.p;
+        ap.tree_off = tb->d_tree_off;
+        ap.t0 = t0;
+        ap.n_batch = nb;
+        ap.leaf_base = leaf_base;
+        ap.w = g->d_w;
+        ap.ld = g->ld;
+        ap.n = n;
+        ap.row_begin = row_begin;
+        ap.row_end = row_end;
+        ap.load_w = bi > 0;
+        SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
+        const unsigned nt = (unsigned)tiles.size();
+        if (cpt == 1) {
+            if (sym) k_accumulate<1, true><<<nt, SCS_TCW, 0, s>>>(ap);
+            else k_accumulate<1, false><<<nt, SCS_TCW, 0, s>>>(ap);
+        } else {
+            if (sym) k_accumulate<2, true><<<nt, SCS_TCW, 0, s>>>(ap);
+            else k_accumulate<2, false><<<nt, SCS_TCW, 0, s>>>(ap);
+        }
+        SCS_HIP_CHECK(hipGetLastError());
+        SCS_HIP_CHECK(hipEventRecord(ev_acc.b, s));
+        SCS_HIP_CHECK(hipEventSynchronize(ev_acc.b));
+        float ms = 0.f;
+        SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_prep.a, ev_prep.b));
+        prep_ms += ms;
+        SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_acc.a, ev_acc.b));
+        acc_ms += ms;
+    }
+    SCS_HIP_CHECK(hipEventRecord(ev_total.b, s));
+    SCS_HIP_CHECK(hipEventSynchronize(ev_total.b));
+    float total_ms = 0.f;
+    SCS_HIP_CHECK(hipEventElapsedTime(&total_ms, ev_total.a, ev_total.b));
+
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->n_taxa = n;
+        stats->n_trees = M;
+        stats->row_begin = row_begin;
+        stats->row_end = row_end;
+        stats->symmetric = sym;
+        stats->n_tiles = (int32_t)tiles.size();
+        stats->n_batches = n_batches;
+        stats->cell_trees = (double)tiles.size() * SCS_TR * cols_per_tile * (double)M;
+        stats->prep_ms = prep_ms;
+        stats->accumulate_ms = acc_ms;
+        stats->total_ms = total_ms;
+        stats->bytes_w = 8.0 * rows * (double)n;
+        stats->bytes_tables = 16.0 * (double)tb->n_leaves + 8.0 * M;
+    }
+    gd.g = nullptr;
+    *out = g;
+    return SCS_OK;
+}
+
+extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *group_start,
+                                  int32_t n_groups, scs_graph **out) {
+    SCS_REQUIRE(ctx && g && group_start && out, "scs_graph_contract: null argument");
+    SCS_REQUIRE(n_groups >= 1 && n_groups <= g->n, "scs_graph_contract: bad group count %d",
+                n_groups);
+    SCS_REQUIRE(group_start[0] == 0 && group_start[n_groups] == g->n,
+                "scs_graph_contract: group_start must span [0, %d]", g->n);
+    int g_begin = -1, g_end = -1;
+    for (int i = 0; i < n_groups; ++i) {
+        SCS_REQUIRE(group_start[i] < group_start[i + 1], "scs_graph_contract: empty group %d", i);
+        if (group_start[i] == g->row_begin) g_begin = i;
+        if (group_start[i + 1] == g->row_end) g_end = i + 1;
+    }
+    SCS_REQUIRE(g_begin >= 0 && g_end > g_begin,
+                "scs_graph_contract: a group straddles this rank's row block [%d, %d)",
+                g->row_begin, g->row_end);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    scs_graph *ng = nullptr;
+    SCS_TRY(graph_alloc(n_groups, g_begin, g_end, &ng));
+    int32_t *d_gs = nullptr;
+    hipError_t e = hipMalloc((void **)&d_gs, (size_t)(n_groups + 1) * 4);
+    if (e != hipSuccess) {
+        scs_graph_free(ctx, ng);
+        scs_set_error("scs_graph_contract: hipMalloc failed: %s", hipGetErrorString(e));
+        return SCS_ENOMEM;
+    }
+    hipMemcpyAsync(d_gs, group_start, (size_t)(n_groups + 1) * 4, hipMemcpyHostToDevice,
+                   ctx->stream);
+    dim3 grid((unsigned)((n_groups + 255) / 256), (unsigned)(g_end - g_begin));
+    k_contract<<<grid, 256, 0, ctx->stream>>>(g->d_w, g->ld, g->row_begin, d_gs, g_begin, g_end,
+                                              n_groups, ng->d_w, ng->ld);
+    e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_gs);
+    if (e != hipSuccess) {
+        scs_graph_free(ctx, ng);
+        scs_set_error("scs_graph_contract: kernel failed: %s", hipGetErrorString(e));
+        return SCS_EHIP;
+    }
+    scs_graph_free(ctx, g);
+    *out = ng;
+    return SCS_OK;
+}
+
+extern "C" int scs_graph_download(scs_ctx *ctx, const scs_graph *g, double *out) {
+    SCS_REQUIRE(ctx && g && out, "scs_graph_download: null argument");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const size_t rows = (size_t)(g->row_end - g->row_begin);
+    SCS_HIP_CHECK(hipMemcpy2D(out, (size_t)g->n * 8, g->d_w, (size_t)g->ld * 8, (size_t)g->n * 8,
+                              rows, hipMemcpyDeviceToHost));
+    return SCS_OK;
+}
+
+// degrees of ALL vertices on every rank (local rows computed here, the rest
+// gathered), plus 1/sqrt(d)
+int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
+    if (g->have_deg) return SCS_OK;
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int n = g->n;
+    const int rows = g->row_end - g->row_begin;
+    if (!g->d_deg) SCS_HIP_CHECK(hipMalloc((void **)&g->d_deg, (size_t)n * 8));
+    if (!g->d_dinv) SCS_HIP_CHECK(hipMalloc((void **)&g->d_dinv, (size_t)n * 8));
+    const int world = ctx->comm.world;
+    if (world == 1) {
+        k_degrees<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg);
+    } else {
+        // every rank contributes a V-long vector that is zero outside its rows
+        dev_buf send, recv;
+        SCS_TRY(send.alloc((size_t)n * 8));
+        SCS_TRY(recv.alloc((size_t)n * 8 * world));
+        SCS_HIP_CHECK(hipMemsetAsync(send.p, 0, (size_t)n * 8, s));
+        k_degrees<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin,
+                                                 (double *)send.p);
+        SCS_TRY(scs_comm_allgather_f64(&ctx->comm, (const double *)send.p, (double *)recv.p,
+                                       (size_t)n, s));
+        std::vector<double> h((size_t)n * world), d((size_t)n, 0.0);
+        SCS_HIP_CHECK(hipMemcpyAsync(h.data(), recv.p, h.size() * 8, hipMemcpyDeviceToHost, s));
+        SCS_HIP_CHECK(hipStreamSynchronize(s));
+        for (int r = 0; r < world; ++r)
+            for (int i = 0; i < n; ++i)
+                if (h[(size_t)r * n + i] != 0.0) d[i] = h[(size_t)r * n + i];
+        SCS_HIP_CHECK(hipMemcpyAsync(g->d_deg, d.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+        SCS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    k_dinv<<<(n + 255) / 256, 256, 0, s>>>(g->d_deg, n, g->d_dinv);
+    std::vector<double> deg((size_t)n);
+    SCS_HIP_CHECK(hipMemcpyAsync(deg.data(), g->d_deg, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    int iso = 0;
+    double nrm2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        if (deg[i] == 0.0) {
+            ++iso;
+            nrm2 += 1.0;
+        } else {
+            nrm2 += deg[i];
+        }
+    }
+    g->n_isolated = iso;
+    g->dd_norm = sqrt(nrm2);
+    g->have_deg = true;
+    return SCS_OK;
+}
+
+extern "C" int scs_graph_degrees(scs_ctx *ctx, scs_graph *g, double *out) {
+    SCS_REQUIRE(ctx && g && out, "scs_graph_degrees: null argument");
+    SCS_TRY(scs_graph_prepare_degrees(ctx, g));
+    SCS_HIP_CHECK(hipMemcpy(out, g->d_deg + g->row_begin,
+                            (size_t)(g->row_end - g->row_begin) * 8, hipMemcpyDeviceToHost));
+    return SCS_OK;
+}

@@ -1,0 +1,376 @@
+// Context, communicator and table upload for libscs_hip.so.
+//
+// One context = one process-side handle on one MI355X: a HIP stream, an
+// optional communicator (RCCL over xGMI for world > 1, or the in-process test
+// group) and the scratch policy of the build.  RCCL is bound with dlopen so a
+// single-GPU run never pays for loading it.
+
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <mutex>
+
+#include "scs_internal.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void scs_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char *scs_last_error(void) { return g_last_error.c_str(); }
+extern "C" int scs_version(void) { return 100; }
+
+extern "C" int scs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// RCCL binding (dlopen)
+// ---------------------------------------------------------------------------
+namespace {
+
+struct rccl_uid {
+    char internal[SCS_UNIQUE_ID_BYTES];
+};
+typedef int (*fn_get_uid)(rccl_uid *);
+typedef int (*fn_init_rank)(void **, int, rccl_uid, int);
+typedef int (*fn_destroy)(void *);
+typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*fn_errstr)(int);
+
+struct rccl_api {
+    void *handle = nullptr;
+    fn_get_uid get_uid = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_destroy destroy = nullptr;
+    fn_allgather allgather = nullptr;
+    fn_errstr errstr = nullptr;
+};
+
+rccl_api g_rccl;
+std::mutex g_rccl_mutex;
+
+int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return SCS_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) {
+        scs_set_error("cannot load librccl: %s", dlerror());
+        return SCS_ECOMM;
+    }
+    g_rccl.get_uid = (fn_get_uid)dlsym(h, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(h, "ncclCommInitRank");
+    g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
+    g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allgather) {
+        scs_set_error("librccl lacks an expected symbol");
+        dlclose(h);
+        return SCS_ECOMM;
+    }
+    g_rccl.handle = h;
+    return SCS_OK;
+}
+
+const char *rccl_err(int rc) { return g_rccl.errstr ? g_rccl.errstr(rc) : "rccl error"; }
+
+}  // namespace
+
+extern "C" int scs_comm_unique_id(void *out128) {
+    SCS_REQUIRE(out128 != nullptr, "scs_comm_unique_id: null output");
+    SCS_TRY(load_rccl());
+    rccl_uid uid;
+    int rc = g_rccl.get_uid(&uid);
+    if (rc != 0) {
+        scs_set_error("ncclGetUniqueId failed: %s", rccl_err(rc));
+        return SCS_ECOMM;
+    }
+    memcpy(out128, uid.internal, SCS_UNIQUE_ID_BYTES);
+    return SCS_OK;
+}
+
+int scs_comm_init_rccl(scs_comm *comm, int rank, int world, const void *uid_bytes) {
+    SCS_TRY(load_rccl());
+    rccl_uid uid;
+    memcpy(uid.internal, uid_bytes, SCS_UNIQUE_ID_BYTES);
+    void *c = nullptr;
+    int rc = g_rccl.init_rank(&c, world, uid, rank);
+    if (rc != 0) {
+        scs_set_error("ncclCommInitRank(rank %d of %d) failed: %s", rank, world, rccl_err(rc));
+        return SCS_ECOMM;
+    }
+    comm->rank = rank;
+    comm->world = world;
+    comm->kind = 1;
+    comm->rccl_comm = c;
+    return SCS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// in-process group (test communicator)
+// ---------------------------------------------------------------------------
+struct scs_local_group {
+    int world = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const double *> send;
+    void barrier() {
+        std::unique_lock<std::mutex> lock(m);
+        uint64_t gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return generation != gen; });
+        }
+    }
+};
+
+extern "C" int scs_local_group_create(int world, scs_local_group **out) {
+    SCS_REQUIRE(out != nullptr && world >= 1 && world <= 64, "scs_local_group_create: bad world %d",
+                world);
+    auto *g = new scs_local_group();
+    g->world = world;
+    g->send.assign(world, nullptr);
+    *out = g;
+    return SCS_OK;
+}
+
+extern "C" int scs_local_group_destroy(scs_local_group *group) {
+    delete group;
+    return SCS_OK;
+}
+
+int scs_comm_allgather_f64(scs_comm *comm, const double *sendbuf, double *recvbuf, size_t count,
+                           hipStream_t stream) {
+    if (comm->world == 1 || comm->kind == 0) {
+        if (recvbuf != sendbuf)
+            SCS_HIP_CHECK(hipMemcpyAsync(recvbuf, sendbuf, count * sizeof(double),
+                                         hipMemcpyDeviceToDevice, stream));
+        return SCS_OK;
+    }
+    if (comm->kind == 1) {
+        int rc = g_rccl.allgather(sendbuf, recvbuf, count, /*ncclFloat64*/ 8, comm->rccl_comm,
+                                  stream);
+        if (rc != 0) {
+            scs_set_error("ncclAllGather failed: %s", rccl_err(rc));
+            return SCS_ECOMM;
+        }
+        return SCS_OK;
+    }
+    // local group: publish, meet, copy every slice, meet again
+    scs_local_group *g = comm->group;
+    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    g->send[comm->rank] = sendbuf;
+    g->barrier();
+    for (int r = 0; r < g->world; ++r)
+        SCS_HIP_CHECK(hipMemcpyAsync(recvbuf + (size_t)r * count, g->send[r],
+                                     count * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    g->barrier();
+    return SCS_OK;
+}
+
+int scs_comm_destroy(scs_comm *comm) {
+    if (comm->kind == 1 && comm->rccl_comm) {
+        g_rccl.destroy(comm->rccl_comm);
+        comm->rccl_comm = nullptr;
+    }
+    comm->kind = 0;
+    return SCS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+static int ctx_common(int device, scs_ctx **out) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        scs_set_error("no HIP device available (%s); this library has no CPU path",
+                      e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return SCS_EHIP;
+    }
+    SCS_REQUIRE(device >= 0 && device < ndev, "device %d out of range (have %d)", device, ndev);
+    SCS_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SCS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    auto *ctx = new scs_ctx();
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (se != hipSuccess) {
+        delete ctx;
+        scs_set_error("hipStreamCreate failed: %s", hipGetErrorString(se));
+        return SCS_EHIP;
+    }
+    // scratch budget per tree batch: a quarter of what is free now, at most 64 GiB
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+    size_t lim = free_b / 4;
+    const size_t cap = (size_t)64 << 30;
+    ctx->ws_limit = lim < cap ? lim : cap;
+    if (const char *s = getenv("SCS_WS_LIMIT_MB")) {
+        long mb = atol(s);
+        if (mb > 0) ctx->ws_limit = (size_t)mb << 20;
+    }
+    *out = ctx;
+    return SCS_OK;
+}
+
+extern "C" int scs_ctx_create(int device, int rank, int world, const void *unique_id128,
+                              scs_ctx **out) {
+    SCS_REQUIRE(out != nullptr, "scs_ctx_create: null output");
+    SCS_REQUIRE(world >= 1 && rank >= 0 && rank < world, "scs_ctx_create: bad rank %d / world %d",
+                rank, world);
+    scs_ctx *ctx = nullptr;
+    SCS_TRY(ctx_common(device, &ctx));
+    ctx->comm.rank = rank;
+    ctx->comm.world = world;
+    if (world > 1 || unique_id128 != nullptr) {
+        if (unique_id128 == nullptr) {
+            scs_ctx_destroy(ctx);
+            scs_set_error("scs_ctx_create: world > 1 needs a unique id");
+            return SCS_EINVAL;
+        }
+        int rc = scs_comm_init_rccl(&ctx->comm, rank, world, unique_id128);
+        if (rc != SCS_OK) {
+            std::string keep = g_last_error;
+            scs_ctx_destroy(ctx);
+            g_last_error = keep;
+            return rc;
+        }
+    }
+    *out = ctx;
+    return SCS_OK;
+}
+
+extern "C" int scs_ctx_create_local(int device, int rank, scs_local_group *group, scs_ctx **out) {
+    SCS_REQUIRE(out != nullptr && group != nullptr, "scs_ctx_create_local: null argument");
+    SCS_REQUIRE(rank >= 0 && rank < group->world, "scs_ctx_create_local: bad rank %d", rank);
+    scs_ctx *ctx = nullptr;
+    SCS_TRY(ctx_common(device, &ctx));
+    ctx->comm.rank = rank;
+    ctx->comm.world = group->world;
+    ctx->comm.kind = group->world > 1 ? 2 : 0;
+    ctx->comm.group = group;
+    *out = ctx;
+    return SCS_OK;
+}
+
+extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
+    if (!ctx) return SCS_OK;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        hipStreamSynchronize(ctx->stream);
+    }
+    scs_comm_destroy(&ctx->comm);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SCS_OK;
+}
+
+extern "C" int scs_ctx_synchronize(scs_ctx *ctx) {
+    SCS_REQUIRE(ctx != nullptr, "scs_ctx_synchronize: null context");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SCS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------
+template <typename T>
+static int upload(T **dst, const T *src, size_t count, hipStream_t stream) {
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    SCS_HIP_CHECK(hipMalloc((void **)dst, bytes));
+    if (count)
+        SCS_HIP_CHECK(hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+    return SCS_OK;
+}
+
+extern "C" int scs_tables_free(scs_ctx *ctx, scs_tables *t) {
+    if (!t) return SCS_OK;
+    if (ctx) hipSetDevice(ctx->device);
+    hipFree(t->d_tree_off);
+    hipFree(t->d_leaf_taxon);
+    hipFree(t->d_adj_depth);
+    hipFree(t->d_adj_val);
+    hipFree(t->d_tree_w);
+    delete t;
+    return SCS_OK;
+}
+
+extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
+                                 const int64_t *tree_off, const int32_t *leaf_taxon,
+                                 const int32_t *adj_depth, const double *adj_val,
+                                 const double *tree_w, scs_tables **out) {
+    SCS_REQUIRE(ctx && out, "scs_tables_upload: null context or output");
+    SCS_REQUIRE(n_taxa >= 1 && n_trees >= 1, "scs_tables_upload: need >= 1 taxon and >= 1 tree");
+    SCS_REQUIRE(tree_off && leaf_taxon && adj_depth && adj_val && tree_w,
+                "scs_tables_upload: null table pointer");
+    SCS_REQUIRE(tree_off[0] == 0, "scs_tables_upload: tree_off[0] must be 0");
+    int64_t max_leaves = 0;
+    for (int32_t t = 0; t < n_trees; ++t) {
+        int64_t n = tree_off[t + 1] - tree_off[t];
+        SCS_REQUIRE(n >= 1, "scs_tables_upload: tree %d has %lld leaves", t, (long long)n);
+        SCS_REQUIRE(n <= n_taxa, "scs_tables_upload: tree %d has more leaves (%lld) than taxa (%d)",
+                    t, (long long)n, n_taxa);
+        if (n > max_leaves) max_leaves = n;
+    }
+    const int64_t L = tree_off[n_trees];
+    // every leaf id must be in range: an out-of-range id would index past the
+    // position table on the device
+    for (int64_t p = 0; p < L; ++p) {
+        SCS_REQUIRE(leaf_taxon[p] >= 0 && leaf_taxon[p] < n_taxa,
+                    "scs_tables_upload: leaf_taxon[%lld] = %d out of range", (long long)p,
+                    leaf_taxon[p]);
+        SCS_REQUIRE(adj_depth[p] >= 0, "scs_tables_upload: adj_depth[%lld] negative",
+                    (long long)p);
+    }
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    auto *t = new scs_tables();
+    t->n_taxa = n_taxa;
+    t->n_trees = n_trees;
+    t->n_leaves = L;
+    t->max_leaves = (int32_t)max_leaves;
+    t->h_tree_off.assign(tree_off, tree_off + n_trees + 1);
+    int rc = SCS_OK;
+    if ((rc = upload(&t->d_tree_off, tree_off, (size_t)n_trees + 1, ctx->stream)) != SCS_OK ||
+        (rc = upload(&t->d_leaf_taxon, leaf_taxon, (size_t)L, ctx->stream)) != SCS_OK ||
+        (rc = upload(&t->d_adj_depth, adj_depth, (size_t)L, ctx->stream)) != SCS_OK ||
+        (rc = upload(&t->d_adj_val, adj_val, (size_t)L, ctx->stream)) != SCS_OK ||
+        (rc = upload(&t->d_tree_w, tree_w, (size_t)n_trees, ctx->stream)) != SCS_OK) {
+        std::string keep = g_last_error;
+        scs_tables_free(ctx, t);
+        g_last_error = keep;
+        return rc;
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        scs_tables_free(ctx, t);
+        scs_set_error("table upload failed: %s", hipGetErrorString(e));
+        return SCS_EHIP;
+    }
+    *out = t;
+    return SCS_OK;
+}

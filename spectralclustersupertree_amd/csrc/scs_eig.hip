@@ -1,0 +1,1153 @@
+// Fiedler solve on gfx950: LOBPCG on S = D^-1/2 A D^-1/2 (A = this rank's row
+// block of W, zero diagonal), replacing scikit-learn's shift-invert ARPACK path
+// (reference call site: src/sc_supertree/scs.py:235-252; arithmetic replaced:
+// sklearn/manifold/_spectral_embedding.py:332-376, scipy _laplacian.py:547-558).
+//
+// The only kernel that touches the N x N matrix is k_symm (HBM-bound: 8 N^2
+// bytes per launch, b/4 flop per byte): one wave streams four rows with 16-byte
+// loads, multiplies against the scaled block Z = D^-1/2 X and reduces across
+// the 64 lanes with wave shuffles.  Everything else works on N x 3b panels.
+// The Rayleigh-Ritz Gram product runs on v_mfma_f64_16x16x4_f64; the 3b x 3b
+// eigenproblem is solved on the device by a one-workgroup parallel Jacobi, so
+// an iteration needs one small device->host read (the residual norms).
+
+#include <algorithm>
+#include <cmath>
+
+#include "scs_internal.h"
+
+constexpr int MAXB = 16;      // widest LOBPCG block
+constexpr int MAXS = 64;      // largest matrix the Jacobi kernel takes
+constexpr int SLD = MAXS + 1; // LDS leading dimension (breaks the power-of-two stride)
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// SYMM: y[r][:] = dinv[r] * sum_j W[r][j] * z[j][:],  z = dinv (.) x  (n x B)
+// ---------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(256) void k_symm(const double *__restrict__ w, int64_t ld, int n,
+                                               int rows, int row_begin,
+                                               const double *__restrict__ z,
+                                               const double *__restrict__ dinv,
+                                               double *__restrict__ y) {
+    constexpr int RPW = 4;  // rows per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.x * 4 + wave) * RPW;
+    if (r0 >= rows) return;
+    const double *rowp[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = r0 + i < rows ? r0 + i : rows - 1;  // clamp: duplicate work, never stored
+        rowp[i] = w + (int64_t)r * ld;
+    }
+    double acc[RPW][B];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int k = 0; k < B; ++k) acc[i][k] = 0.0;
+
+    const int n2 = n & ~1;
+    for (int j = lane * 2; j < n2; j += 128) {
+        double2 a[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) a[i] = *(const double2 *)(rowp[i] + j);
+        double z0[B], z1[B];
+        const double2 *zp0 = (const double2 *)(z + (int64_t)j * B);
+        const double2 *zp1 = (const double2 *)(z + (int64_t)(j + 1) * B);
+        if (B % 2 == 0) {
+#pragma unroll
+            for (int k = 0; k < B / 2; ++k) {
+                const double2 u0 = zp0[k], u1 = zp1[k];
+                z0[2 * k] = u0.x;
+                z0[2 * k + 1] = u0.y;
+                z1[2 * k] = u1.x;
+                z1[2 * k + 1] = u1.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < B; ++k) {
+                z0[k] = z[(int64_t)j * B + k];
+                z1[k] = z[(int64_t)(j + 1) * B + k];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int k = 0; k < B; ++k) acc[i][k] += a[i].x * z0[k] + a[i].y * z1[k];
+    }
+    if ((n & 1) && lane == 0) {
+        const int j = n - 1;
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const double a = rowp[i][j];
+#pragma unroll
+            for (int k = 0; k < B; ++k) acc[i][k] += a * z[(int64_t)j * B + k];
+        }
+    }
+    // wavefront-shuffle reduction over the 64 lanes
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            double s = acc[i][k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            acc[i][k] = s;
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = r0 + i;
+            if (r < rows) {
+                const double d = dinv[row_begin + r];
+#pragma unroll
+                for (int k = 0; k < B; ++k) y[(int64_t)r * B + k] = d * acc[i][k];
+            }
+        }
+    }
+}
+
+// z[i][k] = dinv[i] * x[i*ldx + c0 + k]
+__global__ void k_scale_rows(const double *__restrict__ x, int ldx, int c0, int b, int n,
+                             const double *__restrict__ dinv, double *__restrict__ z) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * b) return;
+    const int i = idx / b, k = idx - i * b;
+    z[idx] = dinv[i] * x[(int64_t)i * ldx + c0 + k];
+}
+
+// dst[i*ldd + c0 + k] = src[i*b + k]
+__global__ void k_store_cols(const double *__restrict__ src, int b, int n, double *__restrict__ dst,
+                             int ldd, int c0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * b) return;
+    const int i = idx / b, k = idx - i * b;
+    dst[(int64_t)i * ldd + c0 + k] = src[idx];
+}
+
+// gathered chunks [world][chunk_rows*b] -> y_full rows by row_splits
+__global__ void k_unpack(const double *__restrict__ recv, int64_t chunk, int b,
+                         const int32_t *__restrict__ splits, int world, int n,
+                         double *__restrict__ y) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * b) return;
+    const int i = idx / b, k = idx - i * b;
+    int r = 0;
+    while (r + 1 < world && i >= splits[r + 1]) ++r;
+    y[idx] = recv[(int64_t)r * chunk + (int64_t)(i - splits[r]) * b + k];
+}
+
+// ---------------------------------------------------------------------------
+// Gram products on tall panels: out (ka x kb) = A^T B, A: n x ka (lda), B: n x kb (ldb)
+// Deterministic: per-workgroup partials, then a fixed-order reduction.
+// ---------------------------------------------------------------------------
+constexpr int GRAM_CH = 64;
+
+__global__ __launch_bounds__(256) void k_gram(const double *__restrict__ a, int lda, int ka,
+                                               const double *__restrict__ b, int ldb, int kb,
+                                               int n, double *__restrict__ partial) {
+    __shared__ double sa[GRAM_CH][3 * MAXB + 1];
+    __shared__ double sb[GRAM_CH][3 * MAXB + 1];
+    const int tid = threadIdx.x;
+    const int nout = ka * kb;
+    constexpr int MAXO = (3 * MAXB * 3 * MAXB + 255) / 256;  // outputs per thread
+    double acc[MAXO];
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) acc[o] = 0.0;
+    for (int base = blockIdx.x * GRAM_CH; base < n; base += gridDim.x * GRAM_CH) {
+        const int rows = min(GRAM_CH, n - base);
+        for (int e = tid; e < rows * ka; e += 256) {
+            const int r = e / ka, c = e - r * ka;
+            sa[r][c] = a[(int64_t)(base + r) * lda + c];
+        }
+        for (int e = tid; e < rows * kb; e += 256) {
+            const int r = e / kb, c = e - r * kb;
+            sb[r][c] = b[(int64_t)(base + r) * ldb + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < MAXO; ++o) {
+            const int e = tid + o * 256;
+            if (e < nout) {
+                const int ia = e / kb, jb = e - ia * kb;
+                double s = acc[o];
+                for (int r = 0; r < rows; ++r) s += sa[r][ia] * sb[r][jb];
+                acc[o] = s;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 0; o < MAXO; ++o) {
+        const int e = tid + o * 256;
+        if (e < nout) partial[(int64_t)blockIdx.x * nout + e] = acc[o];
+    }
+}
+
+// fp64 MFMA variant: one wave per workgroup slab, tiles of 16 x 16 outputs.
+// A operand lane l: A^T[i = l&15][k = l>>4] = a[row k][col i]; B operand lane l:
+// B[k = l>>4][j = l&15]; accumulator reg r of lane l: row (l>>4) + 4r, col l&15.
+template <int TA, int TB>
+__global__ __launch_bounds__(64) void k_gram_mfma(const double *__restrict__ a, int lda, int ka,
+                                                  const double *__restrict__ b, int ldb, int kb,
+                                                  int n, double *__restrict__ partial) {
+    const int lane = threadIdx.x;
+    const int kk = lane >> 4, cc = lane & 15;
+    v4d acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
+        const int r = base + kk;
+        double fa[TA], fb[TB];
+#pragma unroll
+        for (int i = 0; i < TA; ++i) {
+            const int c = i * 16 + cc;
+            fa[i] = (r < n && c < ka) ? a[(int64_t)r * lda + c] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int c = j * 16 + cc;
+            fb[j] = (r < n && c < kb) ? b[(int64_t)r * ldb + c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int j = 0; j < TB; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    const int nout = ka * kb;
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i * 16 + kk + 4 * r;
+                const int col = j * 16 + cc;
+                if (row < ka && col < kb)
+                    partial[(int64_t)blockIdx.x * nout + row * kb + col] = acc[i][j][r];
+            }
+}
+
+__global__ void k_reduce_partials(const double *__restrict__ partial, int nparts, int nout,
+                                  double *__restrict__ out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nout) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * nout + e];
+    out[e] = s;
+}
+
+// ---------------------------------------------------------------------------
+// panel updates (row-local, safe in place)
+// ---------------------------------------------------------------------------
+// y[:, 0:kc] = alpha_y * y[:, 0:kc] + sign * a[:, 0:ka] * c   (c: ka x kc, row-major, ldc)
+// (y and a may alias: the update is row-local and reads the whole row first)
+__global__ __launch_bounds__(256) void k_update(double *y, int ldy, int kc, double alpha_y,
+                                                 const double *a,
+                                                 int lda, int ka, const double *__restrict__ c,
+                                                 int ldc, double sign, int n) {
+    __shared__ double sc[3 * MAXB][MAXB];
+    for (int e = threadIdx.x; e < ka * kc; e += 256) {
+        const int i = e / kc, j = e - i * kc;
+        sc[i][j] = c[i * ldc + j];
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double acc[MAXB];
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) acc[j] = 0.0;
+    const double *ar = a + (int64_t)r * lda;
+    for (int i = 0; i < ka; ++i) {
+        const double ai = ar[i];
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j)
+            if (j < kc) acc[j] += ai * sc[i][j];
+    }
+    double *yr = y + (int64_t)r * ldy;
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j)
+        if (j < kc) yr[j] = (alpha_y == 0.0 ? 0.0 : alpha_y * yr[j]) + sign * acc[j];
+}
+
+// Rayleigh-Ritz update of a panel q = [X | R | P] (n x 3b, ld 3b) with coefficients
+// c (nq x b, nq = 2b or 3b):  P' = [R P] c[b:, :],  X' = X c[:b, :] + P'.
+__global__ __launch_bounds__(256) void k_rr_update(double *__restrict__ q, int b, int nq,
+                                                    const double *__restrict__ c, int n) {
+    __shared__ double sc[3 * MAXB][MAXB];
+    for (int e = threadIdx.x; e < nq * b; e += 256) {
+        const int i = e / b, j = e - i * b;
+        sc[i][j] = c[i * b + j];
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double *qr = q + (int64_t)r * (3 * b);
+    double xa[MAXB], pa[MAXB];
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) xa[j] = pa[j] = 0.0;
+    for (int i = 0; i < b; ++i) {
+        const double v = qr[i];
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j)
+            if (j < b) xa[j] += v * sc[i][j];
+    }
+    for (int i = b; i < nq; ++i) {
+        const double v = qr[i];
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j)
+            if (j < b) pa[j] += v * sc[i][j];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j)
+        if (j < b) {
+            qr[j] = xa[j] + pa[j];
+            qr[2 * b + j] = pa[j];
+        }
+}
+
+// R = AX - X diag(theta) into q[:, b:2b]; per-workgroup partial squared norms
+__global__ __launch_bounds__(256) void k_residual(double *__restrict__ q,
+                                                   const double *__restrict__ aq, int b,
+                                                   const double *__restrict__ theta, int n,
+                                                   double *__restrict__ partial) {
+    __shared__ double red[4][MAXB];
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sq[MAXB];
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) sq[j] = 0.0;
+    if (r < n) {
+        double *qr = q + (int64_t)r * (3 * b);
+        const double *ar = aq + (int64_t)r * (3 * b);
+#pragma unroll
+        for (int j = 0; j < MAXB; ++j)
+            if (j < b) {
+                const double v = ar[j] - qr[j] * theta[j];
+                qr[b + j] = v;
+                sq[j] = v * v;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXB; ++j) {
+        double s = sq[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) red[wave][j] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < b)
+        partial[(int64_t)blockIdx.x * b + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                         red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__device__ __forceinline__ double hash_uniform(unsigned long long i, unsigned long long j) {
+    unsigned long long x = i * 0x9E3779B97F4A7C15ull + j * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (double)(x >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+// q[:, 0:b] = [x_init | hashed uniform(-1,1)]
+__global__ void k_init_block(double *__restrict__ q, int b, int n, const double *__restrict__ x0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * b) return;
+    const int i = idx / b, k = idx - i * b;
+    double v = hash_uniform((unsigned long long)i, (unsigned long long)k + 1);
+    if (k == 0 && x0) v = x0[i];
+    q[(int64_t)i * (3 * b) + k] = v;
+}
+
+__global__ void k_fill_int(int *p, int n, int v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// u[i] = sqrt(deg[i]) / ||sqrt(deg)||   (trivial eigenvector of S when no row is isolated)
+__global__ void k_trivial(const double *__restrict__ deg, double inv_norm, int n,
+                          double *__restrict__ u) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) u[i] = sqrt(deg[i]) * inv_norm;
+}
+
+// ---------------------------------------------------------------------------
+// one-workgroup parallel Jacobi eigensolver (n <= 64), LDS resident
+// ---------------------------------------------------------------------------
+struct jacobi_lds {
+    double a[MAXS][SLD];
+    double e[MAXS][SLD];
+    double cs[MAXS / 2][2];
+    int pq[MAXS / 2][2];
+    double red[256];
+    double w[MAXS];
+    int perm[MAXS];
+};
+
+// On entry s.a holds the symmetric matrix (n x n).  On exit s.w holds the
+// eigenvalues in DESCENDING order and s.perm[k] the column of s.e holding the
+// k-th eigenvector.  All 256 threads of the workgroup must call.
+__device__ void jacobi_eig(jacobi_lds &s, int n) {
+    const int tid = threadIdx.x;
+    const int m = n + (n & 1);  // even; a padded index has zero row/column
+    for (int e = tid; e < m * m; e += 256) {
+        const int i = e / m, j = e - i * m;
+        s.e[i][j] = i == j ? 1.0 : 0.0;
+        if (i >= n || j >= n) s.a[i][j] = 0.0;
+    }
+    __syncthreads();
+    const int half = m / 2;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        // convergence: off-diagonal mass against the diagonal
+        double off = 0.0, dia = 0.0;
+        for (int e = tid; e < n * n; e += 256) {
+            const int i = e / n, j = e - i * n;
+            const double v = s.a[i][j];
+            if (i == j) dia += v * v;
+            else off += v * v;
+        }
+        s.red[tid] = off;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) s.red[tid] += s.red[tid + st];
+            __syncthreads();
+        }
+        off = s.red[0];
+        __syncthreads();
+        s.red[tid] = dia;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) s.red[tid] += s.red[tid + st];
+            __syncthreads();
+        }
+        dia = s.red[0];
+        __syncthreads();
+        if (off <= 1e-32 * dia || off == 0.0) break;
+
+        for (int step = 0; step < m - 1; ++step) {
+            if (tid < half) {
+                // round-robin tournament: index m-1 stays, the others rotate
+                int p, q;
+                if (tid == 0) {
+                    p = m - 1;
+                    q = step;
+                } else {
+                    p = (step + tid) % (m - 1);
+                    q = (step - tid + (m - 1)) % (m - 1);
+                }
+                if (p > q) {
+                    const int t = p;
+                    p = q;
+                    q = t;
+                }
+                const double apq = s.a[p][q];
+                double c = 1.0, sn = 0.0;
+                if (apq != 0.0) {
+                    const double th = (s.a[q][q] - s.a[p][p]) / (2.0 * apq);
+                    const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0);
+                    sn = t * c;
+                }
+                s.cs[tid][0] = c;
+                s.cs[tid][1] = sn;
+                s.pq[tid][0] = p;
+                s.pq[tid][1] = q;
+            }
+            __syncthreads();
+            // columns: A <- A J, E <- E J
+            for (int e = tid; e < half * m; e += 256) {
+                const int k = e / m, r = e - k * m;
+                const int p = s.pq[k][0], q = s.pq[k][1];
+                const double c = s.cs[k][0], sn = s.cs[k][1];
+                const double ap = s.a[r][p], aq = s.a[r][q];
+                s.a[r][p] = c * ap - sn * aq;
+                s.a[r][q] = sn * ap + c * aq;
+                const double ep = s.e[r][p], eq = s.e[r][q];
+                s.e[r][p] = c * ep - sn * eq;
+                s.e[r][q] = sn * ep + c * eq;
+            }
+            __syncthreads();
+            // rows: A <- J^T A
+            for (int e = tid; e < half * m; e += 256) {
+                const int k = e / m, r = e - k * m;
+                const int p = s.pq[k][0], q = s.pq[k][1];
+                const double c = s.cs[k][0], sn = s.cs[k][1];
+                const double ap = s.a[p][r], aq = s.a[q][r];
+                s.a[p][r] = c * ap - sn * aq;
+                s.a[q][r] = sn * ap + c * aq;
+            }
+            __syncthreads();
+            if (tid < half) {
+                const int p = s.pq[tid][0], q = s.pq[tid][1];
+                s.a[p][q] = 0.0;
+                s.a[q][p] = 0.0;
+            }
+            __syncthreads();
+        }
+    }
+    // sort descending (rank by counting)
+    if (tid < n) {
+        const double wi = s.a[tid][tid];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double wj = s.a[j][j];
+            if (wj > wi || (wj == wi && j < tid)) ++rank;
+        }
+        s.w[rank] = wi;
+        s.perm[rank] = tid;
+    }
+    __syncthreads();
+}
+
+// plain eigen-decomposition of a global n x n matrix (debug entry point, dense path)
+__global__ __launch_bounds__(256) void k_small_eig(const double *__restrict__ a, int n,
+                                                    double *__restrict__ w, double *__restrict__ v) {
+    __shared__ jacobi_lds s;
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        s.a[i][j] = 0.5 * (a[i * n + j] + a[j * n + i]);
+    }
+    __syncthreads();
+    jacobi_eig(s, n);
+    for (int e = threadIdx.x; e < n * n; e += 256) {
+        const int i = e / n, k = e - i * n;
+        v[i * n + k] = s.e[i][s.perm[k]];
+    }
+    if (threadIdx.x < n) w[threadIdx.x] = s.w[threadIdx.x];
+}
+
+// SVQB (Stathopoulos & Wu): from G = Y^T Y (k x k) build T (k x k) with
+// (Y T)^T (Y T) = I on the kept directions; directions whose scaled eigenvalue is
+// below drop_tol * largest are dropped (zero column of T, mask 0).
+__global__ __launch_bounds__(256) void k_small_svqb(const double *__restrict__ g, int k,
+                                                     double drop_tol, double *__restrict__ t,
+                                                     int *__restrict__ mask) {
+    __shared__ jacobi_lds s;
+    __shared__ double dsc[MAXS];
+    const int tid = threadIdx.x;
+    if (tid < k) {
+        const double d = g[tid * k + tid];
+        dsc[tid] = d > 1e-290 ? 1.0 / sqrt(d) : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, j = e - i * k;
+        double v = 0.5 * (g[i * k + j] + g[j * k + i]) * dsc[i] * dsc[j];
+        if (dsc[i] == 0.0 || dsc[j] == 0.0) v = 0.0;  // dead column: decoupled, eigenvalue 0
+        s.a[i][j] = v;
+    }
+    __syncthreads();
+    jacobi_eig(s, k);
+    const double wmax = s.w[0];
+    for (int e = tid; e < k * k; e += 256) {
+        const int i = e / k, c = e - i * k;
+        const double lam = s.w[c];
+        const bool keep = wmax > 0.0 && lam > drop_tol * wmax;
+        t[i * k + c] = keep ? dsc[i] * s.e[i][s.perm[c]] / sqrt(lam) : 0.0;
+    }
+    if (tid < k) mask[tid] = (wmax > 0.0 && s.w[tid] > drop_tol * wmax) ? 1 : 0;
+}
+
+// Rayleigh-Ritz: T (nq x nq) = Q^T A Q, mask marks live basis columns.
+// Output: c (nq x b) top-b eigenvectors, theta[0..b) their values, theta[b] the next one.
+__global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm, int nq, int b,
+                                                   const int *__restrict__ mask,
+                                                   double *__restrict__ c,
+                                                   double *__restrict__ theta) {
+    __shared__ jacobi_lds s;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < nq * nq; e += 256) {
+        const int i = e / nq, j = e - i * nq;
+        double v = 0.5 * (tm[i * nq + j] + tm[j * nq + i]);
+        const bool live = mask[i] && mask[j];
+        if (!live) v = (i == j) ? -1e30 : 0.0;  // dead directions can never be selected
+        s.a[i][j] = v;
+    }
+    __syncthreads();
+    jacobi_eig(s, nq);
+    for (int e = tid; e < nq * b; e += 256) {
+        const int i = e / b, k = e - i * b;
+        c[i * b + k] = s.e[i][s.perm[k]];
+    }
+    if (tid <= b && tid < nq) theta[tid] = s.w[tid];
+}
+
+// dense S for the small-V path: s[i][j] = dinv[i] * w[i][j] * dinv[j], zero diagonal
+__global__ void k_dense_s(const double *__restrict__ w, int64_t ld, int n,
+                          const double *__restrict__ dinv, double *__restrict__ s) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    s[idx] = i == j ? 0.0 : dinv[i] * w[(int64_t)i * ld + j] * dinv[j];
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+namespace {
+
+struct dbuf {
+    void *p = nullptr;
+    ~dbuf() {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        SCS_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        return SCS_OK;
+    }
+    double *d() const { return (double *)p; }
+};
+
+struct solver {
+    scs_ctx *ctx = nullptr;
+    scs_graph *g = nullptr;
+    hipStream_t s = nullptr;
+    int n = 0, b = 0, rows = 0, world = 1;
+    bool use_mfma = true;
+    dbuf q, aq, z, yloc, yfull, recv, u, part, small, splits_d;
+    int64_t chunk = 0;
+    int gram_blocks = 0;
+    std::vector<int32_t> splits;
+    // timing of SYMM launches
+    std::vector<hipEvent_t> ev;
+    int n_apply = 0;
+
+    ~solver() {
+        for (auto e : ev) hipEventDestroy(e);
+    }
+
+    double *small_at(int off) const { return small.d() + off; }
+
+    int launch_symm(const double *zin, double *yout) {
+        const int grid = (rows + 15) / 16;
+        switch (b) {
+#define SYMM_CASE(B)                                                                          \
+    case B:                                                                                   \
+        k_symm<B><<<grid, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, zin, g->d_dinv,  \
+                                       yout);                                                 \
+        break;
+            SYMM_CASE(1)
+            SYMM_CASE(2)
+            SYMM_CASE(3)
+            SYMM_CASE(4)
+            SYMM_CASE(6)
+            SYMM_CASE(8)
+            SYMM_CASE(12)
+            SYMM_CASE(16)
+#undef SYMM_CASE
+            default:
+                scs_set_error("unsupported block width %d", b);
+                return SCS_EUNSUP;
+        }
+        SCS_HIP_CHECK(hipGetLastError());
+        return SCS_OK;
+    }
+
+    // dst_panel[:, c0:c0+b] = S * src_panel[:, c0s:c0s+b]   (panels have ld 3b)
+    int apply(const double *src, int c0s, double *dst, int c0d) {
+        const int nb = n * b;
+        k_scale_rows<<<(nb + 255) / 256, 256, 0, s>>>(src, 3 * b, c0s, b, n, g->d_dinv, z.d());
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        SCS_HIP_CHECK(hipEventCreate(&e0));
+        SCS_HIP_CHECK(hipEventCreate(&e1));
+        ev.push_back(e0);
+        ev.push_back(e1);
+        SCS_HIP_CHECK(hipEventRecord(e0, s));
+        SCS_TRY(launch_symm(z.d(), yloc.d()));
+        SCS_HIP_CHECK(hipEventRecord(e1, s));
+        ++n_apply;
+        const double *yf = yloc.d();
+        if (world > 1) {
+            SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
+            k_unpack<<<(nb + 255) / 256, 256, 0, s>>>(recv.d(), chunk, b,
+                                                      (const int32_t *)splits_d.p, world, n,
+                                                      yfull.d());
+            yf = yfull.d();
+        }
+        k_store_cols<<<(nb + 255) / 256, 256, 0, s>>>(yf, b, n, dst, 3 * b, c0d);
+        return SCS_OK;
+    }
+
+    // out (ka x kb, device) = A^T B
+    int gram(const double *a, int lda, int ka, const double *bm, int ldb, int kb, double *out,
+             bool mfma) {
+        const int nout = ka * kb;
+        int nparts;
+        if (mfma && ka <= 48 && kb <= 48) {
+            nparts = std::min(gram_blocks * 4, std::max(1, (n + 3) / 4));
+            const int ta = (ka + 15) / 16, tb = (kb + 15) / 16;
+#define GM(TA, TB)                                                                               \
+    if (ta == TA && tb == TB)                                                                    \
+        k_gram_mfma<TA, TB><<<nparts, 64, 0, s>>>(a, lda, ka, bm, ldb, kb, n, part.d());
+            GM(1, 1) GM(1, 2) GM(1, 3) GM(2, 1) GM(2, 2) GM(2, 3) GM(3, 1) GM(3, 2) GM(3, 3)
+#undef GM
+        } else {
+            nparts = std::min(gram_blocks, std::max(1, (n + GRAM_CH - 1) / GRAM_CH));
+            k_gram<<<nparts, 256, 0, s>>>(a, lda, ka, bm, ldb, kb, n, part.d());
+        }
+        k_reduce_partials<<<(nout + 255) / 256, 256, 0, s>>>(part.d(), nparts, nout, out);
+        SCS_HIP_CHECK(hipGetLastError());
+        return SCS_OK;
+    }
+
+    int update(double *y, int ldy, int kc, double alpha, const double *a, int lda, int ka,
+               const double *c, int ldc, double sign) {
+        k_update<<<(n + 255) / 256, 256, 0, s>>>(y, ldy, kc, alpha, a, lda, ka, c, ldc, sign, n);
+        SCS_HIP_CHECK(hipGetLastError());
+        return SCS_OK;
+    }
+};
+
+// layout of the small-matrix scratch (doubles)
+constexpr int SM_G = 0;                         // up to 48 x 48
+constexpr int SM_T = SM_G + 48 * 48;            // svqb transform (<= 16 x 16) / rr coeffs (48 x 16)
+constexpr int SM_C = SM_T + 48 * 16;            // projection coefficients (<= 32 x 16)
+constexpr int SM_THETA = SM_C + 48 * 16;        // theta[0..b], padded
+constexpr int SM_RN = SM_THETA + 32;            // residual norms^2 [b]
+constexpr int SM_MASK = SM_RN + 32;             // int mask[48] (as 24 doubles)
+constexpr int SM_TOTAL = SM_MASK + 32;
+
+void sign_flip_and_store(const std::vector<double> &col0, const std::vector<double> &col1, int n,
+                         double *maps) {
+    // reference: sklearn/utils/extmath.py _deterministic_vector_sign_flip
+    for (int c = 0; c < 2; ++c) {
+        const std::vector<double> &v = c == 0 ? col0 : col1;
+        int arg = 0;
+        double best = -1.0;
+        for (int i = 0; i < n; ++i)
+            if (std::fabs(v[i]) > best) {
+                best = std::fabs(v[i]);
+                arg = i;
+            }
+        const double sg = v[arg] < 0.0 ? -1.0 : 1.0;
+        for (int i = 0; i < n; ++i) maps[(size_t)i * 2 + c] = sg * v[i];
+    }
+}
+
+}  // namespace
+
+static int gather_full_rows(scs_ctx *ctx, scs_graph *g, std::vector<int32_t> &splits) {
+    // row splits of every rank (the partition is contiguous and ordered by rank)
+    const int world = ctx->comm.world;
+    splits.assign(world + 1, 0);
+    if (world == 1) {
+        splits[0] = g->row_begin;
+        splits[1] = g->row_end;
+        return SCS_OK;
+    }
+    dbuf send, recv;
+    SCS_TRY(send.alloc(8));
+    SCS_TRY(recv.alloc(8 * (size_t)world));
+    double v = (double)g->row_begin;
+    SCS_HIP_CHECK(hipMemcpyAsync(send.p, &v, 8, hipMemcpyHostToDevice, ctx->stream));
+    SCS_TRY(scs_comm_allgather_f64(&ctx->comm, send.d(), recv.d(), 1, ctx->stream));
+    std::vector<double> h(world);
+    SCS_HIP_CHECK(hipMemcpyAsync(h.data(), recv.p, 8 * (size_t)world, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < world; ++r) splits[r] = (int32_t)h[r];
+    splits[world] = g->n;
+    for (int r = 0; r < world; ++r)
+        SCS_REQUIRE(splits[r] < splits[r + 1], "row partition is not contiguous by rank");
+    SCS_REQUIRE(splits[0] == 0 && splits[ctx->comm.rank] == g->row_begin &&
+                    splits[ctx->comm.rank + 1] == g->row_end,
+                "row partition does not tile [0, V)");
+    return SCS_OK;
+}
+
+// small-V path: dense S on the device, full Jacobi, top two eigenvectors
+static int fiedler_dense(scs_ctx *ctx, scs_graph *g, double *maps, scs_stats *st) {
+    const int n = g->n;
+    hipStream_t s = ctx->stream;
+    SCS_REQUIRE(ctx->comm.world == 1, "dense small-V path needs world == 1 (V = %d)", n);
+    dbuf sd, wv, vv;
+    SCS_TRY(sd.alloc((size_t)n * n * 8));
+    SCS_TRY(wv.alloc((size_t)n * 8));
+    SCS_TRY(vv.alloc((size_t)n * n * 8));
+    k_dense_s<<<(n * n + 255) / 256, 256, 0, s>>>(g->d_w, g->ld, n, g->d_dinv, sd.d());
+    k_small_eig<<<1, 256, 0, s>>>(sd.d(), n, wv.d(), vv.d());
+    std::vector<double> w(n), v((size_t)n * n), dinv(n);
+    SCS_HIP_CHECK(hipMemcpyAsync(w.data(), wv.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(v.data(), vv.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(dinv.data(), g->d_dinv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<double> c0(n), c1(n);
+    for (int i = 0; i < n; ++i) {
+        c0[i] = v[(size_t)i * n + 0] * dinv[i];
+        c1[i] = (n > 1 ? v[(size_t)i * n + 1] : 0.0) * dinv[i];
+    }
+    sign_flip_and_store(c0, c1, n, maps);
+    if (st) {
+        st->block = 0;
+        st->converged = 1;
+        st->lambda[0] = w[0];
+        st->lambda[1] = n > 1 ? w[1] : 0.0;
+        st->lambda_next = n > 2 ? w[2] : 0.0;
+    }
+    return SCS_OK;
+}
+
+extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, double tol,
+                           int32_t max_iter, int32_t block, double *maps_out, scs_stats *stats) {
+    SCS_REQUIRE(ctx && g && maps_out, "scs_fiedler: null argument");
+    SCS_REQUIRE(g->n >= 2, "scs_fiedler: need at least 2 vertices (have %d)", g->n);
+    SCS_REQUIRE(block >= 0 && block <= MAXB, "scs_fiedler: block must be in [0, %d]", MAXB);
+    SCS_REQUIRE(tol > 0.0 && max_iter >= 1, "scs_fiedler: tol must be > 0 and max_iter >= 1");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int n = g->n;
+    scs_stats st_local;
+    scs_stats *st = stats ? stats : &st_local;
+    memset(st, 0, sizeof(*st));
+    st->n_vertices = n;
+
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    SCS_HIP_CHECK(hipEventCreate(&ev_a));
+    SCS_HIP_CHECK(hipEventCreate(&ev_b));
+    struct evg {
+        hipEvent_t a, b;
+        ~evg() {
+            hipEventDestroy(a);
+            hipEventDestroy(b);
+        }
+    } evguard{ev_a, ev_b};
+    SCS_HIP_CHECK(hipEventRecord(ev_a, s));
+
+    SCS_TRY(scs_graph_prepare_degrees(ctx, g));
+
+    if (n <= MAXS) {
+        SCS_TRY(fiedler_dense(ctx, g, maps_out, st));
+        SCS_HIP_CHECK(hipEventRecord(ev_b, s));
+        SCS_HIP_CHECK(hipEventSynchronize(ev_b));
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, ev_a, ev_b);
+        st->solve_ms = ms;
+        return SCS_OK;
+    }
+
+    const bool constrained = g->n_isolated == 0;
+    const int want = constrained ? 1 : 2;
+    int b = block ? block : 8;
+    {
+        const int allowed[] = {16, 12, 8, 6, 4, 3, 2, 1};
+        const int cap = (n - 2) / 3;  // 3b basis vectors + the constraint must fit in V
+        int pick = 1;
+        for (int a : allowed)
+            if (a <= b && a <= cap) {
+                pick = a;
+                break;
+            }
+        b = std::max(pick, want);
+    }
+    const int q3 = 3 * b;
+
+    solver sv;
+    sv.ctx = ctx;
+    sv.g = g;
+    sv.s = s;
+    sv.n = n;
+    sv.b = b;
+    sv.rows = g->row_end - g->row_begin;
+    sv.world = ctx->comm.world;
+    sv.use_mfma = !(getenv("SCS_NO_MFMA") && atoi(getenv("SCS_NO_MFMA")));
+    sv.gram_blocks = 256;
+    SCS_TRY(gather_full_rows(ctx, g, sv.splits));
+    int max_rows = 0;
+    for (int r = 0; r < sv.world; ++r)
+        max_rows = std::max(max_rows, sv.splits[r + 1] - sv.splits[r]);
+    sv.chunk = (int64_t)max_rows * b;
+
+    SCS_TRY(sv.q.alloc((size_t)n * q3 * 8));
+    SCS_TRY(sv.aq.alloc((size_t)n * q3 * 8));
+    SCS_TRY(sv.z.alloc((size_t)n * b * 8));
+    SCS_TRY(sv.yloc.alloc((size_t)sv.chunk * 8));
+    SCS_TRY(sv.u.alloc((size_t)n * 8));
+    SCS_TRY(sv.part.alloc((size_t)1024 * q3 * q3 * 8));
+    SCS_TRY(sv.small.alloc((size_t)SM_TOTAL * 8));
+    if (sv.world > 1) {
+        SCS_TRY(sv.yfull.alloc((size_t)n * b * 8));
+        SCS_TRY(sv.recv.alloc((size_t)sv.chunk * sv.world * 8));
+        SCS_TRY(sv.splits_d.alloc((size_t)(sv.world + 1) * 4));
+        SCS_HIP_CHECK(hipMemcpyAsync(sv.splits_d.p, sv.splits.data(), (size_t)(sv.world + 1) * 4,
+                                     hipMemcpyHostToDevice, s));
+    }
+    SCS_HIP_CHECK(hipMemsetAsync(sv.q.p, 0, (size_t)n * q3 * 8, s));
+    SCS_HIP_CHECK(hipMemsetAsync(sv.aq.p, 0, (size_t)n * q3 * 8, s));
+    SCS_HIP_CHECK(hipMemsetAsync(sv.yloc.p, 0, (size_t)sv.chunk * 8, s));
+    SCS_HIP_CHECK(hipMemsetAsync(sv.small.p, 0, (size_t)SM_TOTAL * 8, s));
+
+    double *Q = sv.q.d(), *AQ = sv.aq.d();
+    double *X = Q, *R = Q + b, *P = Q + 2 * b;
+    double *AX = AQ, *AR = AQ + b, *AP = AQ + 2 * b;
+    double *G = sv.small_at(SM_G), *T = sv.small_at(SM_T), *C = sv.small_at(SM_C);
+    double *TH = sv.small_at(SM_THETA), *RN = sv.small_at(SM_RN);
+    int *MASK = (int *)sv.small_at(SM_MASK);
+    const double drop_tol = 1e-13;
+
+    // constraint vector
+    dbuf x0d;
+    if (x_init) {
+        SCS_TRY(x0d.alloc((size_t)n * 8));
+        SCS_HIP_CHECK(hipMemcpyAsync(x0d.p, x_init, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    }
+    if (constrained)
+        k_trivial<<<(n + 255) / 256, 256, 0, s>>>(g->d_deg, 1.0 / g->dd_norm, n, sv.u.d());
+
+    // project the constraint out of a panel block (twice) and SVQB-orthonormalise it;
+    // companion (may be null) receives the same column transform
+    auto project_u = [&](double *Y) -> int {
+        if (!constrained) return SCS_OK;
+        for (int pass = 0; pass < 2; ++pass) {
+            SCS_TRY(sv.gram(sv.u.d(), 1, 1, Y, q3, b, C, false));
+            SCS_TRY(sv.update(Y, q3, b, 1.0, sv.u.d(), 1, 1, C, b, -1.0));
+        }
+        return SCS_OK;
+    };
+    auto svqb = [&](double *Y, double *AY, int *mask_out) -> int {
+        for (int pass = 0; pass < 2; ++pass) {
+            SCS_TRY(sv.gram(Y, q3, b, Y, q3, b, G, sv.use_mfma));
+            k_small_svqb<<<1, 256, 0, s>>>(G, b, pass == 0 ? drop_tol : 0.0, T, mask_out);
+            // second pass: every surviving direction is kept (dead columns stay dead: dsc = 0)
+            SCS_TRY(sv.update(Y, q3, b, 0.0, Y, q3, b, T, b, 1.0));
+            if (AY) SCS_TRY(sv.update(AY, q3, b, 0.0, AY, q3, b, T, b, 1.0));
+        }
+        return SCS_OK;
+    };
+    // mask handling: pass 2 would overwrite mask with all-live for surviving columns and 0
+    // for dead ones (their Gram diagonal is 0 -> dsc 0 -> eigenvalue 0 -> dropped since
+    // 0 > 0 is false), so the mask of the second pass is the final one.
+
+    // ---- start block
+    k_init_block<<<(n * b + 255) / 256, 256, 0, s>>>(Q, b, n, x_init ? x0d.d() : nullptr);
+    SCS_TRY(project_u(X));
+    SCS_TRY(svqb(X, nullptr, MASK));
+    SCS_TRY(sv.apply(Q, 0, AQ, 0));
+    // rotate X so that X^T A X is diagonal
+    SCS_TRY(sv.gram(X, q3, b, AX, q3, b, G, sv.use_mfma));
+    {
+        k_fill_int<<<1, 64, 0, s>>>(MASK, 48, 1);
+        k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, TH);
+        SCS_TRY(sv.update(X, q3, b, 0.0, X, q3, b, T, b, 1.0));
+        SCS_TRY(sv.update(AX, q3, b, 0.0, AX, q3, b, T, b, 1.0));
+    }
+
+    const int res_blocks = (n + 255) / 256;
+    dbuf res_part;
+    SCS_TRY(res_part.alloc((size_t)res_blocks * b * 8));
+    std::vector<double> h_rn(b), h_th(b + 1);
+    bool have_p = false;
+    int iter = 0;
+    double best_res = 1e300;
+    int since_best = 0;
+    int refreshes = 0;
+    bool converged = false;
+    double final_res[2] = {0.0, 0.0};
+
+    for (iter = 0; iter < max_iter; ++iter) {
+        // residual block and its norms
+        k_residual<<<res_blocks, 256, 0, s>>>(Q, AQ, b, TH, n, res_part.d());
+        k_reduce_partials<<<1, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
+        SCS_HIP_CHECK(hipMemcpyAsync(h_rn.data(), RN, (size_t)b * 8, hipMemcpyDeviceToHost, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
+        SCS_HIP_CHECK(hipStreamSynchronize(s));
+        double worst = 0.0;
+        for (int j = 0; j < want; ++j) worst = std::max(worst, std::sqrt(h_rn[j]));
+        for (int j = 0; j < want; ++j) final_res[constrained ? 1 : j] = std::sqrt(h_rn[j]);
+        if (!(worst == worst)) {
+            scs_set_error("scs_fiedler: NaN residual at iteration %d", iter);
+            return SCS_EHIP;
+        }
+        bool stop = worst <= tol;
+        if (worst < 0.5 * best_res) {
+            best_res = worst;
+            since_best = 0;
+        } else if (++since_best >= 12 && worst < 1e-9) {
+            stop = true;  // stagnated at the floating-point floor
+        }
+        if (stop) {
+            // confirm against a freshly applied operator (AX drifts by linear updates)
+            if (refreshes < 3) {
+                ++refreshes;
+                SCS_TRY(sv.apply(Q, 0, AQ, 0));
+                SCS_TRY(sv.gram(X, q3, b, AX, q3, b, G, sv.use_mfma));
+                k_fill_int<<<1, 64, 0, s>>>(MASK, 48, 1);
+                k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, TH);
+                SCS_TRY(sv.update(X, q3, b, 0.0, X, q3, b, T, b, 1.0));
+                SCS_TRY(sv.update(AX, q3, b, 0.0, AX, q3, b, T, b, 1.0));
+                k_residual<<<res_blocks, 256, 0, s>>>(Q, AQ, b, TH, n, res_part.d());
+                k_reduce_partials<<<1, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
+                SCS_HIP_CHECK(hipMemcpyAsync(h_rn.data(), RN, (size_t)b * 8, hipMemcpyDeviceToHost, s));
+                SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8,
+                                             hipMemcpyDeviceToHost, s));
+                SCS_HIP_CHECK(hipStreamSynchronize(s));
+                double w2 = 0.0;
+                for (int j = 0; j < want; ++j) w2 = std::max(w2, std::sqrt(h_rn[j]));
+                for (int j = 0; j < want; ++j) final_res[constrained ? 1 : j] = std::sqrt(h_rn[j]);
+                have_p = false;  // restart the search direction after the refresh
+                if (w2 <= tol || (since_best >= 12 && w2 < 1e-9) || refreshes >= 3) {
+                    converged = w2 <= tol;
+                    break;
+                }
+                best_res = w2;
+                since_best = 0;
+            } else {
+                converged = worst <= tol;
+                break;
+            }
+        }
+
+        // R <- orthonormal complement of [u, X] within span(R)
+        SCS_TRY(project_u(R));
+        for (int pass = 0; pass < 2; ++pass) {
+            SCS_TRY(sv.gram(X, q3, b, R, q3, b, C, sv.use_mfma));
+            SCS_TRY(sv.update(R, q3, b, 1.0, X, q3, b, C, b, -1.0));
+        }
+        SCS_TRY(svqb(R, nullptr, MASK + b));
+        SCS_TRY(sv.apply(Q, b, AQ, b));
+
+        int nq = 2 * b;
+        if (have_p) {
+            // P <- orthonormal complement of [X, R] within span(P); AP follows
+            for (int pass = 0; pass < 2; ++pass) {
+                SCS_TRY(sv.gram(Q, q3, 2 * b, P, q3, b, C, sv.use_mfma));
+                SCS_TRY(sv.update(P, q3, b, 1.0, Q, q3, 2 * b, C, b, -1.0));
+                SCS_TRY(sv.update(AP, q3, b, 1.0, AQ, q3, 2 * b, C, b, -1.0));
+            }
+            SCS_TRY(svqb(P, AP, MASK + 2 * b));
+            nq = 3 * b;
+        }
+        // Rayleigh-Ritz on the orthonormal basis
+        SCS_TRY(sv.gram(Q, q3, nq, AQ, q3, nq, G, sv.use_mfma));
+        k_small_rr<<<1, 256, 0, s>>>(G, nq, b, MASK, T, TH);
+        k_rr_update<<<(n + 255) / 256, 256, 0, s>>>(Q, b, nq, T, n);
+        k_rr_update<<<(n + 255) / 256, 256, 0, s>>>(AQ, b, nq, T, n);
+        SCS_HIP_CHECK(hipGetLastError());
+        have_p = true;
+    }
+
+    // ---- results
+    std::vector<double> xcol((size_t)n * q3), dinv(n);
+    SCS_HIP_CHECK(hipMemcpyAsync(xcol.data(), Q, (size_t)n * q3 * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(dinv.data(), g->d_dinv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipEventRecord(ev_b, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    std::vector<double> c0(n), c1(n);
+    if (constrained) {
+        const double inv = 1.0 / g->dd_norm;
+        for (int i = 0; i < n; ++i) {
+            c0[i] = inv;  // (sqrt(d_i)/||sqrt d||) / sqrt(d_i)
+            c1[i] = xcol[(size_t)i * q3 + 0] * dinv[i];
+        }
+        st->lambda[0] = 1.0;
+        st->lambda[1] = h_th[0];
+        st->lambda_next = b > 1 ? h_th[1] : 0.0;
+    } else {
+        for (int i = 0; i < n; ++i) {
+            c0[i] = xcol[(size_t)i * q3 + 0] * dinv[i];
+            c1[i] = xcol[(size_t)i * q3 + 1] * dinv[i];
+        }
+        st->lambda[0] = h_th[0];
+        st->lambda[1] = h_th[1];
+        st->lambda_next = b > 2 ? h_th[2] : 0.0;
+    }
+    sign_flip_and_store(c0, c1, n, maps_out);
+
+    st->block = b;
+    st->iterations = iter;
+    st->n_apply = sv.n_apply;
+    st->converged = converged ? 1 : 0;
+    st->used_constraint = constrained ? 1 : 0;
+    st->resid[0] = final_res[0];
+    st->resid[1] = final_res[1];
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ev_a, ev_b);
+    st->solve_ms = ms;
+    double tot = 0.0, mn = 1e300;
+    for (size_t i = 0; i + 1 < sv.ev.size(); i += 2) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, sv.ev[i], sv.ev[i + 1]) == hipSuccess) {
+            tot += t;
+            mn = std::min(mn, (double)t);
+        }
+    }
+    st->apply_ms_total = tot;
+    st->apply_ms_min = sv.n_apply ? mn : 0.0;
+    st->apply_bytes = 8.0 * sv.rows * (double)n + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;
+    return SCS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// debug entry points (parity tests of the building blocks)
+// ---------------------------------------------------------------------------
+extern "C" int scs_debug_jacobi(scs_ctx *ctx, const double *a, int32_t n, double *w, double *v) {
+    SCS_REQUIRE(ctx && a && w && v, "scs_debug_jacobi: null argument");
+    SCS_REQUIRE(n >= 1 && n <= MAXS, "scs_debug_jacobi: n must be in [1, %d]", MAXS);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    dbuf da, dw, dv;
+    SCS_TRY(da.alloc((size_t)n * n * 8));
+    SCS_TRY(dw.alloc((size_t)n * 8));
+    SCS_TRY(dv.alloc((size_t)n * n * 8));
+    SCS_HIP_CHECK(hipMemcpyAsync(da.p, a, (size_t)n * n * 8, hipMemcpyHostToDevice, ctx->stream));
+    k_small_eig<<<1, 256, 0, ctx->stream>>>(da.d(), n, dw.d(), dv.d());
+    SCS_HIP_CHECK(hipMemcpyAsync(w, dw.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SCS_HIP_CHECK(hipMemcpyAsync(v, dv.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SCS_OK;
+}
+
+extern "C" int scs_debug_gram(scs_ctx *ctx, const double *a, const double *b, int32_t n,
+                              int32_t ka, int32_t kb, int32_t use_mfma, double *out) {
+    SCS_REQUIRE(ctx && a && b && out, "scs_debug_gram: null argument");
+    SCS_REQUIRE(n >= 1 && ka >= 1 && ka <= 48 && kb >= 1 && kb <= 48, "scs_debug_gram: bad shape");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    solver sv;
+    sv.ctx = ctx;
+    sv.s = ctx->stream;
+    sv.n = n;
+    sv.gram_blocks = 256;
+    dbuf da, db, dout;
+    SCS_TRY(da.alloc((size_t)n * ka * 8));
+    SCS_TRY(db.alloc((size_t)n * kb * 8));
+    SCS_TRY(dout.alloc((size_t)ka * kb * 8));
+    SCS_TRY(sv.part.alloc((size_t)1024 * 48 * 48 * 8));
+    SCS_HIP_CHECK(hipMemcpyAsync(da.p, a, (size_t)n * ka * 8, hipMemcpyHostToDevice, ctx->stream));
+    SCS_HIP_CHECK(hipMemcpyAsync(db.p, b, (size_t)n * kb * 8, hipMemcpyHostToDevice, ctx->stream));
+    SCS_TRY(sv.gram(da.d(), ka, ka, db.d(), kb, kb, dout.d(), use_mfma != 0));
+    SCS_HIP_CHECK(hipMemcpyAsync(out, dout.p, (size_t)ka * kb * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SCS_OK;
+}
+
+extern "C" int scs_debug_apply(scs_ctx *ctx, scs_graph *g, const double *x, int32_t b, double *y) {
+    SCS_REQUIRE(ctx && g && x && y, "scs_debug_apply: null argument");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    SCS_TRY(scs_graph_prepare_degrees(ctx, g));
+    solver sv;
+    sv.ctx = ctx;
+    sv.g = g;
+    sv.s = ctx->stream;
+    sv.n = g->n;
+    sv.b = b;
+    sv.rows = g->row_end - g->row_begin;
+    const int n = g->n;
+    dbuf dx;
+    SCS_TRY(dx.alloc((size_t)n * b * 8));
+    SCS_TRY(sv.z.alloc((size_t)n * b * 8));
+    SCS_TRY(sv.yloc.alloc((size_t)sv.rows * b * 8));
+    SCS_HIP_CHECK(hipMemcpyAsync(dx.p, x, (size_t)n * b * 8, hipMemcpyHostToDevice, ctx->stream));
+    k_scale_rows<<<(n * b + 255) / 256, 256, 0, ctx->stream>>>(dx.d(), b, 0, b, n, g->d_dinv,
+                                                               sv.z.d());
+    SCS_TRY(sv.launch_symm(sv.z.d(), sv.yloc.d()));
+    SCS_HIP_CHECK(hipMemcpyAsync(y, sv.yloc.p, (size_t)sv.rows * b * 8, hipMemcpyDeviceToHost,
+                                 ctx->stream));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SCS_OK;
+}

@@ -1,0 +1,106 @@
+// Internal declarations shared by the translation units of libscs_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/scs_hip.h"
+
+// ---- error plumbing --------------------------------------------------------
+void scs_set_error(const char *fmt, ...);
+
+#define SCS_HIP_CHECK(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            scs_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                          __LINE__);                                                         \
+            return (e_ == hipErrorOutOfMemory) ? SCS_ENOMEM : SCS_EHIP;                      \
+        }                                                                                    \
+    } while (0)
+
+#define SCS_REQUIRE(cond, ...)                                                               \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            scs_set_error(__VA_ARGS__);                                                      \
+            return SCS_EINVAL;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define SCS_TRY(expr)                                                                        \
+    do {                                                                                     \
+        int rc_ = (expr);                                                                    \
+        if (rc_ != SCS_OK) return rc_;                                                       \
+    } while (0)
+
+// ---- tile geometry of the accumulate kernel --------------------------------
+constexpr int SCS_TR = 64;    // rows of W per tile (one block record)
+constexpr int SCS_TCW = 256;  // threads per workgroup = columns per column group
+constexpr int SCS_NPAD = 512; // position tables are padded to a multiple of this
+
+// ---- communicator -----------------------------------------------------------
+struct scs_local_group;  // in-process barrier + exchange slots
+
+struct scs_comm {
+    int rank = 0;
+    int world = 1;
+    int kind = 0;  // 0 none, 1 rccl, 2 local
+    void *rccl_comm = nullptr;
+    scs_local_group *group = nullptr;
+};
+
+// all-gather of equal-sized fp64 chunks: sendbuf has `count` doubles, recvbuf
+// world*count doubles (device pointers), enqueued on `stream`.
+int scs_comm_allgather_f64(scs_comm *comm, const double *sendbuf, double *recvbuf, size_t count,
+                           hipStream_t stream);
+int scs_comm_init_rccl(scs_comm *comm, int rank, int world, const void *uid);
+int scs_comm_destroy(scs_comm *comm);
+
+// ---- context ----------------------------------------------------------------
+struct scs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    scs_comm comm;
+    int n_cu = 256;
+    size_t ws_limit = 0;  // bytes of build scratch allowed per tree batch
+};
+
+struct scs_tables {
+    int32_t n_taxa = 0;
+    int32_t n_trees = 0;
+    int64_t n_leaves = 0;
+    int32_t max_leaves = 0;            // largest tree
+    std::vector<int64_t> h_tree_off;   // host copy (batch planning)
+    int64_t *d_tree_off = nullptr;     // [n_trees+1]
+    int32_t *d_leaf_taxon = nullptr;   // [L]
+    int32_t *d_adj_depth = nullptr;    // [L]
+    double *d_adj_val = nullptr;       // [L]
+    double *d_tree_w = nullptr;        // [n_trees]
+};
+
+struct scs_graph {
+    int32_t n = 0;          // V: number of vertices (columns)
+    int32_t row_begin = 0;  // first row owned by this rank
+    int32_t row_end = 0;
+    int64_t ld = 0;         // leading dimension (doubles) of d_w
+    double *d_w = nullptr;  // (row_end-row_begin) x ld, row-major
+    // degree data for all V vertices (filled lazily by scs_graph_prepare_degrees)
+    bool have_deg = false;
+    double *d_deg = nullptr;   // [V] row sums
+    double *d_dinv = nullptr;  // [V] 1/sqrt(deg) (1 where deg == 0)
+    int32_t n_isolated = 0;
+    double dd_norm = 0.0;  // ||sqrt(deg)||_2 with isolated rows counted as 1
+};
+
+// build.hip
+int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g);
+
+// eig.hip helpers used by debug entry points are declared in scs_hip.h
+
+static inline int64_t scs_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

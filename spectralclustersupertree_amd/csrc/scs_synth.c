@@ -1,0 +1,188 @@
+/*
+ * Deterministic synthetic source trees for benchmarks and parity tests
+ * (host only, no GPU code).  SURVEY.md section 8d: iid random-join (Yule-like)
+ * rooted binary trees, Exp(mean 0.1) branch lengths, supports in 50..100.
+ *
+ * Tree t of a set is a pure function of (seed, t, n_taxa, n_leaves): the same
+ * call always yields the same topology, lengths and supports, so the device
+ * path and the CPU oracle can be fed identical inputs at any size.  The tables
+ * are emitted directly in the flattened layout of include/scs_hip.h
+ * (leaf_taxon / adj_depth / adj_val), the way
+ * spectralclustersupertree_amd/flatten.py produces them from tree objects.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    uint64_t s;
+} rng_t;
+
+static uint64_t rng_next(rng_t *r) { /* splitmix64 */
+    uint64_t z = (r->s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static uint64_t rng_below(rng_t *r, uint64_t k) { /* floor(u * k / 2^64) */
+    return (uint64_t)(((unsigned __int128)rng_next(r) * (unsigned __int128)k) >> 64);
+}
+
+static double rng_unit(rng_t *r) { return (double)(rng_next(r) >> 11) * (1.0 / 9007199254740992.0); }
+
+static void rng_seed(rng_t *r, uint64_t seed, uint64_t tree) {
+    r->s = seed * 0x9E3779B97F4A7C15ull + tree * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull;
+    (void)rng_next(r);
+}
+
+/*
+ * One tree.  Leaves are node ids 0..k-1, internal nodes k..2k-2 (root = 2k-2).
+ *   strategy: 0 one, 1 depth, 2 branch, 3 bootstrap
+ *   leaf_taxon/adj_depth/adj_val: k slots each (last adj slot is padding = 0)
+ * Optional structure outputs (may be NULL), sized 2k-1: left, right (children,
+ * -1 for leaves), length, support; taxon_of_leaf sized k.
+ * Returns 0, or -1 on allocation failure / bad arguments.
+ */
+int scs_synth_tree(uint64_t seed, int64_t tree, int32_t n_taxa, int32_t k, int32_t strategy,
+                   int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val, int32_t *left,
+                   int32_t *right, double *length, double *support, int32_t *taxon_of_leaf) {
+    if (k < 1 || k > n_taxa || strategy < 0 || strategy > 3) return -1;
+    rng_t rng;
+    rng_seed(&rng, seed, (uint64_t)tree);
+    const int32_t nn = 2 * k - 1;
+    int32_t *lf = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+    int32_t *rt = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+    double *len = (double *)malloc(sizeof(double) * (size_t)nn);
+    double *sup = (double *)malloc(sizeof(double) * (size_t)nn);
+    int32_t *tax = (int32_t *)malloc(sizeof(int32_t) * (size_t)(k > n_taxa ? k : n_taxa));
+    int32_t *roots = (int32_t *)malloc(sizeof(int32_t) * (size_t)k);
+    int32_t *stack = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+    int32_t *sdepth = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+    double *sval = (double *)malloc(sizeof(double) * (size_t)nn);
+    int8_t *state = (int8_t *)malloc((size_t)nn);
+    if (!lf || !rt || !len || !sup || !tax || !roots || !stack || !sdepth || !sval || !state) {
+        free(lf); free(rt); free(len); free(sup); free(tax); free(roots); free(stack);
+        free(sdepth); free(sval); free(state);
+        return -1;
+    }
+    /* taxa of this tree: first k entries of a partial Fisher-Yates shuffle */
+    for (int32_t i = 0; i < n_taxa; ++i) tax[i] = i;
+    if (k < n_taxa) {
+        for (int32_t i = 0; i < k; ++i) {
+            int32_t j = i + (int32_t)rng_below(&rng, (uint64_t)(n_taxa - i));
+            int32_t tmp = tax[i];
+            tax[i] = tax[j];
+            tax[j] = tmp;
+        }
+    }
+    /* lengths and supports for every node, in node-id order */
+    for (int32_t v = 0; v < nn; ++v) {
+        len[v] = -0.1 * log(1.0 - rng_unit(&rng));
+        sup[v] = 50.0 + (double)rng_below(&rng, 51);
+        lf[v] = rt[v] = -1;
+    }
+    /* random joins */
+    for (int32_t i = 0; i < k; ++i) roots[i] = i;
+    int32_t cnt = k;
+    for (int32_t step = 0; step < k - 1; ++step) {
+        int32_t i = (int32_t)rng_below(&rng, (uint64_t)cnt);
+        int32_t j = (int32_t)rng_below(&rng, (uint64_t)(cnt - 1));
+        if (j >= i) ++j;
+        const int32_t v = k + step;
+        lf[v] = roots[i];
+        rt[v] = roots[j];
+        roots[i] = v;
+        roots[j] = roots[cnt - 1];
+        --cnt;
+    }
+    const int32_t root = nn - 1;
+    /* depth-first flatten; value carried below a node per weighting strategy
+     * (reference: src/sc_supertree/scs.py:555-564, started at 0 below the root, :577) */
+    int32_t sp = 0, nleaf = 0;
+    int32_t pend_depth = 0;
+    double pend_val = 0.0;
+    stack[0] = root;
+    sdepth[0] = 0;
+    sval[0] = 0.0;
+    state[0] = 0;
+    if (k == 1) {
+        leaf_taxon[0] = tax[0];
+        adj_depth[0] = 0;
+        adj_val[0] = 0.0;
+    } else {
+        while (sp >= 0) {
+            const int32_t v = stack[sp];
+            if (lf[v] < 0) { /* leaf */
+                if (nleaf > 0) {
+                    adj_depth[nleaf - 1] = pend_depth;
+                    adj_val[nleaf - 1] = pend_val;
+                }
+                leaf_taxon[nleaf++] = tax[v];
+                --sp;
+                continue;
+            }
+            if (state[sp] == 2) {
+                --sp;
+                continue;
+            }
+            const int32_t child = state[sp] == 0 ? lf[v] : rt[v];
+            if (state[sp] == 1) { /* entering the second child: v is the next LCA */
+                pend_depth = sdepth[sp];
+                pend_val = sval[sp];
+            }
+            ++state[sp];
+            const int32_t d = sdepth[sp];
+            const double val = sval[sp];
+            ++sp;
+            stack[sp] = child;
+            state[sp] = 0;
+            sdepth[sp] = d + 1;
+            if (lf[child] < 0) {
+                sval[sp] = 0.0;
+            } else if (strategy == 0) {
+                sval[sp] = 1.0;
+            } else if (strategy == 1) {
+                sval[sp] = (d == 0 ? 0.0 : val) + 1.0;
+            } else if (strategy == 2) {
+                sval[sp] = (d == 0 ? 0.0 : val) + len[child];
+            } else {
+                sval[sp] = sup[child];
+            }
+        }
+        adj_depth[k - 1] = 0;
+        adj_val[k - 1] = 0.0;
+    }
+    if (left) memcpy(left, lf, sizeof(int32_t) * (size_t)nn);
+    if (right) memcpy(right, rt, sizeof(int32_t) * (size_t)nn);
+    if (length) memcpy(length, len, sizeof(double) * (size_t)nn);
+    if (support) memcpy(support, sup, sizeof(double) * (size_t)nn);
+    if (taxon_of_leaf) memcpy(taxon_of_leaf, tax, sizeof(int32_t) * (size_t)k);
+    free(lf); free(rt); free(len); free(sup); free(tax); free(roots); free(stack);
+    free(sdepth); free(sval); free(state);
+    return 0;
+}
+
+/* A whole set: trees [0, n_trees), tree t written at slot offset t*k.
+ * weight_mode 0: all weights 1.0; 1: Uniform(0.5, 2.0) drawn per tree. */
+int scs_synth_tables(uint64_t seed, int32_t n_taxa, int32_t n_trees, int32_t k, int32_t strategy,
+                     int32_t weight_mode, int64_t *tree_off, int32_t *leaf_taxon,
+                     int32_t *adj_depth, double *adj_val, double *tree_w) {
+    for (int32_t t = 0; t < n_trees; ++t) {
+        const int64_t off = (int64_t)t * k;
+        tree_off[t] = off;
+        if (scs_synth_tree(seed, t, n_taxa, k, strategy, leaf_taxon + off, adj_depth + off,
+                           adj_val + off, 0, 0, 0, 0, 0) != 0)
+            return -1;
+        if (weight_mode == 1) {
+            rng_t rng;
+            rng_seed(&rng, seed ^ 0xA5A5A5A5A5A5A5A5ull, (uint64_t)t);
+            tree_w[t] = 0.5 + 1.5 * rng_unit(&rng);
+        } else {
+            tree_w[t] = 1.0;
+        }
+    }
+    tree_off[n_trees] = (int64_t)n_trees * k;
+    return 0;
+}

@@ -1,0 +1,82 @@
+"""The table-level oracle (flatten + oracle/pcg_oracle.c + host graph helpers)
+against the dict-based restatement of the reference, bit for bit, on the
+reference's own fixtures and inline cases and on synthetic ragged inputs."""
+
+import numpy as np
+import pytest
+from reference_cases import DATA_DIR, FILE_CASES, INLINE_CASES
+
+from oracle import scs_oracle as so
+from oracle import tables_oracle as to
+from spectralclustersupertree_amd import flatten as fl
+from spectralclustersupertree_amd import synthetic
+from spectralclustersupertree_amd.scs import relabel_for_contraction
+from spectralclustersupertree_amd.tree import make_tree
+
+
+def _dict_side(trees, weights, strategy):
+    names = sorted(so._all_tips(trees))
+    vertices = {(n,) for n in names}
+    adj, weight, occ, together = so.build_pcg(vertices, trees, weights, strategy)
+    order = [(n,) for n in names]
+    return names, vertices, adj, weight, occ, together, so.dense_matrix(order, weight)
+
+
+def _check(trees, weights, strategy):
+    names, vertices, adj, weight, occ, together, dense = _dict_side(trees, weights, strategy)
+    tables = fl.flatten_trees(trees, weights, strategy, names)
+    tables.validate()
+    w, updates = to.pcg_dense(tables)
+    assert updates == sum(together.values())
+    assert np.array_equal(w, dense), "dense W differs from the dict-based restatement"
+    # occurrences
+    assert np.array_equal(fl.taxa_occurrences(tables), [occ[(n,)] for n in names])
+    # components: same partition
+    comps = so.graph_components(set(vertices), adj)
+    lab = fl.pcg_components(tables)
+    got = {}
+    for i, c in enumerate(lab):
+        got.setdefault(int(c), set()).add((names[i],))
+    assert sorted(map(sorted, got.values())) == sorted(map(sorted, comps))
+    # contraction: same groups, same contracted matrix
+    if len(comps) == 1:
+        so.contract_pcg(vertices, adj, weight, occ, together)
+        order = sorted(vertices)
+        groups = fl.contraction_groups(tables)
+        n_groups = int(groups.max()) + 1
+        assert n_groups == len(order)
+        members = [tuple(sorted(names[i] for i in np.flatnonzero(groups == g))) for g in range(n_groups)]
+        assert members == order
+        work, perm, group_start = relabel_for_contraction(tables, groups)
+        w2, _ = to.pcg_dense(work)
+        assert np.array_equal(w2, w[np.ix_(perm, perm)])
+        contracted = to.contract_dense(w2, group_start)
+        assert np.array_equal(contracted, so.dense_matrix(order, weight))
+
+
+@pytest.mark.parametrize("case", INLINE_CASES, ids=lambda c: c.name)
+def test_inline_tables(case):
+    trees = [make_tree(s) for s in case.trees]
+    if len(so._all_tips(trees)) < 2:
+        pytest.skip("trivial")
+    weights = case.weights or [1.0] * len(trees)
+    _check(trees, weights, case.pcg_weighting)
+
+
+@pytest.mark.parametrize(("name", "src", "exp", "weighting"), FILE_CASES, ids=[c[0] for c in FILE_CASES])
+def test_fixture_tables(name, src, exp, weighting):
+    trees = [make_tree(x.strip()) for x in (DATA_DIR / src).read_text().splitlines() if x.strip()]
+    _check(trees, [1.0] * len(trees), weighting)
+
+
+@pytest.mark.parametrize("strategy", ["one", "depth", "branch", "bootstrap"])
+def test_synthetic_ragged_tables(strategy):
+    trees = synthetic.tree_objects(11, 60, 9, leaves_per_tree=37)
+    weights = [1.0, 2.0, 0.5, 1.25, 1.0, 3.0, 1.0, 0.75, 1.5]
+    _check(trees, weights, strategy)
+
+
+def test_contraction_merges_planted():
+    # a and b always together; c, d always together in the trees holding them
+    trees = [make_tree(s) for s in ["(((a,b),(c,d)),(e,f))", "((a,b),((c,d),g))", "(((a,b),e),(c,d))"]]
+    _check(trees, [1.0, 1.0, 1.0], "depth")
