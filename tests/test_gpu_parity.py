@@ -1,0 +1,335 @@
+"""Parity of the HIP path against the oracle, through the C-ABI (needs an MI355X).
+
+Bars: W (integer/rounded-sum work) bit-exact; Fiedler column within 1e-10 of
+scikit-learn's embedding (BASELINE.json north_star); labels identical.
+"""
+
+import threading
+
+import numpy as np
+import pytest
+from reference_cases import DATA_DIR, FILE_CASES, INLINE_CASES, NOT_COMPLETED_CASE
+
+from oracle import scs_oracle as so
+from oracle import tables_oracle as to
+from spectralclustersupertree_amd import _native as nv
+from spectralclustersupertree_amd import flatten as fl
+from spectralclustersupertree_amd import synthetic
+from spectralclustersupertree_amd.backend import Device
+from spectralclustersupertree_amd.scs import relabel_for_contraction
+from spectralclustersupertree_amd.tree import NotCompleted, load_tree, make_tree
+
+pytestmark = pytest.mark.gpu
+
+FIEDLER_TOL = 1e-10  # north_star: Fiedler-vector entries within 1e-10 fp64
+
+
+@pytest.fixture(scope="module")
+def dev():
+    d = Device(0)
+    yield d
+    d.close()
+
+
+# ---------------------------------------------------------------------------
+# building blocks
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 24, 33, 48, 63, 64])
+def test_jacobi_matches_lapack(dev, n):
+    rs = np.random.RandomState(n)
+    a = rs.standard_normal((n, n))
+    a = a + a.T
+    w, v = dev.debug_jacobi(a)
+    w_ref = np.linalg.eigvalsh(a)[::-1]
+    scale = max(1.0, np.abs(w_ref).max())
+    assert np.max(np.abs(w - w_ref)) <= 1e-12 * scale
+    assert np.max(np.abs(a @ v - v * w)) <= 1e-11 * scale
+    assert np.max(np.abs(v.T @ v - np.eye(n))) <= 1e-12
+
+
+@pytest.mark.parametrize("use_mfma", [False, True], ids=["valu", "mfma_f64"])
+@pytest.mark.parametrize(("n", "ka", "kb"), [(5, 1, 8), (257, 8, 8), (1000, 16, 24), (4099, 24, 24), (3000, 48, 48), (777, 32, 16)])
+def test_gram_kernels(dev, use_mfma, n, ka, kb):
+    rs = np.random.RandomState(ka * 100 + kb)
+    a = rs.standard_normal((n, ka))
+    b = rs.standard_normal((n, kb)) + 0.25  # asymmetric on purpose
+    got = dev.debug_gram(a, b, use_mfma)
+    ref = a.T @ b
+    assert np.max(np.abs(got - ref)) <= 1e-10 * np.sqrt(n)
+
+
+# ---------------------------------------------------------------------------
+# proper cluster graph
+# ---------------------------------------------------------------------------
+def _build_and_compare(dev, tables, row_ranges=None):
+    w_ref, _ = to.pcg_dense(tables)
+    dtab = dev.upload(tables)
+    try:
+        for rb, re_ in row_ranges or [(0, tables.n_taxa)]:
+            g = dtab.build(rb, re_)
+            w = g.download()
+            g.free()
+            assert w.shape == (re_ - rb, tables.n_taxa)
+            diff = w != w_ref[rb:re_]
+            assert not diff.any(), (
+                f"{int(diff.sum())} cells differ (rows {rb}:{re_}); first at {np.argwhere(diff)[:5].tolist()}, "
+                f"got {w[diff][:5]}, want {w_ref[rb:re_][diff][:5]}"
+            )
+    finally:
+        dtab.free()
+    return w_ref
+
+
+@pytest.mark.parametrize("strategy", ["one", "depth", "branch", "bootstrap"])
+@pytest.mark.parametrize(("n", "m", "k"), [(37, 6, 20), (64, 5, 64), (100, 9, 71), (300, 12, 300), (700, 7, 512)])
+def test_build_bit_exact_synthetic(dev, strategy, n, m, k):
+    tables = synthetic.make_tables(100 + n, n, m, strategy, leaves_per_tree=k, random_weights=(n % 2 == 0))
+    _build_and_compare(dev, tables)
+
+
+def test_build_row_blocks_bit_exact(dev):
+    # the non-symmetric schedule used by row-partitioned ranks, ragged boundaries
+    tables = synthetic.make_tables(5, 333, 10, "branch", leaves_per_tree=250, random_weights=True)
+    _build_and_compare(dev, tables, [(0, 100), (100, 333), (64, 65), (7, 201)])
+
+
+def test_build_tiny_and_degenerate_trees(dev):
+    trees = [make_tree(s) for s in ["(a,b)", "((a,b),c)", "(d,(e,(f,(g,(h,(a,b))))))", "(a,b,c,d)", "((a,b,c)x,(d,e))"]]
+    names = sorted(so._all_tips(trees))
+    tables = fl.flatten_trees(trees, [1, 2, 0.5, 1, 3], "depth", names)
+    _build_and_compare(dev, tables)
+
+
+@pytest.mark.parametrize(("name", "src", "exp", "weighting"), FILE_CASES, ids=[c[0] for c in FILE_CASES])
+def test_build_reference_fixtures(dev, name, src, exp, weighting):
+    trees = [make_tree(x.strip()) for x in (DATA_DIR / src).read_text().splitlines() if x.strip()]
+    names = sorted(so._all_tips(trees))
+    tables = fl.flatten_trees(trees, [1.0] * len(trees), weighting, names)
+    _build_and_compare(dev, tables)
+
+
+def test_build_batched_matches_single_batch(dev, monkeypatch):
+    # force several tree batches through a tiny workspace limit: same bits
+    tables = synthetic.make_tables(9, 500, 40, "branch", leaves_per_tree=400)
+    monkeypatch.setenv("SCS_WS_LIMIT_MB", "1")
+    small = Device(0)
+    try:
+        dtab = small.upload(tables)
+        g = dtab.build()
+        assert g.build_stats["n_batches"] > 1
+        w = g.download()
+        g.free()
+        dtab.free()
+    finally:
+        small.close()
+    w_ref, _ = to.pcg_dense(tables)
+    assert np.array_equal(w, w_ref)
+
+
+def test_build_config2_shape_properties(dev):
+    # BASELINE.json config 2 (1000 taxa / 100 trees / depth): full size, checked
+    # against the C oracle and through size-independent properties
+    tables = synthetic.make_tables(0, 1000, 100, "depth")
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    w = g.download()
+    deg = g.degrees()
+    g.free()
+    dtab.free()
+    assert np.array_equal(w, w.T)
+    assert np.all(np.diag(w) == 0)
+    assert np.all(w == np.floor(w))  # depth weighting with unit tree weights is integer valued
+    w_ref, _ = to.pcg_dense(tables)
+    assert np.array_equal(w, w_ref)
+    assert np.allclose(deg, w_ref.sum(axis=0), rtol=1e-13, atol=0)
+
+
+def test_contract_matches_oracle(dev):
+    trees = [make_tree(s) for s in ["(((a,b),(c,d)),(e,f))", "((a,b),((c,d),g))", "(((a,b),e),(c,d))", "((e,f),(a,(b,g)))"]]
+    names = sorted(so._all_tips(trees))
+    tables = fl.flatten_trees(trees, [1.0, 2.0, 1.0, 0.5], "branch", names)
+    groups = fl.contraction_groups(tables)
+    work, perm, group_start = relabel_for_contraction(tables, groups)
+    w_ref, _ = to.pcg_dense(work)
+    dtab = dev.upload(work)
+    g = dtab.build().contract(group_start)
+    got = g.download()
+    g.free()
+    dtab.free()
+    assert np.array_equal(got, to.contract_dense(w_ref, group_start))
+
+
+# ---------------------------------------------------------------------------
+# operator and eigen-solve
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("b", [1, 2, 3, 4, 8, 16])
+def test_symm_apply_matches_numpy(dev, b):
+    tables = synthetic.make_tables(21, 515, 20, "branch", leaves_per_tree=480)
+    w_ref, _ = to.pcg_dense(tables)
+    s_ref, _ = to.normalized_operator(w_ref)
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    x = np.random.RandomState(b).standard_normal((515, b))
+    y = g.apply(x)
+    g.free()
+    dtab.free()
+    assert np.max(np.abs(y - s_ref @ x)) <= 1e-12
+
+
+def _fiedler_case(dev, tables, block=0):
+    w_ref, _ = to.pcg_dense(tables)
+    ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    v0 = np.random.RandomState(0).uniform(-1, 1, tables.n_taxa)
+    maps, stats = g.fiedler(v0, block=block)
+    g.free()
+    dtab.free()
+    s_ref, dd = to.normalized_operator(w_ref)
+    err_maps = float(np.max(np.abs(maps[:, 1] - ref[:, 1])))
+    err_unit = float(np.max(np.abs(maps[:, 1] * dd - ref[:, 1] * dd)))
+    err_col0 = float(np.max(np.abs(maps[:, 0] - ref[:, 0])))
+    x = maps[:, 1] * dd
+    x /= np.linalg.norm(x)
+    true_res = float(np.linalg.norm(s_ref @ x - (x @ s_ref @ x) * x))
+    info = dict(stats, err_maps=err_maps, err_unit=err_unit, err_col0=err_col0, true_res=true_res)
+    print("FIEDLER", tables.n_taxa, tables.n_trees, info)
+    assert err_maps <= FIEDLER_TOL, info
+    assert err_col0 <= FIEDLER_TOL, info
+    assert true_res <= 1e-11, info
+    return maps, stats, w_ref
+
+
+@pytest.mark.parametrize(("n", "m", "strategy"), [(70, 10, "depth"), (200, 16, "branch"), (515, 30, "bootstrap"), (1000, 100, "depth")])
+def test_fiedler_matches_sklearn(dev, n, m, strategy):
+    tables = synthetic.make_tables(n, n, m, strategy)
+    _fiedler_case(dev, tables)
+
+
+@pytest.mark.parametrize("block", [2, 4, 16])
+def test_fiedler_block_widths(dev, block):
+    tables = synthetic.make_tables(3, 300, 24, "branch")
+    _fiedler_case(dev, tables, block=block)
+
+
+@pytest.mark.parametrize("n", [3, 4, 8, 33, 64])
+def test_fiedler_small_dense_path(dev, n):
+    # generic (random tree weights, branch lengths) so that no eigenvalue is repeated
+    tables = synthetic.make_tables(n, n, 9, "branch", random_weights=True)
+    w_ref, _ = to.pcg_dense(tables)
+    lam = np.sort(np.linalg.eigvalsh(to.normalized_operator(w_ref)[0]))[::-1]
+    assert lam[1] - lam[2] > 1e-6 if n > 2 else True
+    ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    maps, stats = g.fiedler(None)
+    g.free()
+    dtab.free()
+    assert stats["block"] == 0
+    assert np.max(np.abs(maps - ref)) <= FIEDLER_TOL, (maps, ref)
+
+
+def test_labels_match_spectral_clustering(dev):
+    from spectralclustersupertree_amd.scs import spectral_bipartition_device
+
+    for seed, (n, m, strategy) in enumerate([(120, 12, "depth"), (400, 20, "branch")]):
+        tables = synthetic.make_tables(40 + seed, n, m, strategy)
+        w_ref, _ = to.pcg_dense(tables)
+        want = so.spectral_labels(w_ref, np.random.RandomState(seed))
+        members, got = spectral_bipartition_device(
+            tables, np.random.RandomState(seed), contract_edges=False, device=dev
+        )
+        assert [int(mm[0]) for mm in members] == list(range(n))
+        assert np.array_equal(got, want), f"{int(np.sum(got != want))} labels differ"
+
+
+def test_two_rank_row_partition_matches_single(dev):
+    # row-partitioned build + solve on ONE GPU: two contexts, two host threads,
+    # in-process communicator instead of RCCL
+    tables = synthetic.make_tables(77, 700, 24, "branch", leaves_per_tree=650)
+    w_ref, _ = to.pcg_dense(tables)
+    ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+    lib = nv.load_library()
+    group = nv.C.c_void_p()
+    nv.check(lib.scs_local_group_create(2, nv.C.byref(group)))
+    splits = [0, 333, 700]
+    v0 = np.random.RandomState(0).uniform(-1, 1, 700)
+    out = [None, None]
+    err = [None, None]
+
+    def worker(rank):
+        try:
+            d = Device(0, rank, 2, _local_group=group)
+            dtab = d.upload(tables)
+            g = dtab.build(splits[rank], splits[rank + 1])
+            w = g.download()
+            assert np.array_equal(w, w_ref[splits[rank] : splits[rank + 1]])
+            maps, stats = g.fiedler(v0)
+            out[rank] = (maps, stats)
+            g.free()
+            dtab.free()
+            d.close()
+        except BaseException as e:  # noqa: BLE001
+            err[rank] = e
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    lib.scs_local_group_destroy(group)
+    assert err == [None, None], err
+    for maps, stats in out:
+        assert np.max(np.abs(maps[:, 1] - ref[:, 1])) <= FIEDLER_TOL, stats
+    assert np.array_equal(out[0][0], out[1][0])  # both ranks hold the same embedding
+
+
+def test_rccl_world_of_one(dev):
+    # exercises the RCCL binding (dlopen, unique id, comm init, all-gather) on one GPU
+    uid = Device.unique_id()
+    d = Device(0, 0, 1, uid)
+    try:
+        tables = synthetic.make_tables(8, 200, 10, "depth")
+        dtab = d.upload(tables)
+        g = dtab.build()
+        maps, stats = g.fiedler(None)
+        g.free()
+        dtab.free()
+    finally:
+        d.close()
+    assert stats["converged"] == 1
+
+
+# ---------------------------------------------------------------------------
+# end to end: the reference's own test cases through construct_supertree
+# ---------------------------------------------------------------------------
+def _scs(trees, expected, **kw):
+    from spectralclustersupertree_amd import construct_supertree
+
+    for seed in (0, 1):
+        got = construct_supertree(trees, random_state=np.random.RandomState(seed), **kw)
+        assert got.sorted().same_shape(expected.sorted()), f"{got} != {expected}"
+
+
+@pytest.mark.parametrize("case", INLINE_CASES, ids=lambda c: c.name)
+def test_reference_inline_cases_end_to_end(case):
+    _scs(
+        [make_tree(s) for s in case.trees],
+        make_tree(case.expected),
+        weights=case.weights,
+        pcg_weighting=case.pcg_weighting,
+        contract_edges=case.contract_edges,
+    )
+
+
+@pytest.mark.parametrize(("name", "src", "exp", "weighting"), FILE_CASES, ids=[c[0] for c in FILE_CASES])
+def test_reference_fixtures_end_to_end(name, src, exp, weighting):
+    from spectralclustersupertree_amd import load_trees
+
+    _scs(load_trees(DATA_DIR / src), load_tree(DATA_DIR / exp), pcg_weighting=weighting)
+
+
+def test_reference_not_completed_end_to_end():
+    case = NOT_COMPLETED_CASE
+    trees = [make_tree(s) for s in case.trees] + [NotCompleted("ERROR", "local", "Example NotCompleted")]
+    _scs(trees, make_tree(case.expected), weights=case.weights)
