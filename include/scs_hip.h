@@ -154,6 +154,11 @@ int scs_graph_shape(const scs_graph *graph, int32_t *n_vertices, int32_t *row_be
  * row-major, caller-owned.  For tests and golden vectors. */
 int scs_graph_download(scs_ctx *ctx, const scs_graph *graph, double *out);
 
+/* Rows [first, first+count) of the graph (global row indices, inside this
+ * rank's block) to the host: out is count x V row-major. */
+int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *graph, int32_t first, int32_t count,
+                            double *out);
+
 /* Row sums of this rank's rows (the degree vector d of scipy's normalized
  * Laplacian, scipy/sparse/csgraph/_laplacian.py:550): out has row_end-row_begin
  * entries. */

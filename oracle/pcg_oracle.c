@@ -74,3 +74,57 @@ void scs_oracle_contract(int32_t n, const double *w, int32_t n_groups,
             out[(int64_t)g * n_groups + h] = best;
         }
 }
+
+/* Selected rows of W only (full-size spot checks): out is n_rows x n_taxa,
+ * zero-initialised by the caller; same addends, same tree order as above. */
+void scs_oracle_pcg_rows(int32_t n_taxa, int32_t n_trees, const int64_t *tree_off,
+                         const int32_t *leaf_taxon, const int32_t *adj_depth,
+                         const double *adj_val, const double *tree_w, int32_t n_rows,
+                         const int32_t *rows, const int32_t *pos_scratch /* unused */,
+                         double *out) {
+    (void)pos_scratch;
+    for (int32_t t = 0; t < n_trees; ++t) {
+        const int64_t off = tree_off[t];
+        const int32_t n = (int32_t)(tree_off[t + 1] - off);
+        const int32_t *tax = leaf_taxon + off;
+        const int32_t *dep = adj_depth + off;
+        const double *val = adj_val + off;
+        const double wt = tree_w[t];
+        for (int32_t r = 0; r < n_rows; ++r) {
+            int32_t a = -1;
+            for (int32_t p = 0; p < n; ++p)
+                if (tax[p] == rows[r]) {
+                    a = p;
+                    break;
+                }
+            if (a < 0) continue;
+            double *o = out + (int64_t)r * n_taxa;
+            /* leaves to the right of a */
+            if (a + 1 < n) {
+                int32_t md = dep[a];
+                double mv = val[a];
+                for (int32_t b = a + 1; b < n; ++b) {
+                    if (b > a + 1 && dep[b - 1] < md) {
+                        md = dep[b - 1];
+                        mv = val[b - 1];
+                    }
+                    if (md == 0) break;
+                    o[tax[b]] = o[tax[b]] + mv * wt;
+                }
+            }
+            /* leaves to the left of a */
+            if (a > 0) {
+                int32_t md = dep[a - 1];
+                double mv = val[a - 1];
+                for (int32_t b = a - 1; b >= 0; --b) {
+                    if (b < a - 1 && dep[b] < md) {
+                        md = dep[b];
+                        mv = val[b];
+                    }
+                    if (md == 0) break;
+                    o[tax[b]] = o[tax[b]] + mv * wt;
+                }
+            }
+        }
+    }
+}

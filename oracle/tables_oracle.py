@@ -25,6 +25,8 @@ def _load():
         ip, dp, lp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)
         lib.scs_oracle_pcg_dense.restype = C.c_int64
         lib.scs_oracle_pcg_dense.argtypes = [C.c_int32, C.c_int32, C.c_int32, lp, ip, ip, dp, dp, dp]
+        lib.scs_oracle_pcg_rows.restype = None
+        lib.scs_oracle_pcg_rows.argtypes = [C.c_int32, C.c_int32, lp, ip, ip, dp, dp, C.c_int32, ip, ip, dp]
         lib.scs_oracle_contract.restype = None
         lib.scs_oracle_contract.argtypes = [C.c_int32, dp, C.c_int32, ip, dp]
         _lib = lib
@@ -45,6 +47,21 @@ def pcg_dense(tables, t_begin: int = 0, t_end: int | None = None, out: np.ndarra
         tables.tree_w.ctypes.data_as(dp), w.ctypes.data_as(dp),
     )
     return w, int(updates)
+
+
+def pcg_rows(tables, rows) -> np.ndarray:
+    """Selected rows of W (len(rows) x n_taxa), for spot checks at full size."""
+    lib = _load()
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    out = np.zeros((len(rows), tables.n_taxa))
+    ip, dp, lp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    lib.scs_oracle_pcg_rows(
+        tables.n_taxa, tables.n_trees, tables.tree_off.ctypes.data_as(lp),
+        tables.leaf_taxon.ctypes.data_as(ip), tables.adj_depth.ctypes.data_as(ip),
+        tables.adj_val.ctypes.data_as(dp), tables.tree_w.ctypes.data_as(dp), len(rows),
+        rows.ctypes.data_as(ip), None, out.ctypes.data_as(dp),
+    )
+    return out
 
 
 def contract_dense(w: np.ndarray, group_start: np.ndarray) -> np.ndarray:

@@ -98,6 +98,7 @@ SIGNATURES = {
     "scs_graph_contract": (C.c_int, [_P, _P, _IP, _I32, _PP]),
     "scs_graph_shape": (C.c_int, [_P, _IP, _IP, _IP]),
     "scs_graph_download": (C.c_int, [_P, _P, _DP]),
+    "scs_graph_download_rows": (C.c_int, [_P, _P, _I32, _I32, _DP]),
     "scs_graph_degrees": (C.c_int, [_P, _P, _DP]),
     "scs_graph_free": (C.c_int, [_P, _P]),
     "scs_fiedler": (C.c_int, [_P, _P, _DP, C.c_double, _I32, _I32, _DP, C.POINTER(Stats)]),

@@ -161,6 +161,12 @@ class DeviceGraph:
         nv.check(self.dev._lib.scs_graph_download(self.dev._ctx, self._h, nv.dptr(out)))
         return out
 
+    def download_rows(self, first: int, count: int) -> np.ndarray:
+        out = np.empty((count, self.shape[0]))
+        nv.check(self.dev._lib.scs_graph_download_rows(self.dev._ctx, self._h, first, count,
+                                                       nv.dptr(out)))
+        return out
+
     def degrees(self) -> np.ndarray:
         n, rb, re_ = self.shape
         out = np.empty(re_ - rb)

@@ -412,18 +412,30 @@ int levels_for(int64_t m) {
 
 }  // namespace
 
-static int graph_alloc(int32_t n, int32_t row_begin, int32_t row_end, scs_graph **out) {
+static int graph_alloc(int32_t n, int32_t row_begin, int32_t row_end, hipStream_t stream,
+                       scs_graph **out) {
     auto *g = new scs_graph();
     g->n = n;
     g->row_begin = row_begin;
     g->row_end = row_end;
-    g->ld = scs_round_up(n, 8);
-    size_t bytes = (size_t)(row_end - row_begin) * (size_t)g->ld * sizeof(double);
+    // k_symm's layout contract: ld a multiple of 512 doubles, padding columns zero
+    g->ld = scs_round_up(n, SCS_LD_ALIGN);
+    const size_t rows = (size_t)(row_end - row_begin);
+    size_t bytes = rows * (size_t)g->ld * sizeof(double);
     hipError_t e = hipMalloc((void **)&g->d_w, bytes ? bytes : 16);
     if (e != hipSuccess) {
         delete g;
         scs_set_error("cannot allocate %zu bytes for W: %s", bytes, hipGetErrorString(e));
         return SCS_ENOMEM;
+    }
+    if (g->ld > n) {
+        e = hipMemset2DAsync(g->d_w + n, (size_t)g->ld * 8, 0, (size_t)(g->ld - n) * 8, rows, stream);
+        if (e != hipSuccess) {
+            hipFree(g->d_w);
+            delete g;
+            scs_set_error("cannot clear the padding of W: %s", hipGetErrorString(e));
+            return SCS_EHIP;
+        }
     }
     *out = g;
     return SCS_OK;
@@ -466,7 +478,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     const int64_t npad = scs_round_up(n, SCS_NPAD);
 
     scs_graph *g = nullptr;
-    SCS_TRY(graph_alloc(n, row_begin, row_end, &g));
+    SCS_TRY(graph_alloc(n, row_begin, row_end, s, &g));
     struct guard {
         scs_ctx *c;
         scs_graph *g;
@@ -641,7 +653,7 @@ extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *gro
                 g->row_begin, g->row_end);
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     scs_graph *ng = nullptr;
-    SCS_TRY(graph_alloc(n_groups, g_begin, g_end, &ng));
+    SCS_TRY(graph_alloc(n_groups, g_begin, g_end, ctx->stream, &ng));
     int32_t *d_gs = nullptr;
     hipError_t e = hipMalloc((void **)&d_gs, (size_t)(n_groups + 1) * 4);
     if (e != hipSuccess) {
@@ -673,6 +685,20 @@ extern "C" int scs_graph_download(scs_ctx *ctx, const scs_graph *g, double *out)
     const size_t rows = (size_t)(g->row_end - g->row_begin);
     SCS_HIP_CHECK(hipMemcpy2D(out, (size_t)g->n * 8, g->d_w, (size_t)g->ld * 8, (size_t)g->n * 8,
                               rows, hipMemcpyDeviceToHost));
+    return SCS_OK;
+}
+
+extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t first,
+                                       int32_t count, double *out) {
+    SCS_REQUIRE(ctx && g && out, "scs_graph_download_rows: null argument");
+    SCS_REQUIRE(count >= 1 && first >= g->row_begin && first + count <= g->row_end,
+                "scs_graph_download_rows: rows [%d, %d) outside this rank's block [%d, %d)", first,
+                first + count, g->row_begin, g->row_end);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SCS_HIP_CHECK(hipMemcpy2D(out, (size_t)g->n * 8, g->d_w + (int64_t)(first - g->row_begin) * g->ld,
+                              (size_t)g->ld * 8, (size_t)g->n * 8, (size_t)count,
+                              hipMemcpyDeviceToHost));
     return SCS_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <cmath>
 
 #include "scs_internal.h"
+#include "scs_symm.h"
 
 constexpr int MAXB = 16;      // widest LOBPCG block
 constexpr int MAXS = 64;      // largest matrix the Jacobi kernel takes
@@ -22,100 +23,14 @@ constexpr int SLD = MAXS + 1; // LDS leading dimension (breaks the power-of-two 
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-// ---------------------------------------------------------------------------
-// SYMM: y[r][:] = dinv[r] * sum_j W[r][j] * z[j][:],  z = dinv (.) x  (n x B)
-// ---------------------------------------------------------------------------
-template <int B>
-__global__ __launch_bounds__(256) void k_symm(const double *__restrict__ w, int64_t ld, int n,
-                                               int rows, int row_begin,
-                                               const double *__restrict__ z,
-                                               const double *__restrict__ dinv,
-                                               double *__restrict__ y) {
-    constexpr int RPW = 4;  // rows per wave
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int r0 = (blockIdx.x * 4 + wave) * RPW;
-    if (r0 >= rows) return;
-    const double *rowp[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int r = r0 + i < rows ? r0 + i : rows - 1;  // clamp: duplicate work, never stored
-        rowp[i] = w + (int64_t)r * ld;
-    }
-    double acc[RPW][B];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i)
-#pragma unroll
-        for (int k = 0; k < B; ++k) acc[i][k] = 0.0;
-
-    const int n2 = n & ~1;
-    for (int j = lane * 2; j < n2; j += 128) {
-        double2 a[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) a[i] = *(const double2 *)(rowp[i] + j);
-        double z0[B], z1[B];
-        const double2 *zp0 = (const double2 *)(z + (int64_t)j * B);
-        const double2 *zp1 = (const double2 *)(z + (int64_t)(j + 1) * B);
-        if (B % 2 == 0) {
-#pragma unroll
-            for (int k = 0; k < B / 2; ++k) {
-                const double2 u0 = zp0[k], u1 = zp1[k];
-                z0[2 * k] = u0.x;
-                z0[2 * k + 1] = u0.y;
-                z1[2 * k] = u1.x;
-                z1[2 * k + 1] = u1.y;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < B; ++k) {
-                z0[k] = z[(int64_t)j * B + k];
-                z1[k] = z[(int64_t)(j + 1) * B + k];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < RPW; ++i)
-#pragma unroll
-            for (int k = 0; k < B; ++k) acc[i][k] += a[i].x * z0[k] + a[i].y * z1[k];
-    }
-    if ((n & 1) && lane == 0) {
-        const int j = n - 1;
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const double a = rowp[i][j];
-#pragma unroll
-            for (int k = 0; k < B; ++k) acc[i][k] += a * z[(int64_t)j * B + k];
-        }
-    }
-    // wavefront-shuffle reduction over the 64 lanes
-#pragma unroll
-    for (int i = 0; i < RPW; ++i)
-#pragma unroll
-        for (int k = 0; k < B; ++k) {
-            double s = acc[i][k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            acc[i][k] = s;
-        }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = r0 + i;
-            if (r < rows) {
-                const double d = dinv[row_begin + r];
-#pragma unroll
-                for (int k = 0; k < B; ++k) y[(int64_t)r * B + k] = d * acc[i][k];
-            }
-        }
-    }
-}
-
-// z[i][k] = dinv[i] * x[i*ldx + c0 + k]
+// zt[k][i] = dinv[i] * x[i*ldx + c0 + k]   (k-major, leading dimension ldz; columns >= n stay 0)
 __global__ void k_scale_rows(const double *__restrict__ x, int ldx, int c0, int b, int n,
-                             const double *__restrict__ dinv, double *__restrict__ z) {
+                             const double *__restrict__ dinv, double *__restrict__ zt,
+                             int64_t ldz) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * b) return;
-    const int i = idx / b, k = idx - i * b;
-    z[idx] = dinv[i] * x[(int64_t)i * ldx + c0 + k];
+    const int k = idx / n, i = idx - k * n;
+    zt[(int64_t)k * ldz + i] = dinv[i] * x[(int64_t)i * ldx + c0 + k];
 }
 
 // dst[i*ldd + c0 + k] = src[i*b + k]
@@ -233,13 +148,19 @@ __global__ __launch_bounds__(64) void k_gram_mfma(const double *__restrict__ a, 
             }
 }
 
-__global__ void k_reduce_partials(const double *__restrict__ partial, int nparts, int nout,
-                                  double *__restrict__ out) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per output element: lanes read the partials (fixed assignment), then a
+// fixed-order shuffle tree -> deterministic result
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partial,
+                                                          int nparts, int nout,
+                                                          double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= nout) return;
     double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * nout + e];
-    out[e] = s;
+    for (int p = lane; p < nparts; p += 64) s += partial[(int64_t)p * nout + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[e] = s;
 }
 
 // ---------------------------------------------------------------------------
@@ -611,7 +532,8 @@ struct solver {
     hipStream_t s = nullptr;
     int n = 0, b = 0, rows = 0, world = 1;
     bool use_mfma = true;
-    dbuf q, aq, z, yloc, yfull, recv, u, part, small, splits_d;
+    dbuf q, aq, z, ypart, yloc, yfull, recv, u, part, small, splits_d;
+    size_t ypart_cap = 0;
     int64_t chunk = 0;
     int gram_blocks = 0;
     std::vector<int32_t> splits;
@@ -625,35 +547,60 @@ struct solver {
 
     double *small_at(int off) const { return small.d() + off; }
 
+    // yout (rows x b) = dinv (.) (W_local * Z), Z given k-major in zin (b x ld)
     int launch_symm(const double *zin, double *yout) {
-        const int grid = (rows + 15) / 16;
+        const int64_t ld = g->ld;
+        int rpw = 4, sdepth = 2;
+        if (b == 16) rpw = 2;
+        if (b == 4) sdepth = 4;
+        const int rowblocks = (rows + 4 * rpw - 1) / (4 * rpw);
+        const int n_macros = (int)(ld / (sdepth * SYMM_SUB));
+        int nseg = (1024 + rowblocks - 1) / rowblocks;
+        nseg = std::max(1, std::min(std::min(nseg, 4), n_macros));
+        if (b == 8 && nseg < 2 && n_macros >= 2 && rowblocks < 2048) nseg = 2;
+        const int mps = (n_macros + nseg - 1) / nseg;
+        nseg = (n_macros + mps - 1) / mps;
+        if (ypart_cap < (size_t)nseg * rows * b) {
+            scs_set_error("internal: ypart buffer too small");
+            return SCS_EINVAL;
+        }
+        dim3 grid((unsigned)rowblocks, (unsigned)nseg);
         switch (b) {
-#define SYMM_CASE(B)                                                                          \
-    case B:                                                                                   \
-        k_symm<B><<<grid, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, zin, g->d_dinv,  \
-                                       yout);                                                 \
-        break;
-            SYMM_CASE(1)
-            SYMM_CASE(2)
-            SYMM_CASE(3)
-            SYMM_CASE(4)
-            SYMM_CASE(6)
-            SYMM_CASE(8)
-            SYMM_CASE(12)
-            SYMM_CASE(16)
-#undef SYMM_CASE
+            case 4:
+                k_symm<4, 4, 4, 3><<<grid, 256, 0, s>>>(g->d_w, ld, rows, zin, ypart.d(), mps);
+                break;
+            case 8:
+                k_symm<8, 4, 2, 2><<<grid, 256, 0, s>>>(g->d_w, ld, rows, zin, ypart.d(), mps);
+                break;
+            case 12:
+                k_symm<12, 4, 2, 1><<<grid, 256, 0, s>>>(g->d_w, ld, rows, zin, ypart.d(), mps);
+                break;
+            case 16:
+                k_symm<16, 2, 2, 2><<<grid, 256, 0, s>>>(g->d_w, ld, rows, zin, ypart.d(), mps);
+                break;
             default:
-                scs_set_error("unsupported block width %d", b);
+                scs_set_error("unsupported block width %d (need 4, 8, 12 or 16)", b);
                 return SCS_EUNSUP;
         }
         SCS_HIP_CHECK(hipGetLastError());
+        k_symm_finish<<<(rows * b + 255) / 256, 256, 0, s>>>(ypart.d(), nseg, rows, b, g->d_dinv,
+                                                             g->row_begin, yout);
+        return SCS_OK;
+    }
+
+    int alloc_symm_buffers() {
+        ypart_cap = (size_t)4 * rows * b;
+        SCS_TRY(ypart.alloc(ypart_cap * 8));
+        SCS_TRY(z.alloc((size_t)b * g->ld * 8));
+        SCS_HIP_CHECK(hipMemsetAsync(z.p, 0, (size_t)b * g->ld * 8, s));
         return SCS_OK;
     }
 
     // dst_panel[:, c0:c0+b] = S * src_panel[:, c0s:c0s+b]   (panels have ld 3b)
     int apply(const double *src, int c0s, double *dst, int c0d) {
         const int nb = n * b;
-        k_scale_rows<<<(nb + 255) / 256, 256, 0, s>>>(src, 3 * b, c0s, b, n, g->d_dinv, z.d());
+        k_scale_rows<<<(nb + 255) / 256, 256, 0, s>>>(src, 3 * b, c0s, b, n, g->d_dinv, z.d(),
+                                                      g->ld);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         SCS_HIP_CHECK(hipEventCreate(&e0));
         SCS_HIP_CHECK(hipEventCreate(&e1));
@@ -681,7 +628,7 @@ struct solver {
         const int nout = ka * kb;
         int nparts;
         if (mfma && ka <= 48 && kb <= 48) {
-            nparts = std::min(gram_blocks * 4, std::max(1, (n + 3) / 4));
+            nparts = std::min(gram_blocks, std::max(1, (n + 3) / 4));
             const int ta = (ka + 15) / 16, tb = (kb + 15) / 16;
 #define GM(TA, TB)                                                                               \
     if (ta == TA && tb == TB)                                                                    \
@@ -692,7 +639,7 @@ struct solver {
             nparts = std::min(gram_blocks, std::max(1, (n + GRAM_CH - 1) / GRAM_CH));
             k_gram<<<nparts, 256, 0, s>>>(a, lda, ka, bm, ldb, kb, n, part.d());
         }
-        k_reduce_partials<<<(nout + 255) / 256, 256, 0, s>>>(part.d(), nparts, nout, out);
+        k_reduce_partials<<<(nout + 3) / 4, 256, 0, s>>>(part.d(), nparts, nout, out);
         SCS_HIP_CHECK(hipGetLastError());
         return SCS_OK;
     }
@@ -836,9 +783,9 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     const int want = constrained ? 1 : 2;
     int b = block ? block : 8;
     {
-        const int allowed[] = {16, 12, 8, 6, 4, 3, 2, 1};
+        const int allowed[] = {16, 12, 8, 4};
         const int cap = (n - 2) / 3;  // 3b basis vectors + the constraint must fit in V
-        int pick = 1;
+        int pick = 4;
         for (int a : allowed)
             if (a <= b && a <= cap) {
                 pick = a;
@@ -866,7 +813,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
     SCS_TRY(sv.q.alloc((size_t)n * q3 * 8));
     SCS_TRY(sv.aq.alloc((size_t)n * q3 * 8));
-    SCS_TRY(sv.z.alloc((size_t)n * b * 8));
+    SCS_TRY(sv.alloc_symm_buffers());
     SCS_TRY(sv.yloc.alloc((size_t)sv.chunk * 8));
     SCS_TRY(sv.u.alloc((size_t)n * 8));
     SCS_TRY(sv.part.alloc((size_t)1024 * q3 * q3 * 8));
@@ -953,7 +900,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     for (iter = 0; iter < max_iter; ++iter) {
         // residual block and its norms
         k_residual<<<res_blocks, 256, 0, s>>>(Q, AQ, b, TH, n, res_part.d());
-        k_reduce_partials<<<1, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
+        k_reduce_partials<<<(b + 3) / 4, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
         SCS_HIP_CHECK(hipMemcpyAsync(h_rn.data(), RN, (size_t)b * 8, hipMemcpyDeviceToHost, s));
         SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
         SCS_HIP_CHECK(hipStreamSynchronize(s));
@@ -982,7 +929,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 SCS_TRY(sv.update(X, q3, b, 0.0, X, q3, b, T, b, 1.0));
                 SCS_TRY(sv.update(AX, q3, b, 0.0, AX, q3, b, T, b, 1.0));
                 k_residual<<<res_blocks, 256, 0, s>>>(Q, AQ, b, TH, n, res_part.d());
-                k_reduce_partials<<<1, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
+                k_reduce_partials<<<(b + 3) / 4, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
                 SCS_HIP_CHECK(hipMemcpyAsync(h_rn.data(), RN, (size_t)b * 8, hipMemcpyDeviceToHost, s));
                 SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8,
                                              hipMemcpyDeviceToHost, s));
@@ -1128,6 +1075,7 @@ extern "C" int scs_debug_gram(scs_ctx *ctx, const double *a, const double *b, in
 
 extern "C" int scs_debug_apply(scs_ctx *ctx, scs_graph *g, const double *x, int32_t b, double *y) {
     SCS_REQUIRE(ctx && g && x && y, "scs_debug_apply: null argument");
+    SCS_REQUIRE(b == 4 || b == 8 || b == 12 || b == 16, "scs_debug_apply: b must be 4, 8, 12 or 16");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));
     solver sv;
@@ -1140,11 +1088,11 @@ extern "C" int scs_debug_apply(scs_ctx *ctx, scs_graph *g, const double *x, int3
     const int n = g->n;
     dbuf dx;
     SCS_TRY(dx.alloc((size_t)n * b * 8));
-    SCS_TRY(sv.z.alloc((size_t)n * b * 8));
+    SCS_TRY(sv.alloc_symm_buffers());
     SCS_TRY(sv.yloc.alloc((size_t)sv.rows * b * 8));
     SCS_HIP_CHECK(hipMemcpyAsync(dx.p, x, (size_t)n * b * 8, hipMemcpyHostToDevice, ctx->stream));
     k_scale_rows<<<(n * b + 255) / 256, 256, 0, ctx->stream>>>(dx.d(), b, 0, b, n, g->d_dinv,
-                                                               sv.z.d());
+                                                               sv.z.d(), g->ld);
     SCS_TRY(sv.launch_symm(sv.z.d(), sv.yloc.d()));
     SCS_HIP_CHECK(hipMemcpyAsync(y, sv.yloc.p, (size_t)sv.rows * b * 8, hipMemcpyDeviceToHost,
                                  ctx->stream));

@@ -43,6 +43,7 @@ void scs_set_error(const char *fmt, ...);
 constexpr int SCS_TR = 64;    // rows of W per tile (one block record)
 constexpr int SCS_TCW = 256;  // threads per workgroup = columns per column group
 constexpr int SCS_NPAD = 512; // position tables are padded to a multiple of this
+constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_symm.h
 
 // ---- communicator -----------------------------------------------------------
 struct scs_local_group;  // in-process barrier + exchange slots

@@ -162,7 +162,7 @@ def test_contract_matches_oracle(dev):
 # ---------------------------------------------------------------------------
 # operator and eigen-solve
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("b", [1, 2, 3, 4, 8, 16])
+@pytest.mark.parametrize("b", [4, 8, 12, 16])
 def test_symm_apply_matches_numpy(dev, b):
     tables = synthetic.make_tables(21, 515, 20, "branch", leaves_per_tree=480)
     w_ref, _ = to.pcg_dense(tables)
@@ -206,7 +206,7 @@ def test_fiedler_matches_sklearn(dev, n, m, strategy):
     _fiedler_case(dev, tables)
 
 
-@pytest.mark.parametrize("block", [2, 4, 16])
+@pytest.mark.parametrize("block", [4, 12, 16])
 def test_fiedler_block_widths(dev, block):
     tables = synthetic.make_tables(3, 300, 24, "branch")
     _fiedler_case(dev, tables, block=block)
