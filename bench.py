@@ -284,6 +284,15 @@ def main() -> int:
         },
     }
 
+    # HBM traffic of the dominant kernel from the committed PMC pass of this workload, if any
+    try:
+        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(name)
+        if pmc and world == 1 and pmc["kernel"].startswith(f"k_symm<{stats['block']},"):
+            result["roofline"]["traffic"] = pmc["traffic"]
+            result["roofline"]["traffic_source"] = pmc["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     if rank == 0 and world == 1:
         # parity gate at full size: rows of W against the oracle, bit for bit
         from oracle import tables_oracle as to
