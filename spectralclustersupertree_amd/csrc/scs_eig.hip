@@ -167,72 +167,67 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // panel updates (row-local, safe in place)
 // ---------------------------------------------------------------------------
 // y[:, 0:kc] = alpha_y * y[:, 0:kc] + sign * a[:, 0:ka] * c   (c: ka x kc, row-major, ldc)
-// (y and a may alias: the update is row-local and reads the whole row first)
+// y and a may alias (in-place y = y*c): every thread of a row reads the row's inputs
+// before any thread of that row writes, because a row lives inside one workgroup
+// and a barrier separates the two phases.
 __global__ __launch_bounds__(256) void k_update(double *y, int ldy, int kc, double alpha_y,
-                                                 const double *a,
-                                                 int lda, int ka, const double *__restrict__ c,
-                                                 int ldc, double sign, int n) {
+                                                 const double *a, int lda, int ka,
+                                                 const double *__restrict__ c, int ldc,
+                                                 double sign, int n) {
     __shared__ double sc[3 * MAXB][MAXB];
     for (int e = threadIdx.x; e < ka * kc; e += 256) {
         const int i = e / kc, j = e - i * kc;
         sc[i][j] = c[i * ldc + j];
     }
     __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    double acc[MAXB];
-#pragma unroll
-    for (int j = 0; j < MAXB; ++j) acc[j] = 0.0;
-    const double *ar = a + (int64_t)r * lda;
-    for (int i = 0; i < ka; ++i) {
-        const double ai = ar[i];
-#pragma unroll
-        for (int j = 0; j < MAXB; ++j)
-            if (j < kc) acc[j] += ai * sc[i][j];
-    }
-    double *yr = y + (int64_t)r * ldy;
-#pragma unroll
-    for (int j = 0; j < MAXB; ++j)
-        if (j < kc) yr[j] = (alpha_y == 0.0 ? 0.0 : alpha_y * yr[j]) + sign * acc[j];
-}
-
-// Rayleigh-Ritz update of a panel q = [X | R | P] (n x 3b, ld 3b) with coefficients
-// c (nq x b, nq = 2b or 3b):  P' = [R P] c[b:, :],  X' = X c[:b, :] + P'.
-__global__ __launch_bounds__(256) void k_rr_update(double *__restrict__ q, int b, int nq,
-                                                    const double *__restrict__ c, int n) {
-    __shared__ double sc[3 * MAXB][MAXB];
-    for (int e = threadIdx.x; e < nq * b; e += 256) {
-        const int i = e / b, j = e - i * b;
-        sc[i][j] = c[i * b + j];
+    // 256 / 16 = 16 rows per workgroup, 16 column slots per row
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15;
+    double acc = 0.0, yold = 0.0;
+    const bool live = r < n && j < kc;
+    if (live) {
+        const double *ar = a + (int64_t)r * lda;
+        for (int i = 0; i < ka; ++i) acc += ar[i] * sc[i][j];
+        if (alpha_y != 0.0) yold = y[(int64_t)r * ldy + j];
     }
     __syncthreads();
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    double *qr = q + (int64_t)r * (3 * b);
-    double xa[MAXB], pa[MAXB];
-#pragma unroll
-    for (int j = 0; j < MAXB; ++j) xa[j] = pa[j] = 0.0;
-    for (int i = 0; i < b; ++i) {
-        const double v = qr[i];
-#pragma unroll
-        for (int j = 0; j < MAXB; ++j)
-            if (j < b) xa[j] += v * sc[i][j];
-    }
-    for (int i = b; i < nq; ++i) {
-        const double v = qr[i];
-#pragma unroll
-        for (int j = 0; j < MAXB; ++j)
-            if (j < b) pa[j] += v * sc[i][j];
-    }
-#pragma unroll
-    for (int j = 0; j < MAXB; ++j)
-        if (j < b) {
-            qr[j] = xa[j] + pa[j];
-            qr[2 * b + j] = pa[j];
-        }
+    if (live) y[(int64_t)r * ldy + j] = (alpha_y == 0.0 ? 0.0 : alpha_y * yold) + sign * acc;
 }
 
-// R = AX - X diag(theta) into q[:, b:2b]; per-workgroup partial squared norms
+// Rayleigh-Ritz update of a panel q = [X | R | P] (n x 3b, ld 3b): with coefficient
+// matrices c, d (nq x b each, nq = 2b or 3b)   X' = q[:, :nq] c,   P' = q[:, :nq] d,
+// written in place (a row lives inside one workgroup; a barrier separates reads from writes).
+__global__ __launch_bounds__(256) void k_rr_update(double *q, int b, int nq,
+                                                    const double *__restrict__ c,
+                                                    const double *__restrict__ d, int n) {
+    __shared__ double sc[3 * MAXB][MAXB];
+    __shared__ double sd[3 * MAXB][MAXB];
+    for (int e = threadIdx.x; e < nq * b; e += 256) {
+        const int i = e / b, j = e - i * b;
+        sc[i][j] = c[e];
+        sd[i][j] = d[e];
+    }
+    __syncthreads();
+    const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int j = threadIdx.x & 15;
+    const bool live = r < n && j < b;
+    double xa = 0.0, pa = 0.0;
+    double *qr = q + (int64_t)(live ? r : 0) * (3 * b);
+    if (live) {
+        for (int i = 0; i < nq; ++i) {
+            const double v = qr[i];
+            xa += v * sc[i][j];
+            pa += v * sd[i][j];
+        }
+    }
+    __syncthreads();
+    if (live) {
+        qr[j] = xa;
+        qr[b + j] = pa;
+    }
+}
+
+// R = AX - X diag(theta) into q[:, 2b:3b]; per-workgroup partial squared norms
 __global__ __launch_bounds__(256) void k_residual(double *__restrict__ q,
                                                    const double *__restrict__ aq, int b,
                                                    const double *__restrict__ theta, int n,
@@ -250,7 +245,7 @@ __global__ __launch_bounds__(256) void k_residual(double *__restrict__ q,
         for (int j = 0; j < MAXB; ++j)
             if (j < b) {
                 const double v = ar[j] - qr[j] * theta[j];
-                qr[b + j] = v;
+                qr[2 * b + j] = v;
                 sq[j] = v * v;
             }
     }
@@ -315,8 +310,13 @@ struct jacobi_lds {
 // On entry s.a holds the symmetric matrix (n x n).  On exit s.w holds the
 // eigenvalues in DESCENDING order and s.perm[k] the column of s.e holding the
 // k-th eigenvector.  All 256 threads of the workgroup must call.
+//
+// Parallel-ordered two-sided Jacobi.  A step rotates m/2 disjoint index pairs at
+// once: A <- J^T A J splits into independent 2x2 blocks (row pair x column pair),
+// each updated by one thread, so a step costs two barriers.
 __device__ void jacobi_eig(jacobi_lds &s, int n) {
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int m = n + (n & 1);  // even; a padded index has zero row/column
     for (int e = tid; e < m * m; e += 256) {
         const int i = e / m, j = e - i * m;
@@ -331,26 +331,25 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
         for (int e = tid; e < n * n; e += 256) {
             const int i = e / n, j = e - i * n;
             const double v = s.a[i][j];
-            if (i == j) dia += v * v;
+            // dead directions carry -1e30 on the diagonal (k_small_rr): not part of the scale
+            if (i == j) dia += v > -1e29 ? v * v : 0.0;
             else off += v * v;
         }
-        s.red[tid] = off;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st) s.red[tid] += s.red[tid + st];
-            __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            off += __shfl_xor(off, o, 64);
+            dia += __shfl_xor(dia, o, 64);
         }
-        off = s.red[0];
-        __syncthreads();
-        s.red[tid] = dia;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st) s.red[tid] += s.red[tid + st];
-            __syncthreads();
+        if (lane == 0) {
+            s.red[wave] = off;
+            s.red[4 + wave] = dia;
         }
-        dia = s.red[0];
         __syncthreads();
-        if (off <= 1e-32 * dia || off == 0.0) break;
+        off = s.red[0] + s.red[1] + s.red[2] + s.red[3];
+        dia = s.red[4] + s.red[5] + s.red[6] + s.red[7];
+        __syncthreads();
+        // off-diagonal mass at the rounding floor of an n x n matrix: (n * eps)^2 * ||diag||^2
+        if (off <= 1.25e-32 * (double)(n * n) * dia || off == 0.0) break;
 
         for (int step = 0; step < m - 1; ++step) {
             if (tid < half) {
@@ -382,33 +381,40 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
                 s.pq[tid][1] = q;
             }
             __syncthreads();
-            // columns: A <- A J, E <- E J
-            for (int e = tid; e < half * m; e += 256) {
-                const int k = e / m, r = e - k * m;
-                const int p = s.pq[k][0], q = s.pq[k][1];
-                const double c = s.cs[k][0], sn = s.cs[k][1];
-                const double ap = s.a[r][p], aq = s.a[r][q];
-                s.a[r][p] = c * ap - sn * aq;
-                s.a[r][q] = sn * ap + c * aq;
-                const double ep = s.e[r][p], eq = s.e[r][q];
-                s.e[r][p] = c * ep - sn * eq;
-                s.e[r][q] = sn * ep + c * eq;
-            }
-            __syncthreads();
-            // rows: A <- J^T A
-            for (int e = tid; e < half * m; e += 256) {
-                const int k = e / m, r = e - k * m;
-                const int p = s.pq[k][0], q = s.pq[k][1];
-                const double c = s.cs[k][0], sn = s.cs[k][1];
-                const double ap = s.a[p][r], aq = s.a[q][r];
-                s.a[p][r] = c * ap - sn * aq;
-                s.a[q][r] = sn * ap + c * aq;
-            }
-            __syncthreads();
-            if (tid < half) {
-                const int p = s.pq[tid][0], q = s.pq[tid][1];
-                s.a[p][q] = 0.0;
-                s.a[q][p] = 0.0;
+            // work items: half*half 2x2 blocks of A, then m*half column pairs of E
+            const int nblk = half * half;
+            for (int e = tid; e < nblk + m * half; e += 256) {
+                if (e < nblk) {
+                    const int kr = e / half, kc = e - kr * half;
+                    const int p = s.pq[kr][0], q = s.pq[kr][1];
+                    const int pc = s.pq[kc][0], qc = s.pq[kc][1];
+                    const double c1 = s.cs[kr][0], s1 = s.cs[kr][1];
+                    const double c2 = s.cs[kc][0], s2 = s.cs[kc][1];
+                    const double a00 = s.a[p][pc], a01 = s.a[p][qc];
+                    const double a10 = s.a[q][pc], a11 = s.a[q][qc];
+                    // right: columns (pc, qc) <- (c2*x - s2*y, s2*x + c2*y)
+                    const double t00 = c2 * a00 - s2 * a01, t01 = s2 * a00 + c2 * a01;
+                    const double t10 = c2 * a10 - s2 * a11, t11 = s2 * a10 + c2 * a11;
+                    // left: rows (p, q) <- (c1*rp - s1*rq, s1*rp + c1*rq)
+                    double n00 = c1 * t00 - s1 * t10, n01 = c1 * t01 - s1 * t11;
+                    double n10 = s1 * t00 + c1 * t10, n11 = s1 * t01 + c1 * t11;
+                    if (kr == kc) {  // the rotated pair itself: annihilated exactly
+                        n01 = 0.0;
+                        n10 = 0.0;
+                    }
+                    s.a[p][pc] = n00;
+                    s.a[p][qc] = n01;
+                    s.a[q][pc] = n10;
+                    s.a[q][qc] = n11;
+                } else {
+                    const int f = e - nblk;
+                    const int r = f / half, kc = f - r * half;
+                    const int pc = s.pq[kc][0], qc = s.pq[kc][1];
+                    const double c2 = s.cs[kc][0], s2 = s.cs[kc][1];
+                    const double ep = s.e[r][pc], eq = s.e[r][qc];
+                    s.e[r][pc] = c2 * ep - s2 * eq;
+                    s.e[r][qc] = s2 * ep + c2 * eq;
+                }
             }
             __syncthreads();
         }
@@ -476,13 +482,23 @@ __global__ __launch_bounds__(256) void k_small_svqb(const double *__restrict__ g
     if (tid < k) mask[tid] = (wmax > 0.0 && s.w[tid] > drop_tol * wmax) ? 1 : 0;
 }
 
-// Rayleigh-Ritz: T (nq x nq) = Q^T A Q, mask marks live basis columns.
-// Output: c (nq x b) top-b eigenvectors, theta[0..b) their values, theta[b] the next one.
+// Rayleigh-Ritz: T (nq x nq) = Q^T A Q on an orthonormal basis Q = [X R P]; mask marks
+// live basis columns.  Outputs
+//   c (nq x b): top-b eigenvectors  -> X' = Q c,   theta[0..b) their values, theta[b] the next;
+//   d (nq x b): coefficients of the next search directions P' = Q d, orthonormal and
+//     orthogonal to X' *in coefficient space* (Q is orthonormal, so no tall Gram product is
+//     needed): start from the [R P] part of c (the LOBPCG direction), project out c twice,
+//     SVQB-orthonormalise with rank-revealing drop; mask_p[k] = 0 marks a dropped direction.
 __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm, int nq, int b,
                                                    const int *__restrict__ mask,
-                                                   double *__restrict__ c,
-                                                   double *__restrict__ theta) {
+                                                   double *__restrict__ c, double *__restrict__ d,
+                                                   double *__restrict__ theta,
+                                                   int *__restrict__ mask_p, double drop_tol) {
     __shared__ jacobi_lds s;
+    __shared__ double cc[3 * MAXB][MAXB];
+    __shared__ double dd[3 * MAXB][MAXB];
+    __shared__ double gg[MAXB][MAXB];
+    __shared__ double dsc[MAXB];
     const int tid = threadIdx.x;
     for (int e = tid; e < nq * nq; e += 256) {
         const int i = e / nq, j = e - i * nq;
@@ -495,9 +511,63 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
     jacobi_eig(s, nq);
     for (int e = tid; e < nq * b; e += 256) {
         const int i = e / b, k = e - i * b;
-        c[i * b + k] = s.e[i][s.perm[k]];
+        const double v = s.e[i][s.perm[k]];
+        cc[i][k] = v;
+        dd[i][k] = i >= b ? v : 0.0;
+        c[e] = v;
     }
     if (tid <= b && tid < nq) theta[tid] = s.w[tid];
+    __syncthreads();
+    if (nq == b) return;  // plain rotation of X (start-up / refresh): no search directions
+    // D <- (I - C C^T) D, twice
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int e = tid; e < b * b; e += 256) {
+            const int a = e / b, k = e - a * b;
+            double g = 0.0;
+            for (int i = 0; i < nq; ++i) g += cc[i][a] * dd[i][k];
+            gg[a][k] = g;
+        }
+        __syncthreads();
+        for (int e = tid; e < nq * b; e += 256) {
+            const int i = e / b, k = e - i * b;
+            double v = dd[i][k];
+            for (int a = 0; a < b; ++a) v -= cc[i][a] * gg[a][k];
+            dd[i][k] = v;
+        }
+        __syncthreads();
+    }
+    // SVQB on D (b columns in an nq-dimensional coefficient space)
+    for (int e = tid; e < b * b; e += 256) {
+        const int a = e / b, k = e - a * b;
+        double g = 0.0;
+        for (int i = 0; i < nq; ++i) g += dd[i][a] * dd[i][k];
+        gg[a][k] = g;
+    }
+    __syncthreads();
+    if (tid < b) dsc[tid] = gg[tid][tid] > 1e-290 ? 1.0 / sqrt(gg[tid][tid]) : 0.0;
+    __syncthreads();
+    for (int e = tid; e < b * b; e += 256) {
+        const int a = e / b, k = e - a * b;
+        s.a[a][k] = 0.5 * (gg[a][k] + gg[k][a]) * dsc[a] * dsc[k];
+    }
+    __syncthreads();
+    jacobi_eig(s, b);
+    const double wmax = s.w[0];
+    // transform T = diag(dsc) U Lambda^-1/2 (dropped columns zero), D_hat = D T
+    for (int e = tid; e < b * b; e += 256) {
+        const int a = e / b, k = e - a * b;
+        const double lam = s.w[k];
+        const bool keep = wmax > 0.0 && lam > drop_tol * wmax;
+        gg[a][k] = keep ? dsc[a] * s.e[a][s.perm[k]] / sqrt(lam) : 0.0;
+    }
+    if (tid < b) mask_p[tid] = (wmax > 0.0 && s.w[tid] > drop_tol * wmax) ? 1 : 0;
+    __syncthreads();
+    for (int e = tid; e < nq * b; e += 256) {
+        const int i = e / b, k = e - i * b;
+        double v = 0.0;
+        for (int a = 0; a < b; ++a) v += dd[i][a] * gg[a][k];
+        d[e] = v;
+    }
 }
 
 // dense S for the small-V path: s[i][j] = dinv[i] * w[i][j] * dinv[j], zero diagonal
@@ -646,7 +716,7 @@ struct solver {
 
     int update(double *y, int ldy, int kc, double alpha, const double *a, int lda, int ka,
                const double *c, int ldc, double sign) {
-        k_update<<<(n + 255) / 256, 256, 0, s>>>(y, ldy, kc, alpha, a, lda, ka, c, ldc, sign, n);
+        k_update<<<(n + 15) / 16, 256, 0, s>>>(y, ldy, kc, alpha, a, lda, ka, c, ldc, sign, n);
         SCS_HIP_CHECK(hipGetLastError());
         return SCS_OK;
     }
@@ -656,7 +726,8 @@ struct solver {
 constexpr int SM_G = 0;                         // up to 48 x 48
 constexpr int SM_T = SM_G + 48 * 48;            // svqb transform (<= 16 x 16) / rr coeffs (48 x 16)
 constexpr int SM_C = SM_T + 48 * 16;            // projection coefficients (<= 32 x 16)
-constexpr int SM_THETA = SM_C + 48 * 16;        // theta[0..b], padded
+constexpr int SM_D = SM_C + 48 * 16;            // search-direction coefficients (48 x 16)
+constexpr int SM_THETA = SM_D + 48 * 16;        // theta[0..b], padded
 constexpr int SM_RN = SM_THETA + 32;            // residual norms^2 [b]
 constexpr int SM_MASK = SM_RN + 32;             // int mask[48] (as 24 doubles)
 constexpr int SM_TOTAL = SM_MASK + 32;
@@ -831,9 +902,11 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_HIP_CHECK(hipMemsetAsync(sv.small.p, 0, (size_t)SM_TOTAL * 8, s));
 
     double *Q = sv.q.d(), *AQ = sv.aq.d();
-    double *X = Q, *R = Q + b, *P = Q + 2 * b;
-    double *AX = AQ, *AR = AQ + b, *AP = AQ + 2 * b;
+    // panel layout [X | P | R]: the blocks R is projected against are contiguous
+    double *X = Q, *R = Q + 2 * b;
+    double *AX = AQ;
     double *G = sv.small_at(SM_G), *T = sv.small_at(SM_T), *C = sv.small_at(SM_C);
+    double *D = sv.small_at(SM_D);
     double *TH = sv.small_at(SM_THETA), *RN = sv.small_at(SM_RN);
     int *MASK = (int *)sv.small_at(SM_MASK);
     const double drop_tol = 1e-13;
@@ -849,9 +922,9 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
     // project the constraint out of a panel block (twice) and SVQB-orthonormalise it;
     // companion (may be null) receives the same column transform
-    auto project_u = [&](double *Y) -> int {
+    auto project_u = [&](double *Y, int passes) -> int {
         if (!constrained) return SCS_OK;
-        for (int pass = 0; pass < 2; ++pass) {
+        for (int pass = 0; pass < passes; ++pass) {
             SCS_TRY(sv.gram(sv.u.d(), 1, 1, Y, q3, b, C, false));
             SCS_TRY(sv.update(Y, q3, b, 1.0, sv.u.d(), 1, 1, C, b, -1.0));
         }
@@ -873,23 +946,23 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
     // ---- start block
     k_init_block<<<(n * b + 255) / 256, 256, 0, s>>>(Q, b, n, x_init ? x0d.d() : nullptr);
-    SCS_TRY(project_u(X));
+    SCS_TRY(project_u(X, 2));
     SCS_TRY(svqb(X, nullptr, MASK));
     SCS_TRY(sv.apply(Q, 0, AQ, 0));
     // rotate X so that X^T A X is diagonal
     SCS_TRY(sv.gram(X, q3, b, AX, q3, b, G, sv.use_mfma));
     {
         k_fill_int<<<1, 64, 0, s>>>(MASK, 48, 1);
-        k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, TH);
+        k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, D, TH, MASK + b, drop_tol);
         SCS_TRY(sv.update(X, q3, b, 0.0, X, q3, b, T, b, 1.0));
         SCS_TRY(sv.update(AX, q3, b, 0.0, AX, q3, b, T, b, 1.0));
+        k_fill_int<<<1, 64, 0, s>>>(MASK + b, b, 0);  // no search directions yet
     }
 
     const int res_blocks = (n + 255) / 256;
     dbuf res_part;
     SCS_TRY(res_part.alloc((size_t)res_blocks * b * 8));
     std::vector<double> h_rn(b), h_th(b + 1);
-    bool have_p = false;
     int iter = 0;
     double best_res = 1e300;
     int since_best = 0;
@@ -925,9 +998,11 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 SCS_TRY(sv.apply(Q, 0, AQ, 0));
                 SCS_TRY(sv.gram(X, q3, b, AX, q3, b, G, sv.use_mfma));
                 k_fill_int<<<1, 64, 0, s>>>(MASK, 48, 1);
-                k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, TH);
+                k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, D, TH, MASK + b, drop_tol);
                 SCS_TRY(sv.update(X, q3, b, 0.0, X, q3, b, T, b, 1.0));
                 SCS_TRY(sv.update(AX, q3, b, 0.0, AX, q3, b, T, b, 1.0));
+                // restart the search directions after the refresh: P slot dead and zero
+                k_fill_int<<<1, 64, 0, s>>>(MASK + b, b, 0);
                 k_residual<<<res_blocks, 256, 0, s>>>(Q, AQ, b, TH, n, res_part.d());
                 k_reduce_partials<<<(b + 3) / 4, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
                 SCS_HIP_CHECK(hipMemcpyAsync(h_rn.data(), RN, (size_t)b * 8, hipMemcpyDeviceToHost, s));
@@ -937,7 +1012,6 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 double w2 = 0.0;
                 for (int j = 0; j < want; ++j) w2 = std::max(w2, std::sqrt(h_rn[j]));
                 for (int j = 0; j < want; ++j) final_res[constrained ? 1 : j] = std::sqrt(h_rn[j]);
-                have_p = false;  // restart the search direction after the refresh
                 if (w2 <= tol || (since_best >= 12 && w2 < 1e-9) || refreshes >= 3) {
                     converged = w2 <= tol;
                     break;
@@ -950,33 +1024,24 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             }
         }
 
-        // R <- orthonormal complement of [u, X] within span(R)
-        SCS_TRY(project_u(R));
+        // R <- orthonormal complement of [u, X, P] within span(R); P is orthonormal and
+        // orthogonal to X by construction (k_small_rr), dead P columns are zero vectors
+        // S u = u exactly, so R = S X - X theta inherits X's orthogonality to u; one
+        // pass keeps rounding drift from accumulating
+        SCS_TRY(project_u(R, 1));
         for (int pass = 0; pass < 2; ++pass) {
-            SCS_TRY(sv.gram(X, q3, b, R, q3, b, C, sv.use_mfma));
-            SCS_TRY(sv.update(R, q3, b, 1.0, X, q3, b, C, b, -1.0));
+            SCS_TRY(sv.gram(Q, q3, 2 * b, R, q3, b, C, sv.use_mfma));
+            SCS_TRY(sv.update(R, q3, b, 1.0, Q, q3, 2 * b, C, b, -1.0));
         }
-        SCS_TRY(svqb(R, nullptr, MASK + b));
-        SCS_TRY(sv.apply(Q, b, AQ, b));
+        SCS_TRY(svqb(R, nullptr, MASK + 2 * b));
+        SCS_TRY(sv.apply(Q, 2 * b, AQ, 2 * b));
 
-        int nq = 2 * b;
-        if (have_p) {
-            // P <- orthonormal complement of [X, R] within span(P); AP follows
-            for (int pass = 0; pass < 2; ++pass) {
-                SCS_TRY(sv.gram(Q, q3, 2 * b, P, q3, b, C, sv.use_mfma));
-                SCS_TRY(sv.update(P, q3, b, 1.0, Q, q3, 2 * b, C, b, -1.0));
-                SCS_TRY(sv.update(AP, q3, b, 1.0, AQ, q3, 2 * b, C, b, -1.0));
-            }
-            SCS_TRY(svqb(P, AP, MASK + 2 * b));
-            nq = 3 * b;
-        }
-        // Rayleigh-Ritz on the orthonormal basis
-        SCS_TRY(sv.gram(Q, q3, nq, AQ, q3, nq, G, sv.use_mfma));
-        k_small_rr<<<1, 256, 0, s>>>(G, nq, b, MASK, T, TH);
-        k_rr_update<<<(n + 255) / 256, 256, 0, s>>>(Q, b, nq, T, n);
-        k_rr_update<<<(n + 255) / 256, 256, 0, s>>>(AQ, b, nq, T, n);
+        // Rayleigh-Ritz on the orthonormal basis [X P R]; new X and new P in one pass each
+        SCS_TRY(sv.gram(Q, q3, q3, AQ, q3, q3, G, sv.use_mfma));
+        k_small_rr<<<1, 256, 0, s>>>(G, q3, b, MASK, T, D, TH, MASK + b, drop_tol);
+        k_rr_update<<<(n + 15) / 16, 256, 0, s>>>(Q, b, q3, T, D, n);
+        k_rr_update<<<(n + 15) / 16, 256, 0, s>>>(AQ, b, q3, T, D, n);
         SCS_HIP_CHECK(hipGetLastError());
-        have_p = true;
     }
 
     // ---- results
