@@ -158,7 +158,7 @@ struct acc_params {
 };
 
 template <int CPT, bool SYM>
-__global__ __launch_bounds__(SCS_TCW, (CPT == 1 ? 2 : 1)) void k_accumulate(acc_params p) {
+__global__ __launch_bounds__(SCS_TCW, (CPT == 1 ? 3 : 1)) void k_accumulate(acc_params p) {
     __shared__ int s_spos[64];
     __shared__ double s_gvw[64];
     __shared__ unsigned char s_sorig[64];
