@@ -132,7 +132,11 @@ int scs_tables_free(scs_ctx *ctx, scs_tables *tables);
  * adds in tree order.  Replaces _proper_cluster_graph_edges/_dfs_pcg_weights
  * (scs.py:495-663) and the dense fill loop (scs.py:246-250).
  * row_begin = 0, row_end = n_taxa with world == 1 uses the symmetric schedule.
- * flags: reserved, pass 0.  stats may be NULL. */
+ * flags: SCS_BUILD_MONOTONE promises that adj_val never decreases from an
+ * ancestor to a descendant inside any tree (true for `one`, `depth`, and for
+ * `branch` when no internal branch length is negative); it selects a cheaper
+ * kernel that produces the same bits.  Pass 0 when unsure.  stats may be NULL. */
+#define SCS_BUILD_MONOTONE 1
 int scs_pcg_build(scs_ctx *ctx, const scs_tables *tables, int32_t row_begin, int32_t row_end,
                   int32_t flags, scs_graph **out, scs_build_stats *stats);
 

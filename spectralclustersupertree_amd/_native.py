@@ -16,6 +16,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libscs_hip.so"
 
 UNIQUE_ID_BYTES = 128
+BUILD_MONOTONE = 1  # SCS_BUILD_MONOTONE
 
 
 class ScsError(RuntimeError):

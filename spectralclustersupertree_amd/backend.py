@@ -76,7 +76,7 @@ class Device:
                 nv.dptr(tables.tree_w), C.byref(handle),
             )
         )
-        return DeviceTables(self, handle, tables.n_taxa, tables.n_trees)
+        return DeviceTables(self, handle, tables.n_taxa, tables.n_trees, bool(tables.monotone))
 
     # -- building blocks exposed for the parity tests -----------------------
     def debug_jacobi(self, a: np.ndarray):
@@ -97,9 +97,10 @@ class Device:
 
 
 class DeviceTables:
-    def __init__(self, dev: Device, handle, n_taxa: int, n_trees: int) -> None:
+    def __init__(self, dev: Device, handle, n_taxa: int, n_trees: int, monotone: bool = False) -> None:
         self.dev, self._h = dev, handle
         self.n_taxa, self.n_trees = n_taxa, n_trees
+        self.monotone = monotone
 
     def free(self) -> None:
         if self._h:
@@ -118,7 +119,8 @@ class DeviceTables:
             row_end = self.n_taxa
         handle = C.c_void_p()
         stats = nv.BuildStats()
-        nv.check(self.dev._lib.scs_pcg_build(self.dev._ctx, self._h, row_begin, row_end, 0,
+        flags = nv.BUILD_MONOTONE if self.monotone else 0
+        nv.check(self.dev._lib.scs_pcg_build(self.dev._ctx, self._h, row_begin, row_end, flags,
                                              C.byref(handle), C.byref(stats)))
         return DeviceGraph(self.dev, handle, stats.as_dict())
 

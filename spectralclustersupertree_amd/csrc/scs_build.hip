@@ -320,6 +320,173 @@ __global__ __launch_bounds__(SCS_TCW, (CPT == 1 ? 3 : 1)) void k_accumulate(acc_
 }
 
 // ---------------------------------------------------------------------------
+// tile accumulate, monotone fast path
+// ---------------------------------------------------------------------------
+// When the weighting value never decreases from an ancestor to a descendant
+// (`one`, `depth`, and `branch` with non-negative lengths; the host sets
+// SCS_BUILD_MONOTONE), value(LCA) is itself a monotone image of the LCA depth:
+// the value of the shallower of two nodes on one root path is the smaller one.
+// The row-row table then only needs values, range minima can be taken over
+// values, and a cell is   acc += min(Dv[i][nb(c)], vn(c))   -- one LDS gather,
+// one v_min_f64, one v_add_f64.  Same addends in the same (tree) order as the
+// general kernel, hence the same bits.
+// The kernel is bound by dependent memory latency, not arithmetic: the per-tree record
+// and the column's DFS position are therefore requested one tree ahead (registers) so
+// that only the range-minimum chain of the column step is exposed.
+template <bool SYM, int MINW>
+__global__ __launch_bounds__(SCS_TCW, MINW) void k_accumulate_mono(acc_params p) {
+    __shared__ int s_spos[64];
+    __shared__ unsigned char s_sorig[64];
+    __shared__ unsigned char s_rank[64];
+    __shared__ int s_cnt;
+    __shared__ double s_sp[6][64];
+    __shared__ double s_dv[64][64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int2 tile = p.tiles[blockIdx.x];
+    const int blk = tile.x;
+    const int row0 = p.row_begin + blk * SCS_TR;
+    const int col = tile.y * SCS_TCW + tid;
+    const int nt = p.n_batch;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+
+    double acc[SCS_TR];
+#pragma unroll
+    for (int i = 0; i < SCS_TR; ++i) {
+        double v = 0.0;
+        if (p.load_w && col < p.n && row0 + i < p.row_end)
+            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
+        acc[i] = v;
+    }
+
+    const unsigned char *rec_base = p.rec + (int64_t)blk * nt * REC_BYTES;
+    // record of the next tree, requested one iteration ahead
+    int rr_i = 0, rr_cnt = 0;  // tid < 64: sorted position, row count
+    double rr_d = 0.0;         // tid < 64: gap value
+    unsigned char rr_c = 0;    // tid 64..127: sorted->row, tid 128..191: row->rank
+    int cpos_next = -1;
+    auto issue_record = [&](int tl) {
+        const unsigned char *rec = rec_base + (int64_t)tl * REC_BYTES;
+        if (tid < 64) {
+            rr_i = ((const int *)(rec + REC_SPOS))[tid];
+            rr_d = ((const double *)(rec + REC_GVW))[tid];
+            rr_cnt = *(const int *)(rec + REC_CNT);
+        } else if (tid < 128) {
+            rr_c = rec[REC_SORIG + tid - 64];
+        } else if (tid < 192) {
+            rr_c = rec[REC_RANK + tid - 128];
+        }
+        cpos_next = p.pos[(int64_t)tl * p.npad + col];
+    };
+    issue_record(0);
+
+    for (int tl = 0; tl < nt; ++tl) {
+        // ---- this tree's record -> LDS (wave 0 builds the min-table over the 63 gap
+        // values with shuffles), then request the next tree's
+        if (tid < 64) {
+            s_spos[tid] = rr_i;
+            double key = tid < rr_cnt - 1 ? rr_d : inf;
+            s_sp[0][tid] = key;
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                const double other = __shfl_down(key, 1 << (j - 1), 64);
+                if (tid + (1 << (j - 1)) < 64) key = other < key ? other : key;
+                s_sp[j][tid] = key;
+            }
+            if (tid == 0) s_cnt = rr_cnt;
+        } else if (tid < 128) {
+            s_sorig[tid - 64] = rr_c;
+        } else if (tid < 192) {
+            s_rank[tid - 128] = rr_c;
+        }
+        const int cpos = cpos_next;
+        if (tl + 1 < nt) issue_record(tl + 1);
+        __syncthreads();
+
+        // ---- column step, part 1: nearest tile rows in DFS order; the two range-minimum
+        // queries are issued now and fly while the table is expanded below
+        int lo = -1;
+        u64 gl = 0, gr = 0;
+        const int t = p.t0 + tl;
+        const int64_t off = p.tree_off[t];
+        const int cnt = s_cnt;
+        if (cpos >= 0 && cnt > 0) {
+            const int m = (int)(p.tree_off[t + 1] - off) - 1;
+            const u64 *st = p.st + p.st_off[tl];
+            lo = 0;
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1)
+                if (s_spos[lo + s - 1] < cpos) lo += s;
+            if (s_spos[lo] < cpos) lo += 1;
+            // (tiles whose columns overlap their rows go to the general kernel, so the
+            // column is never one of the tile's rows here)
+            if (lo > 0) gl = rmq_tree(st, m, s_spos[lo - 1], cpos);
+            if (lo < cnt) gr = rmq_tree(st, m, cpos, s_spos[lo]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- expand the row-row value table: wave w fills rows w, w+4, ...
+        {
+            const int rj = s_rank[lane];
+#pragma unroll 4
+            for (int i = wave; i < SCS_TR; i += 4) {
+                const int ri = s_rank[i];
+                double v = 0.0;
+                if (i == lane) {
+                    v = inf;  // min(inf, vn) = vn: the cell (nb, c) itself
+                } else if (ri != 255 && rj != 255) {
+                    const int a = ri < rj ? ri : rj;
+                    const int b = ri < rj ? rj : ri;
+                    const int k = 31 - __clz(b - a);
+                    const double x = s_sp[k][a];
+                    const double y = s_sp[k][b - (1 << k)];
+                    v = y < x ? y : x;
+                }
+                s_dv[i][lane] = v;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- column step, part 2: the neighbour with the deeper LCA and that LCA's value
+        int nb = 0;
+        double vn = 0.0;
+        if (lo >= 0) {
+            const bool left = lo > 0 && (lo >= cnt || (gl >> 32) >= (gr >> 32));
+            const u64 g = left ? gl : gr;
+            nb = s_sorig[left ? lo - 1 : lo];
+            if ((u32)(g >> 32)) vn = p.vw[off - p.leaf_base + (u32)(g & 0xFFFFFFFFu)];
+        }
+        __syncthreads();
+
+        // ---- 64 cells of this column: one gather, one min, one add each
+        const double *dv = &s_dv[0][nb];
+#pragma unroll
+        for (int i0 = 0; i0 < SCS_TR; i0 += 8) {
+#pragma unroll
+            for (int i = i0; i < i0 + 8; ++i) {
+                const double ev = dv[i * 64];
+                acc[i] += ev < vn ? ev : vn;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // at most eight gathers in flight
+        }
+        // (no barrier here: the record and min-table were last read before the barrier
+        // above, and the next expansion of s_dv waits behind the next iteration's barrier)
+    }
+
+    if (col < p.n) {
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) {
+            const int r = row0 + i;
+            if (r < p.row_end) {
+                p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
+                if (SYM && ((r / SCS_TCW) + 1) * SCS_TCW <= (col / SCS_TR) * SCS_TR)
+                    p.w[(int64_t)col * p.ld + r] = acc[i];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // contraction: consecutive index ranges -> one vertex, weight = max over members
 // ---------------------------------------------------------------------------
 __global__ void k_contract(const double *__restrict__ w, int64_t ld, int old_row_begin,
@@ -463,7 +630,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                              int32_t row_end, int32_t flags, scs_graph **out,
                              scs_build_stats *stats) {
     SCS_REQUIRE(ctx && tb && out, "scs_pcg_build: null argument");
-    SCS_REQUIRE(flags == 0, "scs_pcg_build: flags must be 0");
+    SCS_REQUIRE((flags & ~SCS_BUILD_MONOTONE) == 0, "scs_pcg_build: unknown flag bits 0x%x", flags);
+    const bool monotone = (flags & SCS_BUILD_MONOTONE) != 0 &&
+                          !(getenv("SCS_NO_MONOTONE") && atoi(getenv("SCS_NO_MONOTONE")));
     const int n = tb->n_taxa;
     SCS_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= n,
                 "scs_pcg_build: bad row range [%d, %d) for %d taxa", row_begin, row_end, n);
@@ -487,14 +656,21 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         }
     } gd{ctx, g};
 
-    // ---- tile list
-    std::vector<int2> tiles;
+    // ---- tile lists: tiles whose column range overlaps their row range (a column can be
+    // one of the tile's own rows) always take the general kernel
+    std::vector<int2> tiles, tiles_diag;
     tiles.reserve((size_t)n_blocks * n_cgroups);
     for (int b = 0; b < n_blocks; ++b)
         for (int c = 0; c < n_cgroups; ++c) {
             if (sym && (int64_t)(c + 1) * cols_per_tile <= (int64_t)b * SCS_TR) continue;
-            tiles.push_back(make_int2(b, c));
+            const int64_t r_lo = (int64_t)row_begin + (int64_t)b * SCS_TR, r_hi = r_lo + SCS_TR;
+            const int64_t c_lo = (int64_t)c * cols_per_tile, c_hi = c_lo + cols_per_tile;
+            const bool overlap = c_lo < r_hi && r_lo < c_hi;
+            if (monotone && cpt == 1 && overlap) tiles_diag.push_back(make_int2(b, c));
+            else tiles.push_back(make_int2(b, c));
         }
+    const size_t n_main = tiles.size();
+    tiles.insert(tiles.end(), tiles_diag.begin(), tiles_diag.end());
     dev_buf d_tiles;
     SCS_TRY(d_tiles.alloc(tiles.size() * sizeof(int2)));
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
@@ -593,7 +769,25 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         ap.load_w = bi > 0;
         SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
         const unsigned nt = (unsigned)tiles.size();
-        if (cpt == 1) {
+        if (monotone && cpt == 1) {
+            const unsigned n_fast = (unsigned)n_main, n_diag = (unsigned)(tiles.size() - n_main);
+            if (n_fast) {
+                static const int minw = getenv("SCS_ACC_MINW") ? atoi(getenv("SCS_ACC_MINW")) : 3;
+                if (minw >= 3) {
+                    if (sym) k_accumulate_mono<true, 3><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    else k_accumulate_mono<false, 3><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                } else {
+                    if (sym) k_accumulate_mono<true, 2><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    else k_accumulate_mono<false, 2><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                }
+            }
+            if (n_diag) {
+                acc_params ad = ap;
+                ad.tiles = (const int2 *)d_tiles.p + n_main;
+                if (sym) k_accumulate<1, true><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                else k_accumulate<1, false><<<n_diag, SCS_TCW, 0, s>>>(ad);
+            }
+        } else if (cpt == 1) {
             if (sym) k_accumulate<1, true><<<nt, SCS_TCW, 0, s>>>(ap);
             else k_accumulate<1, false><<<nt, SCS_TCW, 0, s>>>(ap);
         } else {

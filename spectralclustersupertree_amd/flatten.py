@@ -43,6 +43,10 @@ class TreeTables:
     adj_val: np.ndarray  # float64 [L]
     tree_w: np.ndarray  # float64 [M]
     taxa: list[str] | None = None  # id -> name (None for synthetic tables)
+    # True when the strategy value never decreases from an ancestor to a descendant in any
+    # tree (`one`, `depth`, `branch` without negative internal lengths): lets the device take
+    # its cheaper monotone kernel (same bits).  False is always safe.
+    monotone: bool = False
 
     @property
     def n_trees(self) -> int:
@@ -115,6 +119,8 @@ def flatten_trees(
     taxa = list(taxa)
     index = {name: i for i, name in enumerate(taxa)}
 
+    # value * tree_weight must not decrease along any root path: no negative tree weights
+    monotone = strategy in ("one", "depth", "branch") and all(float(w) >= 0 for w in weights)
     tree_off = [0]
     leaf_taxon: list[int] = []
     adj_depth: list[int] = []
@@ -159,6 +165,8 @@ def flatten_trees(
                     # missing support (reference: scs.py:656)
                     msg = "unsupported operand type(s) for *: 'NoneType' and 'float'"
                     raise TypeError(msg)
+                if strategy == "branch" and child.length is not None and child.length < 0:
+                    monotone = False
                 children_cache[id(child)] = ckids
                 stack.append([child, depth + 1, 0 if cval is None else cval, 0])
         # padding slot so adj_* share tree_off with leaf_taxon
@@ -177,6 +185,7 @@ def flatten_trees(
         adj_val=np.asarray(adj_val, dtype=np.float64),
         tree_w=np.asarray([float(w) for w in weights], dtype=np.float64),
         taxa=taxa,
+        monotone=monotone,
     )
     return tables
 

@@ -75,6 +75,7 @@ def relabel_for_contraction(tables: fl.TreeTables, groups: np.ndarray):
         adj_val=tables.adj_val,
         tree_w=tables.tree_w,
         taxa=None,
+        monotone=tables.monotone,
     )
     return relabelled, order.astype(np.int32), group_start
 

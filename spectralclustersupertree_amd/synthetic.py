@@ -71,7 +71,9 @@ def make_tables(
         msg = "scs_synth_tables failed (bad arguments or out of memory)"
         raise RuntimeError(msg)
     return TreeTables(n_taxa, tree_off, leaf_taxon, adj_depth, adj_val, tree_w,
-                      [taxon_name(i) for i in range(n_taxa)] if n_taxa <= 200000 else None)
+                      [taxon_name(i) for i in range(n_taxa)] if n_taxa <= 200000 else None,
+                      # Exp() branch lengths are positive: everything but bootstrap is monotone
+                      monotone=strategy != "bootstrap")
 
 
 STRATEGIES_INDEX = {"one": 0, "depth": 1, "branch": 2, "bootstrap": 3}

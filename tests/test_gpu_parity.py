@@ -93,6 +93,27 @@ def test_build_row_blocks_bit_exact(dev):
     _build_and_compare(dev, tables, [(0, 100), (100, 333), (64, 65), (7, 201)])
 
 
+def test_build_monotone_and_general_kernels_agree(dev, monkeypatch):
+    # the monotone fast path must give the bits of the general kernel (and of the oracle)
+    tables = synthetic.make_tables(31, 700, 15, "branch", leaves_per_tree=600, random_weights=True)
+    assert tables.monotone
+    w_fast = _build_and_compare(dev, tables)
+    tables.monotone = False
+    w_general = _build_and_compare(dev, tables)
+    assert np.array_equal(w_fast, w_general)
+
+
+def test_build_negative_lengths_and_weights_take_general_kernel(dev):
+    trees = [make_tree(s) for s in ["((a:1,b:1):-0.5,((c:1,d:1):2,e:1):0.25)", "(((a:1,c:1):1,b:1):1,(d:1,e:1):1)"]]
+    names = sorted(so._all_tips(trees))
+    t1 = fl.flatten_trees(trees, [1.0, 2.0], "branch", names)
+    assert not t1.monotone
+    _build_and_compare(dev, t1)
+    t2 = fl.flatten_trees(trees[1:], [-1.5], "depth", names)
+    assert not t2.monotone
+    _build_and_compare(dev, t2)
+
+
 def test_build_tiny_and_degenerate_trees(dev):
     trees = [make_tree(s) for s in ["(a,b)", "((a,b),c)", "(d,(e,(f,(g,(h,(a,b))))))", "(a,b,c,d)", "((a,b,c)x,(d,e))"]]
     names = sorted(so._all_tips(trees))
