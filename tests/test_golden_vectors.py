@@ -1,0 +1,97 @@
+"""Golden vectors (tests/golden/vectors, made by tests/golden/make_golden.py from the
+dict-based restatement of the reference + scikit-learn): the table-level oracle must
+reproduce them on the CPU, the HIP path on the GPU."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import scs_oracle as so
+from oracle import tables_oracle as to
+from spectralclustersupertree_amd import flatten as fl
+from spectralclustersupertree_amd.scs import relabel_for_contraction
+
+VEC_DIR = Path(__file__).resolve().parent / "golden" / "vectors"
+FILES = sorted(VEC_DIR.glob("*.npz"))
+
+
+def _tables(z):
+    return fl.TreeTables(int(z["n_taxa"]), z["tree_off"], z["leaf_taxon"], z["adj_depth"], z["adj_val"],
+                         z["tree_w"], None, bool(z["monotone"]))
+
+
+def _well_separated(z):
+    lam = z["lam"]
+    return lam[0] - lam[1] > 1e-6 and (len(lam) < 3 or lam[1] - lam[2] > 1e-6)
+
+
+def test_vectors_present():
+    assert len(FILES) >= 12
+
+
+@pytest.mark.parametrize("path", FILES, ids=lambda p: p.stem)
+def test_oracle_reproduces_golden(path):
+    z = np.load(path)
+    tables = _tables(z)
+    tables.validate()
+    w, _ = to.pcg_dense(tables)
+    assert np.array_equal(w, z["w"])
+    groups = z["groups"]
+    if groups.max() + 1 < tables.n_taxa:
+        assert np.array_equal(fl.contraction_groups(tables), groups)
+        work, perm, gs = relabel_for_contraction(tables, groups)
+        w2, _ = to.pcg_dense(work)
+        a = to.contract_dense(w2, gs)
+    else:
+        a = w
+    assert np.array_equal(a, z["a"])
+    if _well_separated(z):
+        maps = to.sign_flip_columns(so.spectral_maps(a, np.random.RandomState(int(z["seed"]))))
+        assert np.max(np.abs(maps - z["maps"])) <= 1e-12
+    labels = so.spectral_labels(a, np.random.RandomState(int(z["seed"])))
+    assert np.array_equal(labels, z["labels"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FILES, ids=lambda p: p.stem)
+def test_device_reproduces_golden(path):
+    from sklearn.cluster import k_means
+
+    from spectralclustersupertree_amd.backend import Device
+
+    z = np.load(path)
+    tables = _tables(z)
+    groups = z["groups"]
+    contracted = groups.max() + 1 < tables.n_taxa
+    with Device(0) as dev:
+        dtab = dev.upload(tables)
+        g = dtab.build()
+        assert np.array_equal(g.download(), z["w"])  # bit-exact
+        g.free()
+        dtab.free()
+        if contracted:
+            work, perm, gs = relabel_for_contraction(tables, groups)
+            dtab = dev.upload(work)
+            g = dtab.build().contract(gs)
+            dtab.free()
+        else:
+            dtab = dev.upload(tables)
+            g = dtab.build()
+            dtab.free()
+        assert np.array_equal(g.download(), z["a"])  # bit-exact
+        rs = np.random.RandomState(int(z["seed"]))
+        v0 = rs.uniform(-1, 1, z["a"].shape[0])
+        maps, stats = g.fiedler(v0)
+        g.free()
+    if _well_separated(z):
+        # north_star bar: Fiedler-vector entries within 1e-10 fp64
+        assert np.max(np.abs(maps - z["maps"])) <= 1e-10, stats
+        _, labels, _ = k_means(maps, 2, random_state=rs, n_init=10)
+        assert np.array_equal(labels, z["labels"])
+    else:
+        # repeated eigenvalue: only the invariant subspace is defined; check the residual
+        s, dd = to.normalized_operator(z["a"])
+        x = maps[:, 1] * dd
+        x /= np.linalg.norm(x)
+        assert np.linalg.norm(s @ x - (x @ s @ x) * x) <= 1e-10
