@@ -167,7 +167,10 @@ def main() -> int:
             buf = torch.frombuffer(bytearray(Device.unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(buf, 0)
         uid = bytes(buf.numpy().tobytes())
-    dev = Device(local_rank, rank, world, uid)
+    # SCS_BENCH_DEVICE pins every rank to one device index (single-GPU rehearsal of the
+    # multi-rank path); the driver's runs leave it unset: one GPU per local rank
+    dev_index = int(os.environ.get("SCS_BENCH_DEVICE", local_rank))
+    dev = Device(dev_index, rank, world, uid)
     splits = even_splits(n, world)
     rb, re_ = splits[rank], splits[rank + 1]
 

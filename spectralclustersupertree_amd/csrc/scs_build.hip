@@ -77,6 +77,14 @@ __global__ void k_sparse_level(const int64_t *__restrict__ tree_off, int t0, int
     base[(int64_t)k * m + p] = a < b ? a : b;
 }
 
+// one v_min_f64 (the builtin fmin adds a canonicalising v_max_f64 in front of it);
+// operands are finite non-negative values or +inf, so IEEE minNum semantics are moot
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ u64 rmq_tree(const u64 *__restrict__ st, int m, int a, int b) {
     // minimum over gaps [a, b), a < b <= m
     const int len = b - a;
@@ -333,8 +341,8 @@ __global__ __launch_bounds__(SCS_TCW, (CPT == 1 ? 3 : 1)) void k_accumulate(acc_
 // The kernel is bound by dependent memory latency, not arithmetic: the per-tree record
 // and the column's DFS position are therefore requested one tree ahead (registers) so
 // that only the range-minimum chain of the column step is exposed.
-template <bool SYM, int MINW>
-__global__ __launch_bounds__(SCS_TCW, MINW) void k_accumulate_mono(acc_params p) {
+template <bool SYM>
+__global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
     __shared__ int s_spos[64];
     __shared__ unsigned char s_sorig[64];
     __shared__ unsigned char s_rank[64];
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(SCS_TCW, MINW) void k_accumulate_mono(acc_params p)
 #pragma unroll
             for (int i = i0; i < i0 + 8; ++i) {
                 const double ev = dv[i * 64];
-                acc[i] += ev < vn ? ev : vn;
+                acc[i] += min_f64(ev, vn);
             }
             __builtin_amdgcn_sched_barrier(0);  // at most eight gathers in flight
         }
@@ -772,14 +780,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         if (monotone && cpt == 1) {
             const unsigned n_fast = (unsigned)n_main, n_diag = (unsigned)(tiles.size() - n_main);
             if (n_fast) {
-                static const int minw = getenv("SCS_ACC_MINW") ? atoi(getenv("SCS_ACC_MINW")) : 3;
-                if (minw >= 3) {
-                    if (sym) k_accumulate_mono<true, 3><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                    else k_accumulate_mono<false, 3><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                } else {
-                    if (sym) k_accumulate_mono<true, 2><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                    else k_accumulate_mono<false, 2><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                }
+                if (sym) k_accumulate_mono<true><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                else k_accumulate_mono<false><<<n_fast, SCS_TCW, 0, s>>>(ap);
             }
             if (n_diag) {
                 acc_params ad = ap;
