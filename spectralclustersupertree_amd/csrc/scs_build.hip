@@ -32,7 +32,10 @@ constexpr int REC_GVW = 512;      // f64[64]   value*w of that LCA (0 where dept
 constexpr int REC_SORIG = 1024;   // u8[64]    row (0..63) at sorted rank k
 constexpr int REC_RANK = 1088;    // u8[64]    sorted rank of row i (255 = absent)
 constexpr int REC_CNT = 1152;     // int32     rows present in the tree
-constexpr int REC_BYTES = 1168;
+constexpr int REC_M = 1156;       // int32     gaps of the tree (n_t - 1)
+constexpr int REC_STOFF = 1160;   // int64     offset of the tree's sparse table in the batch
+constexpr int REC_VWOFF = 1168;   // int64     offset of the tree's gaps in the batch vw array
+constexpr int REC_BYTES = 1184;
 constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------
@@ -140,7 +143,12 @@ __global__ __launch_bounds__(64) void k_block_records(
     ((double *)(rec + REC_GVW))[lane] = gvw;
     rec[REC_SORIG + lane] = (unsigned char)orig;
     rec[REC_RANK + orig] = present ? (unsigned char)lane : (unsigned char)255;
-    if (lane == 0) *(int *)(rec + REC_CNT) = cnt;
+    if (lane == 0) {
+        *(int *)(rec + REC_CNT) = cnt;
+        *(int *)(rec + REC_M) = m;
+        *(int64_t *)(rec + REC_STOFF) = st_off[tl];
+        *(int64_t *)(rec + REC_VWOFF) = off - leaf_base;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -163,6 +171,7 @@ struct acc_params {
     int n;       // V
     int row_begin, row_end;
     int load_w;  // 1: continue a sum started by an earlier batch
+    unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
 };
 
 template <int CPT, bool SYM>
@@ -341,14 +350,32 @@ __global__ __launch_bounds__(SCS_TCW, (CPT == 1 ? 3 : 1)) void k_accumulate(acc_
 // The kernel is bound by dependent memory latency, not arithmetic: the per-tree record
 // and the column's DFS position are therefore requested one tree ahead (registers) so
 // that only the range-minimum chain of the column step is exposed.
-template <bool SYM>
+constexpr int DV_LD = 65;  // leading dimension of the row-row table (doubles): with 65 a
+                           // lane's ds_read_b64 of row nb hits bank pair (nb + i) mod 32
+
+template <bool SYM, bool STAMPED>
 __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
     __shared__ int s_spos[64];
     __shared__ unsigned char s_sorig[64];
     __shared__ unsigned char s_rank[64];
-    __shared__ int s_cnt;
-    __shared__ double s_sp[6][64];
-    __shared__ double s_dv[64][64];
+    __shared__ int s_cnt, s_m;
+    __shared__ long long s_stoff, s_vwoff;
+    __shared__ double s_sp[64 * 7];  // [rank][level], stride 7: conflict-free gathers
+    __shared__ double s_dv[64 * DV_LD];
+
+    // phase timers of the STAMPED diagnostic build (SCS_ACC_STAMP=1; never timed)
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if (STAMPED) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            ts[k] += tnow - tprev;
+            tprev = tnow;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -370,21 +397,29 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
     }
 
     const unsigned char *rec_base = p.rec + (int64_t)blk * nt * REC_BYTES;
-    // record of the next tree, requested one iteration ahead
-    int rr_i = 0, rr_cnt = 0;  // tid < 64: sorted position, row count
-    double rr_d = 0.0;         // tid < 64: gap value
-    unsigned char rr_c = 0;    // tid 64..127: sorted->row, tid 128..191: row->rank
+    // record of the next tree, requested one step ahead
+    int rr_i = 0, rr_cnt = 0, rr_m = 0;  // tid < 64: sorted position; row count; tree gaps
+    double rr_d = 0.0;                   // tid < 64: gap value
+    long long rr_st = 0, rr_vw = 0;      // tid == 0: table / value offsets of the tree
+    unsigned char rr_c = 0;  // tid 64..127: sorted->row, tid 128..191: row->rank
     int cpos_next = -1;
     auto issue_record = [&](int tl) {
         const unsigned char *rec = rec_base + (int64_t)tl * REC_BYTES;
         if (tid < 64) {
             rr_i = ((const int *)(rec + REC_SPOS))[tid];
-            rr_d = ((const double *)(rec + REC_GVW))[tid];
+            rr_d = ((const double *)(rec + REC_GVW))[tid];  // 0 beyond the last real gap
             rr_cnt = *(const int *)(rec + REC_CNT);
+            if (tid == 0) {
+                rr_m = *(const int *)(rec + REC_M);
+                rr_st = *(const long long *)(rec + REC_STOFF);
+                rr_vw = *(const long long *)(rec + REC_VWOFF);
+            }
         } else if (tid < 128) {
             rr_c = rec[REC_SORIG + tid - 64];
         } else if (tid < 192) {
-            rr_c = rec[REC_RANK + tid - 128];
+            // absent rows get rank 63: every range that reaches it crosses a zero gap
+            const unsigned char r = rec[REC_RANK + tid - 128];
+            rr_c = r > 63 ? 63 : r;
         }
         cpos_next = p.pos[(int64_t)tl * p.npad + col];
     };
@@ -395,15 +430,20 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         // values with shuffles), then request the next tree's
         if (tid < 64) {
             s_spos[tid] = rr_i;
-            double key = tid < rr_cnt - 1 ? rr_d : inf;
-            s_sp[0][tid] = key;
+            double key = rr_d;
+            s_sp[tid * 7] = key;
 #pragma unroll
             for (int j = 1; j < 6; ++j) {
                 const double other = __shfl_down(key, 1 << (j - 1), 64);
-                if (tid + (1 << (j - 1)) < 64) key = other < key ? other : key;
-                s_sp[j][tid] = key;
+                if (tid + (1 << (j - 1)) < 64) key = min_f64(key, other);
+                s_sp[tid * 7 + j] = key;
             }
-            if (tid == 0) s_cnt = rr_cnt;
+            if (tid == 0) {
+                s_cnt = rr_cnt;
+                s_m = rr_m;
+                s_stoff = rr_st;
+                s_vwoff = rr_vw;
+            }
         } else if (tid < 128) {
             s_sorig[tid - 64] = rr_c;
         } else if (tid < 192) {
@@ -411,50 +451,54 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         }
         const int cpos = cpos_next;
         if (tl + 1 < nt) issue_record(tl + 1);
+        stamp(0);
         __syncthreads();
+        stamp(1);
 
         // ---- column step, part 1: nearest tile rows in DFS order; the two range-minimum
         // queries are issued now and fly while the table is expanded below
         int lo = -1;
         u64 gl = 0, gr = 0;
-        const int t = p.t0 + tl;
-        const int64_t off = p.tree_off[t];
         const int cnt = s_cnt;
         if (cpos >= 0 && cnt > 0) {
-            const int m = (int)(p.tree_off[t + 1] - off) - 1;
-            const u64 *st = p.st + p.st_off[tl];
+            const int m = s_m;
+            const u64 *st = p.st + s_stoff;
+            // count of tile rows before the column: eight independent pivot compares pick
+            // the octet, three dependent reads finish (instead of seven dependent reads)
             lo = 0;
 #pragma unroll
-            for (int s = 32; s > 0; s >>= 1)
-                if (s_spos[lo + s - 1] < cpos) lo += s;
-            if (s_spos[lo] < cpos) lo += 1;
+            for (int j = 0; j < 8; ++j) lo += (s_spos[8 * j + 7] < cpos) ? 8 : 0;
+            if (lo < 64) {
+#pragma unroll
+                for (int s = 4; s > 0; s >>= 1)
+                    if (s_spos[lo + s - 1] < cpos) lo += s;
+            }
             // (tiles whose columns overlap their rows go to the general kernel, so the
             // column is never one of the tile's rows here)
             if (lo > 0) gl = rmq_tree(st, m, s_spos[lo - 1], cpos);
             if (lo < cnt) gr = rmq_tree(st, m, cpos, s_spos[lo]);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- expand the row-row value table: wave w fills rows w, w+4, ...
+        stamp(2);
+        // ---- expand the row-row value table: wave w fills rows w, w+4, ...; entry (i, j)
+        // is the minimum gap value between the sorted ranks of rows i and j (0 as soon
+        // as one of them is absent), +inf on the diagonal
         {
             const int rj = s_rank[lane];
-#pragma unroll 4
+#pragma unroll 8
             for (int i = wave; i < SCS_TR; i += 4) {
                 const int ri = s_rank[i];
-                double v = 0.0;
-                if (i == lane) {
-                    v = inf;  // min(inf, vn) = vn: the cell (nb, c) itself
-                } else if (ri != 255 && rj != 255) {
-                    const int a = ri < rj ? ri : rj;
-                    const int b = ri < rj ? rj : ri;
-                    const int k = 31 - __clz(b - a);
-                    const double x = s_sp[k][a];
-                    const double y = s_sp[k][b - (1 << k)];
-                    v = y < x ? y : x;
-                }
-                s_dv[i][lane] = v;
+                const int a = min(ri, rj);
+                const int d = max(max(ri, rj) - a, 1);
+                const int a1 = min(a, 62);  // two absent rows: the zero gap 62
+                const int k = 31 - __clz(d);
+                const double x = s_sp[a1 * 7 + k];
+                const double y = s_sp[(a1 + d - (1 << k)) * 7 + k];
+                double v = min_f64(x, y);
+                if (i == lane) v = inf;  // min(inf, vn) = vn: the cell (nb, c) itself
+                s_dv[i * DV_LD + lane] = v;
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        stamp(3);
         // ---- column step, part 2: the neighbour with the deeper LCA and that LCA's value
         int nb = 0;
         double vn = 0.0;
@@ -462,25 +506,32 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
             const bool left = lo > 0 && (lo >= cnt || (gl >> 32) >= (gr >> 32));
             const u64 g = left ? gl : gr;
             nb = s_sorig[left ? lo - 1 : lo];
-            if ((u32)(g >> 32)) vn = p.vw[off - p.leaf_base + (u32)(g & 0xFFFFFFFFu)];
+            if ((u32)(g >> 32)) vn = p.vw[s_vwoff + (u32)(g & 0xFFFFFFFFu)];
         }
+        if (STAMPED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(4);
         __syncthreads();
+        stamp(5);
 
-        // ---- 64 cells of this column: one gather, one min, one add each
-        const double *dv = &s_dv[0][nb];
+        // ---- 64 cells of this column: row nb of the (symmetric) table is contiguous:
+        // one conflict-free ds_read_b64, one v_min_f64, one v_add_f64 per cell
+        const double *dv = &s_dv[nb * DV_LD];
 #pragma unroll
         for (int i0 = 0; i0 < SCS_TR; i0 += 8) {
 #pragma unroll
-            for (int i = i0; i < i0 + 8; ++i) {
-                const double ev = dv[i * 64];
-                acc[i] += min_f64(ev, vn);
-            }
-            __builtin_amdgcn_sched_barrier(0);  // at most eight gathers in flight
+            for (int i = i0; i < i0 + 8; ++i) acc[i] += min_f64(dv[i], vn);
+            __builtin_amdgcn_sched_barrier(0);  // at most eight reads in flight
         }
+        stamp(6);
         // (no barrier here: the record and min-table were last read before the barrier
-        // above, and the next expansion of s_dv waits behind the next iteration's barrier)
+        // above, and the next expansion of s_dv waits behind the next step's barrier)
     }
 
+    if (STAMPED && lane == 0 && p.stamps) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
+        atomicAdd(&p.stamps[7], 1ull);
+    }
     if (col < p.n) {
 #pragma unroll
         for (int i = 0; i < SCS_TR; ++i) {
@@ -775,13 +826,31 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         ap.row_begin = row_begin;
         ap.row_end = row_end;
         ap.load_w = bi > 0;
+        ap.stamps = nullptr;
         SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
         const unsigned nt = (unsigned)tiles.size();
         if (monotone && cpt == 1) {
             const unsigned n_fast = (unsigned)n_main, n_diag = (unsigned)(tiles.size() - n_main);
             if (n_fast) {
-                if (sym) k_accumulate_mono<true><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                else k_accumulate_mono<false><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
+                if (stamp) {
+                    dev_buf d_st8;
+                    SCS_TRY(d_st8.alloc(64));
+                    SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
+                    ap.stamps = (unsigned long long *)d_st8.p;
+                    if (sym) k_accumulate_mono<true, true><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    else k_accumulate_mono<false, true><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    unsigned long long h[8];
+                    SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
+                    SCS_HIP_CHECK(hipStreamSynchronize(s));
+                    const char *nm[7] = {"record->LDS", "barrier1", "bsearch+rmq issue", "expand", "wait rmq+vw", "barrier2", "cells"};
+                    double tot = 0;
+                    for (int i = 0; i < 7; ++i) tot += (double)h[i];
+                    for (int i = 0; i < 7; ++i)
+                        fprintf(stderr, "[stamp] %-18s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i], 100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
+                    ap.stamps = nullptr;
+                } else if (sym) k_accumulate_mono<true, false><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                else k_accumulate_mono<false, false><<<n_fast, SCS_TCW, 0, s>>>(ap);
             }
             if (n_diag) {
                 acc_params ad = ap;
