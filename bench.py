@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--tol", type=float, default=1e-13)
     ap.add_argument("--max-iter", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the short reference passes over the other single-GPU configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="target CPU time of each leg of the bounded cpu_baseline sample")
     return ap.parse_args()
@@ -126,29 +128,10 @@ def cpu_baseline(tables, graph, args, n, m):
     }
 
 
-def main() -> int:
-    args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    if args.gpus > 1 and world == 1:
-        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
-              f"--nproc-per-node {args.gpus}", file=sys.stderr)
-        return 2
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # host-side rendezvous only (gloo)
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
+def run_workload(name, args, dev, dist, rank, world, steps, warmup, full):
+    """Time `steps` passes of build + solve on one named workload; returns the report."""
     from spectralclustersupertree_amd import synthetic
-    from spectralclustersupertree_amd.backend import Device
 
-    name = args.workload or ("cfg2" if world == 1 else "cfg3")
     if name == "custom":
         n, m, strategy, rw, cfg_idx = args.taxa, args.trees, args.strategy, False, -1
     else:
@@ -157,20 +140,6 @@ def main() -> int:
     t_gen0 = time.perf_counter()
     tables = synthetic.make_tables(args.seed, n, m, strategy, random_weights=rw)
     t_gen = time.perf_counter() - t_gen0
-
-    uid = None
-    if world > 1:
-        import torch
-
-        buf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = torch.frombuffer(bytearray(Device.unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(buf, 0)
-        uid = bytes(buf.numpy().tobytes())
-    # SCS_BENCH_DEVICE pins every rank to one device index (single-GPU rehearsal of the
-    # multi-rank path); the driver's runs leave it unset: one GPU per local rank
-    dev_index = int(os.environ.get("SCS_BENCH_DEVICE", local_rank))
-    dev = Device(dev_index, rank, world, uid)
     splits = even_splits(n, world)
     rb, re_ = splits[rank], splits[rank + 1]
 
@@ -178,7 +147,6 @@ def main() -> int:
     dtab = dev.upload(tables)
     dev.synchronize()
     t_upload = time.perf_counter() - t_up0
-
     v0 = np.random.RandomState(args.seed).uniform(-1, 1, n)
 
     def barrier():
@@ -195,7 +163,7 @@ def main() -> int:
         graph.free()
         return None, maps, stats, bstats
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
 
     acc = {"apply_ms": 0.0, "n_apply": 0, "iters": 0, "build_ms": 0.0, "acc_ms": 0.0, "prep_ms": 0.0,
@@ -203,7 +171,7 @@ def main() -> int:
     barrier()
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    for _ in range(steps):
         _, maps, stats, bstats = one_step()
         acc["apply_ms"] += stats["apply_ms_total"]
         acc["n_apply"] += stats["n_apply"]
@@ -223,25 +191,19 @@ def main() -> int:
         elapsed = float(tt.item())
 
     maps, stats, bstats = last
-    steps = max(args.steps, 1)
+    steps = max(steps, 1)
     sec_per_step = elapsed / steps
     apply_avg_ms = acc["apply_ms"] / max(acc["n_apply"], 1)
     achieved = stats["apply_bytes"] / (apply_avg_ms * 1e-3) / 1e9 if apply_avg_ms > 0 else 0.0
-    cell_rate = bstats["cell_trees"] / (acc["acc_ms"] / steps * 1e-3) if acc["acc_ms"] > 0 else 0.0
+    acc_ms = acc["acc_ms"] / steps
+    cell_rate = bstats["cell_trees"] / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
+    build_bytes = bstats["bytes_w"] + bstats["bytes_tables"]
+    build_gbs = build_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
 
-    result = {
-        "metric": "top-level PCG build + Fiedler solve wall-time (s) at N taxa, 1/2/4/8 MI355X",
+    report = {
         "value": round(sec_per_step, 6),
-        "unit": "s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
         "ms_per_step": round(sec_per_step * 1e3, 3),
-        "higher_is_better": False,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
+        "steps": steps,
         "config": {
             "workload": (
                 f"BASELINE.json configs[{cfg_idx}]: synthetic {n} taxa / {m} random-join rooted trees, "
@@ -258,7 +220,8 @@ def main() -> int:
             "tol": args.tol,
         },
         "roofline": {
-            "kernel": f"k_symm<{stats['block']}> (S*X, the only kernel that streams W)",
+            "kernel": f"k_symm<{stats['block']}> (S*X: the kernel that streams the N x N matrix, "
+                      "HBM-bound stage of the path)",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -269,12 +232,25 @@ def main() -> int:
             "avg_launch_ms": round(apply_avg_ms, 5),
             "launches_per_step": acc["n_apply"] / steps,
         },
+        # the PCG accumulation is LDS/issue-bound by construction (0.5*V^2*M cell-tree
+        # evaluations against 8*V^2 bytes written once): its HBM fraction is reported as is
+        "roofline_build": {
+            "kernel": "k_accumulate_mono / k_accumulate (PCG weights; largest single kernel by time)",
+            "bound": "hbm",
+            "achieved": round(build_gbs, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(build_gbs / HBM_PEAK_GBS, 5),
+            "bytes_per_launch": build_bytes,
+            "avg_launch_ms": round(acc_ms, 3),
+            "cell_trees_per_launch": bstats["cell_trees"],
+            "cell_trees_per_s": round(cell_rate, 0),
+            "note": "not HBM-bound: limited by LDS gathers, VALU issue and L2 gather latency",
+        },
         "stages": {
             "build_ms": round(acc["build_ms"] / steps, 3),
             "build_prep_ms": round(acc["prep_ms"] / steps, 3),
-            "build_accumulate_ms": round(acc["acc_ms"] / steps, 3),
-            "build_cell_trees_per_s": round(cell_rate, 0),
-            "build_w_GBs": round(bstats["bytes_w"] / max(acc["build_ms"] / steps * 1e-3, 1e-9) / 1e9, 1),
+            "build_accumulate_ms": round(acc_ms, 3),
             "fiedler_ms": round(acc["solve_ms"] / steps, 3),
             "fiedler_symm_ms": round(acc["apply_ms"] / steps, 3),
             "lobpcg_iterations": acc["iters"] / steps,
@@ -286,13 +262,12 @@ def main() -> int:
             "tables_generate_s": round(t_gen, 3),
         },
     }
-
-    # HBM traffic of the dominant kernel from the committed PMC pass of this workload, if any
+    # HBM traffic of k_symm from the committed PMC pass of this workload, if any
     try:
         pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(name)
         if pmc and world == 1 and pmc["kernel"].startswith(f"k_symm<{stats['block']},"):
-            result["roofline"]["traffic"] = pmc["traffic"]
-            result["roofline"]["traffic_source"] = pmc["source"]
+            report["roofline"]["traffic"] = pmc["traffic"]
+            report["roofline"]["traffic_source"] = pmc["source"]
     except (OSError, ValueError, KeyError):
         pass
 
@@ -307,17 +282,90 @@ def main() -> int:
         for i, r in enumerate(rows):
             got = graph.download_rows(int(r), 1)[0]
             mismatch += int(np.count_nonzero(got != want[i]))
-        result["parity"] = {
+        report["parity"] = {
             "w_rows_checked": int(len(rows)),
             "w_cells_mismatched": mismatch,
             "fiedler_residual": stats2["resid"][1],
             "maps_repeatable": bool(np.array_equal(maps, maps2)),
         }
-        if not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(tables, graph, args, n, m)
+        if full and not args.no_cpu_baseline:
+            report["cpu_baseline"] = cpu_baseline(tables, graph, args, n, m)
         graph.free()
-
     dtab.free()
+    return report
+
+
+def main() -> int:
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if args.gpus > 1 and world == 1:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
+              f"--nproc-per-node {args.gpus}", file=sys.stderr)
+        return 2
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # host-side rendezvous only (gloo)
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from spectralclustersupertree_amd.backend import Device
+
+    uid = None
+    if world > 1:
+        import torch
+
+        buf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = torch.frombuffer(bytearray(Device.unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(buf, 0)
+        uid = bytes(buf.numpy().tobytes())
+    # SCS_BENCH_DEVICE pins every rank to one device index (single-GPU rehearsal of the
+    # multi-rank path); the driver's runs leave it unset: one GPU per local rank
+    dev_index = int(os.environ.get("SCS_BENCH_DEVICE", local_rank))
+    dev = Device(dev_index, rank, world, uid)
+
+    name = args.workload or ("cfg2" if world == 1 else "cfg3")
+    main_rep = run_workload(name, args, dev, dist, rank, world, args.steps, args.warmup, full=True)
+
+    result = {
+        "metric": "top-level PCG build + Fiedler solve wall-time (s) at N taxa, 1/2/4/8 MI355X",
+        "value": main_rep["value"],
+        "unit": "s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": main_rep["ms_per_step"],
+        "higher_is_better": False,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+    }
+    for key in ("config", "roofline", "roofline_build", "stages", "parity", "cpu_baseline"):
+        if key in main_rep:
+            result[key] = main_rep[key]
+
+    # the other single-GPU configurations of BASELINE.json, one short pass each, for
+    # reference (configs[3] is the workload the N > 1 runs use: its N = 1 time is the
+    # strong-scaling baseline)
+    if world == 1 and args.workload is None and not args.no_extra:
+        others = {}
+        for extra, st in (("cfg1", 3), ("cfg3", 1)):
+            try:
+                rep = run_workload(extra, args, dev, dist, rank, world, st, 1 if extra == "cfg1" else 0,
+                                   full=False)
+                others[extra] = {k: rep[k] for k in ("value", "steps", "config", "roofline",
+                                                     "roofline_build", "stages", "parity") if k in rep}
+            except Exception as exc:  # noqa: BLE001 - report, never hide the main line
+                others[extra] = {"error": str(exc)}
+        result["other_workloads"] = others
+
     dev.close()
     if dist is not None:
         dist.barrier()

@@ -852,7 +852,9 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
     const bool constrained = g->n_isolated == 0;
     const int want = constrained ? 1 : 2;
-    int b = block ? block : 8;
+    // default width: 4 while the panel kernels and the 3b x 3b Rayleigh-Ritz solve weigh
+    // against the SYMM stream, 8 once streaming W dominates (measured crossover ~ 16k)
+    int b = block ? block : (n >= 16384 ? 8 : 4);
     {
         const int allowed[] = {16, 12, 8, 4};
         const int cap = (n - 2) / 3;  // 3b basis vectors + the constraint must fit in V
