@@ -35,7 +35,10 @@ constexpr int REC_CNT = 1152;     // int32     rows present in the tree
 constexpr int REC_M = 1156;       // int32     gaps of the tree (n_t - 1)
 constexpr int REC_STOFF = 1160;   // int64     offset of the tree's sparse table in the batch
 constexpr int REC_VWOFF = 1168;   // int64     offset of the tree's gaps in the batch vw array
-constexpr int REC_BYTES = 1184;
+constexpr int REC_RANK63 = 1184;  // u8[64]    row -> rank with absent rows mapped to 63 (monotone kernel)
+constexpr int REC_SPV = 1248;     // f64[64*7] min-table over the gap values, [rank][level] (monotone kernel)
+constexpr int REC_PIV = 1248 + 64 * 7 * 8;  // int32[8] sorted positions 7, 15, ..., 63 (search pivots)
+constexpr int REC_BYTES = REC_PIV + 32;     // 4864
 constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------
@@ -139,10 +142,25 @@ __global__ __launch_bounds__(64) void k_block_records(
     }
     unsigned char *rec = rec_all + ((int64_t)blk * n_batch + tl) * REC_BYTES;
     ((int *)(rec + REC_SPOS))[lane] = spos;
+    if ((lane & 7) == 7) ((int *)(rec + REC_PIV))[lane >> 3] = spos;
     ((u32 *)(rec + REC_GDEPTH))[lane] = gdepth;
     ((double *)(rec + REC_GVW))[lane] = gvw;
     rec[REC_SORIG + lane] = (unsigned char)orig;
     rec[REC_RANK + orig] = present ? (unsigned char)lane : (unsigned char)255;
+    rec[REC_RANK63 + orig] = present ? (unsigned char)lane : (unsigned char)63;
+    {
+        // min-table over the gap values (0 beyond the last real gap), stored in the LDS
+        // layout of k_accumulate_mono so that staging it is a plain copy
+        double *spv = (double *)(rec + REC_SPV);
+        double key = gvw;
+        spv[lane * 7] = key;
+        for (int j = 1; j < 6; ++j) {
+            const double other = __shfl_down(key, 1 << (j - 1), 64);
+            if (lane + (1 << (j - 1)) < 64) key = other < key ? other : key;
+            spv[lane * 7 + j] = key;
+        }
+        spv[lane * 7 + 6] = 0.0;
+    }
     if (lane == 0) {
         *(int *)(rec + REC_CNT) = cnt;
         *(int *)(rec + REC_M) = m;
@@ -355,12 +373,9 @@ constexpr int DV_LD = 65;  // leading dimension of the row-row table (doubles): 
 
 template <bool SYM, bool STAMPED>
 __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
-    __shared__ int s_spos[64];
-    __shared__ unsigned char s_sorig[64];
-    __shared__ unsigned char s_rank[64];
-    __shared__ int s_cnt, s_m;
-    __shared__ long long s_stoff, s_vwoff;
-    __shared__ double s_sp[64 * 7];  // [rank][level], stride 7: conflict-free gathers
+    // block record of the current / next tree, staged by LDS-DMA (global_load_lds_dwordx4:
+    // no registers held across the step); same byte layout as in global memory
+    __shared__ __attribute__((aligned(16))) unsigned char s_rec[2][REC_BYTES];
     __shared__ double s_dv[64 * DV_LD];
 
     // phase timers of the STAMPED diagnostic build (SCS_ACC_STAMP=1; never timed)
@@ -397,86 +412,76 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
     }
 
     const unsigned char *rec_base = p.rec + (int64_t)blk * nt * REC_BYTES;
-    // record of the next tree, requested one step ahead
-    int rr_i = 0, rr_cnt = 0, rr_m = 0;  // tid < 64: sorted position; row count; tree gaps
-    double rr_d = 0.0;                   // tid < 64: gap value
-    long long rr_st = 0, rr_vw = 0;      // tid == 0: table / value offsets of the tree
-    unsigned char rr_c = 0;  // tid 64..127: sorted->row, tid 128..191: row->rank
     int cpos_next = -1;
-    auto issue_record = [&](int tl) {
+    // request tree tl's record into LDS buffer `b`: wave w copies bytes [1024 w, 1024 w + 1024),
+    // wave 0 also the tail; one 16-byte piece per lane, landing at base + 16 * lane
+    auto issue_record = [&](int tl, int b) {
         const unsigned char *rec = rec_base + (int64_t)tl * REC_BYTES;
-        if (tid < 64) {
-            rr_i = ((const int *)(rec + REC_SPOS))[tid];
-            rr_d = ((const double *)(rec + REC_GVW))[tid];  // 0 beyond the last real gap
-            rr_cnt = *(const int *)(rec + REC_CNT);
-            if (tid == 0) {
-                rr_m = *(const int *)(rec + REC_M);
-                rr_st = *(const long long *)(rec + REC_STOFF);
-                rr_vw = *(const long long *)(rec + REC_VWOFF);
-            }
-        } else if (tid < 128) {
-            rr_c = rec[REC_SORIG + tid - 64];
-        } else if (tid < 192) {
-            // absent rows get rank 63: every range that reaches it crosses a zero gap
-            const unsigned char r = rec[REC_RANK + tid - 128];
-            rr_c = r > 63 ? 63 : r;
-        }
+        typedef __attribute__((address_space(3))) void *lds_ptr;
+        __builtin_amdgcn_global_load_lds((const void *)(rec + tid * 16),
+                                         (lds_ptr)(s_rec[b] + wave * 1024), 16, 0, 0);
+        if (wave == 0 && lane < (REC_BYTES - 4096) / 16)
+            __builtin_amdgcn_global_load_lds((const void *)(rec + 4096 + lane * 16),
+                                             (lds_ptr)(s_rec[b] + 4096), 16, 0, 0);
         cpos_next = p.pos[(int64_t)tl * p.npad + col];
     };
-    issue_record(0);
+    issue_record(0, 0);
 
     for (int tl = 0; tl < nt; ++tl) {
-        // ---- this tree's record -> LDS (wave 0 builds the min-table over the 63 gap
-        // values with shuffles), then request the next tree's
-        if (tid < 64) {
-            s_spos[tid] = rr_i;
-            double key = rr_d;
-            s_sp[tid * 7] = key;
-#pragma unroll
-            for (int j = 1; j < 6; ++j) {
-                const double other = __shfl_down(key, 1 << (j - 1), 64);
-                if (tid + (1 << (j - 1)) < 64) key = min_f64(key, other);
-                s_sp[tid * 7 + j] = key;
-            }
-            if (tid == 0) {
-                s_cnt = rr_cnt;
-                s_m = rr_m;
-                s_stoff = rr_st;
-                s_vwoff = rr_vw;
-            }
-        } else if (tid < 128) {
-            s_sorig[tid - 64] = rr_c;
-        } else if (tid < 192) {
-            s_rank[tid - 128] = rr_c;
-        }
+        const unsigned char *rb = s_rec[tl & 1];
+        const int *s_spos = (const int *)(rb + REC_SPOS);
+        const unsigned char *s_sorig = rb + REC_SORIG;
+        const unsigned char *s_rank = rb + REC_RANK63;
+        const double *s_sp = (const double *)(rb + REC_SPV);
+        const int *s_piv = (const int *)(rb + REC_PIV);
+        // the DMA of this tree's record was issued a whole step ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int cpos = cpos_next;
-        if (tl + 1 < nt) issue_record(tl + 1);
         stamp(0);
         __syncthreads();
         stamp(1);
 
-        // ---- column step, part 1: nearest tile rows in DFS order; the two range-minimum
-        // queries are issued now and fly while the table is expanded below
-        int lo = -1;
-        u64 gl = 0, gr = 0;
-        const int cnt = s_cnt;
-        if (cpos >= 0 && cnt > 0) {
-            const int m = s_m;
-            const u64 *st = p.st + s_stoff;
-            // count of tile rows before the column: eight independent pivot compares pick
-            // the octet, three dependent reads finish (instead of seven dependent reads)
-            lo = 0;
+        // ---- column step, part 1: nearest tile rows in DFS order.  Branch-free, and the
+        // four sparse-table loads of the two range-minimum queries are only ISSUED here
+        // (raw values, combined in part 2) so that they fly while the table is expanded
+        const int cnt = *(const int *)(rb + REC_CNT);
+        const bool present = cpos >= 0 && cnt > 0;
+        int lo;
+        {
+            // count of tile rows before the column: eight pivots (every eighth sorted
+            // position, two independent 16-byte reads) pick the octet, three dependent
+            // reads finish the count
+            const int4 pa = *(const int4 *)&s_piv[0];
+            const int4 pb = *(const int4 *)&s_piv[4];
+            lo = ((pa.x < cpos) + (pa.y < cpos) + (pa.z < cpos) + (pa.w < cpos) + (pb.x < cpos) +
+                  (pb.y < cpos) + (pb.z < cpos) + (pb.w < cpos)) * 8;
+            const int base = min(lo, 56);  // lo == 64: all rows precede; reads stay in range
+            int l2 = base;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) lo += (s_spos[8 * j + 7] < cpos) ? 8 : 0;
-            if (lo < 64) {
-#pragma unroll
-                for (int s = 4; s > 0; s >>= 1)
-                    if (s_spos[lo + s - 1] < cpos) lo += s;
-            }
-            // (tiles whose columns overlap their rows go to the general kernel, so the
-            // column is never one of the tile's rows here)
-            if (lo > 0) gl = rmq_tree(st, m, s_spos[lo - 1], cpos);
-            if (lo < cnt) gr = rmq_tree(st, m, cpos, s_spos[lo]);
+            for (int s = 4; s > 0; s >>= 1)
+                if (s_spos[l2 + s - 1] < cpos) l2 += s;
+            lo = lo == 64 ? 64 : l2;
+        }
+        const bool hasl = present && lo > 0;
+        const bool hasr = present && lo < cnt;
+        // (tiles whose columns overlap their rows go to the general kernel, so the column
+        // is never one of the tile's rows here)
+        u64 xl, yl, xr, yr;
+        {
+            const int ql = s_spos[max(lo - 1, 0)];
+            const int qr = s_spos[min(lo, 63)];
+            const int m = *(const int *)(rb + REC_M);
+            const u64 *st = p.st + *(const long long *)(rb + REC_STOFF);
+            // left query: gaps [ql, cpos); right query: gaps [cpos, qr); a side that does
+            // not exist reads entry 0 of the tree's level 0 (always there) and is ignored
+            const int al = hasl ? ql : 0, bl = hasl ? cpos : 1;
+            const int ar = hasr ? cpos : 0, br = hasr ? qr : 1;
+            const int kl = 31 - __clz(bl - al), kr = 31 - __clz(br - ar);
+            const u64 *ll = st + (int64_t)kl * m, *lr = st + (int64_t)kr * m;
+            xl = ll[al];
+            yl = ll[bl - (1 << kl)];
+            xr = lr[ar];
+            yr = lr[br - (1 << kr)];
         }
         stamp(2);
         // ---- expand the row-row value table: wave w fills rows w, w+4, ...; entry (i, j)
@@ -484,8 +489,11 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         // as one of them is absent), +inf on the diagonal
         {
             const int rj = s_rank[lane];
+            // constant trip count, eight rows per batch: the rank reads, gathers and writes
+            // of different rows overlap instead of serialising (sixteen at once spills)
 #pragma unroll 8
-            for (int i = wave; i < SCS_TR; i += 4) {
+            for (int kk = 0; kk < SCS_TR / 4; ++kk) {
+                const int i = wave + 4 * kk;
                 const int ri = s_rank[i];
                 const int a = min(ri, rj);
                 const int d = max(max(ri, rj) - a, 1);
@@ -499,19 +507,27 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
             }
         }
         stamp(3);
-        // ---- column step, part 2: the neighbour with the deeper LCA and that LCA's value
+        // ---- column step, part 2: combine the loads; the neighbour with the deeper LCA
+        // and that LCA's value
         int nb = 0;
         double vn = 0.0;
-        if (lo >= 0) {
-            const bool left = lo > 0 && (lo >= cnt || (gl >> 32) >= (gr >> 32));
+        if (hasl || hasr) {
+            const u64 gl = hasl ? (xl < yl ? xl : yl) : 0;
+            const u64 gr = hasr ? (xr < yr ? xr : yr) : 0;
+            const bool left = hasl && (!hasr || (gl >> 32) >= (gr >> 32));
             const u64 g = left ? gl : gr;
             nb = s_sorig[left ? lo - 1 : lo];
-            if ((u32)(g >> 32)) vn = p.vw[s_vwoff + (u32)(g & 0xFFFFFFFFu)];
+            if ((u32)(g >> 32)) vn = p.vw[*(const long long *)(rb + REC_VWOFF) + (u32)(g & 0xFFFFFFFFu)];
         }
         if (STAMPED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(4);
         __syncthreads();
         stamp(5);
+        // request the next tree's record now: the cell loop below only reads s_dv, so no
+        // wait on this DMA is needed until the top of the next step (the compiler orders
+        // every read of s_rec behind pending DMA into s_rec); the other buffer was last
+        // read before the barrier above
+        if (tl + 1 < nt) issue_record(tl + 1, (tl + 1) & 1);
 
         // ---- 64 cells of this column: row nb of the (symmetric) table is contiguous:
         // one conflict-free ds_read_b64, one v_min_f64, one v_add_f64 per cell
@@ -782,7 +798,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         }
         const size_t need_pos = (size_t)nb * npad * 4;
         const size_t need_vw = (size_t)leaves * 8;
-        const size_t need_st = (size_t)st_off[nb] * 8;
+        const size_t need_st = (size_t)st_off[nb] * 8 + 64;  // +64: a tree without gaps may be probed at entry 0
         const size_t need_stoff = (size_t)(nb + 1) * 8;
         const size_t need_rec = (size_t)n_blocks * nb * REC_BYTES;
         if (need_pos > cap_pos) { SCS_TRY(d_pos.alloc(need_pos)); cap_pos = need_pos; }
