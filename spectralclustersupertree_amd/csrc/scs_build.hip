@@ -192,8 +192,9 @@ struct acc_params {
     unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
 };
 
-template <int CPT, bool SYM>
-__global__ __launch_bounds__(SCS_TCW, (CPT == 1 ? 3 : 1)) void k_accumulate(acc_params p) {
+template <bool SYM>
+__global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
+    constexpr int CPT = 1;  // columns per thread
     __shared__ int s_spos[64];
     __shared__ double s_gvw[64];
     __shared__ unsigned char s_sorig[64];
@@ -716,8 +717,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     const bool sym = (row_begin == 0 && row_end == n && ctx->comm.world == 1);
     const int rows = row_end - row_begin;
     const int n_blocks = (rows + SCS_TR - 1) / SCS_TR;
-    const int cpt = (getenv("SCS_BUILD_CPT") && atoi(getenv("SCS_BUILD_CPT")) == 2) ? 2 : 1;
-    const int cols_per_tile = SCS_TCW * cpt;
+    const int cols_per_tile = SCS_TCW;
     const int n_cgroups = (n + cols_per_tile - 1) / cols_per_tile;
     const int64_t npad = scs_round_up(n, SCS_NPAD);
 
@@ -741,7 +741,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             const int64_t r_lo = (int64_t)row_begin + (int64_t)b * SCS_TR, r_hi = r_lo + SCS_TR;
             const int64_t c_lo = (int64_t)c * cols_per_tile, c_hi = c_lo + cols_per_tile;
             const bool overlap = c_lo < r_hi && r_lo < c_hi;
-            if (monotone && cpt == 1 && overlap) tiles_diag.push_back(make_int2(b, c));
+            if (monotone && overlap) tiles_diag.push_back(make_int2(b, c));
             else tiles.push_back(make_int2(b, c));
         }
     const size_t n_main = tiles.size();
@@ -845,7 +845,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         ap.stamps = nullptr;
         SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
         const unsigned nt = (unsigned)tiles.size();
-        if (monotone && cpt == 1) {
+        if (monotone) {
             const unsigned n_fast = (unsigned)n_main, n_diag = (unsigned)(tiles.size() - n_main);
             if (n_fast) {
                 static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
@@ -871,15 +871,12 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             if (n_diag) {
                 acc_params ad = ap;
                 ad.tiles = (const int2 *)d_tiles.p + n_main;
-                if (sym) k_accumulate<1, true><<<n_diag, SCS_TCW, 0, s>>>(ad);
-                else k_accumulate<1, false><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                if (sym) k_accumulate<true><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                else k_accumulate<false><<<n_diag, SCS_TCW, 0, s>>>(ad);
             }
-        } else if (cpt == 1) {
-            if (sym) k_accumulate<1, true><<<nt, SCS_TCW, 0, s>>>(ap);
-            else k_accumulate<1, false><<<nt, SCS_TCW, 0, s>>>(ap);
         } else {
-            if (sym) k_accumulate<2, true><<<nt, SCS_TCW, 0, s>>>(ap);
-            else k_accumulate<2, false><<<nt, SCS_TCW, 0, s>>>(ap);
+            if (sym) k_accumulate<true><<<nt, SCS_TCW, 0, s>>>(ap);
+            else k_accumulate<false><<<nt, SCS_TCW, 0, s>>>(ap);
         }
         SCS_HIP_CHECK(hipGetLastError());
         SCS_HIP_CHECK(hipEventRecord(ev_acc.b, s));
