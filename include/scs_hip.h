@@ -64,14 +64,14 @@ typedef struct scs_build_stats {
     int32_t n_taxa;
     int32_t n_trees;
     int32_t row_begin, row_end; /* rows of W this rank owns                          */
-    int32_t symmetric;          /* 1: upper tiles computed, lower mirrored           */
+    int32_t symmetric;          /* 1: upper tiles computed, lower mirrored; 2: shared */
     int32_t n_tiles;            /* workgroups of the accumulate kernel per batch     */
     int32_t n_batches;          /* tree batches (scratch bounded by ctx workspace)   */
     int32_t reserved;
     double cell_trees;          /* (matrix cell, tree) evaluations performed         */
     double prep_ms;             /* position / sparse-table / block-record kernels    */
     double accumulate_ms;       /* the tile accumulate kernel(s)                     */
-    double degree_ms;           /* row-sum kernel                                    */
+    double exchange_ms;         /* shared build: tile all-gather + unpack            */
     double total_ms;            /* whole call, device time                           */
     double bytes_w;             /* algorithmic bytes: W written once (8 * rows * V)  */
     double bytes_tables;        /* algorithmic bytes: tables read once               */
@@ -135,8 +135,16 @@ int scs_tables_free(scs_ctx *ctx, scs_tables *tables);
  * flags: SCS_BUILD_MONOTONE promises that adj_val never decreases from an
  * ancestor to a descendant inside any tree (true for `one`, `depth`, and for
  * `branch` when no internal branch length is negative); it selects a cheaper
- * kernel that produces the same bits.  Pass 0 when unsure.  stats may be NULL. */
+ * kernel that produces the same bits.  Pass 0 when unsure.
+ * SCS_BUILD_SHARED (collective, world > 1, every rank passes it or none does):
+ * instead of every rank evaluating all the cells of its own rows -- each
+ * off-diagonal cell twice across the job -- the ranks split the upper-triangle
+ * tiles of the whole matrix round-robin, all-gather the packed tiles and unpack
+ * their own rows (direct cells and mirror images).  Same bits, half the
+ * evaluations, one exchange of ~4 V^2 bytes per rank; falls back to the plain row
+ * build when the packed triangle would exceed 96 GiB.  stats may be NULL. */
 #define SCS_BUILD_MONOTONE 1
+#define SCS_BUILD_SHARED 2
 int scs_pcg_build(scs_ctx *ctx, const scs_tables *tables, int32_t row_begin, int32_t row_end,
                   int32_t flags, scs_graph **out, scs_build_stats *stats);
 

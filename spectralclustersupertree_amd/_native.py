@@ -17,6 +17,7 @@ LIB_PATH = _PKG / "libscs_hip.so"
 
 UNIQUE_ID_BYTES = 128
 BUILD_MONOTONE = 1  # SCS_BUILD_MONOTONE
+BUILD_SHARED = 2  # SCS_BUILD_SHARED
 
 
 class ScsError(RuntimeError):
@@ -65,7 +66,7 @@ class BuildStats(C.Structure):
         ("cell_trees", C.c_double),
         ("prep_ms", C.c_double),
         ("accumulate_ms", C.c_double),
-        ("degree_ms", C.c_double),
+        ("exchange_ms", C.c_double),
         ("total_ms", C.c_double),
         ("bytes_w", C.c_double),
         ("bytes_tables", C.c_double),

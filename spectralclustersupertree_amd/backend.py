@@ -113,13 +113,23 @@ class DeviceTables:
         except Exception:  # noqa: BLE001
             pass
 
-    def build(self, row_begin: int = 0, row_end: int | None = None) -> "DeviceGraph":
-        """Rows [row_begin, row_end) of W (reference: scs.py:495-663)."""
+    def build(self, row_begin: int = 0, row_end: int | None = None,
+              shared: bool | None = None) -> "DeviceGraph":
+        """Rows [row_begin, row_end) of W (reference: scs.py:495-663).
+
+        ``shared`` (default: on whenever the device belongs to a multi-rank job) makes the
+        call collective: the ranks split the upper-triangle tiles, exchange them and keep
+        their own rows, so no cell is evaluated twice across the job.
+        """
         if row_end is None:
             row_end = self.n_taxa
         handle = C.c_void_p()
         stats = nv.BuildStats()
         flags = nv.BUILD_MONOTONE if self.monotone else 0
+        if shared is None:
+            shared = self.dev.world > 1
+        if shared:
+            flags |= nv.BUILD_SHARED
         nv.check(self.dev._lib.scs_pcg_build(self.dev._ctx, self._h, row_begin, row_end, flags,
                                              C.byref(handle), C.byref(stats)))
         return DeviceGraph(self.dev, handle, stats.as_dict())

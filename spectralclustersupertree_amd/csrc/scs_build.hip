@@ -189,6 +189,8 @@ struct acc_params {
     int n;       // V
     int row_begin, row_end;
     int load_w;  // 1: continue a sum started by an earlier batch
+    double *tile_out;  // shared multi-rank build: packed 64 x 256 tiles instead of W (else null)
+    int slot_base;     // slot of this launch's first tile in tile_out
     unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
 };
 
@@ -220,7 +222,9 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
 #pragma unroll
         for (int i = 0; i < SCS_TR; ++i) {
             double v = 0.0;
-            if (p.load_w && col[q] < p.n && row0 + i < p.row_end)
+            if (p.load_w && p.tile_out)
+                v = p.tile_out[((int64_t)(p.slot_base + blockIdx.x) * SCS_TR + i) * SCS_TCW + tid];
+            else if (p.load_w && col[q] < p.n && row0 + i < p.row_end)
                 v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col[q]];
             acc[q][i] = v;
         }
@@ -335,7 +339,14 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
         }
     }
 
-    // ---- write the tile once (and its mirror image in the symmetric schedule)
+    // ---- write the tile once: packed (shared multi-rank build) or straight into W, with
+    // its mirror image in the symmetric schedule
+    if (p.tile_out) {
+        double *tp = p.tile_out + (int64_t)(p.slot_base + blockIdx.x) * SCS_TR * SCS_TCW + tid;
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) tp[i * SCS_TCW] = acc[0][i];
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < CPT; ++q) {
         const int c = col[q];
@@ -407,7 +418,9 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
 #pragma unroll
     for (int i = 0; i < SCS_TR; ++i) {
         double v = 0.0;
-        if (p.load_w && col < p.n && row0 + i < p.row_end)
+        if (p.load_w && p.tile_out)
+            v = p.tile_out[((int64_t)(p.slot_base + blockIdx.x) * SCS_TR + i) * SCS_TCW + tid];
+        else if (p.load_w && col < p.n && row0 + i < p.row_end)
             v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
         acc[i] = v;
     }
@@ -549,7 +562,11 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
         atomicAdd(&p.stamps[7], 1ull);
     }
-    if (col < p.n) {
+    if (p.tile_out) {
+        double *tp = p.tile_out + (int64_t)(p.slot_base + blockIdx.x) * SCS_TR * SCS_TCW + tid;
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) tp[i * SCS_TCW] = acc[i];
+    } else if (col < p.n) {
 #pragma unroll
         for (int i = 0; i < SCS_TR; ++i) {
             const int r = row0 + i;
@@ -559,6 +576,37 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
                     p.w[(int64_t)col * p.ld + r] = acc[i];
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// shared multi-rank build: gathered upper-triangle tiles -> this rank's rows of W
+// ---------------------------------------------------------------------------
+// Tile t of the global upper-triangle list was computed by rank t % world into slot
+// t / world of that rank's chunk of `gathered`.  A rank copies the cells of every tile
+// that fall into its rows, and -- for cells no tile owns directly -- the transposed
+// image of the tile's cells whose COLUMN falls into its rows.
+__global__ __launch_bounds__(256) void k_unpack_tiles(const double *__restrict__ gathered,
+                                                      const int2 *__restrict__ tiles, int world,
+                                                      int64_t chunk_doubles, int n, int row_begin,
+                                                      int row_end, double *__restrict__ w,
+                                                      int64_t ld) {
+    const int t = blockIdx.x;
+    const int2 tile = tiles[t];
+    const double *src = gathered + (int64_t)(t % world) * chunk_doubles +
+                        (int64_t)(t / world) * SCS_TR * SCS_TCW;
+    const int c = tile.y * SCS_TCW + threadIdx.x;  // global column of this thread
+    if (c >= n) return;
+    const int r0 = tile.x * SCS_TR;
+    const bool col_is_my_row = c >= row_begin && c < row_end;
+    for (int i = 0; i < SCS_TR; ++i) {
+        const int r = r0 + i;
+        if (r >= n) break;
+        const double v = src[i * SCS_TCW + threadIdx.x];
+        if (r >= row_begin && r < row_end) w[(int64_t)(r - row_begin) * ld + c] = v;
+        // cell (c, r) has no tile of its own iff its column group ends at or before its row block
+        if (col_is_my_row && ((r / SCS_TCW) + 1) * SCS_TCW <= (c / SCS_TR) * SCS_TR)
+            w[(int64_t)(c - row_begin) * ld + r] = v;
     }
 }
 
@@ -706,7 +754,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                              int32_t row_end, int32_t flags, scs_graph **out,
                              scs_build_stats *stats) {
     SCS_REQUIRE(ctx && tb && out, "scs_pcg_build: null argument");
-    SCS_REQUIRE((flags & ~SCS_BUILD_MONOTONE) == 0, "scs_pcg_build: unknown flag bits 0x%x", flags);
+    SCS_REQUIRE((flags & ~(SCS_BUILD_MONOTONE | SCS_BUILD_SHARED)) == 0,
+                "scs_pcg_build: unknown flag bits 0x%x", flags);
     const bool monotone = (flags & SCS_BUILD_MONOTONE) != 0 &&
                           !(getenv("SCS_NO_MONOTONE") && atoi(getenv("SCS_NO_MONOTONE")));
     const int n = tb->n_taxa;
@@ -714,12 +763,26 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 "scs_pcg_build: bad row range [%d, %d) for %d taxa", row_begin, row_end, n);
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const bool sym = (row_begin == 0 && row_end == n && ctx->comm.world == 1);
-    const int rows = row_end - row_begin;
-    const int n_blocks = (rows + SCS_TR - 1) / SCS_TR;
+    const int world = ctx->comm.world, rank = ctx->comm.rank;
     const int cols_per_tile = SCS_TCW;
     const int n_cgroups = (n + cols_per_tile - 1) / cols_per_tile;
     const int64_t npad = scs_round_up(n, SCS_NPAD);
+    // Shared build (world > 1): the ranks split the upper-triangle tiles of the WHOLE matrix
+    // round-robin, all-gather them and each unpacks its own rows -- every cell is computed
+    // once across the job, as in the single-GPU symmetric schedule.  The decision depends
+    // only on n and world, so every rank takes the same branch.
+    bool shared = (flags & SCS_BUILD_SHARED) != 0 && world > 1;
+    if (shared) {
+        const int64_t nb_all = (n + SCS_TR - 1) / SCS_TR;
+        const double tile_bytes = 0.5 * (double)nb_all * n_cgroups * SCS_TR * SCS_TCW * 8.0;
+        if (tile_bytes * (1.0 + 1.0 / world) > 96.0 * 1024 * 1024 * 1024) shared = false;
+    }
+    // rows the accumulate kernels see: the whole matrix when shared
+    const int b_row_begin = shared ? 0 : row_begin, b_row_end = shared ? n : row_end;
+    const bool sym = !shared && (row_begin == 0 && row_end == n && world == 1);
+    const bool upper = sym || shared;
+    const int rows = row_end - row_begin;
+    const int n_blocks = (b_row_end - b_row_begin + SCS_TR - 1) / SCS_TR;
 
     scs_graph *g = nullptr;
     SCS_TRY(graph_alloc(n, row_begin, row_end, s, &g));
@@ -737,17 +800,41 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     tiles.reserve((size_t)n_blocks * n_cgroups);
     for (int b = 0; b < n_blocks; ++b)
         for (int c = 0; c < n_cgroups; ++c) {
-            if (sym && (int64_t)(c + 1) * cols_per_tile <= (int64_t)b * SCS_TR) continue;
-            const int64_t r_lo = (int64_t)row_begin + (int64_t)b * SCS_TR, r_hi = r_lo + SCS_TR;
+            if (upper && (int64_t)(c + 1) * cols_per_tile <= (int64_t)b * SCS_TR) continue;
+            const int64_t r_lo = (int64_t)b_row_begin + (int64_t)b * SCS_TR, r_hi = r_lo + SCS_TR;
             const int64_t c_lo = (int64_t)c * cols_per_tile, c_hi = c_lo + cols_per_tile;
             const bool overlap = c_lo < r_hi && r_lo < c_hi;
             if (monotone && overlap) tiles_diag.push_back(make_int2(b, c));
             else tiles.push_back(make_int2(b, c));
         }
-    const size_t n_main = tiles.size();
+    size_t n_main = tiles.size();
     tiles.insert(tiles.end(), tiles_diag.begin(), tiles_diag.end());
+    // shared: tile i of the job-wide list belongs to rank i % world and lands in slot
+    // i / world of that rank's packed buffer
+    std::vector<int2> all_tiles;
+    dev_buf d_all_tiles, d_tile_out, d_gathered;
+    size_t chunk_doubles = 0;
+    if (shared) {
+        all_tiles.swap(tiles);
+        size_t my_main = 0;
+        for (size_t i = rank; i < all_tiles.size(); i += world) {
+            tiles.push_back(all_tiles[i]);
+            if (i < n_main) ++my_main;
+        }
+        n_main = my_main;
+        const size_t slots = (all_tiles.size() + world - 1) / world;
+        chunk_doubles = slots * SCS_TR * SCS_TCW;
+        SCS_TRY(d_all_tiles.alloc(all_tiles.size() * sizeof(int2)));
+        SCS_HIP_CHECK(hipMemcpyAsync(d_all_tiles.p, all_tiles.data(),
+                                     all_tiles.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+        SCS_TRY(d_tile_out.alloc(chunk_doubles * 8));
+        SCS_TRY(d_gathered.alloc(chunk_doubles * 8 * world));
+        if (tiles.size() < slots)  // the unused last slot is gathered too: keep it defined
+            SCS_HIP_CHECK(hipMemsetAsync((double *)d_tile_out.p + (slots - 1) * SCS_TR * SCS_TCW,
+                                         0, (size_t)SCS_TR * SCS_TCW * 8, s));
+    }
     dev_buf d_tiles;
-    SCS_TRY(d_tiles.alloc(tiles.size() * sizeof(int2)));
+    SCS_TRY(d_tiles.alloc(std::max<size_t>(tiles.size(), 1) * sizeof(int2)));
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                  hipMemcpyHostToDevice, s));
 
@@ -820,8 +907,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                                                   (const int64_t *)d_stoff.p, (u64 *)d_st.p);
         k_block_records<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
             tb->d_tree_off, t0, nb, leaf_base, (const int32_t *)d_pos.p, npad,
-            (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const u64 *)d_st.p, row_begin,
-            row_end, (unsigned char *)d_rec.p);
+            (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const u64 *)d_st.p, b_row_begin,
+            b_row_end, (unsigned char *)d_rec.p);
         SCS_HIP_CHECK(hipEventRecord(ev_prep.b, s));
 
         acc_params ap;
@@ -839,9 +926,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         ap.w = g->d_w;
         ap.ld = g->ld;
         ap.n = n;
-        ap.row_begin = row_begin;
-        ap.row_end = row_end;
+        ap.row_begin = b_row_begin;
+        ap.row_end = b_row_end;
         ap.load_w = bi > 0;
+        ap.tile_out = shared ? (double *)d_tile_out.p : nullptr;
+        ap.slot_base = 0;
         ap.stamps = nullptr;
         SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
         const unsigned nt = (unsigned)tiles.size();
@@ -871,11 +960,13 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             if (n_diag) {
                 acc_params ad = ap;
                 ad.tiles = (const int2 *)d_tiles.p + n_main;
+                ad.slot_base = (int)n_main;
                 if (sym) k_accumulate<true><<<n_diag, SCS_TCW, 0, s>>>(ad);
                 else k_accumulate<false><<<n_diag, SCS_TCW, 0, s>>>(ad);
             }
         } else {
-            if (sym) k_accumulate<true><<<nt, SCS_TCW, 0, s>>>(ap);
+            if (!nt) {
+            } else if (sym) k_accumulate<true><<<nt, SCS_TCW, 0, s>>>(ap);
             else k_accumulate<false><<<nt, SCS_TCW, 0, s>>>(ap);
         }
         SCS_HIP_CHECK(hipGetLastError());
@@ -886,6 +977,21 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         prep_ms += ms;
         SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_acc.a, ev_acc.b));
         acc_ms += ms;
+    }
+    float exch_ms = 0.f;
+    if (shared) {
+        ev_pair ev_x;
+        SCS_TRY(ev_x.init());
+        SCS_HIP_CHECK(hipEventRecord(ev_x.a, s));
+        SCS_TRY(scs_comm_allgather_f64(&ctx->comm, (const double *)d_tile_out.p,
+                                       (double *)d_gathered.p, chunk_doubles, s));
+        k_unpack_tiles<<<(unsigned)all_tiles.size(), SCS_TCW, 0, s>>>(
+            (const double *)d_gathered.p, (const int2 *)d_all_tiles.p, world,
+            (int64_t)chunk_doubles, n, row_begin, row_end, g->d_w, g->ld);
+        SCS_HIP_CHECK(hipGetLastError());
+        SCS_HIP_CHECK(hipEventRecord(ev_x.b, s));
+        SCS_HIP_CHECK(hipEventSynchronize(ev_x.b));
+        SCS_HIP_CHECK(hipEventElapsedTime(&exch_ms, ev_x.a, ev_x.b));
     }
     SCS_HIP_CHECK(hipEventRecord(ev_total.b, s));
     SCS_HIP_CHECK(hipEventSynchronize(ev_total.b));
@@ -898,7 +1004,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         stats->n_trees = M;
         stats->row_begin = row_begin;
         stats->row_end = row_end;
-        stats->symmetric = sym;
+        stats->symmetric = shared ? 2 : (sym ? 1 : 0);
+        stats->exchange_ms = exch_ms;
         stats->n_tiles = (int32_t)tiles.size();
         stats->n_batches = n_batches;
         stats->cell_trees = (double)tiles.size() * SCS_TR * cols_per_tile * (double)M;

@@ -264,45 +264,78 @@ def test_labels_match_spectral_clustering(dev):
         assert np.array_equal(got, want), f"{int(np.sum(got != want))} labels differ"
 
 
-def test_two_rank_row_partition_matches_single(dev):
-    # row-partitioned build + solve on ONE GPU: two contexts, two host threads,
-    # in-process communicator instead of RCCL
-    tables = synthetic.make_tables(77, 700, 24, "branch", leaves_per_tree=650)
-    w_ref, _ = to.pcg_dense(tables)
-    ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+def _run_local_group(tables, splits, shared, v0):
+    """Row-partitioned build + solve on ONE GPU: `world` contexts, one host thread each,
+    the in-process communicator instead of RCCL.  Returns [(W rows, maps, stats, build stats)]."""
+    world = len(splits) - 1
     lib = nv.load_library()
     group = nv.C.c_void_p()
-    nv.check(lib.scs_local_group_create(2, nv.C.byref(group)))
-    splits = [0, 333, 700]
-    v0 = np.random.RandomState(0).uniform(-1, 1, 700)
-    out = [None, None]
-    err = [None, None]
+    nv.check(lib.scs_local_group_create(world, nv.C.byref(group)))
+    out = [None] * world
+    err = [None] * world
 
     def worker(rank):
         try:
-            d = Device(0, rank, 2, _local_group=group)
+            d = Device(0, rank, world, _local_group=group)
             dtab = d.upload(tables)
-            g = dtab.build(splits[rank], splits[rank + 1])
+            g = dtab.build(splits[rank], splits[rank + 1], shared=shared)
             w = g.download()
-            assert np.array_equal(w, w_ref[splits[rank] : splits[rank + 1]])
             maps, stats = g.fiedler(v0)
-            out[rank] = (maps, stats)
+            out[rank] = (w, maps, stats, g.build_stats)
             g.free()
             dtab.free()
             d.close()
         except BaseException as e:  # noqa: BLE001
             err[rank] = e
 
-    threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
         t.join(timeout=300)
     lib.scs_local_group_destroy(group)
-    assert err == [None, None], err
-    for maps, stats in out:
+    assert err == [None] * world, err
+    return out
+
+
+@pytest.mark.parametrize(
+    "splits,shared,strategy",
+    [
+        ([0, 333, 700], False, "branch"),
+        ([0, 333, 700], True, "branch"),
+        ([0, 333, 700], True, "bootstrap"),  # general kernel writes the packed tiles
+        ([0, 100, 290, 700], True, "branch"),  # three ranks, uneven rows, a spare tile slot
+        ([0, 64, 700], True, "depth"),
+    ],
+)
+def test_multi_rank_row_partition_matches_single(dev, splits, shared, strategy):
+    tables = synthetic.make_tables(77, 700, 24, strategy, leaves_per_tree=650)
+    w_ref, _ = to.pcg_dense(tables)
+    ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+    v0 = np.random.RandomState(0).uniform(-1, 1, 700)
+    out = _run_local_group(tables, splits, shared, v0)
+    for rank, (w, maps, stats, bstats) in enumerate(out):
+        assert bstats["symmetric"] == (2 if shared else 0)
+        assert np.array_equal(w, w_ref[splits[rank] : splits[rank + 1]]), rank
         assert np.max(np.abs(maps[:, 1] - ref[:, 1])) <= FIEDLER_TOL, stats
-    assert np.array_equal(out[0][0], out[1][0])  # both ranks hold the same embedding
+        assert np.array_equal(maps, out[0][1])  # every rank holds the same embedding
+    if shared:
+        # every cell evaluated once across the job: the ranks' tile counts add up to the
+        # single-GPU symmetric schedule's
+        single = dev.upload(tables).build()
+        assert sum(o[3]["n_tiles"] for o in out) == single.build_stats["n_tiles"]
+        single.free()
+
+
+def test_shared_build_multi_batch(dev, monkeypatch):
+    # a workspace small enough to force several tree batches: the packed tiles carry the
+    # running sums between batches
+    monkeypatch.setenv("SCS_WS_LIMIT_MB", "2")
+    tables = synthetic.make_tables(5, 900, 40, "branch", leaves_per_tree=800)
+    w_ref, _ = to.pcg_dense(tables)
+    out = _run_local_group(tables, [0, 500, 900], True, None)
+    assert out[0][3]["n_batches"] > 1
+    assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
 
 
 def test_rccl_world_of_one(dev):
