@@ -86,9 +86,13 @@ __global__ void k_sparse_level(const int64_t *__restrict__ tree_off, int t0, int
 // one v_min_f64 (the builtin fmin adds a canonicalising v_max_f64 in front of it);
 // operands are finite non-negative values or +inf, so IEEE minNum semantics are moot
 __device__ __forceinline__ double min_f64(double a, double b) {
+#ifdef SCS_MIN_ASM
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#else
+    return __builtin_fmin(a, b);
+#endif
 }
 
 __device__ __forceinline__ u64 rmq_tree(const u64 *__restrict__ st, int m, int a, int b) {
@@ -413,6 +417,9 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
     const int col = tile.y * SCS_TCW + tid;
     const int nt = p.n_batch;
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    // a column that is one of the tile's own rows (tiles on the diagonal): its cells are the
+    // row-row table itself, no search or range-minimum needed; W[c][c] stays 0
+    const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
 
     double acc[SCS_TR];
 #pragma unroll
@@ -476,10 +483,8 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
                 if (s_spos[l2 + s - 1] < cpos) l2 += s;
             lo = lo == 64 ? 64 : l2;
         }
-        const bool hasl = present && lo > 0;
-        const bool hasr = present && lo < cnt;
-        // (tiles whose columns overlap their rows go to the general kernel, so the column
-        // is never one of the tile's rows here)
+        const bool hasl = present && self < 0 && lo > 0;
+        const bool hasr = present && self < 0 && lo < cnt;
         u64 xl, yl, xr, yr;
         {
             const int ql = s_spos[max(lo - 1, 0)];
@@ -532,6 +537,11 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
             const u64 g = left ? gl : gr;
             nb = s_sorig[left ? lo - 1 : lo];
             if ((u32)(g >> 32)) vn = p.vw[*(const long long *)(rb + REC_VWOFF) + (u32)(g & 0xFFFFFFFFu)];
+        } else if (present && self >= 0) {
+            // cell (i, c) = table entry (self, i); the diagonal entry is +inf and makes
+            // acc[self] meaningless -- it is reset after the last tree
+            nb = self;
+            vn = inf;
         }
         if (STAMPED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(4);
@@ -561,6 +571,11 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
         atomicAdd(&p.stamps[7], 1ull);
+    }
+    if (self >= 0) {
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i)
+            if (i == self) acc[i] = 0.0;
     }
     if (p.tile_out) {
         double *tp = p.tile_out + (int64_t)(p.slot_base + blockIdx.x) * SCS_TR * SCS_TCW + tid;
@@ -794,8 +809,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         }
     } gd{ctx, g};
 
-    // ---- tile lists: tiles whose column range overlaps their row range (a column can be
-    // one of the tile's own rows) always take the general kernel
+    // ---- tile lists.  SCS_DIAG_GENERAL=1 (diagnostic) sends the tiles whose column range
+    // overlaps their row range to the general kernel even in a monotone build
+    static const bool diag_general = getenv("SCS_DIAG_GENERAL") && atoi(getenv("SCS_DIAG_GENERAL"));
     std::vector<int2> tiles, tiles_diag;
     tiles.reserve((size_t)n_blocks * n_cgroups);
     for (int b = 0; b < n_blocks; ++b)
@@ -804,7 +820,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             const int64_t r_lo = (int64_t)b_row_begin + (int64_t)b * SCS_TR, r_hi = r_lo + SCS_TR;
             const int64_t c_lo = (int64_t)c * cols_per_tile, c_hi = c_lo + cols_per_tile;
             const bool overlap = c_lo < r_hi && r_lo < c_hi;
-            if (monotone && overlap) tiles_diag.push_back(make_int2(b, c));
+            if (monotone && diag_general && overlap) tiles_diag.push_back(make_int2(b, c));
             else tiles.push_back(make_int2(b, c));
         }
     size_t n_main = tiles.size();
