@@ -285,6 +285,7 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     }
     scs_comm_destroy(&ctx->comm);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->h_report) hipHostFree(ctx->h_report);
     delete ctx;
     return SCS_OK;
 }

@@ -16,6 +16,7 @@
 
 #include "scs_internal.h"
 #include "scs_symm.h"
+#include "scs_panel.h"
 
 constexpr int MAXB = 16;      // widest LOBPCG block
 constexpr int MAXS = 64;      // largest matrix the Jacobi kernel takes
@@ -433,6 +434,32 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
     __syncthreads();
 }
 
+// Sum `nparts` per-workgroup partials of `nout` outputs (partial[p * nout + e]) in a fixed
+// order with all 256 threads of the workgroup: eight interleaved slices of the partials are
+// summed with the loads of a slice in flight together, then the slices are combined.
+// out(e, value) is called by one thread per output; ends with a workgroup barrier.
+template <typename F>
+__device__ __forceinline__ void sum_partials(const double *__restrict__ partial, int nparts,
+                                             int nout, double (*tmp)[3 * MAXB * 3 * MAXB / 4],
+                                             F out) {
+    // tmp: [8][>= nout] doubles of LDS
+    for (int f = threadIdx.x; f < nout * 8; f += 256) {
+        const int slice = f / nout, e = f - slice * nout;
+        double v = 0.0;
+#pragma unroll 8
+        for (int p = slice; p < nparts; p += 8) v += partial[(int64_t)p * nout + e];
+        tmp[slice][e] = v;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nout; e += 256) {
+        double v = tmp[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += tmp[k][e];
+        out(e, v);
+    }
+    __syncthreads();
+}
+
 // plain eigen-decomposition of a global n x n matrix (debug entry point, dense path)
 __global__ __launch_bounds__(256) void k_small_eig(const double *__restrict__ a, int n,
                                                     double *__restrict__ w, double *__restrict__ v) {
@@ -489,8 +516,10 @@ __global__ __launch_bounds__(256) void k_small_svqb(const double *__restrict__ g
 //     orthogonal to X' *in coefficient space* (Q is orthonormal, so no tall Gram product is
 //     needed): start from the [R P] part of c (the LOBPCG direction), project out c twice,
 //     SVQB-orthonormalise with rank-revealing drop; mask_p[k] = 0 marks a dropped direction.
-__global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm, int nq, int b,
-                                                   const int *__restrict__ mask,
+//   nparts > 0: tm holds nparts per-workgroup partials of T (k_gram_qaq), summed here in
+//   fixed order.
+__global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm, int nparts,
+                                                   int nq, int b, const int *__restrict__ mask,
                                                    double *__restrict__ c, double *__restrict__ d,
                                                    double *__restrict__ theta,
                                                    int *__restrict__ mask_p, double drop_tol) {
@@ -500,9 +529,15 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
     __shared__ double gg[MAXB][MAXB];
     __shared__ double dsc[MAXB];
     const int tid = threadIdx.x;
+    if (nparts > 0) {
+        __shared__ double tmp[8][3 * MAXB * 3 * MAXB / 4];  // fused path: nq <= 24
+        // parked in the eigenvector array until symmetrised
+        sum_partials(tm, nparts, nq * nq, tmp, [&](int e, double v) { s.e[e / nq][e % nq] = v; });
+    }
     for (int e = tid; e < nq * nq; e += 256) {
         const int i = e / nq, j = e - i * nq;
-        double v = 0.5 * (tm[i * nq + j] + tm[j * nq + i]);
+        double v = nparts > 0 ? 0.5 * (s.e[i][j] + s.e[j][i])
+                              : 0.5 * (tm[i * nq + j] + tm[j * nq + i]);
         const bool live = mask[i] && mask[j];
         if (!live) v = (i == j) ? -1e30 : 0.0;  // dead directions can never be selected
         s.a[i][j] = v;
@@ -570,6 +605,89 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
     }
 }
 
+// Projected SVQB (fused path, b <= 8).  Input: per-workgroup partials of
+//   Cxp = [x p]^T r (2b x b),  G = r^T r (b x b),  cu = u^T r (1 x b)
+// for an orthonormal [u x p].  With M = G - Cxp^T Cxp - cu^T cu (the Gram matrix of r
+// after projecting [u x p] out) and M = D^-1 V L V^T D^-1 its scaled eigen-decomposition,
+// T = D V L^-1/2 and K = -C T make   r T + [x p u] K   orthonormal and orthogonal to
+// [u x p] up to the cancellation in M -- a second pass of the same step removes that.
+// Output coef: rows [x (b) | p (b) | r (b) | u | 3 zero rows] x b, the operand of
+// k_panel_tf; mask[c] = 0 marks a dropped direction (zero column).
+// report (mapped host memory, may be null): [0, b) squared residual norms diag(G),
+// [16, 16 + b] the current Ritz values.
+__global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ partial,
+                                                     int nparts, int b, double drop_tol,
+                                                     double *__restrict__ coef,
+                                                     int *__restrict__ mask,
+                                                     const double *__restrict__ theta,
+                                                     double *report) {
+    __shared__ jacobi_lds s;
+    __shared__ double cxp[16][8], gm[9][8], mm[8][8], tt[8][8], dsc[8];
+    const int tid = threadIdx.x;
+    const int nxp = 2 * b * b, nout = 3 * b * b + b;
+    {
+        __shared__ double tmp[8][3 * MAXB * 3 * MAXB / 4];
+        sum_partials(partial, nparts, nout, tmp, [&](int e, double v) {
+            if (e < nxp) cxp[e / b][e % b] = v;
+            else gm[(e - nxp) / b][(e - nxp) % b] = v;
+        });
+    }
+    if (report) {
+        if (tid < b) report[tid] = gm[tid][tid];
+        if (tid <= b) report[16 + tid] = theta[tid];
+    }
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, j = e - i * b;
+        double v = 0.5 * (gm[i][j] + gm[j][i]) - gm[b][i] * gm[b][j];
+        for (int k = 0; k < 2 * b; ++k) v -= cxp[k][i] * cxp[k][j];
+        mm[i][j] = v;
+    }
+    __syncthreads();
+    if (tid < b) {
+        // a column whose projected norm^2 is at the cancellation floor of G carries no
+        // direction of its own: dead
+        const double dgn = mm[tid][tid];
+        dsc[tid] = (dgn > 1e-290 && dgn > 1e-13 * gm[tid][tid]) ? 1.0 / sqrt(dgn) : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, j = e - i * b;
+        s.a[i][j] = 0.5 * (mm[i][j] + mm[j][i]) * dsc[i] * dsc[j];
+    }
+    __syncthreads();
+    jacobi_eig(s, b);
+    const double wmax = s.w[0];
+    for (int e = tid; e < b * b; e += 256) {
+        const int i = e / b, c = e - i * b;
+        const double lam = s.w[c];
+        const bool keep = wmax > 0.0 && lam > drop_tol * wmax;
+        tt[i][c] = keep ? dsc[i] * s.e[i][s.perm[c]] / sqrt(lam) : 0.0;
+    }
+    if (tid < b) mask[tid] = (wmax > 0.0 && s.w[tid] > drop_tol * wmax) ? 1 : 0;
+    __syncthreads();
+    for (int e = tid; e < (3 * b + 4) * b; e += 256) {
+        const int k = e / b, c = e - k * b;
+        double v = 0.0;
+        if (k < 2 * b) {
+            for (int i = 0; i < b; ++i) v -= cxp[k][i] * tt[i][c];
+        } else if (k < 3 * b) {
+            v = tt[k - 2 * b][c];
+        } else if (k == 3 * b) {
+            for (int i = 0; i < b; ++i) v -= gm[b][i] * tt[i][c];
+        }
+        coef[e] = v;
+    }
+}
+
+// c = first b columns of the 3b x 3b identity, d = 0: the Rayleigh-Ritz coefficients that
+// leave X alone and clear the search directions (first iteration, and after a refresh)
+__global__ void k_unit_coeffs(double *__restrict__ c, double *__restrict__ d, int b) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 3 * b * b) return;
+    c[e] = (e / b == e % b) ? 1.0 : 0.0;
+    d[e] = 0.0;
+}
+
 // dense S for the small-V path: s[i][j] = dinv[i] * w[i][j] * dinv[j], zero diagonal
 __global__ void k_dense_s(const double *__restrict__ w, int64_t ld, int n,
                           const double *__restrict__ dinv, double *__restrict__ s) {
@@ -617,7 +735,10 @@ struct solver {
 
     double *small_at(int off) const { return small.d() + off; }
 
-    // yout (rows x b) = dinv (.) (W_local * Z), Z given k-major in zin (b x ld)
+    int last_nseg = 1;  // column segments of the most recent k_symm launch
+
+    // yout (rows x b) = dinv (.) (W_local * Z), Z given k-major in zin (b x ld);
+    // yout == null leaves the column segments in ypart for the caller to combine
     int launch_symm(const double *zin, double *yout) {
         const int64_t ld = g->ld;
         int rpw = 4, sdepth = 2;
@@ -653,8 +774,10 @@ struct solver {
                 return SCS_EUNSUP;
         }
         SCS_HIP_CHECK(hipGetLastError());
-        k_symm_finish<<<(rows * b + 255) / 256, 256, 0, s>>>(ypart.d(), nseg, rows, b, g->d_dinv,
-                                                             g->row_begin, yout);
+        last_nseg = nseg;
+        if (yout)
+            k_symm_finish<<<(rows * b + 255) / 256, 256, 0, s>>>(ypart.d(), nseg, rows, b,
+                                                                 g->d_dinv, g->row_begin, yout);
         return SCS_OK;
     }
 
@@ -717,6 +840,62 @@ struct solver {
     int update(double *y, int ldy, int kc, double alpha, const double *a, int lda, int ka,
                const double *c, int ldc, double sign) {
         k_update<<<(n + 15) / 16, 256, 0, s>>>(y, ldy, kc, alpha, a, lda, ka, c, ldc, sign, n);
+        SCS_HIP_CHECK(hipGetLastError());
+        return SCS_OK;
+    }
+
+    // ---- fused iteration (scs_panel.h), block widths 4 and 8 ----
+    int panel_blocks16() const { return std::max(1, std::min(PANEL_BLOCKS_MAX, ((n + 15) / 16 + 3) / 4)); }
+    int panel_blocks4() const { return std::max(1, std::min(PANEL_BLOCKS_MAX, ((n + 3) / 4 + 3) / 4)); }
+
+    template <int B>
+    int fused_front(const double *uvec, const double *c, const double *d, const double *theta,
+                    double *coef, int *mask_r, double drop_tol, double *report, hipEvent_t ev_report) {
+        const int nb = panel_blocks16();
+        k_panel_rr<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, c, d, theta, n, part.d());
+        k_small_orth<<<1, 256, 0, s>>>(part.d(), nb, B, drop_tol, coef, mask_r, theta, report);
+        SCS_HIP_CHECK(hipEventRecord(ev_report, s));
+        k_panel_tf<B, true, false><<<nb, 256, 0, s>>>(q.d(), uvec, coef, n, part.d(), nullptr,
+                                                      nullptr, 0);
+        k_small_orth<<<1, 256, 0, s>>>(part.d(), nb, B, 0.0, coef, mask_r, theta, nullptr);
+        k_panel_tf<B, false, true><<<nb, 256, 0, s>>>(q.d(), uvec, coef, n, nullptr, g->d_dinv,
+                                                      z.d(), g->ld);
+        SCS_HIP_CHECK(hipGetLastError());
+        return SCS_OK;
+    }
+
+    // AR = S R (R's scaled transpose already sits in z) into AQ's R slot, then the
+    // partials of Q^T AQ; returns their count
+    template <int B>
+    int fused_back(int *nparts) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        SCS_HIP_CHECK(hipEventCreate(&e0));
+        SCS_HIP_CHECK(hipEventCreate(&e1));
+        ev.push_back(e0);
+        ev.push_back(e1);
+        const int nb = panel_blocks4();
+        *nparts = nb;
+        if (world == 1) {
+            SCS_HIP_CHECK(hipEventRecord(e0, s));
+            SCS_TRY(launch_symm(z.d(), nullptr));
+            SCS_HIP_CHECK(hipEventRecord(e1, s));
+            ++n_apply;
+            k_gram_qaq<B, true><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
+                                                   g->d_dinv, part.d());
+        } else {
+            SCS_HIP_CHECK(hipEventRecord(e0, s));
+            SCS_TRY(launch_symm(z.d(), yloc.d()));
+            SCS_HIP_CHECK(hipEventRecord(e1, s));
+            ++n_apply;
+            SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
+            const int nbq = n * B;
+            k_unpack<<<(nbq + 255) / 256, 256, 0, s>>>(recv.d(), chunk, B,
+                                                       (const int32_t *)splits_d.p, world, n,
+                                                       yfull.d());
+            k_store_cols<<<(nbq + 255) / 256, 256, 0, s>>>(yfull.d(), B, n, aq.d(), 3 * B, 2 * B);
+            k_gram_qaq<B, false><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, nullptr, 0, g->d_dinv,
+                                                    part.d());
+        }
         SCS_HIP_CHECK(hipGetLastError());
         return SCS_OK;
     }
@@ -955,7 +1134,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_TRY(sv.gram(X, q3, b, AX, q3, b, G, sv.use_mfma));
     {
         k_fill_int<<<1, 64, 0, s>>>(MASK, 48, 1);
-        k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, D, TH, MASK + b, drop_tol);
+        k_small_rr<<<1, 256, 0, s>>>(G, 0, b, b, MASK, T, D, TH, MASK + b, drop_tol);
         SCS_TRY(sv.update(X, q3, b, 0.0, X, q3, b, T, b, 1.0));
         SCS_TRY(sv.update(AX, q3, b, 0.0, AX, q3, b, T, b, 1.0));
         k_fill_int<<<1, 64, 0, s>>>(MASK + b, b, 0);  // no search directions yet
@@ -972,13 +1151,55 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     bool converged = false;
     double final_res[2] = {0.0, 0.0};
 
+    // Fused iteration (scs_panel.h) for the default block widths; SCS_LEGACY_LOOP=1 keeps
+    // the one-kernel-per-step formulation (also used for widths 12 and 16).
+    const bool fused = (b == 4 || b == 8) &&
+                       !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP")));
+    hipEvent_t ev_report = nullptr;
+    struct evg1 {
+        hipEvent_t *e;
+        ~evg1() {
+            if (*e) hipEventDestroy(*e);
+        }
+    } evguard1{&ev_report};
+    if (fused) {
+        if (!ctx->h_report) {
+            SCS_HIP_CHECK(hipHostMalloc((void **)&ctx->h_report, 64 * sizeof(double),
+                                        hipHostMallocMapped | hipHostMallocCoherent));
+            SCS_HIP_CHECK(hipHostGetDevicePointer((void **)&ctx->d_report, ctx->h_report, 0));
+        }
+        SCS_HIP_CHECK(hipEventCreateWithFlags(&ev_report, hipEventDisableTiming));
+        k_unit_coeffs<<<(3 * b * b + 255) / 256, 256, 0, s>>>(T, D, b);
+    }
+    const double *uvec = constrained ? sv.u.d() : nullptr;
+
     for (iter = 0; iter < max_iter; ++iter) {
-        // residual block and its norms
-        k_residual<<<res_blocks, 256, 0, s>>>(Q, AQ, b, TH, n, res_part.d());
-        k_reduce_partials<<<(b + 3) / 4, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
-        SCS_HIP_CHECK(hipMemcpyAsync(h_rn.data(), RN, (size_t)b * 8, hipMemcpyDeviceToHost, s));
-        SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
-        SCS_HIP_CHECK(hipStreamSynchronize(s));
+        if (fused) {
+            // The whole iteration is enqueued before the host looks at the residual norms the
+            // first small kernel reported: the device never waits for the host.  Nothing
+            // after that kernel touches X, so on a stop X is the block the norms belong to.
+            int nparts = 0;
+            if (b == 4) {
+                SCS_TRY(sv.fused_front<4>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, ev_report));
+                SCS_TRY(sv.fused_back<4>(&nparts));
+            } else {
+                SCS_TRY(sv.fused_front<8>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, ev_report));
+                SCS_TRY(sv.fused_back<8>(&nparts));
+            }
+            k_small_rr<<<1, 256, 0, s>>>(sv.part.d(), nparts, q3, b, MASK, T, D, TH, MASK + b,
+                                         drop_tol);
+            SCS_HIP_CHECK(hipGetLastError());
+            SCS_HIP_CHECK(hipEventSynchronize(ev_report));
+            for (int j = 0; j < b; ++j) h_rn[j] = ((volatile double *)ctx->h_report)[j];
+            for (int j = 0; j <= b; ++j) h_th[j] = ((volatile double *)ctx->h_report)[16 + j];
+        } else {
+            // residual block and its norms
+            k_residual<<<res_blocks, 256, 0, s>>>(Q, AQ, b, TH, n, res_part.d());
+            k_reduce_partials<<<(b + 3) / 4, 256, 0, s>>>(res_part.d(), res_blocks, b, RN);
+            SCS_HIP_CHECK(hipMemcpyAsync(h_rn.data(), RN, (size_t)b * 8, hipMemcpyDeviceToHost, s));
+            SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
+            SCS_HIP_CHECK(hipStreamSynchronize(s));
+        }
         double worst = 0.0;
         for (int j = 0; j < want; ++j) worst = std::max(worst, std::sqrt(h_rn[j]));
         for (int j = 0; j < want; ++j) final_res[constrained ? 1 : j] = std::sqrt(h_rn[j]);
@@ -1000,7 +1221,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 SCS_TRY(sv.apply(Q, 0, AQ, 0));
                 SCS_TRY(sv.gram(X, q3, b, AX, q3, b, G, sv.use_mfma));
                 k_fill_int<<<1, 64, 0, s>>>(MASK, 48, 1);
-                k_small_rr<<<1, 256, 0, s>>>(G, b, b, MASK, T, D, TH, MASK + b, drop_tol);
+                k_small_rr<<<1, 256, 0, s>>>(G, 0, b, b, MASK, T, D, TH, MASK + b, drop_tol);
                 SCS_TRY(sv.update(X, q3, b, 0.0, X, q3, b, T, b, 1.0));
                 SCS_TRY(sv.update(AX, q3, b, 0.0, AX, q3, b, T, b, 1.0));
                 // restart the search directions after the refresh: P slot dead and zero
@@ -1020,12 +1241,14 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 }
                 best_res = w2;
                 since_best = 0;
+                if (fused) k_unit_coeffs<<<(3 * b * b + 255) / 256, 256, 0, s>>>(T, D, b);
             } else {
                 converged = worst <= tol;
                 break;
             }
         }
 
+        if (fused) continue;
         // R <- orthonormal complement of [u, X, P] within span(R); P is orthonormal and
         // orthogonal to X by construction (k_small_rr), dead P columns are zero vectors
         // S u = u exactly, so R = S X - X theta inherits X's orthogonality to u; one
@@ -1040,7 +1263,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
         // Rayleigh-Ritz on the orthonormal basis [X P R]; new X and new P in one pass each
         SCS_TRY(sv.gram(Q, q3, q3, AQ, q3, q3, G, sv.use_mfma));
-        k_small_rr<<<1, 256, 0, s>>>(G, q3, b, MASK, T, D, TH, MASK + b, drop_tol);
+        k_small_rr<<<1, 256, 0, s>>>(G, 0, q3, b, MASK, T, D, TH, MASK + b, drop_tol);
         k_rr_update<<<(n + 15) / 16, 256, 0, s>>>(Q, b, q3, T, D, n);
         k_rr_update<<<(n + 15) / 16, 256, 0, s>>>(AQ, b, q3, T, D, n);
         SCS_HIP_CHECK(hipGetLastError());
@@ -1050,7 +1273,9 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     std::vector<double> xcol((size_t)n * q3), dinv(n);
     SCS_HIP_CHECK(hipMemcpyAsync(xcol.data(), Q, (size_t)n * q3 * 8, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipMemcpyAsync(dinv.data(), g->d_dinv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
+    // (fused loop: TH already holds the next iteration's Ritz values; h_th has X's)
+    if (!fused)
+        SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipEventRecord(ev_b, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<double> c0(n), c1(n);

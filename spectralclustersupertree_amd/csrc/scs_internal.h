@@ -70,6 +70,10 @@ struct scs_ctx {
     scs_comm comm;
     int n_cu = 256;
     size_t ws_limit = 0;  // bytes of build scratch allowed per tree batch
+    // 64 doubles of mapped, coherent host memory the eigensolver's small kernel reports
+    // residual norms into (allocated on first use)
+    double *h_report = nullptr;
+    double *d_report = nullptr;
 };
 
 struct scs_tables {

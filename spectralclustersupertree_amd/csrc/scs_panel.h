@@ -1,0 +1,253 @@
+// Fused panel kernels of the LOBPCG iteration (block widths 4 and 8).
+//
+// Everything in an iteration except k_symm works on N x 3b panels Q = [X | P | R] and
+// AQ = S Q, a megabyte or two that lives in L2: those steps are bound by kernel-launch
+// and dependency latency, not bandwidth, so an iteration is cut into as few launches as
+// the data dependencies allow:
+//
+//   k_panel_rr        X' = Q c, P' = Q d, AX' = AQ c, AP' = AQ d, R = AX' - X' theta,
+//                     and the Gram products [u X' P']^T R, R^T R          (one pass over Q, AQ)
+//   k_small_orth      projected SVQB: from those Gram products the transform that makes R
+//                     orthonormal and orthogonal to [u X P]  (one workgroup; also hands the
+//                     residual norms to the host)
+//   k_panel_tf        R <- R T + [u X P] K, again with the Gram products     (second pass)
+//   k_small_orth
+//   k_panel_tf        final transform, also emits Z = D^-1/2 R k-major for k_symm
+//   k_symm
+//   k_gram_qaq        combines k_symm's column segments into AR and forms Q^T AQ
+//   k_small_rr        Rayleigh-Ritz (scs_eig.hip)
+//
+// The tall kernels are MFMA pipelines (v_mfma_f64_16x16x4_f64): a wave owns groups of 16
+// rows; the row transform is a 16 x K x 16 product whose accumulator layout (register r
+// of lane l = row (l>>4) + 4r, column l&15) is exactly the operand layout of the Gram
+// product over four rows, so transformed rows feed the Gram MFMAs straight from
+// registers.  All sums are formed in a fixed order (per-wave accumulators, workgroup
+// partials, then one thread per output in the small kernel): results are deterministic.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+typedef double panel_v4d __attribute__((ext_vector_type(4)));
+
+constexpr int PANEL_BLOCKS_MAX = 64;   // workgroups of a tall panel kernel (partials per output)
+
+// outputs per workgroup partial: [x p]^T r (2B x B), then [r | u]^T r ((B + 1) x B)
+template <int B>
+struct panel_out {
+    static constexpr int XP = 2 * B * B;
+    static constexpr int RU = (B + 1) * B;
+    static constexpr int TOTAL = XP + RU;
+};
+
+// coefficient matrix of k_panel_tf: rows [x (B) | p (B) | r (B) | u | 3 x pad], B columns
+template <int B>
+constexpr int PANEL_COEF_ROWS = 3 * B + 4;
+
+template <int B>
+__device__ __forceinline__ void panel_store_partials(panel_v4d g1, panel_v4d g2,
+                                                     double *__restrict__ partial) {
+    // cross-wave sum in fixed order through LDS, then one partial per workgroup
+    __shared__ double red[4][2][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[wave][0][r][lane] = g1[r];
+        red[wave][1][r][lane] = g2[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double *out = partial + (int64_t)blockIdx.x * panel_out<B>::TOTAL;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = kk + 4 * r;  // output row
+            const double s1 = ((red[0][0][r][lane] + red[1][0][r][lane]) + red[2][0][r][lane]) +
+                              red[3][0][r][lane];
+            const double s2 = ((red[0][1][r][lane] + red[1][1][r][lane]) + red[2][1][r][lane]) +
+                              red[3][1][r][lane];
+            if (i < 2 * B && cc < B) out[i * B + cc] = s1;
+            if (i <= B && cc < B) out[panel_out<B>::XP + i * B + cc] = s2;
+        }
+    }
+}
+
+// Rayleigh-Ritz update + residual + Gram products.  q, aq: n x 3B (ld 3B), updated in
+// place (a group of 16 rows is read completely by its wave before it is written).
+// c, d: 3B x B row-major; theta: B; u: n or null.
+template <int B>
+__global__ __launch_bounds__(256) void k_panel_rr(double *q, double *aq,
+                                                   const double *__restrict__ u,
+                                                   const double *__restrict__ c,
+                                                   const double *__restrict__ d,
+                                                   const double *__restrict__ theta, int n,
+                                                   double *__restrict__ partial) {
+    static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
+    constexpr int LD = 3 * B;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    const int n_groups = (n + 15) / 16;
+    panel_v4d g1 = {0.0, 0.0, 0.0, 0.0}, g2 = {0.0, 0.0, 0.0, 0.0};
+    const double th = cc < B ? theta[cc] : 0.0;
+    // B operand of the transform: coefficient rows k0 + kk, column cc of [c | d]
+    double coef[LD / 4];
+#pragma unroll
+    for (int k = 0; k < LD / 4; ++k) {
+        const int row = 4 * k + kk;
+        coef[k] = cc < B ? c[row * B + cc] : (cc < 2 * B ? d[row * B + cc - B] : 0.0);
+    }
+    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+        const int base = grp * 16;
+        const int ra = base + cc;  // row of this lane's A operand
+        panel_v4d dq = {0.0, 0.0, 0.0, 0.0}, da = {0.0, 0.0, 0.0, 0.0};
+        double aq_op[LD / 4], q_op[LD / 4];
+#pragma unroll
+        for (int k = 0; k < LD / 4; ++k) {
+            q_op[k] = ra < n ? q[(int64_t)ra * LD + 4 * k + kk] : 0.0;
+            aq_op[k] = ra < n ? aq[(int64_t)ra * LD + 4 * k + kk] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < LD / 4; ++k) {
+            dq = __builtin_amdgcn_mfma_f64_16x16x4f64(q_op[k], coef[k], dq, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f64_16x16x4f64(aq_op[k], coef[k], da, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = base + kk + 4 * r;
+            const bool live = row < n;
+            const double res = cc < B ? da[r] - dq[r] * th : 0.0;
+            double ru = res;
+            if (cc == B) ru = (u && live) ? u[row] : 0.0;
+            if (live && cc < 2 * B) {
+                q[(int64_t)row * LD + cc] = dq[r];
+                aq[(int64_t)row * LD + cc] = da[r];
+            }
+            if (live && cc < B) q[(int64_t)row * LD + 2 * B + cc] = res;
+            g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[r], res, g1, 0, 0, 0);
+            g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ru, res, g2, 0, 0, 0);
+        }
+    }
+    panel_store_partials<B>(g1, g2, partial);
+}
+
+// R <- R T + [u X P] K (coefficients: PANEL_COEF_ROWS<B> x B, rows [x | p | r | u | pad]).
+// GRAM: also the Gram products of the new R.  WRITE_Z: also zt[k][row] = dinv[row] R[row][k].
+template <int B, bool GRAM, bool WRITE_Z>
+__global__ __launch_bounds__(256) void k_panel_tf(double *q, const double *__restrict__ u,
+                                                   const double *__restrict__ coefm, int n,
+                                                   double *__restrict__ partial,
+                                                   const double *__restrict__ dinv,
+                                                   double *__restrict__ zt, int64_t ldz) {
+    static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
+    constexpr int LD = 3 * B;
+    constexpr int KC = PANEL_COEF_ROWS<B> / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    const int n_groups = (n + 15) / 16;
+    panel_v4d g1 = {0.0, 0.0, 0.0, 0.0}, g2 = {0.0, 0.0, 0.0, 0.0};
+    double coef[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k) coef[k] = cc < B ? coefm[(4 * k + kk) * B + cc] : 0.0;
+    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+        const int base = grp * 16;
+        const int ra = base + cc;
+        double a_op[KC];
+#pragma unroll
+        for (int k = 0; k < KC - 1; ++k) a_op[k] = ra < n ? q[(int64_t)ra * LD + 4 * k + kk] : 0.0;
+        a_op[KC - 1] = (kk == 0 && u && ra < n) ? u[ra] : 0.0;
+        panel_v4d dr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            dr = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[k], coef[k], dr, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = base + kk + 4 * r;
+            const bool live = row < n;
+            const double res = dr[r];  // columns >= B are zero (zero coefficients)
+            if (live && cc < B) {
+                q[(int64_t)row * LD + 2 * B + cc] = res;
+                if (WRITE_Z) zt[(int64_t)cc * ldz + row] = dinv[row] * res;
+            }
+            if (GRAM) {
+                const double xp = (live && cc < 2 * B) ? q[(int64_t)row * LD + cc] : 0.0;
+                double ru = res;
+                if (cc == B) ru = (u && live) ? u[row] : 0.0;
+                g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xp, res, g1, 0, 0, 0);
+                g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ru, res, g2, 0, 0, 0);
+            }
+        }
+    }
+    if (GRAM) panel_store_partials<B>(g1, g2, partial);
+}
+
+// T = Q^T AQ (3B x 3B) as per-workgroup partials; FINISH: first combine k_symm's column
+// segments into AR = dinv (.) sum_seg ypart[seg] and store it into AQ's R slot (single-rank
+// runs; multi-rank runs gather AR before this kernel).
+template <int B, bool FINISH>
+__global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, double *aq, int n,
+                                                   const double *__restrict__ ypart, int nseg,
+                                                   const double *__restrict__ dinv,
+                                                   double *__restrict__ partial) {
+    static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
+    constexpr int LD = 3 * B;
+    constexpr int NT = (LD + 15) / 16;  // 16-column tiles of the panels
+    __shared__ double red[4][NT * NT][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    panel_v4d acc[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (panel_v4d){0.0, 0.0, 0.0, 0.0};
+    const int n_groups = (n + 3) / 4;
+    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+        const int row = grp * 4 + kk;
+        const bool live = row < n;
+        double fa[NT], fb[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int col = t * 16 + cc;
+            fa[t] = (live && col < LD) ? q[(int64_t)row * LD + col] : 0.0;
+            double v = 0.0;
+            if (live && col < LD) {
+                if (FINISH && col >= 2 * B) {
+                    const int64_t idx = (int64_t)row * B + (col - 2 * B);
+                    double s = 0.0;
+                    for (int g = 0; g < nseg; ++g) s += ypart[(int64_t)g * n * B + idx];
+                    v = dinv[row] * s;
+                    aq[(int64_t)row * LD + col] = v;
+                } else {
+                    v = aq[(int64_t)row * LD + col];
+                }
+            }
+            fb[t] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][i * NT + j][r][lane] = acc[i][j][r];
+    __syncthreads();
+    if (wave == 0) {
+        double *out = partial + (int64_t)blockIdx.x * LD * LD;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = i * NT + j;
+                    const double s = ((red[0][t][r][lane] + red[1][t][r][lane]) + red[2][t][r][lane]) +
+                                     red[3][t][r][lane];
+                    const int orow = i * 16 + kk + 4 * r, ocol = j * 16 + cc;
+                    if (orow < LD && ocol < LD) out[orow * LD + ocol] = s;
+                }
+    }
+}
