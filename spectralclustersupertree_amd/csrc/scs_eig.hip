@@ -315,7 +315,221 @@ struct jacobi_lds {
 // Parallel-ordered two-sided Jacobi.  A step rotates m/2 disjoint index pairs at
 // once: A <- J^T A J splits into independent 2x2 blocks (row pair x column pair),
 // each updated by one thread, so a step costs two barriers.
+// ---- fast variant for n <= 24 (the sizes the fused LOBPCG loop solves every iteration)
+// A lone wave issues about one instruction per 8 clocks, so a Jacobi step is bound by the
+// instruction count on its critical path, not by arithmetic.  This variant therefore
+//   * keeps the rotated pairs at FIXED positions (2k, 2k+1) and moves the data instead: every
+//     work item -- a 2 x 2 block of A or a column pair of one row of E -- reads from one copy
+//     of the matrices and writes its results to precomputed, round-robin-permuted addresses
+//     in the other copy, so a step is one barrier and no index arithmetic;
+//   * lets every item compute the (at most two) rotations it needs itself from the diagonal
+//     blocks, with hardware rsq/rcp seeds refined by Newton steps instead of IEEE
+//     division and square root.
+// At most two items per thread (256 threads).  Interface as jacobi_eig.
+__device__ __forceinline__ void jacobi_rot(double app, double apq, double aqq, double &c,
+                                           double &sn) {
+    c = 1.0;
+    sn = 0.0;
+    if (apq != 0.0) {
+        const double dl = 0.5 * (aqq - app);
+        const double x = fma(dl, dl, apq * apq);
+        double y = __builtin_amdgcn_rsq(x);
+        double r = x * y;                      // sqrt(x), refined once
+        r = fma(fma(-r, r, x), 0.5 * y, r);
+        const double den = fabs(dl) + r;
+        double inv = __builtin_amdgcn_rcp(den);
+        inv = inv * fma(-den, inv, 2.0);
+        inv = inv * fma(-den, inv, 2.0);
+        double t = apq * inv;
+        t = dl >= 0.0 ? t : -t;
+        // |t| <= 1 by construction; a rounding excess is clamped, anything else means x
+        // overflowed or vanished: no rotation
+        if (!(fabs(t) <= 1.0)) t = fabs(t) <= 1.0000001 ? copysign(1.0, t) : 0.0;
+        const double x2 = fma(t, t, 1.0);
+        double y2 = __builtin_amdgcn_rsq(x2);
+        y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
+        y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
+        c = y2;
+        sn = t * y2;
+    }
+}
+
+__device__ void jacobi_eig_fast(jacobi_lds &s, int n) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int m = n + (n & 1), half = m / 2;
+    const int nblk = half * half, ne = m * half;
+    double *fa = &s.a[0][0];  // [2][nblk][4]: 2 x 2 blocks, row-major inside a block
+    double *fe = &s.e[0][0];  // [2][ne][2]:   E[r][2 kc], E[r][2 kc + 1]
+    // position after one round-robin move: 0 stays, the rest cycles 1 -> 3 -> ... -> m-1 ->
+    // m-2 -> ... -> 4 -> 2 -> 1
+    auto next_pos = [&](int i) {
+        if (i == 0 || m == 2) return i;
+        if (i & 1) return i == m - 1 ? m - 2 : i + 2;
+        return i == 2 ? 1 : i - 2;
+    };
+    int kind[2], ia[2], ib[2], dst[2][4];
+    double v[2][4];
+    // blocks take whole waves (a wave that mixes blocks and E items would run both code
+    // paths one after the other), E items follow
+    const int nblk_pad = (nblk + 63) & ~63;
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int e = tid + 256 * w;
+        kind[w] = 0;
+        ia[w] = ib[w] = 0;
+        if (e < nblk) {
+            kind[w] = 1;
+            const int kr = e / half, kc = e - kr * half;
+            ia[w] = kr;
+            ib[w] = kc;
+#pragma unroll
+            for (int al = 0; al < 2; ++al)
+#pragma unroll
+                for (int be = 0; be < 2; ++be) {
+                    const int i = 2 * kr + al, j = 2 * kc + be;
+                    v[w][al * 2 + be] = (i < n && j < n) ? s.a[i][j] : 0.0;
+                    const int pi = next_pos(i), pj = next_pos(j);
+                    dst[w][al * 2 + be] = ((pi >> 1) * half + (pj >> 1)) * 4 + (pi & 1) * 2 + (pj & 1);
+                }
+        } else if (e >= nblk_pad && e < nblk_pad + ne) {
+            kind[w] = 2;
+            const int r = (e - nblk_pad) / half, kc = (e - nblk_pad) - r * half;
+            ia[w] = r;
+            ib[w] = kc;
+#pragma unroll
+            for (int be = 0; be < 2; ++be) {
+                const int j = 2 * kc + be;
+                v[w][be] = r == j ? 1.0 : 0.0;
+                const int pj = next_pos(j);
+                dst[w][be] = (r * half + (pj >> 1)) * 2 + (pj & 1);
+            }
+        }
+    }
+    __syncthreads();  // everyone has read its part of the input matrix
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        if (kind[w] == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fa[(ia[w] * half + ib[w]) * 4 + k] = v[w][k];
+        } else if (kind[w] == 2) {
+            fe[(ia[w] * half + ib[w]) * 2 + 0] = v[w][0];
+            fe[(ia[w] * half + ib[w]) * 2 + 1] = v[w][1];
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double *ac = fa + cur * nblk * 4;
+        // convergence: off-diagonal mass against the diagonal (dead directions carry -1e30 on
+        // the diagonal, k_small_rr: not part of the scale)
+        double off = 0.0, dia = 0.0;
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+            if (kind[w] == 1) {
+                const double *bp = ac + (ia[w] * half + ib[w]) * 4;
+                const double b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
+                if (ia[w] == ib[w]) {
+                    dia += (b0 > -1e29 ? b0 * b0 : 0.0) + (b3 > -1e29 ? b3 * b3 : 0.0);
+                    off += b1 * b1 + b2 * b2;
+                } else {
+                    off += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+                }
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            off += __shfl_xor(off, o, 64);
+            dia += __shfl_xor(dia, o, 64);
+        }
+        if (lane == 0) {
+            s.red[wave] = off;
+            s.red[4 + wave] = dia;
+        }
+        __syncthreads();
+        off = s.red[0] + s.red[1] + s.red[2] + s.red[3];
+        dia = s.red[4] + s.red[5] + s.red[6] + s.red[7];
+        __syncthreads();
+        if (off <= 1.25e-32 * (double)(n * n) * dia || off == 0.0) break;
+
+        for (int step = 0; step < m - 1; ++step) {
+            const double *a0 = fa + cur * nblk * 4;
+            const double *e0 = fe + cur * ne * 2;
+            double *a1 = fa + (cur ^ 1) * nblk * 4;
+            double *e1 = fe + (cur ^ 1) * ne * 2;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                if (kind[w] == 0) continue;
+                const double *dc = a0 + (ib[w] * half + ib[w]) * 4;
+                double c2, s2;
+                jacobi_rot(dc[0], dc[1], dc[3], c2, s2);
+                if (kind[w] == 1) {
+                    const double *dr = a0 + (ia[w] * half + ia[w]) * 4;
+                    double c1, s1;
+                    jacobi_rot(dr[0], dr[1], dr[3], c1, s1);
+                    const double *bp = a0 + (ia[w] * half + ib[w]) * 4;
+                    const double a00 = bp[0], a01 = bp[1], a10 = bp[2], a11 = bp[3];
+                    const double t00 = c2 * a00 - s2 * a01, t01 = s2 * a00 + c2 * a01;
+                    const double t10 = c2 * a10 - s2 * a11, t11 = s2 * a10 + c2 * a11;
+                    a1[dst[w][0]] = c1 * t00 - s1 * t10;
+                    a1[dst[w][1]] = c1 * t01 - s1 * t11;
+                    a1[dst[w][2]] = s1 * t00 + c1 * t10;
+                    a1[dst[w][3]] = s1 * t01 + c1 * t11;
+                } else {
+                    const double *ep = e0 + (ia[w] * half + ib[w]) * 2;
+                    const double x = ep[0], y = ep[1];
+                    e1[dst[w][0]] = c2 * x - s2 * y;
+                    e1[dst[w][1]] = s2 * x + c2 * y;
+                }
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    // back to the caller's layout: eigenvector of position j in column j of s.e, positions
+    // ranked by eigenvalue (descending); an odd n leaves out the padded coordinate, whose
+    // column is the only one with a non-zero in row n
+    const double *ac = fa + cur * nblk * 4;
+    const double *ec = fe + cur * ne * 2;
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+        if (kind[w] == 2) {
+            v[w][0] = ec[(ia[w] * half + ib[w]) * 2 + 0];
+            v[w][1] = ec[(ia[w] * half + ib[w]) * 2 + 1];
+        }
+    double wi = 0.0;
+    int rank = -1;
+    if (tid < m) {
+        auto diag_at = [&](int i) { return ac[((i >> 1) * half + (i >> 1)) * 4 + (i & 1) * 3]; };
+        auto is_pad = [&](int i) { return m != n && ec[(n * half + (i >> 1)) * 2 + (i & 1)] != 0.0; };
+        if (!is_pad(tid)) {
+            wi = diag_at(tid);
+            rank = 0;
+            for (int j = 0; j < m; ++j) {
+                if (is_pad(j)) continue;
+                const double wj = diag_at(j);
+                if (wj > wi || (wj == wi && j < tid)) ++rank;
+            }
+        }
+    }
+    __syncthreads();  // all reads of the flat copies are done: s.e may be overwritten
+#pragma unroll
+    for (int w = 0; w < 2; ++w)
+        if (kind[w] == 2 && ia[w] < n) {
+            s.e[ia[w]][2 * ib[w] + 0] = v[w][0];
+            s.e[ia[w]][2 * ib[w] + 1] = v[w][1];
+        }
+    if (rank >= 0) {
+        s.w[rank] = wi;
+        s.perm[rank] = tid;
+    }
+    __syncthreads();
+}
+
 __device__ void jacobi_eig(jacobi_lds &s, int n) {
+    if (n <= 24) {
+        jacobi_eig_fast(s, n);
+        return;
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = n + (n & 1);  // even; a padded index has zero row/column
@@ -509,6 +723,69 @@ __global__ __launch_bounds__(256) void k_small_svqb(const double *__restrict__ g
     if (tid < k) mask[tid] = (wmax > 0.0 && s.w[tid] > drop_tol * wmax) ? 1 : 0;
 }
 
+// Search-direction coefficients of the fused loop (b = 4, 8), one wave, registers and
+// wave shuffles only: lane i holds row i of C (the top-b eigenvectors) and of D.
+//   D <- the [P R] rows of C;  D <- (I - C C^T) D twice;  then classical Gram-Schmidt with
+//   re-orthogonalisation over the columns in Ritz order, a column being dropped (zero,
+//   mask 0) when less than drop_tol of its squared norm is left.
+// Same role as the SVQB step of the general path below; cheaper because nothing iterates.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int B>
+__device__ void rr_directions_wave(const jacobi_lds &s, int nq, double drop_tol,
+                                   double *__restrict__ d_out, int *__restrict__ mask_p) {
+    const int i = threadIdx.x;  // lane of wave 0
+    const bool row = i < nq;
+    double c[B], d[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        const double v = row ? s.e[i][s.perm[k]] : 0.0;
+        c[k] = v;
+        d[k] = i >= B ? v : 0.0;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        double g[B][B];
+#pragma unroll
+        for (int a = 0; a < B; ++a)
+#pragma unroll
+            for (int k = 0; k < B; ++k) g[a][k] = wave_sum(c[a] * d[k]);
+#pragma unroll
+        for (int k = 0; k < B; ++k)
+#pragma unroll
+            for (int a = 0; a < B; ++a) d[k] -= c[a] * g[a][k];
+    }
+    double n0[B];
+#pragma unroll
+    for (int k = 0; k < B; ++k) n0[k] = wave_sum(d[k] * d[k]);
+    int keep_mask = 0;
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            double r[B];
+#pragma unroll
+            for (int j = 0; j < k; ++j) r[j] = wave_sum(d[j] * d[k]);
+#pragma unroll
+            for (int j = 0; j < k; ++j) d[k] -= r[j] * d[j];
+        }
+        const double n1 = wave_sum(d[k] * d[k]);
+        const bool keep = n0[k] > 1e-290 && n1 > drop_tol * n0[k];
+        const double sc = keep ? 1.0 / sqrt(n1) : 0.0;
+        d[k] *= sc;
+        keep_mask |= keep ? (1 << k) : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < B; ++k) {
+        if (row) d_out[i * B + k] = d[k];
+        if (i == k) mask_p[k] = (keep_mask >> k) & 1;
+    }
+}
+
 // Rayleigh-Ritz: T (nq x nq) = Q^T A Q on an orthonormal basis Q = [X R P]; mask marks
 // live basis columns.  Outputs
 //   c (nq x b): top-b eigenvectors  -> X' = Q c,   theta[0..b) their values, theta[b] the next;
@@ -554,6 +831,13 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
     if (tid <= b && tid < nq) theta[tid] = s.w[tid];
     __syncthreads();
     if (nq == b) return;  // plain rotation of X (start-up / refresh): no search directions
+    if (nq == 3 * b && (b == 4 || b == 8)) {
+        if (tid < 64) {
+            if (b == 4) rr_directions_wave<4>(s, nq, drop_tol, d, mask_p);
+            else rr_directions_wave<8>(s, nq, drop_tol, d, mask_p);
+        }
+        return;
+    }
     // D <- (I - C C^T) D, twice
     for (int pass = 0; pass < 2; ++pass) {
         for (int e = tid; e < b * b; e += 256) {
