@@ -194,39 +194,60 @@ __global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, 
     __shared__ double red[4][NT * NT][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = lane >> 4, cc = lane & 15;
+    const double *aq_in = aq;
     panel_v4d acc[NT][NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (panel_v4d){0.0, 0.0, 0.0, 0.0};
     const int n_groups = (n + 3) / 4;
-    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
-        const int row = grp * 4 + kk;
-        const bool live = row < n;
-        double fa[NT], fb[NT];
+    // U groups of four rows per trip: all their loads are issued before the first store and
+    // the first MFMA, so the trips of a wave are bound by one memory latency, not U
+    constexpr int U = 4;
+    const int stride = gridDim.x * 4;
+    for (int grp0 = blockIdx.x * 4 + wave; grp0 < n_groups; grp0 += stride * U) {
+        double fa[U][NT], fb[U][NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int col = t * 16 + cc;
-            fa[t] = (live && col < LD) ? q[(int64_t)row * LD + col] : 0.0;
-            double v = 0.0;
-            if (live && col < LD) {
-                if (FINISH && col >= 2 * B) {
-                    const int64_t idx = (int64_t)row * B + (col - 2 * B);
-                    double s = 0.0;
-                    for (int g = 0; g < nseg; ++g) s += ypart[(int64_t)g * n * B + idx];
-                    v = dinv[row] * s;
-                    aq[(int64_t)row * LD + col] = v;
-                } else {
-                    v = aq[(int64_t)row * LD + col];
+        for (int uu = 0; uu < U; ++uu) {
+            const int row = (grp0 + uu * stride) * 4 + kk;
+            const bool live = grp0 + uu * stride < n_groups && row < n;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + cc;
+                fa[uu][t] = (live && col < LD) ? q[(int64_t)row * LD + col] : 0.0;
+                double v = 0.0;
+                if (live && col < LD) {
+                    if (FINISH && col >= 2 * B) {
+                        const int64_t idx = (int64_t)row * B + (col - 2 * B);
+                        // k_symm uses at most four column segments; the loads are independent
+                        double part[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            part[g] = g < nseg ? ypart[(int64_t)g * n * B + idx] : 0.0;
+                        const double sum = ((part[0] + part[1]) + part[2]) + part[3];
+                        v = dinv[row] * sum;
+                    } else {
+                        v = aq_in[(int64_t)row * LD + col];
+                    }
                 }
+                fb[uu][t] = v;
             }
-            fb[t] = v;
         }
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int uu = 0; uu < U; ++uu) {
+            const int row = (grp0 + uu * stride) * 4 + kk;
+            const bool live = grp0 + uu * stride < n_groups && row < n;
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                const int col = t * 16 + cc;
+                if (FINISH && live && col < LD && col >= 2 * B) aq[(int64_t)row * LD + col] = fb[uu][t];
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[uu][i], fb[uu][j], acc[i][j], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NT; ++i)
