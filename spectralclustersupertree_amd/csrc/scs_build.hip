@@ -45,14 +45,73 @@ constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
 // prep kernels
 // ---------------------------------------------------------------------------
 
-// grid (ceil(max_leaves/256), trees in batch)
+// ---- range-minimum tables ---------------------------------------------------
+// A gap p of a tree (the LCA of leaves p and p + 1) is keyed (depth << pos_bits) | p, so
+// the minimum key over a range of gaps names the shallowest LCA in it, i.e. the LCA of
+// the range's end leaves.  Keys are 32-bit when depth and position fit together (K = u32,
+// pos_bits = bits of the largest tree), else 64-bit with pos_bits = 32.
+// Per tree with m gaps and nb = ceil(m / 16) blocks, in entries of K:
+//   [k m, (k+1) m), k = 0..3   min over [p, min(p + 2^k, m))      (ranges inside a block)
+//   [4 m, 5 m)                 pre[p]: min over [16 (p / 16), p]
+//   [5 m, 6 m)                 suf[p]: min over [p, end of p's block)
+//   [6 m + k nb, ...)          sparse table over the block minima, level k: blocks
+//                              [B, min(B + 2^k, nb))
+// 6.75 m entries instead of the m log2(m) of a plain sparse table: a tree's table stays
+// L2-resident at 50 000 leaves, and a query is still at most four independent loads.
+constexpr int RMQ_SHIFT = 4, RMQ_S = 1 << RMQ_SHIFT;
+
+template <typename K>
+__device__ __forceinline__ K key_make(u32 depth, u32 pos, int pos_bits) {
+    return ((K)depth << pos_bits) | (K)pos;
+}
+template <typename K>
+__device__ __forceinline__ u32 key_depth(K k, int pos_bits) {
+    return (u32)(k >> pos_bits);
+}
+template <typename K>
+__device__ __forceinline__ u32 key_pos(K k, int pos_bits) {
+    return (u32)(k & (((K)1 << pos_bits) - 1));
+}
+
+// offsets (entries from the tree's table base) of the four loads of a query over gaps
+// [a, b), 0 <= a < b <= m; slots a query does not need repeat another slot
+__device__ __forceinline__ void rmq_offsets(int m, int nb, int a, int b, int (&o)[4]) {
+    const int blk_a = a >> RMQ_SHIFT, blk_b = (b - 1) >> RMQ_SHIFT;
+    const bool same = blk_a == blk_b;
+    const int k = min(31 - __clz(b - a), RMQ_SHIFT - 1);
+    const int between = blk_b - blk_a - 1;
+    const bool far = between > 0;
+    const int kb = 31 - __clz(max(between, 1));
+    o[0] = same ? k * m + a : 5 * m + a;
+    o[1] = same ? k * m + b - (1 << k) : 4 * m + b - 1;
+    const int bs = 6 * m + kb * nb;
+    o[2] = far ? bs + blk_a + 1 : o[0];
+    o[3] = far ? bs + blk_b - (1 << kb) : o[1];
+}
+
+template <typename K>
+__device__ __forceinline__ K min4(K a, K b, K c, K d) {
+    const K x = a < b ? a : b, y = c < d ? c : d;
+    return x < y ? x : y;
+}
+
+template <typename K>
+__device__ __forceinline__ K rmq_min(const K *__restrict__ base, int m, int a, int b) {
+    int o[4];
+    rmq_offsets(m, (m + RMQ_S - 1) >> RMQ_SHIFT, a, b, o);
+    return min4(base[o[0]], base[o[1]], base[o[2]], base[o[3]]);
+}
+
+// grid (ceil(max_leaves/256), trees in batch): positions, leaf values, level-0 keys
+template <typename K>
 __global__ void k_positions(const int64_t *__restrict__ tree_off,
                             const int32_t *__restrict__ leaf_taxon,
                             const int32_t *__restrict__ adj_depth,
                             const double *__restrict__ adj_val,
                             const double *__restrict__ tree_w, int t0, int64_t leaf_base,
                             int32_t *__restrict__ pos, int64_t npad, double *__restrict__ vw,
-                            const int64_t *__restrict__ st_off, u64 *__restrict__ st) {
+                            const int64_t *__restrict__ st_off, K *__restrict__ st,
+                            int pos_bits) {
     const int tl = blockIdx.y;
     const int t = t0 + tl;
     const int64_t off = tree_off[t];
@@ -64,23 +123,73 @@ __global__ void k_positions(const int64_t *__restrict__ tree_off,
         const u32 d = (u32)adj_depth[off + p];
         // one rounded multiply, as the reference's `length * tree_weight`
         vw[off - leaf_base + p] = d ? adj_val[off + p] * tree_w[t] : 0.0;
-        st[st_off[tl] + p] = ((u64)d << 32) | (u32)p;
+        st[st_off[tl] + p] = key_make<K>(d, (u32)p, pos_bits);
     }
 }
 
-// level k >= 1 of every tree's sparse table; grid as above
-__global__ void k_sparse_level(const int64_t *__restrict__ tree_off, int t0, int k,
-                               const int64_t *__restrict__ st_off, u64 *__restrict__ st) {
+// levels 1..3 from level 0 (grid as above)
+template <typename K>
+__global__ void k_rmq_levels(const int64_t *__restrict__ tree_off, int t0,
+                             const int64_t *__restrict__ st_off, K *__restrict__ st) {
     const int tl = blockIdx.y;
-    const int t = t0 + tl;
-    const int m = (int)(tree_off[t + 1] - tree_off[t]) - 1;
+    const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    const int half = 1 << (k - 1);
-    if (m < (1 << k) || p > m - (1 << k)) return;
-    u64 *base = st + st_off[tl];
-    const u64 *prev = base + (int64_t)(k - 1) * m;
-    const u64 a = prev[p], b = prev[p + half];
-    base[(int64_t)k * m + p] = a < b ? a : b;
+    if (p >= m) return;
+    K *base = st + st_off[tl];
+    K v = base[p];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        const K w = base[min(p + j, m - 1)];
+        v = w < v ? w : v;
+        if (j == 1) base[(int64_t)m + p] = v;
+        if (j == 3) base[2 * (int64_t)m + p] = v;
+        if (j == 7) base[3 * (int64_t)m + p] = v;
+    }
+}
+
+// in-block prefix / suffix minima and the block minimum; one thread per block of 16 gaps,
+// grid (ceil(max_blocks/256), trees in batch)
+template <typename K>
+__global__ void k_rmq_blocks(const int64_t *__restrict__ tree_off, int t0,
+                             const int64_t *__restrict__ st_off, K *__restrict__ st) {
+    const int tl = blockIdx.y;
+    const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
+    const int nb = (m + RMQ_S - 1) >> RMQ_SHIFT;
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nb) return;
+    K *base = st + st_off[tl];
+    const int lo = blk << RMQ_SHIFT, hi = min(lo + RMQ_S, m);
+    K v[RMQ_S];
+#pragma unroll
+    for (int j = 0; j < RMQ_S; ++j) v[j] = base[min(lo + j, hi - 1)];
+    K run = v[0];
+#pragma unroll
+    for (int j = 0; j < RMQ_S; ++j) {
+        run = v[j] < run ? v[j] : run;
+        if (lo + j < hi) base[4 * (int64_t)m + lo + j] = run;
+    }
+    base[6 * (int64_t)m + blk] = run;  // block minimum = level 0 of the block table
+    run = v[RMQ_S - 1];
+#pragma unroll
+    for (int j = RMQ_S - 1; j >= 0; --j) {
+        run = v[j] < run ? v[j] : run;
+        if (lo + j < hi) base[5 * (int64_t)m + lo + j] = run;
+    }
+}
+
+// level k >= 1 of the block table (grid as k_rmq_blocks)
+template <typename K>
+__global__ void k_rmq_block_level(const int64_t *__restrict__ tree_off, int t0, int k,
+                                  const int64_t *__restrict__ st_off, K *__restrict__ st) {
+    const int tl = blockIdx.y;
+    const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
+    const int nb = (m + RMQ_S - 1) >> RMQ_SHIFT;
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk >= nb || (1 << k) > nb) return;
+    K *bt = st + st_off[tl] + 6 * (int64_t)m;
+    const K a = bt[(int64_t)(k - 1) * nb + blk];
+    const K b = bt[(int64_t)(k - 1) * nb + min(blk + (1 << (k - 1)), nb - 1)];
+    bt[(int64_t)k * nb + blk] = a < b ? a : b;
 }
 
 // one v_min_f64 (the builtin fmin adds a canonicalising v_max_f64 in front of it);
@@ -95,22 +204,13 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 #endif
 }
 
-__device__ __forceinline__ u64 rmq_tree(const u64 *__restrict__ st, int m, int a, int b) {
-    // minimum over gaps [a, b), a < b <= m
-    const int len = b - a;
-    const int k = 31 - __clz(len);
-    const u64 *lvl = st + (int64_t)k * m;
-    const u64 x = lvl[a];
-    const u64 y = lvl[b - (1 << k)];
-    return x < y ? x : y;
-}
-
 // one wave per (local row block, tree): grid (n_blocks, trees in batch), 64 threads
+template <typename K>
 __global__ __launch_bounds__(64) void k_block_records(
     const int64_t *__restrict__ tree_off, int t0, int n_batch, int64_t leaf_base,
     const int32_t *__restrict__ pos, int64_t npad, const double *__restrict__ vw,
-    const int64_t *__restrict__ st_off, const u64 *__restrict__ st, int row_begin, int row_end,
-    unsigned char *__restrict__ rec_all) {
+    const int64_t *__restrict__ st_off, const K *__restrict__ st, int pos_bits, int row_begin,
+    int row_end, unsigned char *__restrict__ rec_all) {
     const int blk = blockIdx.x;
     const int tl = blockIdx.y;
     const int t = t0 + tl;
@@ -140,9 +240,9 @@ __global__ __launch_bounds__(64) void k_block_records(
     u32 gdepth = 0;
     double gvw = 0.0;
     if (lane < cnt - 1) {
-        const u64 r = rmq_tree(st + st_off[tl], m, spos, next_pos);
-        gdepth = (u32)(r >> 32);
-        gvw = gdepth ? vw[off - leaf_base + (u32)(r & 0xFFFFFFFFu)] : 0.0;
+        const K r = rmq_min<K>(st + st_off[tl], m, spos, next_pos);
+        gdepth = key_depth<K>(r, pos_bits);
+        gvw = gdepth ? vw[off - leaf_base + key_pos<K>(r, pos_bits)] : 0.0;
     }
     unsigned char *rec = rec_all + ((int64_t)blk * n_batch + tl) * REC_BYTES;
     ((int *)(rec + REC_SPOS))[lane] = spos;
@@ -183,7 +283,8 @@ struct acc_params {
     int64_t npad;
     const double *vw;
     const int64_t *st_off;
-    const u64 *st;
+    const void *st;  // range-minimum tables, entries of the kernel's key type
+    int pos_bits;    // key = (depth << pos_bits) | position
     const int64_t *tree_off;
     int t0;
     int n_batch;
@@ -198,7 +299,7 @@ struct acc_params {
     unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
 };
 
-template <bool SYM>
+template <bool SYM, typename K>
 __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
     constexpr int CPT = 1;  // columns per thread
     __shared__ int s_spos[64];
@@ -295,7 +396,8 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
             const int t = p.t0 + tl;
             const int64_t off = p.tree_off[t];
             const int m = (int)(p.tree_off[t + 1] - off) - 1;
-            const u64 *st = p.st + p.st_off[tl];
+            const K *st = (const K *)p.st + p.st_off[tl];
+            const int pos_bits = p.pos_bits;
             const int cnt = s_cnt;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
@@ -313,14 +415,15 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
                         nb[q] = s_sorig[lo];  // the column is one of the tile's rows
                         dn[q] = DEPTH_INF;
                     } else {
-                        u64 gl = 0, gr = 0;
-                        if (lo > 0) gl = rmq_tree(st, m, s_spos[lo - 1], cp);
-                        if (lo < cnt) gr = rmq_tree(st, m, cp, s_spos[lo]);
-                        const bool left = lo > 0 && (lo >= cnt || (gl >> 32) >= (gr >> 32));
-                        const u64 g = left ? gl : gr;
+                        K gl = 0, gr = 0;
+                        if (lo > 0) gl = rmq_min<K>(st, m, s_spos[lo - 1], cp);
+                        if (lo < cnt) gr = rmq_min<K>(st, m, cp, s_spos[lo]);
+                        const bool left = lo > 0 && (lo >= cnt || key_depth<K>(gl, pos_bits) >=
+                                                                      key_depth<K>(gr, pos_bits));
+                        const K g = left ? gl : gr;
                         nb[q] = s_sorig[left ? lo - 1 : lo];
-                        dn[q] = (u32)(g >> 32);
-                        if (dn[q]) vn[q] = p.vw[off - p.leaf_base + (u32)(g & 0xFFFFFFFFu)];
+                        dn[q] = key_depth<K>(g, pos_bits);
+                        if (dn[q]) vn[q] = p.vw[off - p.leaf_base + key_pos<K>(g, pos_bits)];
                     }
                 }
             }
@@ -387,7 +490,7 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
 constexpr int DV_LD = 65;  // leading dimension of the row-row table (doubles): with 65 a
                            // lane's ds_read_b64 of row nb hits bank pair (nb + i) mod 32
 
-template <bool SYM, bool STAMPED>
+template <bool SYM, bool STAMPED, typename K>
 __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
     // block record of the current / next tree, staged by LDS-DMA (global_load_lds_dwordx4:
     // no registers held across the step); same byte layout as in global memory
@@ -485,22 +588,25 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         }
         const bool hasl = present && self < 0 && lo > 0;
         const bool hasr = present && self < 0 && lo < cnt;
-        u64 xl, yl, xr, yr;
+        K ql4[4], qr4[4];
         {
             const int ql = s_spos[max(lo - 1, 0)];
             const int qr = s_spos[min(lo, 63)];
             const int m = *(const int *)(rb + REC_M);
-            const u64 *st = p.st + *(const long long *)(rb + REC_STOFF);
+            const int nbk = (m + RMQ_S - 1) >> RMQ_SHIFT;
+            const K *st = (const K *)p.st + *(const long long *)(rb + REC_STOFF);
             // left query: gaps [ql, cpos); right query: gaps [cpos, qr); a side that does
             // not exist reads entry 0 of the tree's level 0 (always there) and is ignored
             const int al = hasl ? ql : 0, bl = hasl ? cpos : 1;
             const int ar = hasr ? cpos : 0, br = hasr ? qr : 1;
-            const int kl = 31 - __clz(bl - al), kr = 31 - __clz(br - ar);
-            const u64 *ll = st + (int64_t)kl * m, *lr = st + (int64_t)kr * m;
-            xl = ll[al];
-            yl = ll[bl - (1 << kl)];
-            xr = lr[ar];
-            yr = lr[br - (1 << kr)];
+            int ol[4], orr[4];
+            rmq_offsets(m, nbk, al, bl, ol);
+            rmq_offsets(m, nbk, ar, br, orr);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ql4[j] = st[ol[j]];
+                qr4[j] = st[orr[j]];
+            }
         }
         stamp(2);
         // ---- expand the row-row value table: wave w fills rows w, w+4, ...; entry (i, j)
@@ -531,12 +637,14 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         int nb = 0;
         double vn = 0.0;
         if (hasl || hasr) {
-            const u64 gl = hasl ? (xl < yl ? xl : yl) : 0;
-            const u64 gr = hasr ? (xr < yr ? xr : yr) : 0;
-            const bool left = hasl && (!hasr || (gl >> 32) >= (gr >> 32));
-            const u64 g = left ? gl : gr;
+            const int pos_bits = p.pos_bits;
+            const K gl = hasl ? min4<K>(ql4[0], ql4[1], ql4[2], ql4[3]) : 0;
+            const K gr = hasr ? min4<K>(qr4[0], qr4[1], qr4[2], qr4[3]) : 0;
+            const bool left = hasl && (!hasr || key_depth<K>(gl, pos_bits) >= key_depth<K>(gr, pos_bits));
+            const K g = left ? gl : gr;
             nb = s_sorig[left ? lo - 1 : lo];
-            if ((u32)(g >> 32)) vn = p.vw[*(const long long *)(rb + REC_VWOFF) + (u32)(g & 0xFFFFFFFFu)];
+            if (key_depth<K>(g, pos_bits))
+                vn = p.vw[*(const long long *)(rb + REC_VWOFF) + key_pos<K>(g, pos_bits)];
         } else if (present && self >= 0) {
             // cell (i, c) = table entry (self, i); the diagonal entry is +inf and makes
             // acc[self] meaningless -- it is reset after the last tree
@@ -854,7 +962,20 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                  hipMemcpyHostToDevice, s));
 
-    // ---- batch plan: bound sparse tables + records + positions by the workspace
+    // ---- key width of the range-minimum tables: 32 bits when depth and position fit
+    // together (SCS_KEY64=1 forces the 64-bit path: tests)
+    int pos_bits = 1;
+    while ((1ll << pos_bits) < std::max<int64_t>(tb->max_leaves, 2)) ++pos_bits;
+    const bool key64 = (int64_t)tb->max_depth >= (1ll << (32 - pos_bits)) ||
+                       (getenv("SCS_KEY64") && atoi(getenv("SCS_KEY64")));
+    if (key64) pos_bits = 32;
+    const size_t key_bytes = key64 ? 8 : 4;
+    auto table_entries = [](int64_t m) -> int64_t {
+        const int64_t nblk = (m + RMQ_S - 1) >> RMQ_SHIFT;
+        return 6 * m + (int64_t)levels_for(nblk) * nblk;
+    };
+
+    // ---- batch plan: bound range-minimum tables + records + positions by the workspace
     const int M = tb->n_trees;
     std::vector<int> batch_start{0};
     {
@@ -862,7 +983,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
             const int64_t m = nt - 1;
-            size_t need = (size_t)levels_for(m) * (size_t)m * 8 + (size_t)nt * 8 +
+            size_t need = (size_t)table_entries(m) * key_bytes + (size_t)nt * 8 +
                           (size_t)npad * 4 + (size_t)n_blocks * REC_BYTES;
             if (used + need > ctx->ws_limit && t > batch_start.back()) {
                 batch_start.push_back(t);
@@ -889,19 +1010,18 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         const int64_t leaf_base = tb->h_tree_off[t0];
         const int64_t leaves = tb->h_tree_off[t1] - leaf_base;
         std::vector<int64_t> st_off(nb + 1);
-        int max_levels = 0;
+        int max_levels = 0;  // of the block tables
         int64_t max_n = 0;
         st_off[0] = 0;
         for (int t = t0; t < t1; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
-            const int lv = levels_for(nt - 1);
-            st_off[t - t0 + 1] = st_off[t - t0] + (int64_t)lv * (nt - 1);
-            max_levels = std::max(max_levels, lv);
+            st_off[t - t0 + 1] = st_off[t - t0] + table_entries(nt - 1);
+            max_levels = std::max(max_levels, levels_for((nt - 1 + RMQ_S - 1) >> RMQ_SHIFT));
             max_n = std::max(max_n, nt);
         }
         const size_t need_pos = (size_t)nb * npad * 4;
         const size_t need_vw = (size_t)leaves * 8;
-        const size_t need_st = (size_t)st_off[nb] * 8 + 64;  // +64: a tree without gaps may be probed at entry 0
+        const size_t need_st = (size_t)st_off[nb] * key_bytes + 64;  // +64: a tree without gaps may be probed at entry 0
         const size_t need_stoff = (size_t)(nb + 1) * 8;
         const size_t need_rec = (size_t)n_blocks * nb * REC_BYTES;
         if (need_pos > cap_pos) { SCS_TRY(d_pos.alloc(need_pos)); cap_pos = need_pos; }
@@ -914,17 +1034,28 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_HIP_CHECK(hipMemcpyAsync(d_stoff.p, st_off.data(), need_stoff, hipMemcpyHostToDevice, s));
         SCS_HIP_CHECK(hipMemsetAsync(d_pos.p, 0xFF, need_pos, s));
         dim3 grid_l((unsigned)((max_n + 255) / 256), (unsigned)nb);
-        k_positions<<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon, tb->d_adj_depth,
-                                           tb->d_adj_val, tb->d_tree_w, t0, leaf_base,
-                                           (int32_t *)d_pos.p, npad, (double *)d_vw.p,
-                                           (const int64_t *)d_stoff.p, (u64 *)d_st.p);
-        for (int k = 1; k < max_levels; ++k)
-            k_sparse_level<<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
-                                                  (const int64_t *)d_stoff.p, (u64 *)d_st.p);
-        k_block_records<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
-            tb->d_tree_off, t0, nb, leaf_base, (const int32_t *)d_pos.p, npad,
-            (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const u64 *)d_st.p, b_row_begin,
-            b_row_end, (unsigned char *)d_rec.p);
+        const dim3 grid_b((unsigned)((((max_n + RMQ_S - 1) >> RMQ_SHIFT) + 255) / 256), (unsigned)nb);
+#define SCS_PREP(K)                                                                              \
+    do {                                                                                         \
+        k_positions<K><<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon, tb->d_adj_depth, \
+                                              tb->d_adj_val, tb->d_tree_w, t0, leaf_base,        \
+                                              (int32_t *)d_pos.p, npad, (double *)d_vw.p,        \
+                                              (const int64_t *)d_stoff.p, (K *)d_st.p, pos_bits); \
+        k_rmq_levels<K><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, (const int64_t *)d_stoff.p,   \
+                                               (K *)d_st.p);                                     \
+        k_rmq_blocks<K><<<grid_b, 256, 0, s>>>(tb->d_tree_off, t0, (const int64_t *)d_stoff.p,   \
+                                               (K *)d_st.p);                                     \
+        for (int k = 1; k < max_levels; ++k)                                                     \
+            k_rmq_block_level<K><<<grid_b, 256, 0, s>>>(tb->d_tree_off, t0, k,                   \
+                                                        (const int64_t *)d_stoff.p, (K *)d_st.p); \
+        k_block_records<K><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(                \
+            tb->d_tree_off, t0, nb, leaf_base, (const int32_t *)d_pos.p, npad,                   \
+            (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const K *)d_st.p, pos_bits,     \
+            b_row_begin, b_row_end, (unsigned char *)d_rec.p);                                   \
+    } while (0)
+        if (key64) SCS_PREP(u64);
+        else SCS_PREP(u32);
+#undef SCS_PREP
         SCS_HIP_CHECK(hipEventRecord(ev_prep.b, s));
 
         acc_params ap;
@@ -934,7 +1065,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         ap.npad = npad;
         ap.vw = (const double *)d_vw.p;
         ap.st_off = (const int64_t *)d_stoff.p;
-        ap.st = (const u64 *)d_st.p;
+        ap.st = d_st.p;
+        ap.pos_bits = pos_bits;
         ap.tree_off = tb->d_tree_off;
         ap.t0 = t0;
         ap.n_batch = nb;
@@ -959,8 +1091,13 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                     SCS_TRY(d_st8.alloc(64));
                     SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
                     ap.stamps = (unsigned long long *)d_st8.p;
-                    if (sym) k_accumulate_mono<true, true><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                    else k_accumulate_mono<false, true><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    if (key64) {
+                        if (sym) k_accumulate_mono<true, true, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                        else k_accumulate_mono<false, true, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    } else {
+                        if (sym) k_accumulate_mono<true, true, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                        else k_accumulate_mono<false, true, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    }
                     unsigned long long h[8];
                     SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
                     SCS_HIP_CHECK(hipStreamSynchronize(s));
@@ -970,20 +1107,35 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                     for (int i = 0; i < 7; ++i)
                         fprintf(stderr, "[stamp] %-18s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i], 100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
                     ap.stamps = nullptr;
-                } else if (sym) k_accumulate_mono<true, false><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                else k_accumulate_mono<false, false><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                } else if (key64) {
+                    if (sym) k_accumulate_mono<true, false, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    else k_accumulate_mono<false, false, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                } else {
+                    if (sym) k_accumulate_mono<true, false, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                    else k_accumulate_mono<false, false, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
+                }
             }
             if (n_diag) {
                 acc_params ad = ap;
                 ad.tiles = (const int2 *)d_tiles.p + n_main;
                 ad.slot_base = (int)n_main;
-                if (sym) k_accumulate<true><<<n_diag, SCS_TCW, 0, s>>>(ad);
-                else k_accumulate<false><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                if (key64) {
+                    if (sym) k_accumulate<true, u64><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                    else k_accumulate<false, u64><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                } else {
+                    if (sym) k_accumulate<true, u32><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                    else k_accumulate<false, u32><<<n_diag, SCS_TCW, 0, s>>>(ad);
+                }
             }
         } else {
             if (!nt) {
-            } else if (sym) k_accumulate<true><<<nt, SCS_TCW, 0, s>>>(ap);
-            else k_accumulate<false><<<nt, SCS_TCW, 0, s>>>(ap);
+            } else if (key64) {
+                if (sym) k_accumulate<true, u64><<<nt, SCS_TCW, 0, s>>>(ap);
+                else k_accumulate<false, u64><<<nt, SCS_TCW, 0, s>>>(ap);
+            } else {
+                if (sym) k_accumulate<true, u32><<<nt, SCS_TCW, 0, s>>>(ap);
+                else k_accumulate<false, u32><<<nt, SCS_TCW, 0, s>>>(ap);
+            }
         }
         SCS_HIP_CHECK(hipGetLastError());
         SCS_HIP_CHECK(hipEventRecord(ev_acc.b, s));

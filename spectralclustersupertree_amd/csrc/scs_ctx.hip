@@ -331,6 +331,7 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
                 "scs_tables_upload: null table pointer");
     SCS_REQUIRE(tree_off[0] == 0, "scs_tables_upload: tree_off[0] must be 0");
     int64_t max_leaves = 0;
+    int32_t max_depth = 0;
     for (int32_t t = 0; t < n_trees; ++t) {
         int64_t n = tree_off[t + 1] - tree_off[t];
         SCS_REQUIRE(n >= 1, "scs_tables_upload: tree %d has %lld leaves", t, (long long)n);
@@ -347,6 +348,7 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
                     leaf_taxon[p]);
         SCS_REQUIRE(adj_depth[p] >= 0, "scs_tables_upload: adj_depth[%lld] negative",
                     (long long)p);
+        if (adj_depth[p] > max_depth) max_depth = adj_depth[p];
     }
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     auto *t = new scs_tables();
@@ -354,6 +356,7 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
     t->n_trees = n_trees;
     t->n_leaves = L;
     t->max_leaves = (int32_t)max_leaves;
+    t->max_depth = max_depth;
     t->h_tree_off.assign(tree_off, tree_off + n_trees + 1);
     int rc = SCS_OK;
     if ((rc = upload(&t->d_tree_off, tree_off, (size_t)n_trees + 1, ctx->stream)) != SCS_OK ||

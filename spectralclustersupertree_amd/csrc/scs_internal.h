@@ -81,6 +81,7 @@ struct scs_tables {
     int32_t n_trees = 0;
     int64_t n_leaves = 0;
     int32_t max_leaves = 0;            // largest tree
+    int32_t max_depth = 0;             // deepest LCA of adjacent leaves in any tree
     std::vector<int64_t> h_tree_off;   // host copy (batch planning)
     int64_t *d_tree_off = nullptr;     // [n_trees+1]
     int32_t *d_leaf_taxon = nullptr;   // [L]
