@@ -49,17 +49,13 @@ constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
 // A gap p of a tree (the LCA of leaves p and p + 1) is keyed (depth << pos_bits) | p, so
 // the minimum key over a range of gaps names the shallowest LCA in it, i.e. the LCA of
 // the range's end leaves.  Keys are 32-bit when depth and position fit together (K = u32,
-// pos_bits = bits of the largest tree), else 64-bit with pos_bits = 32.
-// Per tree with m gaps and nb = ceil(m / 16) blocks, in entries of K:
-//   [k m, (k+1) m), k = 0..3   min over [p, min(p + 2^k, m))      (ranges inside a block)
-//   [4 m, 5 m)                 pre[p]: min over [16 (p / 16), p]
-//   [5 m, 6 m)                 suf[p]: min over [p, end of p's block)
-//   [6 m + k nb, ...)          sparse table over the block minima, level k: blocks
-//                              [B, min(B + 2^k, nb))
-// 6.75 m entries instead of the m log2(m) of a plain sparse table: a tree's table stays
-// L2-resident at 50 000 leaves, and a query is still at most four independent loads.
-constexpr int RMQ_SHIFT = 4, RMQ_S = 1 << RMQ_SHIFT;
-
+// pos_bits = bits of the largest tree), else 64-bit with pos_bits = 32: half the table
+// bytes of a (depth, position) pair of words, which is what the gathers of the accumulate
+// kernels miss the L2 on.  Per tree with m gaps: a plain sparse table, level k at
+// [k m, (k + 1) m), entry p = min over [p, p + 2^k); a query is two independent loads.
+// (A blocked table -- in-block prefix/suffix minima plus a sparse table over block minima,
+// 6.75 m entries -- was measured slower: twice the gathers per query cost more than the
+// smaller footprint saved.)
 template <typename K>
 __device__ __forceinline__ K key_make(u32 depth, u32 pos, int pos_bits) {
     return ((K)depth << pos_bits) | (K)pos;
@@ -73,33 +69,20 @@ __device__ __forceinline__ u32 key_pos(K k, int pos_bits) {
     return (u32)(k & (((K)1 << pos_bits) - 1));
 }
 
-// offsets (entries from the tree's table base) of the four loads of a query over gaps
-// [a, b), 0 <= a < b <= m; slots a query does not need repeat another slot
-__device__ __forceinline__ void rmq_offsets(int m, int nb, int a, int b, int (&o)[4]) {
-    const int blk_a = a >> RMQ_SHIFT, blk_b = (b - 1) >> RMQ_SHIFT;
-    const bool same = blk_a == blk_b;
-    const int k = min(31 - __clz(b - a), RMQ_SHIFT - 1);
-    const int between = blk_b - blk_a - 1;
-    const bool far = between > 0;
-    const int kb = 31 - __clz(max(between, 1));
-    o[0] = same ? k * m + a : 5 * m + a;
-    o[1] = same ? k * m + b - (1 << k) : 4 * m + b - 1;
-    const int bs = 6 * m + kb * nb;
-    o[2] = far ? bs + blk_a + 1 : o[0];
-    o[3] = far ? bs + blk_b - (1 << kb) : o[1];
-}
-
-template <typename K>
-__device__ __forceinline__ K min4(K a, K b, K c, K d) {
-    const K x = a < b ? a : b, y = c < d ? c : d;
-    return x < y ? x : y;
+// offsets (entries from the tree's table base) of the two loads of a query over gaps
+// [a, b), 0 <= a < b <= m
+__device__ __forceinline__ void rmq_offsets(int m, int a, int b, int (&o)[2]) {
+    const int k = 31 - __clz(b - a);
+    o[0] = k * m + a;
+    o[1] = k * m + b - (1 << k);
 }
 
 template <typename K>
 __device__ __forceinline__ K rmq_min(const K *__restrict__ base, int m, int a, int b) {
-    int o[4];
-    rmq_offsets(m, (m + RMQ_S - 1) >> RMQ_SHIFT, a, b, o);
-    return min4(base[o[0]], base[o[1]], base[o[2]], base[o[3]]);
+    int o[2];
+    rmq_offsets(m, a, b, o);
+    const K x = base[o[0]], y = base[o[1]];
+    return x < y ? x : y;
 }
 
 // grid (ceil(max_leaves/256), trees in batch): positions, leaf values, level-0 keys
@@ -127,69 +110,17 @@ __global__ void k_positions(const int64_t *__restrict__ tree_off,
     }
 }
 
-// levels 1..3 from level 0 (grid as above)
+// level k >= 1 of every tree's sparse table; grid as k_positions
 template <typename K>
-__global__ void k_rmq_levels(const int64_t *__restrict__ tree_off, int t0,
-                             const int64_t *__restrict__ st_off, K *__restrict__ st) {
+__global__ void k_sparse_level(const int64_t *__restrict__ tree_off, int t0, int k,
+                               const int64_t *__restrict__ st_off, K *__restrict__ st) {
     const int tl = blockIdx.y;
     const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= m) return;
+    if (m < (1 << k) || p > m - (1 << k)) return;
     K *base = st + st_off[tl];
-    K v = base[p];
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-        const K w = base[min(p + j, m - 1)];
-        v = w < v ? w : v;
-        if (j == 1) base[(int64_t)m + p] = v;
-        if (j == 3) base[2 * (int64_t)m + p] = v;
-        if (j == 7) base[3 * (int64_t)m + p] = v;
-    }
-}
-
-// in-block prefix / suffix minima and the block minimum; one thread per block of 16 gaps,
-// grid (ceil(max_blocks/256), trees in batch)
-template <typename K>
-__global__ void k_rmq_blocks(const int64_t *__restrict__ tree_off, int t0,
-                             const int64_t *__restrict__ st_off, K *__restrict__ st) {
-    const int tl = blockIdx.y;
-    const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
-    const int nb = (m + RMQ_S - 1) >> RMQ_SHIFT;
-    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= nb) return;
-    K *base = st + st_off[tl];
-    const int lo = blk << RMQ_SHIFT, hi = min(lo + RMQ_S, m);
-    K v[RMQ_S];
-#pragma unroll
-    for (int j = 0; j < RMQ_S; ++j) v[j] = base[min(lo + j, hi - 1)];
-    K run = v[0];
-#pragma unroll
-    for (int j = 0; j < RMQ_S; ++j) {
-        run = v[j] < run ? v[j] : run;
-        if (lo + j < hi) base[4 * (int64_t)m + lo + j] = run;
-    }
-    base[6 * (int64_t)m + blk] = run;  // block minimum = level 0 of the block table
-    run = v[RMQ_S - 1];
-#pragma unroll
-    for (int j = RMQ_S - 1; j >= 0; --j) {
-        run = v[j] < run ? v[j] : run;
-        if (lo + j < hi) base[5 * (int64_t)m + lo + j] = run;
-    }
-}
-
-// level k >= 1 of the block table (grid as k_rmq_blocks)
-template <typename K>
-__global__ void k_rmq_block_level(const int64_t *__restrict__ tree_off, int t0, int k,
-                                  const int64_t *__restrict__ st_off, K *__restrict__ st) {
-    const int tl = blockIdx.y;
-    const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
-    const int nb = (m + RMQ_S - 1) >> RMQ_SHIFT;
-    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blk >= nb || (1 << k) > nb) return;
-    K *bt = st + st_off[tl] + 6 * (int64_t)m;
-    const K a = bt[(int64_t)(k - 1) * nb + blk];
-    const K b = bt[(int64_t)(k - 1) * nb + min(blk + (1 << (k - 1)), nb - 1)];
-    bt[(int64_t)k * nb + blk] = a < b ? a : b;
+    const K a = base[(int64_t)(k - 1) * m + p], b = base[(int64_t)(k - 1) * m + p + (1 << (k - 1))];
+    base[(int64_t)k * m + p] = a < b ? a : b;
 }
 
 // one v_min_f64 (the builtin fmin adds a canonicalising v_max_f64 in front of it);
@@ -588,25 +519,21 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         }
         const bool hasl = present && self < 0 && lo > 0;
         const bool hasr = present && self < 0 && lo < cnt;
-        K ql4[4], qr4[4];
+        K xl, yl, xr, yr;
         {
             const int ql = s_spos[max(lo - 1, 0)];
             const int qr = s_spos[min(lo, 63)];
             const int m = *(const int *)(rb + REC_M);
-            const int nbk = (m + RMQ_S - 1) >> RMQ_SHIFT;
             const K *st = (const K *)p.st + *(const long long *)(rb + REC_STOFF);
             // left query: gaps [ql, cpos); right query: gaps [cpos, qr); a side that does
             // not exist reads entry 0 of the tree's level 0 (always there) and is ignored
-            const int al = hasl ? ql : 0, bl = hasl ? cpos : 1;
-            const int ar = hasr ? cpos : 0, br = hasr ? qr : 1;
-            int ol[4], orr[4];
-            rmq_offsets(m, nbk, al, bl, ol);
-            rmq_offsets(m, nbk, ar, br, orr);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ql4[j] = st[ol[j]];
-                qr4[j] = st[orr[j]];
-            }
+            int ol[2], orr[2];
+            rmq_offsets(m, hasl ? ql : 0, hasl ? cpos : 1, ol);
+            rmq_offsets(m, hasr ? cpos : 0, hasr ? qr : 1, orr);
+            xl = st[ol[0]];
+            yl = st[ol[1]];
+            xr = st[orr[0]];
+            yr = st[orr[1]];
         }
         stamp(2);
         // ---- expand the row-row value table: wave w fills rows w, w+4, ...; entry (i, j)
@@ -638,8 +565,8 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         double vn = 0.0;
         if (hasl || hasr) {
             const int pos_bits = p.pos_bits;
-            const K gl = hasl ? min4<K>(ql4[0], ql4[1], ql4[2], ql4[3]) : 0;
-            const K gr = hasr ? min4<K>(qr4[0], qr4[1], qr4[2], qr4[3]) : 0;
+            const K gl = hasl ? (xl < yl ? xl : yl) : 0;
+            const K gr = hasr ? (xr < yr ? xr : yr) : 0;
             const bool left = hasl && (!hasr || key_depth<K>(gl, pos_bits) >= key_depth<K>(gr, pos_bits));
             const K g = left ? gl : gr;
             nb = s_sorig[left ? lo - 1 : lo];
@@ -931,6 +858,25 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             if (monotone && diag_general && overlap) tiles_diag.push_back(make_int2(b, c));
             else tiles.push_back(make_int2(b, c));
         }
+    // XCD-aware order: workgroups go to the eight XCDs round-robin by index and all tiles
+    // walk the trees at about the same pace.  Handing XCD x the row blocks b = x (mod 8), one
+    // row block after the other, makes the ~96 workgroups that share an L2 read the same
+    // block records and the same row-side table entries at the same time (measured: -4 % at
+    // 10 000 leaves, -3 % at 50 000).  SCS_TILE_ORDER=0 keeps the plain row-major order.
+    {
+        const bool per_xcd = !(getenv("SCS_TILE_ORDER") && atoi(getenv("SCS_TILE_ORDER")) == 0);
+        if (per_xcd && tiles.size() > 8) {
+            std::vector<int2> per[8];
+            for (const int2 &t : tiles) per[t.x & 7].push_back(t);  // stays (row, column) sorted
+            std::vector<int2> ordered;
+            ordered.reserve(tiles.size());
+            size_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            while (ordered.size() < tiles.size())
+                for (int x = 0; x < 8; ++x)
+                    if (at[x] < per[x].size()) ordered.push_back(per[x][at[x]++]);
+            tiles.swap(ordered);
+        }
+    }
     size_t n_main = tiles.size();
     tiles.insert(tiles.end(), tiles_diag.begin(), tiles_diag.end());
     // shared: tile i of the job-wide list belongs to rank i % world and lands in slot
@@ -970,10 +916,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                        (getenv("SCS_KEY64") && atoi(getenv("SCS_KEY64")));
     if (key64) pos_bits = 32;
     const size_t key_bytes = key64 ? 8 : 4;
-    auto table_entries = [](int64_t m) -> int64_t {
-        const int64_t nblk = (m + RMQ_S - 1) >> RMQ_SHIFT;
-        return 6 * m + (int64_t)levels_for(nblk) * nblk;
-    };
+    auto table_entries = [](int64_t m) -> int64_t { return (int64_t)levels_for(m) * m; };
 
     // ---- batch plan: bound range-minimum tables + records + positions by the workspace
     const int M = tb->n_trees;
@@ -1010,13 +953,13 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         const int64_t leaf_base = tb->h_tree_off[t0];
         const int64_t leaves = tb->h_tree_off[t1] - leaf_base;
         std::vector<int64_t> st_off(nb + 1);
-        int max_levels = 0;  // of the block tables
+        int max_levels = 0;
         int64_t max_n = 0;
         st_off[0] = 0;
         for (int t = t0; t < t1; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
             st_off[t - t0 + 1] = st_off[t - t0] + table_entries(nt - 1);
-            max_levels = std::max(max_levels, levels_for((nt - 1 + RMQ_S - 1) >> RMQ_SHIFT));
+            max_levels = std::max(max_levels, levels_for(nt - 1));
             max_n = std::max(max_n, nt);
         }
         const size_t need_pos = (size_t)nb * npad * 4;
@@ -1034,20 +977,15 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_HIP_CHECK(hipMemcpyAsync(d_stoff.p, st_off.data(), need_stoff, hipMemcpyHostToDevice, s));
         SCS_HIP_CHECK(hipMemsetAsync(d_pos.p, 0xFF, need_pos, s));
         dim3 grid_l((unsigned)((max_n + 255) / 256), (unsigned)nb);
-        const dim3 grid_b((unsigned)((((max_n + RMQ_S - 1) >> RMQ_SHIFT) + 255) / 256), (unsigned)nb);
 #define SCS_PREP(K)                                                                              \
     do {                                                                                         \
         k_positions<K><<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon, tb->d_adj_depth, \
                                               tb->d_adj_val, tb->d_tree_w, t0, leaf_base,        \
                                               (int32_t *)d_pos.p, npad, (double *)d_vw.p,        \
                                               (const int64_t *)d_stoff.p, (K *)d_st.p, pos_bits); \
-        k_rmq_levels<K><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, (const int64_t *)d_stoff.p,   \
-                                               (K *)d_st.p);                                     \
-        k_rmq_blocks<K><<<grid_b, 256, 0, s>>>(tb->d_tree_off, t0, (const int64_t *)d_stoff.p,   \
-                                               (K *)d_st.p);                                     \
         for (int k = 1; k < max_levels; ++k)                                                     \
-            k_rmq_block_level<K><<<grid_b, 256, 0, s>>>(tb->d_tree_off, t0, k,                   \
-                                                        (const int64_t *)d_stoff.p, (K *)d_st.p); \
+            k_sparse_level<K><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,                      \
+                                                     (const int64_t *)d_stoff.p, (K *)d_st.p);   \
         k_block_records<K><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(                \
             tb->d_tree_off, t0, nb, leaf_base, (const int32_t *)d_pos.p, npad,                   \
             (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const K *)d_st.p, pos_bits,     \
