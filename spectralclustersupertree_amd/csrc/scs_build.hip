@@ -863,18 +863,31 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // row block after the other, makes the ~96 workgroups that share an L2 read the same
     // block records and the same row-side table entries at the same time (measured: -4 % at
     // 10 000 leaves, -3 % at 50 000).  SCS_TILE_ORDER=0 keeps the plain row-major order.
+    // In a shared multi-rank build the job-wide list is dealt round-robin to the ranks first
+    // and every rank's share is ordered for its own XCDs (all ranks compute all shares, so
+    // entry world * k + r of the list is still rank r's k-th tile).
     {
         const bool per_xcd = !(getenv("SCS_TILE_ORDER") && atoi(getenv("SCS_TILE_ORDER")) == 0);
-        if (per_xcd && tiles.size() > 8) {
+        auto xcd_reorder = [](std::vector<int2> &v) {
+            if (v.size() <= 8) return;
             std::vector<int2> per[8];
-            for (const int2 &t : tiles) per[t.x & 7].push_back(t);  // stays (row, column) sorted
+            for (const int2 &t : v) per[t.x & 7].push_back(t);  // stays (row, column) sorted
             std::vector<int2> ordered;
-            ordered.reserve(tiles.size());
+            ordered.reserve(v.size());
             size_t at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            while (ordered.size() < tiles.size())
+            while (ordered.size() < v.size())
                 for (int x = 0; x < 8; ++x)
                     if (at[x] < per[x].size()) ordered.push_back(per[x][at[x]++]);
-            tiles.swap(ordered);
+            v.swap(ordered);
+        };
+        if (per_xcd && !shared) {
+            xcd_reorder(tiles);
+        } else if (per_xcd && tiles_diag.empty()) {
+            std::vector<std::vector<int2>> share(world);
+            for (size_t i = 0; i < tiles.size(); ++i) share[i % world].push_back(tiles[i]);
+            for (auto &v : share) xcd_reorder(v);
+            for (int r = 0; r < world; ++r)
+                for (size_t k = 0; k < share[r].size(); ++k) tiles[(size_t)world * k + r] = share[r][k];
         }
     }
     size_t n_main = tiles.size();
