@@ -14,7 +14,12 @@ one recursion node happens:
   position (the ARPACK start vector is still drawn first,
   sklearn/utils/_arpack.py:31-33), so labels match the reference's.
 
-Tree restriction, tie-breaking and assembly stay on the host (north_star).
+Tree restriction, tie-breaking and assembly stay on the host (north_star) -- but
+not on Python tree objects: the source trees are converted once into flat node
+arrays (``treearrays.TreeArrays``) and every level of the recursion restricts and
+flattens them in ``libscs_host.so``.  The
+object-walking recursion of the reference is kept as ``_construct_objects`` for
+the equivalence tests.
 There is no CPU fallback for the device steps: without libscs_hip.so and a
 HIP device this function raises.
 """
@@ -27,6 +32,7 @@ import numpy as np
 
 from spectralclustersupertree_amd import flatten as fl
 from spectralclustersupertree_amd.backend import DEFAULT_MAX_ITER, DEFAULT_TOL, Device
+from spectralclustersupertree_amd.treearrays import TreeArrays
 from spectralclustersupertree_amd.tree import (
     TreeNode,
     connect_trees,
@@ -177,7 +183,9 @@ def construct_supertree(
     trees = [t for t, _ in pairs]
     weights = [w for _, w in pairs]
 
-    result = _construct(trees, weights, pcg_weighting, contract_edges, random_state)
+    taxa = sorted(_all_tip_names(trees))
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    result = _construct(arrays, pcg_weighting, contract_edges, random_state)
     if isinstance(result, TreeNode):
         try:
             import cogent3  # noqa: F401  # type: ignore[import-not-found]
@@ -207,7 +215,60 @@ def _induce(names: set[str], trees, weights):
     return out_trees, out_weights
 
 
-def _construct(trees, weights, pcg_weighting, contract_edges, random_state) -> TreeNode:
+def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
+               bipartition=None) -> TreeNode:
+    """One node of the recursion on flat tree arrays (reference: scs.py:96-174).
+
+    Same decisions in the same order as the reference -- and therefore the same draws from
+    ``random_state`` -- but the induced trees of a child problem come from
+    ``TreeArrays.restrict`` instead of ``get_sub_tree`` on objects.
+    """
+    if bipartition is None:
+        bipartition = spectral_bipartition_device
+    names = arrays.taxa
+    if arrays.n_trees == 1:  # reference: scs.py:96-98
+        return arrays.to_tree(0)
+
+    present = arrays.present_taxa()
+    if len(present) <= 2:
+        return tip_names_to_tree([names[int(i)] for i in present])
+
+    # a node numbers its taxa by sorted name: global ids are ranks of the sorted names
+    tables = arrays.flatten(pcg_weighting, local_ids=present)
+    comp = fl.pcg_components(tables)
+    n_comp = int(comp.max()) + 1
+
+    if n_comp == 1:
+        members, labels = bipartition(tables, random_state, contract_edges=contract_edges)
+        parts: list[list[int]] = [[], []]
+        for ids, lab in zip(members, labels):
+            parts[int(lab)].extend(int(present[int(i)]) for i in ids)
+    else:
+        parts = [[] for _ in range(n_comp)]
+        for i, c in enumerate(comp):
+            parts[int(c)].append(int(present[i]))
+
+    child_trees: list[TreeNode] = []
+    for component in parts:
+        if len(component) == 0:
+            continue
+        component = sorted(component)
+        if len(component) <= 2:
+            child_trees.append(tip_names_to_tree([names[i] for i in component]))
+            continue
+        sub = arrays.restrict(np.asarray(component, dtype=np.int32))
+        child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, bipartition))
+        covered = set(int(i) for i in sub.present_taxa())
+        child_trees.extend(TreeNode(names[i]) for i in component if i not in covered)
+    return connect_trees(child_trees)
+
+
+def _construct_objects(trees, weights, pcg_weighting, contract_edges, random_state,
+                       bipartition=None) -> TreeNode:
+    """The reference's recursion on tree objects (reference: scs.py:96-174); kept for the
+    equivalence tests of the array path."""
+    if bipartition is None:
+        bipartition = spectral_bipartition_device
     if len(trees) == 1:  # reference: scs.py:96-98
         only = trees[0]
         newick = only.get_newick()
@@ -228,9 +289,7 @@ def _construct(trees, weights, pcg_weighting, contract_edges, random_state) -> T
     n_comp = int(comp.max()) + 1
 
     if n_comp == 1:
-        members, labels = spectral_bipartition_device(
-            tables, random_state, contract_edges=contract_edges
-        )
+        members, labels = bipartition(tables, random_state, contract_edges=contract_edges)
         parts: list[set[str]] = [set(), set()]
         for ids, lab in zip(members, labels):
             parts[int(lab)].update(taxa[int(i)] for i in ids)
@@ -248,7 +307,8 @@ def _construct(trees, weights, pcg_weighting, contract_edges, random_state) -> T
             continue
         sub_trees, sub_weights = _induce(component, trees, weights)
         child_trees.append(
-            _construct(sub_trees, sub_weights, pcg_weighting, contract_edges, random_state)
+            _construct_objects(sub_trees, sub_weights, pcg_weighting, contract_edges, random_state,
+                               bipartition)
         )
         missing = component.difference(_all_tip_names(sub_trees))
         child_trees.extend(TreeNode(x) for x in sorted(missing))

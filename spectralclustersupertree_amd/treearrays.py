@@ -1,0 +1,223 @@
+"""Source trees as flat node arrays: the recursion of ``construct_supertree`` without
+Python tree objects below the top level.
+
+The reference restricts every source tree to a taxon subset at every node of the
+recursion (``_generate_induced_trees_with_weights``, reference:
+src/sc_supertree/scs.py:411-455) by walking cogent3 tree objects.  Here the trees are
+converted ONCE into preorder node arrays; restriction (drop, splice, collapse the
+root, drop trees with fewer than two leaves) and the flattening into the device
+tables of ``include/scs_hip.h`` run in ``libscs_host.so`` (plain C,
+``csrc/scs_host.c``) in time linear in the number of nodes, producing bit for bit the
+tables the object path (``tree.TreeNode.get_sub_tree`` + ``flatten.flatten_trees``)
+produces -- ``tests/test_treearrays.py`` checks exactly that.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from collections.abc import Sequence
+from dataclasses import dataclass
+from pathlib import Path
+
+import numpy as np
+
+from spectralclustersupertree_amd.flatten import STRATEGIES, TreeTables
+from spectralclustersupertree_amd.tree import TreeNode
+
+_LIB_PATH = Path(__file__).resolve().parent / "libscs_host.so"
+_lib = None
+
+_STRATEGY_CODE = {"one": 0, "depth": 1, "branch": 2, "bootstrap": 3}  # csrc/scs_host.c
+_ERRORS = {-1: "out of memory", -2: "malformed tree arrays", -3: "missing support"}
+
+
+def _load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            msg = f"{_LIB_PATH} not found: run __graft_entry__.build()"
+            raise ImportError(msg)
+        lib = C.CDLL(str(_LIB_PATH))
+        ip, dp, lp, bp = (C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_uint8))
+        lib.scs_host_restrict_sizes.restype = C.c_int
+        lib.scs_host_restrict_sizes.argtypes = [C.c_int32, lp, ip, ip, bp, bp, ip]
+        lib.scs_host_restrict_fill.restype = C.c_int
+        lib.scs_host_restrict_fill.argtypes = [C.c_int32, lp, ip, ip, dp, dp, bp, bp, lp, ip, ip, dp, dp]
+        lib.scs_host_flatten.restype = C.c_int
+        lib.scs_host_flatten.argtypes = [C.c_int32, lp, ip, ip, dp, dp, C.c_int32, lp, ip, ip, dp, ip]
+        _lib = lib
+    return _lib
+
+
+def _p(a: np.ndarray, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+@dataclass
+class TreeArrays:
+    """A forest over integer taxon ids ``0..n_taxa-1`` in preorder node arrays."""
+
+    n_taxa: int
+    node_off: np.ndarray  # int64 [M+1]
+    parent: np.ndarray  # int32, relative to the tree's first node, -1 = root
+    taxon: np.ndarray  # int32, -1 = internal node
+    length: np.ndarray  # float64, NaN = None
+    support: np.ndarray  # float64, NaN = None
+    weights: np.ndarray  # float64 [M]
+    taxa: list[str]  # id -> name (ids are ranks of the names in sorted order)
+
+    @property
+    def n_trees(self) -> int:
+        return len(self.weights)
+
+    # ------------------------------------------------------------------ build
+    @classmethod
+    def from_trees(cls, trees: Sequence, weights: Sequence[float], taxa: Sequence[str]) -> "TreeArrays":
+        """One preorder walk per tree object (duck-typed: iteration over children,
+        ``is_tip``, ``name``, ``length``, ``support``)."""
+        index = {name: i for i, name in enumerate(taxa)}
+        node_off = [0]
+        parent: list[int] = []
+        taxon: list[int] = []
+        length: list[float] = []
+        support: list[float] = []
+        nan = float("nan")
+        for tree in trees:
+            base = len(parent)
+            stack = [(tree, -1)]
+            while stack:
+                node, par = stack.pop()
+                me = len(parent) - base
+                parent.append(par)
+                tip = node.is_tip()
+                taxon.append(index[node.name] if tip else -1)
+                ln = getattr(node, "length", None)
+                sp = getattr(node, "support", None)
+                length.append(nan if ln is None else float(ln))
+                support.append(nan if sp is None else float(sp))
+                if not tip:
+                    kids = list(node)
+                    for child in reversed(kids):
+                        stack.append((child, me))
+            node_off.append(len(parent))
+        return cls(
+            n_taxa=len(taxa),
+            node_off=np.asarray(node_off, dtype=np.int64),
+            parent=np.asarray(parent, dtype=np.int32),
+            taxon=np.asarray(taxon, dtype=np.int32),
+            length=np.asarray(length, dtype=np.float64),
+            support=np.asarray(support, dtype=np.float64),
+            weights=np.asarray([float(w) for w in weights], dtype=np.float64),
+            taxa=list(taxa),
+        )
+
+    # ---------------------------------------------------------------- queries
+    def present_taxa(self) -> np.ndarray:
+        """Sorted ids of the taxa that occur in at least one tree."""
+        leaves = self.taxon[self.taxon >= 0]
+        return np.flatnonzero(np.bincount(leaves, minlength=self.n_taxa) > 0).astype(np.int32)
+
+    def leaf_counts(self) -> np.ndarray:
+        is_leaf = (self.taxon >= 0).astype(np.int64)
+        csum = np.concatenate(([0], np.cumsum(is_leaf)))
+        return csum[self.node_off[1:]] - csum[self.node_off[:-1]]
+
+    # ------------------------------------------------------------ restriction
+    def restrict(self, keep_ids: np.ndarray) -> "TreeArrays":
+        """Forest induced on the taxa ``keep_ids`` (reference: scs.py:411-455)."""
+        lib = _load()
+        keep = np.zeros(self.n_taxa, dtype=np.uint8)
+        keep[np.asarray(keep_ids, dtype=np.int64)] = 1
+        m = self.n_trees
+        tree_keep = np.zeros(max(m, 1), dtype=np.uint8)
+        nodes = np.zeros(max(m, 1), dtype=np.int32)
+        if m:
+            rc = lib.scs_host_restrict_sizes(m, _p(self.node_off, C.c_int64), _p(self.parent, C.c_int32),
+                                             _p(self.taxon, C.c_int32), _p(keep, C.c_uint8),
+                                             _p(tree_keep, C.c_uint8), _p(nodes, C.c_int32))
+            if rc:
+                raise ValueError(f"scs_host_restrict_sizes: {_ERRORS.get(rc, rc)}")
+        kept = np.flatnonzero(tree_keep[:m])
+        new_off = np.zeros(len(kept) + 1, dtype=np.int64)
+        np.cumsum(nodes[:m][kept], out=new_off[1:])
+        total = int(new_off[-1])
+        out = TreeArrays(
+            n_taxa=self.n_taxa,
+            node_off=new_off,
+            parent=np.empty(total, dtype=np.int32),
+            taxon=np.empty(total, dtype=np.int32),
+            length=np.empty(total, dtype=np.float64),
+            support=np.empty(total, dtype=np.float64),
+            weights=self.weights[kept].copy(),
+            taxa=self.taxa,
+        )
+        if len(kept):
+            rc = lib.scs_host_restrict_fill(
+                m, _p(self.node_off, C.c_int64), _p(self.parent, C.c_int32), _p(self.taxon, C.c_int32),
+                _p(self.length, C.c_double), _p(self.support, C.c_double), _p(keep, C.c_uint8),
+                _p(tree_keep, C.c_uint8), _p(new_off, C.c_int64), _p(out.parent, C.c_int32),
+                _p(out.taxon, C.c_int32), _p(out.length, C.c_double), _p(out.support, C.c_double))
+            if rc:
+                raise ValueError(f"scs_host_restrict_fill: {_ERRORS.get(rc, rc)}")
+        return out
+
+    # -------------------------------------------------------------- flattening
+    def flatten(self, strategy: str, local_ids: np.ndarray | None = None) -> TreeTables:
+        """Device tables of the forest (what ``flatten.flatten_trees`` builds from objects).
+
+        ``local_ids`` (sorted global ids) renumbers the taxa to ``0..len-1`` -- a
+        recursion node numbers its own taxa by sorted name, as the reference does.
+        """
+        if strategy not in STRATEGIES:
+            msg = f"Invalid weighting strategy selected: '{strategy}'"
+            raise ValueError(msg)
+        lib = _load()
+        m = self.n_trees
+        leaf_off = np.zeros(m + 1, dtype=np.int64)
+        np.cumsum(self.leaf_counts(), out=leaf_off[1:])
+        total = int(leaf_off[-1])
+        leaf_taxon = np.empty(total, dtype=np.int32)
+        adj_depth = np.empty(total, dtype=np.int32)
+        adj_val = np.empty(total, dtype=np.float64)
+        mono = C.c_int32(1)
+        if m:
+            rc = lib.scs_host_flatten(m, _p(self.node_off, C.c_int64), _p(self.parent, C.c_int32),
+                                      _p(self.taxon, C.c_int32), _p(self.length, C.c_double),
+                                      _p(self.support, C.c_double), _STRATEGY_CODE[strategy],
+                                      _p(leaf_off, C.c_int64), _p(leaf_taxon, C.c_int32),
+                                      _p(adj_depth, C.c_int32), _p(adj_val, C.c_double), C.byref(mono))
+            if rc == -3:
+                # the reference fails in ``length * tree_weight`` with a missing support
+                # (reference: scs.py:656)
+                msg = "unsupported operand type(s) for *: 'NoneType' and 'float'"
+                raise TypeError(msg)
+            if rc:
+                raise ValueError(f"scs_host_flatten: {_ERRORS.get(rc, rc)}")
+        n_taxa, taxa = self.n_taxa, self.taxa
+        if local_ids is not None:
+            local_ids = np.asarray(local_ids, dtype=np.int32)
+            leaf_taxon = np.searchsorted(local_ids, leaf_taxon).astype(np.int32)
+            n_taxa = len(local_ids)
+            taxa = [self.taxa[int(i)] for i in local_ids]
+        monotone = (strategy in ("one", "depth", "branch") and bool(mono.value)
+                    and bool(np.all(self.weights >= 0)))
+        return TreeTables(n_taxa=n_taxa, tree_off=leaf_off, leaf_taxon=leaf_taxon, adj_depth=adj_depth,
+                          adj_val=adj_val, tree_w=self.weights.copy(), taxa=taxa, monotone=monotone)
+
+    # --------------------------------------------------------------- to object
+    def to_tree(self, t: int) -> TreeNode:
+        """Tree ``t`` as a ``TreeNode`` (internal names are not kept)."""
+        lo, hi = int(self.node_off[t]), int(self.node_off[t + 1])
+        nodes: list[TreeNode] = []
+        for i in range(lo, hi):
+            tx = int(self.taxon[i])
+            ln, sp = float(self.length[i]), float(self.support[i])
+            node = TreeNode(self.taxa[tx] if tx >= 0 else "", None,
+                            None if ln != ln else ln, None if sp != sp else sp)
+            nodes.append(node)
+            par = int(self.parent[i])
+            if par >= 0:
+                nodes[par].children.append(node)
+                node.parent = nodes[par]
+        return nodes[0]

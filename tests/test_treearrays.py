@@ -1,0 +1,206 @@
+"""Flat tree arrays (libscs_host.so) against the tree-object path, bit for bit (CPU).
+
+The array recursion replaces ``get_sub_tree`` + ``flatten_trees`` on Python objects
+(reference: src/sc_supertree/scs.py:411-455 and :495-663).  Everything here compares the two
+on the same inputs: the induced forests' device tables, repeated restrictions, and the whole
+recursion driven by the same (CPU, oracle-based) bipartition.
+"""
+
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import pytest
+
+from oracle import scs_oracle as so
+from oracle import tables_oracle as to
+from spectralclustersupertree_amd import flatten as fl
+from spectralclustersupertree_amd import scs
+from spectralclustersupertree_amd.tree import TreeNode, make_tree
+from spectralclustersupertree_amd.treearrays import TreeArrays
+from tests.reference_cases import INLINE_CASES
+
+
+def random_tree(rng: random.Random, names: list[str], *, multifurcate=0.3, none_len=0.2, none_sup=0.2,
+                unary=0.1, neg_len=0.0) -> TreeNode:
+    """Random rooted tree over ``names``: multifurcations, unary nodes, missing lengths/supports."""
+    nodes = [TreeNode(n, None, rng.choice([None, round(rng.expovariate(10.0), 6)])
+                      if rng.random() < 0.5 else rng.expovariate(10.0)) for n in names]
+    rng.shuffle(nodes)
+    while len(nodes) > 1:
+        k = 2 if rng.random() > multifurcate else rng.randint(3, 4)
+        k = min(k, len(nodes))
+        kids = [nodes.pop(rng.randrange(len(nodes))) for _ in range(k)]
+        ln = None if rng.random() < none_len else rng.expovariate(10.0)
+        if ln is not None and rng.random() < neg_len:
+            ln = -ln
+        sp = None if rng.random() < none_sup else float(rng.randint(50, 100))
+        node = TreeNode("", kids, ln, sp)
+        if rng.random() < unary:
+            node = TreeNode("", [node], rng.expovariate(10.0), sp)
+        nodes.append(node)
+    root = nodes[0]
+    root.length = None
+    return root
+
+
+def random_forest(seed: int, n_taxa: int, n_trees: int, **kw):
+    rng = random.Random(seed)
+    taxa = [f"t{i:04d}" for i in range(n_taxa)]
+    trees, weights = [], []
+    for _ in range(n_trees):
+        k = rng.randint(max(2, n_taxa // 3), n_taxa)
+        trees.append(random_tree(rng, rng.sample(taxa, k), **kw))
+        weights.append(rng.choice([1.0, 2.0, 0.5, rng.random() + 0.1]))
+    return taxa, trees, weights
+
+
+def tables_equal(a: fl.TreeTables, b: fl.TreeTables) -> None:
+    assert a.n_taxa == b.n_taxa
+    assert np.array_equal(a.tree_off, b.tree_off)
+    assert np.array_equal(a.leaf_taxon, b.leaf_taxon)
+    assert np.array_equal(a.adj_depth, b.adj_depth)
+    # bit for bit, signed zeros included
+    assert np.array_equal(a.adj_val.view(np.uint64), b.adj_val.view(np.uint64))
+    assert np.array_equal(a.tree_w, b.tree_w)
+    assert a.monotone == b.monotone
+
+
+def object_tables(trees, weights, strategy):
+    names = sorted(scs._all_tip_names(trees))
+    return fl.flatten_trees(trees, weights, strategy, names)
+
+
+@pytest.mark.parametrize("strategy", ["one", "depth", "branch"])
+@pytest.mark.parametrize("seed", range(6))
+def test_flatten_matches_object_path(seed, strategy):
+    taxa, trees, weights = random_forest(seed, 40, 7, neg_len=0.1 if seed % 2 else 0.0)
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    want = fl.flatten_trees(trees, weights, strategy, taxa)
+    tables_equal(arrays.flatten(strategy), want)
+
+
+def test_flatten_bootstrap_and_missing_support():
+    taxa, trees, weights = random_forest(3, 25, 5, none_sup=0.0, unary=0.0)
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    tables_equal(arrays.flatten("bootstrap"), fl.flatten_trees(trees, weights, "bootstrap", taxa))
+    trees[2].children[0].support = None if trees[2].children[0].children else trees[2].children[0].support
+    target = next(n for n in trees[2].iter_nontips() if len(n.children) >= 2)
+    target.support = None
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    with pytest.raises(TypeError, match="NoneType"):
+        fl.flatten_trees(trees, weights, "bootstrap", taxa)
+    with pytest.raises(TypeError, match="NoneType"):
+        arrays.flatten("bootstrap")
+
+
+@pytest.mark.parametrize("strategy", ["one", "depth", "branch", "bootstrap"])
+@pytest.mark.parametrize("seed", range(8))
+def test_restriction_matches_get_sub_tree(seed, strategy):
+    rng = random.Random(1000 + seed)
+    kw = {"none_sup": 0.0} if strategy == "bootstrap" else {}
+    taxa, trees, weights = random_forest(seed, 60, 9, **kw)
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    for frac in (0.8, 0.5, 0.2, 0.06):
+        keep = sorted(rng.sample(range(len(taxa)), max(2, int(frac * len(taxa)))))
+        names = {taxa[i] for i in keep}
+        sub_trees, sub_weights = scs._induce(names, trees, weights)
+        sub = arrays.restrict(np.asarray(keep))
+        assert sub.n_trees == len(sub_trees)
+        assert np.array_equal(sub.weights, np.asarray(sub_weights, dtype=np.float64))
+        if not sub_trees:
+            continue
+        present = sub.present_taxa()
+        assert [taxa[int(i)] for i in present] == sorted(scs._all_tip_names(sub_trees))
+        tables_equal(sub.flatten(strategy, local_ids=present), object_tables(sub_trees, sub_weights, strategy))
+        # the induced forest itself (structure, merged lengths, supports) is the object path's
+        again = TreeArrays.from_trees(sub_trees, sub_weights, taxa)
+        assert np.array_equal(sub.node_off, again.node_off)
+        assert np.array_equal(sub.parent, again.parent)
+        assert np.array_equal(sub.taxon, again.taxon)
+        assert np.array_equal(sub.support.view(np.uint64), again.support.view(np.uint64))
+        assert np.array_equal(sub.length.view(np.uint64), again.length.view(np.uint64))
+
+
+def test_repeated_restriction_equals_single():
+    rng = random.Random(7)
+    taxa, trees, weights = random_forest(11, 80, 10)
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    keep1 = sorted(rng.sample(range(80), 50))
+    keep2 = sorted(rng.sample(keep1, 20))
+    twice = arrays.restrict(np.asarray(keep1)).restrict(np.asarray(keep2))
+    names1, names2 = {taxa[i] for i in keep1}, {taxa[i] for i in keep2}
+    t1, w1 = scs._induce(names1, trees, weights)
+    t2, w2 = scs._induce(names2, t1, w1)
+    present = twice.present_taxa()
+    tables_equal(twice.flatten("branch", local_ids=present), object_tables(t2, w2, "branch"))
+
+
+def test_ragged_edge_cases():
+    taxa = ["a", "b", "c", "d"]
+    trees = [make_tree("((a,b),(c,d));"), make_tree("(a,b,c);"), make_tree("(d);")]
+    arrays = TreeArrays.from_trees(trees, [1.0, 2.0, 3.0], taxa)
+    assert arrays.leaf_counts().tolist() == [4, 3, 1]
+    # a tree left with fewer than two leaves is dropped (reference: scs.py:447-448)
+    sub = arrays.restrict(np.asarray([2, 3]))
+    assert sub.n_trees == 1 and sub.weights.tolist() == [1.0]
+    assert sub.to_tree(0).sorted().same_shape(make_tree("(c,d);").sorted())
+    # nothing left at all
+    empty = arrays.restrict(np.asarray([3]))
+    assert empty.n_trees == 0 and len(empty.present_taxa()) == 0
+    with pytest.raises(ValueError, match="Invalid weighting strategy"):
+        arrays.flatten("nope")
+
+
+def cpu_bipartition(tables, random_state, *, contract_edges):
+    """The device step's contract, computed with the oracle (scikit-learn) on the CPU."""
+    n = tables.n_taxa
+    groups = fl.contraction_groups(tables) if contract_edges else np.arange(n, dtype=np.int32)
+    n_groups = int(groups.max()) + 1
+    if n_groups < n:
+        work, perm, group_start = scs.relabel_for_contraction(tables, groups)
+    else:
+        work, perm, group_start = tables, np.arange(n, dtype=np.int32), None
+    w, _ = to.pcg_dense(work)
+    if group_start is not None:
+        w = to.contract_dense(w, group_start)
+    labels = so.spectral_labels(w, random_state)
+    if group_start is None:
+        members = [np.array([i], dtype=np.int32) for i in range(n)]
+    else:
+        members = [perm[group_start[g]: group_start[g + 1]] for g in range(n_groups)]
+    return members, np.asarray(labels)
+
+
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("strategy", ["one", "branch"])
+def test_recursion_on_arrays_equals_recursion_on_objects(seed, strategy):
+    import warnings
+
+    taxa, trees, weights = random_forest(50 + seed, 24, 6, unary=0.0)
+    names = sorted(scs._all_tip_names(trees))
+    arrays = TreeArrays.from_trees(trees, weights, names)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = scs._construct(arrays, strategy, True, np.random.RandomState(seed), cpu_bipartition)
+        want = scs._construct_objects(trees, weights, strategy, True, np.random.RandomState(seed),
+                                      cpu_bipartition)
+    assert got.sorted().same_shape(want.sorted()), f"{got.get_newick()} != {want.get_newick()}"
+    assert sorted(got.get_tip_names()) == names
+
+
+@pytest.mark.parametrize("case", INLINE_CASES, ids=lambda c: c.name)
+def test_reference_cases_through_the_array_recursion(case):
+    """The reference's own known-answer cases, array recursion + oracle bipartition (CPU)."""
+    import warnings
+
+    trees = [make_tree(s) for s in case.trees]
+    weights = case.weights if case.weights is not None else [1.0] * len(trees)
+    names = sorted(scs._all_tip_names(trees))
+    arrays = TreeArrays.from_trees(trees, weights, names)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = scs._construct(arrays, case.pcg_weighting, case.contract_edges, np.random.RandomState(0),
+                             cpu_bipartition)
+    assert got.sorted().same_shape(make_tree(case.expected).sorted())
