@@ -21,6 +21,18 @@ from spectralclustersupertree_amd.tree import NotCompleted, load_tree, make_tree
 
 pytestmark = pytest.mark.gpu
 
+def fl_leaf(name):
+    from spectralclustersupertree_amd.tree import TreeNode
+
+    return TreeNode(name, None, 0.05)
+
+
+def fl_tree(children):
+    from spectralclustersupertree_amd.tree import TreeNode
+
+    return TreeNode("", children)
+
+
 FIEDLER_TOL = 1e-10  # north_star: Fiedler-vector entries within 1e-10 fp64
 
 
@@ -248,6 +260,42 @@ def test_fiedler_small_dense_path(dev, n):
     dtab.free()
     assert stats["block"] == 0
     assert np.max(np.abs(maps - ref)) <= FIEDLER_TOL, (maps, ref)
+
+
+@pytest.mark.parametrize("n", [40, 150])
+def test_fiedler_with_isolated_vertices(dev, n):
+    # taxa that never share a root side with anything have degree 0: scipy scales their rows by 1
+    # (reference: scipy/sparse/csgraph/_laplacian.py:550-557), the trivial eigenvector is no
+    # longer sqrt(d) of ALL vertices, and the solver iterates both leading pairs itself
+    import random
+
+    from tests.test_treearrays import random_tree
+
+    rng = random.Random(n)
+    names = [f"t{i:03d}" for i in range(n)]
+    loners, rest = names[:1], names[1:]  # one loner: two would make the second pair degenerate
+    trees = []
+    for _ in range(12):
+        inner = random_tree(rng, rest, multifurcate=0.0, none_len=0.0, none_sup=0.0, unary=0.0)
+        extra = random_tree(rng, rng.sample(rest, 5), multifurcate=0.0, none_len=0.0, none_sup=0.0, unary=0.0)
+        trees.append(fl_tree([fl_leaf(x) for x in loners] + [inner]) if _ % 2 else fl_tree([fl_leaf(loners[0]), extra]))
+    tables = fl.flatten_trees(trees, [1.0 + 0.1 * i for i in range(12)], "branch", names)
+    w_ref, _ = to.pcg_dense(tables)
+    assert np.count_nonzero(w_ref.sum(axis=1) == 0) == 1
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    assert np.array_equal(g.download(), w_ref)
+    maps, stats = g.fiedler(np.random.RandomState(0).uniform(-1, 1, n))
+    g.free()
+    dtab.free()
+    if n > 64:
+        assert stats["used_constraint"] == 0 and stats["converged"] == 1, stats
+    assert np.max(np.abs(maps - ref)) <= FIEDLER_TOL, stats
 
 
 def test_labels_match_spectral_clustering(dev):
