@@ -486,7 +486,6 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
         const unsigned char *rb = s_rec[tl & 1];
         const int *s_spos = (const int *)(rb + REC_SPOS);
         const unsigned char *s_sorig = rb + REC_SORIG;
-        const unsigned char *s_rank = rb + REC_RANK63;
         const double *s_sp = (const double *)(rb + REC_SPV);
         const int *s_piv = (const int *)(rb + REC_PIV);
         // the DMA of this tree's record was issued a whole step ago
@@ -536,26 +535,42 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
             yr = st[orr[1]];
         }
         stamp(2);
-        // ---- expand the row-row value table: wave w fills rows w, w+4, ...; entry (i, j)
-        // is the minimum gap value between the sorted ranks of rows i and j (0 as soon
-        // as one of them is absent), +inf on the diagonal
+        // ---- expand the row-row value table in rank space: entry (a, b), a < b, is the running
+        // minimum of the gap values g[a .. b-1] (0 as soon as one of the rows is absent: the
+        // gaps past the last present row are 0), so lane a carries `cur` along b and every step
+        // is one v_min_f64 and two stores (the entry and its mirror image, at the rows' original
+        // indices).  Wave w walks b in [16 w, 16 w + 16); lanes that start inside an earlier
+        // segment take their running minimum at the segment start from the record's min-table.
+        // A lane's first active step (b == a) stores cur = +inf on the diagonal --
+        // min(inf, vn) = vn: the cell (nb, c) itself -- and picks up g[a].
         {
-            const int rj = s_rank[lane];
-            // constant trip count, eight rows per batch: the rank reads, gathers and writes
-            // of different rows overlap instead of serialising (sixteen at once spills)
-#pragma unroll 8
-            for (int kk = 0; kk < SCS_TR / 4; ++kk) {
-                const int i = wave + 4 * kk;
-                const int ri = s_rank[i];
-                const int a = min(ri, rj);
-                const int d = max(max(ri, rj) - a, 1);
-                const int a1 = min(a, 62);  // two absent rows: the zero gap 62
-                const int k = 31 - __clz(d);
-                const double x = s_sp[a1 * 7 + k];
-                const double y = s_sp[(a1 + d - (1 << k)) * 7 + k];
-                double v = min_f64(x, y);
-                if (i == lane) v = inf;  // min(inf, vn) = vn: the cell (nb, c) itself
-                s_dv[i * DV_LD + lane] = v;
+            const double g_own = ((const double *)(rb + REC_GVW))[lane];
+            const int so_own = s_sorig[lane];
+            const int b0 = wave * 16;
+            double cur = inf;
+            // (opaque copy of the lane id: keeps the table offsets below from being hoisted
+            // out of the tree loop into registers the accumulators need)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            if (ln < b0) {
+                const int len = b0 - ln;
+                const int k = 31 - __clz(len);
+                cur = min_f64(s_sp[ln * 7 + k], s_sp[(b0 - (1 << k)) * 7 + k]);
+            }
+            double *row_a = &s_dv[so_own * DV_LD];  // row of this lane's own row
+            double *col_a = &s_dv[so_own];          // its column
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int b = b0 + j;
+                const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_own), b);
+                const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_own), b);
+                const int so_b = __builtin_amdgcn_readlane(so_own, b);
+                const double gb = __hiloint2double(hi32, lo32);
+                if (lane <= b) {
+                    row_a[so_b] = cur;
+                    col_a[so_b * DV_LD] = cur;
+                    cur = min_f64(cur, gb);
+                }
             }
         }
         stamp(3);
