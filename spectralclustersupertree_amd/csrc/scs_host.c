@@ -277,3 +277,302 @@ int scs_host_flatten(int32_t n_trees, const int64_t *node_off, const int32_t *pa
     free(nch);
     return rc;
 }
+
+/* ---------------------------------------------------------------------------
+ * Newick text -> tree arrays (reference: load.py:7-23, one
+ * tree per line, every line handed to the parser).  The grammar accepted is the one of
+ * spectralclustersupertree_amd/tree.py:make_tree, with the same meaning: a label on a
+ * node with children that parses as a number is its support; ':' introduces a branch
+ * length (empty = None); '[...]' comments are skipped; labels may be quoted with ''
+ * as the escaped quote; everything after ';' on a line is ignored.
+ *
+ * Two passes over the same text:
+ *   scs_host_newick_scan   counts trees (lines), nodes and the bytes of the leaf names
+ *   scs_host_newick_parse  fills parent / length / support, and for every leaf the offset
+ *                          of its NUL-terminated name in name_pool (-1 for internal nodes)
+ * then scs_host_names_rank maps the leaf names to the ranks of the sorted distinct names
+ * (the taxon ids the rest of the package uses) with an open-addressing hash table.
+ * Errors: a negative code; *err_line receives the 0-based line of the offending tree.
+ * ------------------------------------------------------------------------- */
+#define SCS_HOST_EPARSE (-4)
+
+static int is_space(char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\n'; }
+
+/* parse one line [s, e); mode 0 counts, mode 1 fills.  Node indices are relative to the tree. */
+static int newick_line(const char *s, const char *e, int mode, int64_t *n_nodes, int64_t *name_bytes,
+                       int32_t *parent, double *length, double *support, int64_t *name_off,
+                       char *pool, int64_t *pool_at, int32_t *nchild, int32_t *stack, int64_t stack_cap) {
+    int64_t count = 1; /* the root */
+    int64_t depth = 0; /* stack[depth] = current node */
+    int seen_any = 0;
+    int32_t cur = 0;
+    if (mode) {
+        parent[0] = -1;
+        length[0] = NAN;
+        support[0] = NAN;
+        name_off[0] = -1;
+        nchild[0] = 0;
+        stack[0] = 0;
+    }
+    const char *p = s;
+    while (p < e && is_space(*p)) ++p;
+    if (p >= e) return SCS_HOST_EPARSE; /* empty line */
+    while (p < e) {
+        const char c = *p;
+        if (is_space(c)) {
+            ++p;
+        } else if (c == '[') {
+            const char *q = p;
+            while (q < e && *q != ']') ++q;
+            if (q >= e) return SCS_HOST_EPARSE;
+            p = q + 1;
+        } else if (c == '(' || c == ',') {
+            if (c == ',') {
+                if (depth == 0) return SCS_HOST_EPARSE; /* ',' at top level */
+                --depth;                              /* back to the parent */
+            }
+            if (depth + 1 >= stack_cap) return SCS_HOST_EPARSE;
+            if (mode) {
+                const int32_t par = stack[depth];
+                cur = (int32_t)count;
+                parent[cur] = par;
+                length[cur] = NAN;
+                support[cur] = NAN;
+                name_off[cur] = -1;
+                nchild[cur] = 0;
+                nchild[par] += 1;
+                stack[depth + 1] = cur;
+            }
+            ++depth;
+            ++count;
+            seen_any = seen_any || c == '(';
+            ++p;
+        } else if (c == ')') {
+            if (depth == 0) return SCS_HOST_EPARSE;
+            --depth;
+            if (mode) cur = stack[depth];
+            ++p;
+        } else if (c == ';') {
+            break;
+        } else if (c == ':') {
+            const char *q = p + 1;
+            while (q < e && *q != ',' && *q != '(' && *q != ')' && *q != ';' && *q != '[') ++q;
+            if (mode) {
+                const char *a = p + 1, *b = q;
+                while (a < b && is_space(*a)) ++a;
+                while (b > a && is_space(b[-1])) --b;
+                if (a == b) {
+                    length[cur] = NAN;
+                } else {
+                    char buf[64];
+                    const size_t len = (size_t)(b - a);
+                    if (len >= sizeof(buf)) return SCS_HOST_EPARSE;
+                    memcpy(buf, a, len);
+                    buf[len] = 0;
+                    char *end = NULL;
+                    const double v = strtod(buf, &end);
+                    if (end == buf || *end != 0) return SCS_HOST_EPARSE;
+                    length[cur] = v;
+                }
+            }
+            p = q;
+        } else {
+            /* a label: quoted or bare */
+            const char *a, *b; /* [a, b) raw label text */
+            int quoted = 0;
+            if (c == '\'') {
+                quoted = 1;
+                const char *q = p + 1;
+                for (;;) {
+                    if (q >= e) return SCS_HOST_EPARSE;
+                    if (*q == '\'') {
+                        if (q + 1 < e && q[1] == '\'') {
+                            q += 2;
+                            continue;
+                        }
+                        break;
+                    }
+                    ++q;
+                }
+                a = p + 1;
+                b = q;
+                p = q + 1;
+            } else {
+                const char *q = p;
+                while (q < e && *q != ',' && *q != '(' && *q != ')' && *q != ':' && *q != ';' && *q != '[') ++q;
+                a = p;
+                b = q;
+                while (b > a && is_space(b[-1])) --b;
+                p = q;
+            }
+            seen_any = 1;
+            const int64_t raw = b - a;
+            if (!mode) {
+                *name_bytes += raw + 1; /* upper bound: every label could be a leaf's */
+            } else {
+                /* unescape into the pool (tentatively) */
+                const int64_t at = *pool_at;
+                int64_t w = at;
+                for (const char *q = a; q < b; ++q) {
+                    pool[w++] = *q;
+                    if (quoted && *q == '\'' && q + 1 < b && q[1] == '\'') ++q;
+                }
+                pool[w] = 0;
+                if (nchild[cur] > 0) {
+                    /* internal node: a numeric label is the support; the name is not kept */
+                    char *end = NULL;
+                    const double v = strtod(pool + at, &end);
+                    if (end != pool + at && *end == 0 && w > at) support[cur] = v;
+                } else {
+                    name_off[cur] = at;
+                    *pool_at = w + 1;
+                }
+            }
+        }
+    }
+    if (depth != 0) return SCS_HOST_EPARSE; /* missing ')' */
+    if (!seen_any) return SCS_HOST_EPARSE;
+    *n_nodes = count;
+    return SCS_HOST_OK;
+}
+
+static const char *line_end(const char *p, const char *end) {
+    while (p < end && *p != '\n') ++p;
+    return p;
+}
+
+int scs_host_newick_scan(const char *text, int64_t len, int64_t *n_trees, int64_t *n_nodes,
+                         int64_t *name_bytes, int64_t *max_depth_nodes, int64_t *err_line) {
+    const char *p = text, *end = text + len;
+    int64_t trees = 0, nodes = 0, bytes = 0, max_nodes = 0;
+    while (p < end) {
+        const char *e = line_end(p, end);
+        int64_t k = 0;
+        const int rc = newick_line(p, e, 0, &k, &bytes, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL,
+                                   INT64_MAX);
+        if (rc != SCS_HOST_OK) {
+            *err_line = trees;
+            return rc;
+        }
+        nodes += k;
+        if (k > max_nodes) max_nodes = k;
+        ++trees;
+        p = e < end ? e + 1 : e;
+    }
+    *n_trees = trees;
+    *n_nodes = nodes;
+    *name_bytes = bytes + 1;
+    *max_depth_nodes = max_nodes;
+    return SCS_HOST_OK;
+}
+
+int scs_host_newick_parse(const char *text, int64_t len, int64_t n_trees, int64_t max_nodes,
+                          int64_t *node_off, int32_t *parent, double *length, double *support,
+                          int64_t *name_off, char *name_pool, int64_t *pool_used, int64_t *err_line) {
+    const char *p = text, *end = text + len;
+    int32_t *nchild = (int32_t *)malloc(sizeof(int32_t) * (size_t)(max_nodes + 1));
+    int32_t *stack = (int32_t *)malloc(sizeof(int32_t) * (size_t)(max_nodes + 2));
+    if (!nchild || !stack) {
+        free(nchild);
+        free(stack);
+        return SCS_HOST_ENOMEM;
+    }
+    int64_t at = 0, pool_at = 0, t = 0;
+    int rc = SCS_HOST_OK;
+    node_off[0] = 0;
+    while (p < end && t < n_trees) {
+        const char *e = line_end(p, end);
+        int64_t k = 0, unused = 0;
+        rc = newick_line(p, e, 1, &k, &unused, parent + at, length + at, support + at, name_off + at,
+                         name_pool, &pool_at, nchild, stack, max_nodes + 2);
+        if (rc != SCS_HOST_OK) {
+            *err_line = t;
+            break;
+        }
+        at += k;
+        node_off[++t] = at;
+        p = e < end ? e + 1 : e;
+    }
+    *pool_used = pool_at;
+    free(nchild);
+    free(stack);
+    return rc;
+}
+
+static uint64_t fnv1a(const char *s) {
+    uint64_t h = 1469598103934665603ull;
+    for (; *s; ++s) h = (h ^ (unsigned char)*s) * 1099511628211ull;
+    return h;
+}
+
+static const char *g_sort_pool;
+static int cmp_name(const void *a, const void *b) {
+    return strcmp(g_sort_pool + *(const int64_t *)a, g_sort_pool + *(const int64_t *)b);
+}
+
+/*
+ * taxon[i] = rank of node i's name among the sorted distinct leaf names (-1 for internal
+ * nodes).  uniq_off (capacity n_nodes) receives the pool offsets of the distinct names in
+ * sorted order; *n_taxa their count.  (Not re-entrant: uses one static for qsort.)
+ */
+int scs_host_names_rank(const char *name_pool, const int64_t *name_off, int64_t n_nodes,
+                        int32_t *taxon, int64_t *uniq_off, int64_t *n_taxa) {
+    int64_t leaves = 0;
+    for (int64_t i = 0; i < n_nodes; ++i) leaves += name_off[i] >= 0;
+    uint64_t cap = 16;
+    while (cap < (uint64_t)leaves * 2 + 1) cap <<= 1;
+    int64_t *slot_off = (int64_t *)malloc(sizeof(int64_t) * cap);
+    int32_t *slot_id = (int32_t *)malloc(sizeof(int32_t) * cap);
+    if (!slot_off || !slot_id) {
+        free(slot_off);
+        free(slot_id);
+        return SCS_HOST_ENOMEM;
+    }
+    for (uint64_t i = 0; i < cap; ++i) slot_off[i] = -1;
+    int64_t n_uniq = 0;
+    /* first pass: distinct names in order of first appearance; taxon = provisional id */
+    for (int64_t i = 0; i < n_nodes; ++i) {
+        if (name_off[i] < 0) {
+            taxon[i] = -1;
+            continue;
+        }
+        const char *nm = name_pool + name_off[i];
+        uint64_t h = fnv1a(nm) & (cap - 1);
+        while (slot_off[h] >= 0 && strcmp(name_pool + slot_off[h], nm) != 0) h = (h + 1) & (cap - 1);
+        if (slot_off[h] < 0) {
+            slot_off[h] = name_off[i];
+            slot_id[h] = (int32_t)n_uniq;
+            uniq_off[n_uniq++] = name_off[i];
+        }
+        taxon[i] = slot_id[h];
+    }
+    /* rank of every provisional id in sorted-name order */
+    int64_t *order = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_uniq > 0 ? n_uniq : 1));
+    int32_t *rank = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_uniq > 0 ? n_uniq : 1));
+    if (!order || !rank) {
+        free(order);
+        free(rank);
+        free(slot_off);
+        free(slot_id);
+        return SCS_HOST_ENOMEM;
+    }
+    memcpy(order, uniq_off, sizeof(int64_t) * (size_t)n_uniq);
+    g_sort_pool = name_pool;
+    qsort(order, (size_t)n_uniq, sizeof(int64_t), cmp_name);
+    /* provisional id of a sorted name: look it up again */
+    for (int64_t r = 0; r < n_uniq; ++r) {
+        const char *nm = name_pool + order[r];
+        uint64_t h = fnv1a(nm) & (cap - 1);
+        while (strcmp(name_pool + slot_off[h], nm) != 0) h = (h + 1) & (cap - 1);
+        rank[slot_id[h]] = (int32_t)r;
+    }
+    for (int64_t i = 0; i < n_nodes; ++i)
+        if (taxon[i] >= 0) taxon[i] = rank[taxon[i]];
+    memcpy(uniq_off, order, sizeof(int64_t) * (size_t)n_uniq);
+    *n_taxa = n_uniq;
+    free(order);
+    free(rank);
+    free(slot_off);
+    free(slot_id);
+    return SCS_HOST_OK;
+}

@@ -23,3 +23,12 @@ def load_trees(source_tree_file: str | os.PathLike) -> list:
     """
     with Path(source_tree_file).open() as f:
         return [_make_tree(line.strip()) for line in f]
+
+
+def load_tree_arrays(source_tree_file: str | os.PathLike):
+    """The same file as flat tree arrays, parsed in C without building tree objects
+    (``treearrays.TreeArrays.from_newick_file``); ``construct_supertree`` accepts the result
+    in place of the list of trees.  For inputs too large for Python objects."""
+    from spectralclustersupertree_amd.treearrays import TreeArrays
+
+    return TreeArrays.from_newick_file(source_tree_file)

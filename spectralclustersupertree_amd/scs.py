@@ -158,6 +158,26 @@ def construct_supertree(
     if random_state is None:
         random_state = np.random.RandomState()
 
+    if isinstance(trees, TreeArrays):
+        # extension: a forest that was parsed straight into arrays (load.load_tree_arrays)
+        if pcg_weighting not in ("one", "branch", "depth", "bootstrap"):
+            msg = f"Invalid weighting strategy selected: '{pcg_weighting}'"
+            raise ValueError(msg)
+        arrays = trees
+        if weights is not None:
+            if len(weights) != arrays.n_trees:
+                msg = (
+                    f"The number of trees ({arrays.n_trees}) "
+                    f"and tree weights ({len(weights)}) must match."
+                )
+                raise ValueError(msg)
+            arrays = TreeArrays(arrays.n_taxa, arrays.node_off, arrays.parent, arrays.taxon, arrays.length,
+                                arrays.support, np.asarray([float(w) for w in weights]), arrays.taxa)
+        if arrays.n_trees == 0:
+            msg = "There must be at least one tree to make a supertree."
+            raise ValueError(msg)
+        return _finish(_construct(arrays, pcg_weighting, contract_edges, random_state))
+
     if len(trees) == 0:
         msg = "There must be at least one tree to make a supertree."
         raise ValueError(msg)
@@ -185,7 +205,11 @@ def construct_supertree(
 
     taxa = sorted(_all_tip_names(trees))
     arrays = TreeArrays.from_trees(trees, weights, taxa)
-    result = _construct(arrays, pcg_weighting, contract_edges, random_state)
+    return _finish(_construct(arrays, pcg_weighting, contract_edges, random_state))
+
+
+def _finish(result):
+    """A cogent3 tree when cogent3 is installed, as the reference returns."""
     if isinstance(result, TreeNode):
         try:
             import cogent3  # noqa: F401  # type: ignore[import-not-found]

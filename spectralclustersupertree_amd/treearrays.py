@@ -46,6 +46,13 @@ def _load() -> C.CDLL:
         lib.scs_host_restrict_fill.argtypes = [C.c_int32, lp, ip, ip, dp, dp, bp, bp, lp, ip, ip, dp, dp]
         lib.scs_host_flatten.restype = C.c_int
         lib.scs_host_flatten.argtypes = [C.c_int32, lp, ip, ip, dp, dp, C.c_int32, lp, ip, ip, dp, ip]
+        lib.scs_host_newick_scan.restype = C.c_int
+        lib.scs_host_newick_scan.argtypes = [C.c_char_p, C.c_int64, lp, lp, lp, lp, lp]
+        lib.scs_host_newick_parse.restype = C.c_int
+        lib.scs_host_newick_parse.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, lp, ip, dp, dp,
+                                              lp, C.c_char_p, lp, lp]
+        lib.scs_host_names_rank.restype = C.c_int
+        lib.scs_host_names_rank.argtypes = [C.c_char_p, lp, C.c_int64, ip, lp, lp]
         _lib = lib
     return _lib
 
@@ -111,6 +118,50 @@ class TreeArrays:
             weights=np.asarray([float(w) for w in weights], dtype=np.float64),
             taxa=list(taxa),
         )
+
+    @classmethod
+    def from_newick_file(cls, path, weights: Sequence[float] | None = None) -> "TreeArrays":
+        """Parse a line-separated Newick file straight into arrays (reference: load.py:7-23;
+        the grammar and its meaning are those of ``tree.make_tree``), in C, without building
+        tree objects.  Taxon ids are the ranks of the sorted distinct leaf names."""
+        lib = _load()
+        text = Path(path).read_bytes()
+        n_trees, n_nodes, name_bytes, max_nodes, err = (C.c_int64(), C.c_int64(), C.c_int64(),
+                                                        C.c_int64(), C.c_int64())
+        rc = lib.scs_host_newick_scan(text, len(text), C.byref(n_trees), C.byref(n_nodes),
+                                      C.byref(name_bytes), C.byref(max_nodes), C.byref(err))
+        if rc:
+            raise ValueError(f"malformed Newick tree on line {err.value + 1} of {path}")
+        m, k = n_trees.value, n_nodes.value
+        node_off = np.zeros(m + 1, dtype=np.int64)
+        parent = np.empty(k, dtype=np.int32)
+        length = np.empty(k, dtype=np.float64)
+        support = np.empty(k, dtype=np.float64)
+        name_off = np.empty(k, dtype=np.int64)
+        pool = C.create_string_buffer(name_bytes.value + 1)
+        used = C.c_int64()
+        rc = lib.scs_host_newick_parse(text, len(text), m, max_nodes.value, _p(node_off, C.c_int64),
+                                       _p(parent, C.c_int32), _p(length, C.c_double),
+                                       _p(support, C.c_double), _p(name_off, C.c_int64), pool,
+                                       C.byref(used), C.byref(err))
+        if rc:
+            raise ValueError(f"malformed Newick tree on line {err.value + 1} of {path}")
+        taxon = np.empty(k, dtype=np.int32)
+        uniq = np.empty(max(k, 1), dtype=np.int64)
+        n_taxa = C.c_int64()
+        rc = lib.scs_host_names_rank(pool, _p(name_off, C.c_int64), k, _p(taxon, C.c_int32),
+                                     _p(uniq, C.c_int64), C.byref(n_taxa))
+        if rc:
+            raise MemoryError("scs_host_names_rank")
+        raw = pool.raw
+        taxa = []
+        for off in uniq[: n_taxa.value]:
+            end = raw.index(b"\0", int(off))
+            taxa.append(raw[int(off):end].decode())
+        if weights is None:
+            weights = np.ones(m, dtype=np.float64)
+        return cls(n_taxa=n_taxa.value, node_off=node_off, parent=parent, taxon=taxon, length=length,
+                   support=support, weights=np.asarray(weights, dtype=np.float64), taxa=taxa)
 
     # ---------------------------------------------------------------- queries
     def present_taxa(self) -> np.ndarray:

@@ -204,3 +204,92 @@ def test_reference_cases_through_the_array_recursion(case):
         got = scs._construct(arrays, case.pcg_weighting, case.contract_edges, np.random.RandomState(0),
                              cpu_bipartition)
     assert got.sorted().same_shape(make_tree(case.expected).sorted())
+
+
+# ---------------------------------------------------------------------------
+# Newick file -> arrays in C (reference: load.py:7-23)
+# ---------------------------------------------------------------------------
+def arrays_equal(a: TreeArrays, b: TreeArrays) -> None:
+    assert a.taxa == b.taxa
+    assert np.array_equal(a.node_off, b.node_off)
+    assert np.array_equal(a.parent, b.parent)
+    assert np.array_equal(a.taxon, b.taxon)
+    assert np.array_equal(a.length.view(np.uint64), b.length.view(np.uint64))
+    assert np.array_equal(a.support.view(np.uint64), b.support.view(np.uint64))
+
+
+def via_objects(path) -> TreeArrays:
+    from spectralclustersupertree_amd.load import load_trees
+
+    trees = load_trees(path)
+    names = sorted(scs._all_tip_names(trees))
+    return TreeArrays.from_trees(trees, [1.0] * len(trees), names)
+
+
+@pytest.mark.parametrize("name", ["dcm_source_trees.tre", "dcm_iq_source.tre", "supertriplets_source.tre"])
+def test_newick_loader_matches_object_loader_on_reference_fixtures(name):
+    from tests.reference_cases import DATA_DIR
+
+    path = DATA_DIR / name
+    arrays_equal(TreeArrays.from_newick_file(path), via_objects(path))
+
+
+def test_newick_loader_grammar(tmp_path):
+    lines = [
+        "((a:0.1,b:2e-3)90:0.5,(c,d)0.75:1,e);",
+        "(('it''s a name':1, 'x y' ):3,[comment](b , c)[another]:0.25 , d:);",
+        "((a,b),(c,(d,e)label)77);  trailing text is ignored",
+        "a;",
+        "((a));",
+        "(a,b,c,d,e);",
+    ]
+    path = tmp_path / "t.tre"
+    path.write_text("\n".join(lines) + "\n")
+    got = TreeArrays.from_newick_file(path)
+    arrays_equal(got, via_objects(path))
+    assert "it's a name" in got.taxa and "x y" in got.taxa
+    # numeric internal labels are supports, others are not
+    assert np.nanmax(got.support) == 90.0 and np.count_nonzero(~np.isnan(got.support)) == 3
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_newick_loader_random_round_trip(tmp_path, seed):
+    taxa, trees, weights = random_forest(200 + seed, 50, 12)
+    path = tmp_path / "forest.tre"
+    with path.open("w") as f:
+        for t in trees:
+            # supports travel as numeric internal labels, the way the reference's bootstrap
+            # inputs carry them
+            for node in t.iter_nontips(include_self=True):
+                node.name = None if node.support is None else repr(node.support)
+            f.write(t.get_newick(with_distances=True, with_node_names=True) + "\n")
+    got = TreeArrays.from_newick_file(path, weights)
+    want = via_objects(path)
+    arrays_equal(got, want)
+    assert np.array_equal(got.weights, np.asarray(weights))
+    # and the tables they flatten to are the object path's
+    trees2 = __import__("spectralclustersupertree_amd.load", fromlist=["load_trees"]).load_trees(path)
+    names = sorted(scs._all_tip_names(trees2))
+    tables_equal(got.flatten("branch"), fl.flatten_trees(trees2, weights, "branch", names))
+
+
+@pytest.mark.parametrize("bad", ["((a,b);", "(a,b));", "(a,b),c;", "", "   ", "(a:1x,b);", "('unterminated,b);", "(a,[b);"])
+def test_newick_loader_rejects_what_the_object_parser_rejects(tmp_path, bad):
+    path = tmp_path / "bad.tre"
+    path.write_text("(a,b);\n" + bad + "\n(c,d);\n")
+    with pytest.raises(ValueError, match="line 2"):
+        TreeArrays.from_newick_file(path)
+    with pytest.raises(ValueError):
+        make_tree(bad)
+
+
+def test_construct_supertree_accepts_arrays_and_checks_weights(tmp_path):
+    from spectralclustersupertree_amd import construct_supertree
+
+    path = tmp_path / "t.tre"
+    path.write_text("(a,(b,c));\n(c,(a,b));\n")
+    arrays = TreeArrays.from_newick_file(path)
+    with pytest.raises(ValueError, match="must match"):
+        construct_supertree(arrays, weights=[1.0])
+    with pytest.raises(ValueError, match="Invalid weighting strategy"):
+        construct_supertree(arrays, pcg_weighting="nope")
