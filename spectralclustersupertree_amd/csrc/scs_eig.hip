@@ -321,10 +321,11 @@ struct jacobi_lds {
 //   * keeps the rotated pairs at FIXED positions (2k, 2k+1) and moves the data instead: every
 //     work item -- a 2 x 2 block of A or a column pair of one row of E -- reads from one copy
 //     of the matrices and writes its results to precomputed, round-robin-permuted addresses
-//     in the other copy, so a step is one barrier and no index arithmetic;
-//   * lets every item compute the (at most two) rotations it needs itself from the diagonal
-//     blocks, with hardware rsq/rcp seeds refined by Newton steps instead of IEEE
-//     division and square root.
+//     in the other copy, so a step needs no index arithmetic;
+//   * computes each pair's rotation once (m / 2 lanes, from the pair's diagonal block, with
+//     hardware rsq/rcp seeds refined by Newton steps instead of IEEE division and square
+//     root) and hands it to the items through LDS: a second barrier per step, but the long
+//     rotation chain is off the path of the threads that own two items.
 // At most two items per thread (256 threads).  Interface as jacobi_eig.
 __device__ __forceinline__ void jacobi_rot(double app, double apq, double aqq, double &c,
                                            double &sn) {
@@ -456,16 +457,21 @@ __device__ void jacobi_eig_fast(jacobi_lds &s, int n) {
             const double *e0 = fe + cur * ne * 2;
             double *a1 = fa + (cur ^ 1) * nblk * 4;
             double *e1 = fe + (cur ^ 1) * ne * 2;
+            // the rotation of pair k, once, from its diagonal block
+            if (tid < half) {
+                const double *dc = a0 + (tid * half + tid) * 4;
+                double c, sn;
+                jacobi_rot(dc[0], dc[1], dc[3], c, sn);
+                s.cs[tid][0] = c;
+                s.cs[tid][1] = sn;
+            }
+            __syncthreads();
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
                 if (kind[w] == 0) continue;
-                const double *dc = a0 + (ib[w] * half + ib[w]) * 4;
-                double c2, s2;
-                jacobi_rot(dc[0], dc[1], dc[3], c2, s2);
+                const double c2 = s.cs[ib[w]][0], s2 = s.cs[ib[w]][1];
                 if (kind[w] == 1) {
-                    const double *dr = a0 + (ia[w] * half + ia[w]) * 4;
-                    double c1, s1;
-                    jacobi_rot(dr[0], dr[1], dr[3], c1, s1);
+                    const double c1 = s.cs[ia[w]][0], s1 = s.cs[ia[w]][1];
                     const double *bp = a0 + (ia[w] * half + ib[w]) * 4;
                     const double a00 = bp[0], a01 = bp[1], a10 = bp[2], a11 = bp[3];
                     const double t00 = c2 * a00 - s2 * a01, t01 = s2 * a00 + c2 * a01;
