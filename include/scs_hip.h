@@ -53,7 +53,8 @@ typedef struct scs_stats {
     double lambda[2];        /* two largest eigenvalues of S = D^-1/2 A D^-1/2       */
     double resid[2];         /* ||S x - lambda x||_2 of the returned unit vectors    */
     double lambda_next;      /* next Ritz value below lambda[1] (gap estimate)       */
-    double apply_ms_total;   /* sum of SYMM kernel durations                         */
+    double apply_ms_total;   /* SYMM kernel time: HIP-event-timed launches (every 4th
+                              * in the fused loop), scaled to all n_apply launches */
     double apply_ms_min;     /* fastest single SYMM launch                           */
     double solve_ms;         /* whole scs_fiedler call, device time                  */
     double apply_bytes;      /* algorithmic HBM bytes of ONE SYMM launch on this rank */

@@ -12,6 +12,7 @@
 // an iteration needs one small device->host read (the residual norms).
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "scs_internal.h"
@@ -904,13 +905,13 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
 // Output coef: rows [x (b) | p (b) | r (b) | u | 3 zero rows] x b, the operand of
 // k_panel_tf; mask[c] = 0 marks a dropped direction (zero column).
 // report (mapped host memory, may be null): [0, b) squared residual norms diag(G),
-// [16, 16 + b] the current Ritz values.
+// [16, 16 + b] the current Ritz values, [40] the caller's sequence number, written last.
 __global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ partial,
                                                      int nparts, int b, double drop_tol,
                                                      double *__restrict__ coef,
                                                      int *__restrict__ mask,
                                                      const double *__restrict__ theta,
-                                                     double *report) {
+                                                     double *report, double seq) {
     __shared__ jacobi_lds s;
     __shared__ double cxp[16][8], gm[9][8], mm[8][8], tt[8][8], dsc[8];
     const int tid = threadIdx.x;
@@ -923,8 +924,17 @@ __global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ p
         });
     }
     if (report) {
+        // hand the norms to the host through mapped memory: data, system-scope fence, then the
+        // sequence number the host is polling for (no stream event: recording one costs the
+        // device a ~6 us bubble)
         if (tid < b) report[tid] = gm[tid][tid];
         if (tid <= b) report[16 + tid] = theta[tid];
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            ((volatile double *)report)[40] = seq;
+            __threadfence_system();
+        }
     }
     for (int e = tid; e < b * b; e += 256) {
         const int i = e / b, j = e - i * b;
@@ -1140,14 +1150,13 @@ struct solver {
 
     template <int B>
     int fused_front(const double *uvec, const double *c, const double *d, const double *theta,
-                    double *coef, int *mask_r, double drop_tol, double *report, hipEvent_t ev_report) {
+                    double *coef, int *mask_r, double drop_tol, double *report, double seq) {
         const int nb = panel_blocks16();
         k_panel_rr<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, c, d, theta, n, part.d());
-        k_small_orth<<<1, 256, 0, s>>>(part.d(), nb, B, drop_tol, coef, mask_r, theta, report);
-        SCS_HIP_CHECK(hipEventRecord(ev_report, s));
+        k_small_orth<<<1, 256, 0, s>>>(part.d(), nb, B, drop_tol, coef, mask_r, theta, report, seq);
         k_panel_tf<B, true, false><<<nb, 256, 0, s>>>(q.d(), uvec, coef, n, part.d(), nullptr,
                                                       nullptr, 0);
-        k_small_orth<<<1, 256, 0, s>>>(part.d(), nb, B, 0.0, coef, mask_r, theta, nullptr);
+        k_small_orth<<<1, 256, 0, s>>>(part.d(), nb, B, 0.0, coef, mask_r, theta, nullptr, 0.0);
         k_panel_tf<B, false, true><<<nb, 256, 0, s>>>(q.d(), uvec, coef, n, nullptr, g->d_dinv,
                                                       z.d(), g->ld);
         SCS_HIP_CHECK(hipGetLastError());
@@ -1158,24 +1167,29 @@ struct solver {
     // partials of Q^T AQ; returns their count
     template <int B>
     int fused_back(int *nparts) {
+        // k_symm is timed with HIP events on every fourth launch only: recording an event costs
+        // the device a ~6 us bubble
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        SCS_HIP_CHECK(hipEventCreate(&e0));
-        SCS_HIP_CHECK(hipEventCreate(&e1));
-        ev.push_back(e0);
-        ev.push_back(e1);
+        const bool timed = (n_apply & 3) == 0;
+        if (timed) {
+            SCS_HIP_CHECK(hipEventCreate(&e0));
+            SCS_HIP_CHECK(hipEventCreate(&e1));
+            ev.push_back(e0);
+            ev.push_back(e1);
+        }
         const int nb = panel_blocks4();
         *nparts = nb;
         if (world == 1) {
-            SCS_HIP_CHECK(hipEventRecord(e0, s));
+            if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
             SCS_TRY(launch_symm(z.d(), nullptr));
-            SCS_HIP_CHECK(hipEventRecord(e1, s));
+            if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
             k_gram_qaq<B, true><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
                                                    g->d_dinv, part.d());
         } else {
-            SCS_HIP_CHECK(hipEventRecord(e0, s));
+            if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
             SCS_TRY(launch_symm(z.d(), yloc.d()));
-            SCS_HIP_CHECK(hipEventRecord(e1, s));
+            if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
             SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
             const int nbq = n * B;
@@ -1445,20 +1459,13 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // the one-kernel-per-step formulation (also used for widths 12 and 16).
     const bool fused = (b == 4 || b == 8) &&
                        !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP")));
-    hipEvent_t ev_report = nullptr;
-    struct evg1 {
-        hipEvent_t *e;
-        ~evg1() {
-            if (*e) hipEventDestroy(*e);
-        }
-    } evguard1{&ev_report};
     if (fused) {
         if (!ctx->h_report) {
             SCS_HIP_CHECK(hipHostMalloc((void **)&ctx->h_report, 64 * sizeof(double),
                                         hipHostMallocMapped | hipHostMallocCoherent));
             SCS_HIP_CHECK(hipHostGetDevicePointer((void **)&ctx->d_report, ctx->h_report, 0));
+            memset(ctx->h_report, 0, 64 * sizeof(double));
         }
-        SCS_HIP_CHECK(hipEventCreateWithFlags(&ev_report, hipEventDisableTiming));
         k_unit_coeffs<<<(3 * b * b + 255) / 256, 256, 0, s>>>(T, D, b);
     }
     const double *uvec = constrained ? sv.u.d() : nullptr;
@@ -1469,17 +1476,40 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             // first small kernel reported: the device never waits for the host.  Nothing
             // after that kernel touches X, so on a stop X is the block the norms belong to.
             int nparts = 0;
+            const double seq = (double)(++ctx->report_seq);
             if (b == 4) {
-                SCS_TRY(sv.fused_front<4>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, ev_report));
+                SCS_TRY(sv.fused_front<4>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, seq));
                 SCS_TRY(sv.fused_back<4>(&nparts));
             } else {
-                SCS_TRY(sv.fused_front<8>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, ev_report));
+                SCS_TRY(sv.fused_front<8>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, seq));
                 SCS_TRY(sv.fused_back<8>(&nparts));
             }
             k_small_rr<<<1, 256, 0, s>>>(sv.part.d(), nparts, q3, b, MASK, T, D, TH, MASK + b,
                                          drop_tol);
             SCS_HIP_CHECK(hipGetLastError());
-            SCS_HIP_CHECK(hipEventSynchronize(ev_report));
+            {
+                // wait for this iteration's report (the device is already working on the rest of
+                // the iteration); give up if the stream died
+                volatile double *hr = (volatile double *)ctx->h_report;
+                const auto t_wait = std::chrono::steady_clock::now();
+                unsigned spins = 0;
+                while (hr[40] != seq) {
+                    if ((++spins & 0xFFFF) == 0) {
+                        const hipError_t qe = hipStreamQuery(s);
+                        if (qe != hipSuccess && qe != hipErrorNotReady) {
+                            scs_set_error("scs_fiedler: stream failed: %s", hipGetErrorString(qe));
+                            return SCS_EHIP;
+                        }
+                        if (qe == hipSuccess && hr[40] != seq) {
+                            // everything ran and the report never arrived
+                            if (std::chrono::steady_clock::now() - t_wait > std::chrono::seconds(5)) {
+                                scs_set_error("scs_fiedler: residual report lost at iteration %d", iter);
+                                return SCS_EHIP;
+                            }
+                        }
+                    }
+                }
+            }
             for (int j = 0; j < b; ++j) h_rn[j] = ((volatile double *)ctx->h_report)[j];
             for (int j = 0; j <= b; ++j) h_th[j] = ((volatile double *)ctx->h_report)[16 + j];
         } else {
@@ -1600,13 +1630,17 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     hipEventElapsedTime(&ms, ev_a, ev_b);
     st->solve_ms = ms;
     double tot = 0.0, mn = 1e300;
+    int n_timed = 0;
     for (size_t i = 0; i + 1 < sv.ev.size(); i += 2) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, sv.ev[i], sv.ev[i + 1]) == hipSuccess) {
             tot += t;
             mn = std::min(mn, (double)t);
+            ++n_timed;
         }
     }
+    // the fused loop times every fourth launch: scale the sample to all launches
+    if (n_timed > 0) tot *= (double)sv.n_apply / n_timed;
     st->apply_ms_total = tot;
     st->apply_ms_min = sv.n_apply ? mn : 0.0;
     st->apply_bytes = 8.0 * sv.rows * (double)n + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;

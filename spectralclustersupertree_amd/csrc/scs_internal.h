@@ -74,6 +74,7 @@ struct scs_ctx {
     // residual norms into (allocated on first use)
     double *h_report = nullptr;
     double *d_report = nullptr;
+    unsigned long long report_seq = 0;  // sequence number of the last report requested
 };
 
 struct scs_tables {
