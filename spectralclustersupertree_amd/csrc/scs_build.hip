@@ -950,13 +950,22 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     const int M = tb->n_trees;
     std::vector<int> batch_start{0};
     {
+        // A batch is also capped at 256 trees.  All tiles of a launch start at the batch's first
+        // tree and drift apart as they walk the trees; the gathers into a tree's tables hit the
+        // L2 only while the workgroups of an XCD are within a few trees of each other.  A new
+        // launch re-synchronises them for the price of re-reading the tile sums (measured at
+        // 50 000 / 2 000: 2.10 s in one batch, 1.31 s in batches of 256; 64 -> 1.67 s, 512 ->
+        // 1.55 s; at 100 000 / 5 000: 25.3 s -> 14.3 s).  SCS_BATCH_TREES overrides.
+        static const int batch_trees_env = getenv("SCS_BATCH_TREES") ? atoi(getenv("SCS_BATCH_TREES")) : 0;
+        const int max_batch_trees = batch_trees_env > 0 ? batch_trees_env : 256;
         size_t used = 0;
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
             const int64_t m = nt - 1;
             size_t need = (size_t)table_entries(m) * key_bytes + (size_t)nt * 8 +
                           (size_t)npad * 4 + (size_t)n_blocks * REC_BYTES;
-            if (used + need > ctx->ws_limit && t > batch_start.back()) {
+            if ((used + need > ctx->ws_limit || t - batch_start.back() >= max_batch_trees) &&
+                t > batch_start.back()) {
                 batch_start.push_back(t);
                 used = 0;
             }
