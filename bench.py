@@ -385,7 +385,7 @@ def main() -> int:
         others = {}
         for extra, st in (("cfg1", 3), ("cfg3", 1)):
             try:
-                rep = run_workload(extra, args, dev, dist, rank, world, st, 1 if extra == "cfg1" else 0,
+                rep = run_workload(extra, args, dev, dist, rank, world, st, 1,
                                    full=False)
                 others[extra] = {k: rep[k] for k in ("value", "steps", "config", "roofline",
                                                      "roofline_build", "stages", "parity") if k in rep}
