@@ -369,7 +369,8 @@ def main() -> int:
         "higher_is_better": False,
         "scaling": "strong",
         "scaling_note": "N > 1 runs BASELINE.json configs[3]; its one-GPU time, the strong-scaling "
-                        "baseline, is other_workloads.cfg3.value of the N = 1 line",
+                        "baseline, is other_workloads.cfg3.value of the N = 1 line and "
+                        "same_workload_on_one_gpu.value of every N > 1 line",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -394,6 +395,20 @@ def main() -> int:
         result["other_workloads"] = others
 
     dev.close()
+    # N > 1: rank 0 also times the SAME workload alone on its GPU (one warm-up + one pass,
+    # single-rank context, the other ranks wait), so that every multi-GPU line carries the
+    # one-device time it is to be compared with
+    if world > 1 and rank == 0 and not args.no_extra:
+        try:
+            solo = Device(dev_index, 0, 1)
+            try:
+                rep = run_workload(name, args, solo, None, 0, 1, 1, 1, full=False)
+                result["same_workload_on_one_gpu"] = {k: rep[k] for k in ("value", "stages", "roofline", "parity")
+                                                      if k in rep}
+            finally:
+                solo.close()
+        except Exception as exc:  # noqa: BLE001 - report, never hide the main line
+            result["same_workload_on_one_gpu"] = {"error": str(exc)}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
