@@ -93,7 +93,9 @@ def _build_and_compare(dev, tables, row_ranges=None):
 
 
 @pytest.mark.parametrize("strategy", ["one", "depth", "branch", "bootstrap"])
-@pytest.mark.parametrize(("n", "m", "k"), [(37, 6, 20), (64, 5, 64), (100, 9, 71), (300, 12, 300), (700, 7, 512)])
+# (the last case has more trees than one batch takes: 256)
+@pytest.mark.parametrize(("n", "m", "k"), [(37, 6, 20), (64, 5, 64), (100, 9, 71), (300, 12, 300), (700, 7, 512),
+                                           (330, 600, 200)])
 def test_build_bit_exact_synthetic(dev, strategy, n, m, k):
     tables = synthetic.make_tables(100 + n, n, m, strategy, leaves_per_tree=k, random_weights=(n % 2 == 0))
     _build_and_compare(dev, tables)
