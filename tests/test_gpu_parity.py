@@ -433,6 +433,14 @@ def test_reference_fixtures_end_to_end(name, src, exp, weighting):
     _scs(load_trees(DATA_DIR / src), load_tree(DATA_DIR / exp), pcg_weighting=weighting)
 
 
+@pytest.mark.parametrize(("name", "src", "exp", "weighting"), FILE_CASES, ids=[c[0] for c in FILE_CASES])
+def test_reference_fixtures_end_to_end_from_tree_arrays(name, src, exp, weighting):
+    # the same fixtures through the C Newick loader: no tree object is built for the input
+    from spectralclustersupertree_amd.load import load_tree_arrays
+
+    _scs(load_tree_arrays(DATA_DIR / src), load_tree(DATA_DIR / exp), pcg_weighting=weighting)
+
+
 def test_reference_not_completed_end_to_end():
     case = NOT_COMPLETED_CASE
     trees = [make_tree(s) for s in case.trees] + [NotCompleted("ERROR", "local", "Example NotCompleted")]
