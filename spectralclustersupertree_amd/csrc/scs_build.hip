@@ -747,6 +747,35 @@ struct dev_buf {
     }
 };
 
+// a scratch buffer that lives in the context between calls (see scs_ctx::scratch)
+struct pooled_buf {
+    scs_ctx *ctx = nullptr;
+    int slot = 0;
+    void *p = nullptr;
+    pooled_buf(scs_ctx *c, int s) : ctx(c), slot(s) {}
+    ~pooled_buf() {
+        auto &sl = ctx->scratch[slot];
+        if (sl.cap > SCS_SCRATCH_KEEP) {
+            hipFree(sl.p);
+            sl.p = nullptr;
+            sl.cap = 0;
+        }
+    }
+    int alloc(size_t bytes) {
+        auto &sl = ctx->scratch[slot];
+        if (bytes < 16) bytes = 16;
+        if (sl.cap < bytes) {
+            if (sl.p) hipFree(sl.p);
+            sl.p = nullptr;
+            sl.cap = 0;
+            SCS_HIP_CHECK(hipMalloc(&sl.p, bytes));
+            sl.cap = bytes;
+        }
+        p = sl.p;
+        return SCS_OK;
+    }
+};
+
 struct ev_pair {
     hipEvent_t a = nullptr, b = nullptr;
     ~ev_pair() {
@@ -931,7 +960,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             SCS_HIP_CHECK(hipMemsetAsync((double *)d_tile_out.p + (slots - 1) * SCS_TR * SCS_TCW,
                                          0, (size_t)SCS_TR * SCS_TCW * 8, s));
     }
-    dev_buf d_tiles;
+    pooled_buf d_tiles(ctx, 0);
     SCS_TRY(d_tiles.alloc(std::max<size_t>(tiles.size(), 1) * sizeof(int2)));
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                  hipMemcpyHostToDevice, s));
@@ -975,15 +1004,19 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     }
     const int n_batches = (int)batch_start.size() - 1;
 
-    ev_pair ev_total, ev_prep, ev_acc;
-    SCS_TRY(ev_total.init());
-    SCS_TRY(ev_prep.init());
-    SCS_TRY(ev_acc.init());
+    // timing events live in the context (created once)
+    struct ev_ref {
+        hipEvent_t a, b;
+    } ev_total, ev_prep, ev_acc;
+    for (auto &e : ctx->build_events)
+        if (!e) SCS_HIP_CHECK(hipEventCreate(&e));
+    ev_total = {ctx->build_events[0], ctx->build_events[1]};
+    ev_prep = {ctx->build_events[2], ctx->build_events[3]};
+    ev_acc = {ctx->build_events[4], ctx->build_events[5]};
     float prep_ms = 0.f, acc_ms = 0.f;
     SCS_HIP_CHECK(hipEventRecord(ev_total.a, s));
 
-    dev_buf d_pos, d_vw, d_st, d_stoff, d_rec;
-    size_t cap_pos = 0, cap_vw = 0, cap_st = 0, cap_stoff = 0, cap_rec = 0;
+    pooled_buf d_pos(ctx, 1), d_vw(ctx, 2), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5);
     for (int bi = 0; bi < n_batches; ++bi) {
         const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
         const int nb = t1 - t0;
@@ -1004,11 +1037,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         const size_t need_st = (size_t)st_off[nb] * key_bytes + 64;  // +64: a tree without gaps may be probed at entry 0
         const size_t need_stoff = (size_t)(nb + 1) * 8;
         const size_t need_rec = (size_t)n_blocks * nb * REC_BYTES;
-        if (need_pos > cap_pos) { SCS_TRY(d_pos.alloc(need_pos)); cap_pos = need_pos; }
-        if (need_vw > cap_vw) { SCS_TRY(d_vw.alloc(need_vw)); cap_vw = need_vw; }
-        if (need_st > cap_st) { SCS_TRY(d_st.alloc(need_st)); cap_st = need_st; }
-        if (need_stoff > cap_stoff) { SCS_TRY(d_stoff.alloc(need_stoff)); cap_stoff = need_stoff; }
-        if (need_rec > cap_rec) { SCS_TRY(d_rec.alloc(need_rec)); cap_rec = need_rec; }
+        SCS_TRY(d_pos.alloc(need_pos));
+        SCS_TRY(d_vw.alloc(need_vw));
+        SCS_TRY(d_st.alloc(need_st));
+        SCS_TRY(d_stoff.alloc(need_stoff));
+        SCS_TRY(d_rec.alloc(need_rec));
 
         SCS_HIP_CHECK(hipEventRecord(ev_prep.a, s));
         SCS_HIP_CHECK(hipMemcpyAsync(d_stoff.p, st_off.data(), need_stoff, hipMemcpyHostToDevice, s));
@@ -1114,12 +1147,17 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         }
         SCS_HIP_CHECK(hipGetLastError());
         SCS_HIP_CHECK(hipEventRecord(ev_acc.b, s));
-        SCS_HIP_CHECK(hipEventSynchronize(ev_acc.b));
-        float ms = 0.f;
-        SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_prep.a, ev_prep.b));
-        prep_ms += ms;
-        SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_acc.a, ev_acc.b));
-        acc_ms += ms;
+        if (n_batches > 1) {
+            // the one event pair is re-recorded by the next batch: read it now (a single
+            // batch is read after the final synchronisation instead -- small builds are
+            // dominated by host round trips)
+            SCS_HIP_CHECK(hipEventSynchronize(ev_acc.b));
+            float ms = 0.f;
+            SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_prep.a, ev_prep.b));
+            prep_ms += ms;
+            SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_acc.a, ev_acc.b));
+            acc_ms += ms;
+        }
     }
     float exch_ms = 0.f;
     if (shared) {
@@ -1140,6 +1178,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipEventSynchronize(ev_total.b));
     float total_ms = 0.f;
     SCS_HIP_CHECK(hipEventElapsedTime(&total_ms, ev_total.a, ev_total.b));
+    if (n_batches == 1) {
+        SCS_HIP_CHECK(hipEventElapsedTime(&prep_ms, ev_prep.a, ev_prep.b));
+        SCS_HIP_CHECK(hipEventElapsedTime(&acc_ms, ev_acc.a, ev_acc.b));
+    }
 
     if (stats) {
         memset(stats, 0, sizeof(*stats));

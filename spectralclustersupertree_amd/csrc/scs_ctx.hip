@@ -286,6 +286,10 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     scs_comm_destroy(&ctx->comm);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->h_report) hipHostFree(ctx->h_report);
+    for (auto &sl : ctx->scratch)
+        if (sl.p) hipFree(sl.p);
+    for (auto &e : ctx->build_events)
+        if (e) hipEventDestroy(e);
     delete ctx;
     return SCS_OK;
 }

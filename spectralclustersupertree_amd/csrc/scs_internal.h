@@ -45,6 +45,8 @@ constexpr int SCS_TCW = 256;  // threads per workgroup = columns per column grou
 constexpr int SCS_NPAD = 512; // position tables are padded to a multiple of this
 constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_symm.h
 
+constexpr size_t SCS_SCRATCH_KEEP = (size_t)64 << 20;
+
 // ---- communicator -----------------------------------------------------------
 struct scs_local_group;  // in-process barrier + exchange slots
 
@@ -75,6 +77,14 @@ struct scs_ctx {
     double *h_report = nullptr;
     double *d_report = nullptr;
     unsigned long long report_seq = 0;  // sequence number of the last report requested
+    // small scratch buffers of scs_pcg_build kept between calls (the recursion makes
+    // thousands of tiny builds: hipMalloc/hipFree dominated them); anything above
+    // SCS_SCRATCH_KEEP bytes is released at the end of the call that needed it
+    struct scratch_slot {
+        void *p = nullptr;
+        size_t cap = 0;
+    } scratch[8];
+    hipEvent_t build_events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct scs_tables {
