@@ -1,0 +1,40 @@
+"""ctypes binding of libscs_host.so (plain-C host helpers: tree arrays, Newick parsing,
+contraction groups).  Built by ``__graft_entry__.build()`` / ``make -C csrc``."""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "libscs_host.so"
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            msg = f"{_LIB_PATH} not found: run __graft_entry__.build()"
+            raise ImportError(msg)
+        lib = C.CDLL(str(_LIB_PATH))
+        ip, dp, lp, bp = (C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_uint8))
+        lib.scs_host_restrict_sizes.restype = C.c_int
+        lib.scs_host_restrict_sizes.argtypes = [C.c_int32, lp, ip, ip, bp, bp, ip]
+        lib.scs_host_restrict_fill.restype = C.c_int
+        lib.scs_host_restrict_fill.argtypes = [C.c_int32, lp, ip, ip, dp, dp, bp, bp, lp, ip, ip, dp, dp]
+        lib.scs_host_flatten.restype = C.c_int
+        lib.scs_host_flatten.argtypes = [C.c_int32, lp, ip, ip, dp, dp, C.c_int32, lp, ip, ip, dp, ip]
+        lib.scs_host_newick_scan.restype = C.c_int
+        lib.scs_host_newick_scan.argtypes = [C.c_char_p, C.c_int64, lp, lp, lp, lp, lp]
+        lib.scs_host_newick_parse.restype = C.c_int
+        lib.scs_host_newick_parse.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_int64, lp, ip, dp, dp,
+                                              lp, C.c_char_p, lp, lp]
+        lib.scs_host_names_rank.restype = C.c_int
+        lib.scs_host_names_rank.argtypes = [C.c_char_p, lp, C.c_int64, ip, lp, lp]
+        lib.scs_host_contraction_groups.restype = C.c_int
+        lib.scs_host_contraction_groups.argtypes = [C.c_int32, C.c_int32, lp, ip, ip, ip]
+        _lib = lib
+    return _lib
+
+

@@ -576,3 +576,67 @@ int scs_host_names_rank(const char *name_pool, const int64_t *name_off, int64_t 
     free(slot_id);
     return SCS_HOST_OK;
 }
+
+/* ---------------------------------------------------------------------------
+ * Contraction groups from the flattened tables (reference: scs.py:298-334; the equivalence
+ * with "identical (tree, root side) signatures" is argued in flatten.contraction_groups,
+ * whose result this reproduces): partition refinement, one tree at a time, hashing the
+ * pair (current class, root side in this tree; 0 = absent).  groups[x] is the class of taxon
+ * x numbered by smallest member.  O(n_taxa) per tree, stops as soon as every taxon is alone.
+ * ------------------------------------------------------------------------- */
+int scs_host_contraction_groups(int32_t n_taxa, int32_t n_trees, const int64_t *tree_off,
+                                const int32_t *leaf_taxon, const int32_t *adj_depth,
+                                int32_t *groups) {
+    if (n_taxa <= 0) return SCS_HOST_OK;
+    int32_t *cls = (int32_t *)calloc((size_t)n_taxa, sizeof(int32_t));
+    int32_t *side = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_taxa);
+    uint64_t cap = 16;
+    while (cap < (uint64_t)n_taxa * 2 + 1) cap <<= 1;
+    uint64_t *hkey = (uint64_t *)malloc(sizeof(uint64_t) * cap);
+    int32_t *hval = (int32_t *)malloc(sizeof(int32_t) * cap);
+    int32_t *first = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_taxa);
+    if (!cls || !side || !hkey || !hval || !first) {
+        free(cls);
+        free(side);
+        free(hkey);
+        free(hval);
+        free(first);
+        return SCS_HOST_ENOMEM;
+    }
+    int32_t n_cls = 1;
+    for (int32_t t = 0; t < n_trees && n_cls < n_taxa; ++t) {
+        memset(side, 0, sizeof(int32_t) * (size_t)n_taxa);
+        int32_t s = 1;
+        for (int64_t p = tree_off[t]; p < tree_off[t + 1]; ++p) {
+            side[leaf_taxon[p]] = s;
+            if (p + 1 < tree_off[t + 1] && adj_depth[p] == 0) ++s; /* a root gap: next side */
+        }
+        for (uint64_t i = 0; i < cap; ++i) hkey[i] = UINT64_MAX;
+        int32_t next = 0;
+        for (int32_t x = 0; x < n_taxa; ++x) {
+            const uint64_t key = ((uint64_t)(uint32_t)cls[x] << 32) | (uint32_t)side[x];
+            uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 17 & (cap - 1);
+            while (hkey[h] != UINT64_MAX && hkey[h] != key) h = (h + 1) & (cap - 1);
+            if (hkey[h] == UINT64_MAX) {
+                hkey[h] = key;
+                hval[h] = next++;
+            }
+            cls[x] = hval[h];
+        }
+        n_cls = next;
+    }
+    /* number the classes by smallest member: classes were numbered in order of first
+     * appearance over x = 0, 1, ..., which is exactly that order */
+    for (int32_t c = 0; c < n_cls; ++c) first[c] = -1;
+    int32_t next = 0;
+    for (int32_t x = 0; x < n_taxa; ++x) {
+        if (first[cls[x]] < 0) first[cls[x]] = next++;
+        groups[x] = first[cls[x]];
+    }
+    free(cls);
+    free(side);
+    free(hkey);
+    free(hval);
+    free(first);
+    return SCS_HOST_OK;
+}

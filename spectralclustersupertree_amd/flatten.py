@@ -265,6 +265,27 @@ def _find_all(parent: np.ndarray, x: np.ndarray) -> np.ndarray:
 
 
 def contraction_groups(tables: TreeTables) -> np.ndarray:
+    """Group id (0..V'-1, by smallest member) of every taxon after contraction: the classes of
+    identical (tree, root side) signatures (see ``contraction_groups_numpy`` for why these are
+    the reference's groups).  Runs in ``libscs_host.so`` (hash-based partition refinement,
+    O(n_taxa) per tree); ``tests/test_treearrays.py`` checks it against the numpy version."""
+    import ctypes as C
+
+    from spectralclustersupertree_amd._hostlib import load
+
+    n = tables.n_taxa
+    groups = np.zeros(max(n, 1), dtype=np.int32)
+    if n and tables.n_trees:
+        lp, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        rc = load().scs_host_contraction_groups(
+            n, tables.n_trees, tables.tree_off.ctypes.data_as(lp), tables.leaf_taxon.ctypes.data_as(ip),
+            tables.adj_depth.ctypes.data_as(ip), groups.ctypes.data_as(ip))
+        if rc:
+            raise MemoryError("scs_host_contraction_groups")
+    return groups[:n]
+
+
+def contraction_groups_numpy(tables: TreeTables) -> np.ndarray:
     """Group id (0..V'-1, by smallest member) of every taxon after contraction.
 
     The reference merges u, v when their co-occurrence count as a proper

@@ -293,3 +293,33 @@ def test_construct_supertree_accepts_arrays_and_checks_weights(tmp_path):
         construct_supertree(arrays, weights=[1.0])
     with pytest.raises(ValueError, match="Invalid weighting strategy"):
         construct_supertree(arrays, pcg_weighting="nope")
+
+
+# ---------------------------------------------------------------------------
+# contraction groups in C (reference: scs.py:298-334) against the numpy refinement
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(6))
+def test_contraction_groups_c_matches_numpy(seed):
+    rng = random.Random(300 + seed)
+    # forests with real contraction: every tree is a refinement of a few fixed "cherries"
+    taxa = [f"t{i:03d}" for i in range(40)]
+    cherries = [taxa[i:i + rng.randint(1, 4)] for i in range(0, 40, 4)]
+    trees, weights = [], []
+    for _ in range(rng.randint(1, 8)):
+        picked = [c for c in cherries if rng.random() < 0.8] or cherries[:2]
+        units = [TreeNode("", [TreeNode(x) for x in c]) if len(c) > 1 else TreeNode(c[0]) for c in picked]
+        rng.shuffle(units)
+        while len(units) > 1:
+            a, b = units.pop(), units.pop()
+            units.append(TreeNode("", [a, b]))
+        trees.append(units[0])
+        weights.append(1.0)
+    names = sorted(scs._all_tip_names(trees))
+    tables = fl.flatten_trees(trees, weights, "one", names)
+    got, want = fl.contraction_groups(tables), fl.contraction_groups_numpy(tables)
+    assert np.array_equal(got, want)
+    assert got.max() + 1 <= len(names)
+    # and on forests without any structure
+    taxa2, trees2, w2 = random_forest(400 + seed, 50, 9, unary=0.0)
+    tables2 = fl.flatten_trees(trees2, w2, "one", taxa2)
+    assert np.array_equal(fl.contraction_groups(tables2), fl.contraction_groups_numpy(tables2))
