@@ -34,6 +34,8 @@ def load() -> C.CDLL:
         lib.scs_host_names_rank.argtypes = [C.c_char_p, lp, C.c_int64, ip, lp, lp]
         lib.scs_host_contraction_groups.restype = C.c_int
         lib.scs_host_contraction_groups.argtypes = [C.c_int32, C.c_int32, lp, ip, ip, ip]
+        lib.scs_host_components.restype = C.c_int
+        lib.scs_host_components.argtypes = [C.c_int32, C.c_int32, lp, ip, ip, ip]
         _lib = lib
     return _lib
 

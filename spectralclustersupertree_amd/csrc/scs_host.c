@@ -640,3 +640,51 @@ int scs_host_contraction_groups(int32_t n_taxa, int32_t n_trees, const int64_t *
     free(first);
     return SCS_HOST_OK;
 }
+
+/* ---------------------------------------------------------------------------
+ * Connected components of the proper cluster graph from the flattened tables
+ * (reference: scs.py:458-492, 651-652): two taxa are adjacent iff they share a root side
+ * in some tree, so the components are those of "union the leaves of every root side".
+ * Union-find (smaller index becomes the root, path halving); labels[x] = component of x,
+ * components numbered by smallest member.
+ * ------------------------------------------------------------------------- */
+static int32_t uf_find(int32_t *parent, int32_t x) {
+    while (parent[x] != x) {
+        parent[x] = parent[parent[x]];
+        x = parent[x];
+    }
+    return x;
+}
+
+int scs_host_components(int32_t n_taxa, int32_t n_trees, const int64_t *tree_off,
+                        const int32_t *leaf_taxon, const int32_t *adj_depth, int32_t *labels) {
+    if (n_taxa <= 0) return SCS_HOST_OK;
+    int32_t *parent = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_taxa);
+    if (!parent) return SCS_HOST_ENOMEM;
+    for (int32_t x = 0; x < n_taxa; ++x) parent[x] = x;
+    for (int32_t t = 0; t < n_trees; ++t) {
+        int32_t rep = -1; /* first leaf of the current root side */
+        for (int64_t p = tree_off[t]; p < tree_off[t + 1]; ++p) {
+            const int32_t x = leaf_taxon[p];
+            if (rep < 0) {
+                rep = x;
+            } else {
+                int32_t a = uf_find(parent, rep), b = uf_find(parent, x);
+                if (a != b) {
+                    if (a < b) parent[b] = a;
+                    else parent[a] = b;
+                }
+            }
+            if (adj_depth[p] == 0) rep = -1; /* a root gap (or the tree's padding slot) ends the side */
+        }
+    }
+    int32_t next = 0;
+    for (int32_t x = 0; x < n_taxa; ++x) {
+        const int32_t r = uf_find(parent, x);
+        /* roots are smallest members, and they are met in increasing order */
+        if (r == x) labels[x] = next++;
+        else labels[x] = labels[r];
+    }
+    free(parent);
+    return SCS_HOST_OK;
+}

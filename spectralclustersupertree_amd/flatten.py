@@ -219,6 +219,26 @@ def taxa_occurrences(tables: TreeTables) -> np.ndarray:
 
 
 def pcg_components(tables: TreeTables) -> np.ndarray:
+    """Connected-component label (0..k-1, by smallest member) of every taxon (reference:
+    scs.py:458-492): union-find over the root sides in ``libscs_host.so``;
+    ``pcg_components_numpy`` is the vectorised reference implementation the tests compare with."""
+    import ctypes as C
+
+    from spectralclustersupertree_amd._hostlib import load
+
+    n = tables.n_taxa
+    labels = np.zeros(max(n, 1), dtype=np.int32)
+    if n:
+        lp, ip = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+        rc = load().scs_host_components(
+            n, tables.n_trees, tables.tree_off.ctypes.data_as(lp), tables.leaf_taxon.ctypes.data_as(ip),
+            tables.adj_depth.ctypes.data_as(ip), labels.ctypes.data_as(ip))
+        if rc:
+            raise MemoryError("scs_host_components")
+    return labels[:n]
+
+
+def pcg_components_numpy(tables: TreeTables) -> np.ndarray:
     """Connected-component label (0..k-1, by smallest member) of every taxon.
 
     Edges of the proper cluster graph exist wherever the co-occurrence count is

@@ -323,3 +323,15 @@ def test_contraction_groups_c_matches_numpy(seed):
     taxa2, trees2, w2 = random_forest(400 + seed, 50, 9, unary=0.0)
     tables2 = fl.flatten_trees(trees2, w2, "one", taxa2)
     assert np.array_equal(fl.contraction_groups(tables2), fl.contraction_groups_numpy(tables2))
+    # components: the structured forest is disconnected when few cherries were picked
+    assert np.array_equal(fl.pcg_components(tables), fl.pcg_components_numpy(tables))
+    assert np.array_equal(fl.pcg_components(tables2), fl.pcg_components_numpy(tables2))
+
+
+@pytest.mark.parametrize("case", INLINE_CASES, ids=lambda c: c.name)
+def test_host_graph_helpers_on_reference_cases(case):
+    trees = [make_tree(s) for s in case.trees]
+    names = sorted(scs._all_tip_names(trees))
+    tables = fl.flatten_trees(trees, [1.0] * len(trees), "one", names)
+    assert np.array_equal(fl.pcg_components(tables), fl.pcg_components_numpy(tables))
+    assert np.array_equal(fl.contraction_groups(tables), fl.contraction_groups_numpy(tables))
