@@ -40,6 +40,8 @@ while time.time() < t_end:
     if not np.array_equal(w, w_ref):
         fails.append(f"W mismatch: {tag}: {int(np.sum(w != w_ref))} cells")
     n_cases += 1
+    if n_cases % 200 == 0:
+        print(f"... {n_cases} cases, {len(fails)} failures", flush=True)
     deg = w_ref.sum(axis=1)
     if n >= 3 and np.all(deg > 0):
         s_op = to.normalized_operator(w_ref)[0]
