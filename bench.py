@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--no-shared", action="store_true",
                     help="multi-rank runs: every rank evaluates all cells of its own rows "
                          "instead of sharing the upper-triangle tiles")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="profiling runs: skip the oracle gates (never for a reported number)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the short reference passes over the other single-GPU configs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
@@ -281,7 +283,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full):
     except (OSError, ValueError, KeyError):
         pass
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_parity:
         # parity gate at full size: rows of W against the oracle, bit for bit
         from oracle import tables_oracle as to
 

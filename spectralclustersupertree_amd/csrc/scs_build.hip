@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "scs_internal.h"
+#include "scs_cells_asm.h"
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
 
         // ---- 64 cells of this column: row nb of the (symmetric) table is contiguous:
         // one conflict-free ds_read_b64, one v_min_f64, one v_add_f64 per cell
+#ifdef SCS_CELLS_C
         const double *dv = &s_dv[nb * DV_LD];
 #pragma unroll
         for (int i0 = 0; i0 < SCS_TR; i0 += 8) {
@@ -612,6 +614,18 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
             for (int i = i0; i < i0 + 8; ++i) acc[i] += min_f64(dv[i], vn);
             __builtin_amdgcn_sched_barrier(0);  // at most eight reads in flight
         }
+#else
+        {
+            // hand-scheduled (scs_cells_asm.h): eight plain ds_read_b64 in flight, each waited
+            // for just before its use.  Left to the compiler the loop became ds_read2_b64
+            // pairs (half the LDS rate, 4-way bank conflicts on this pattern), each followed
+            // by lgkmcnt(0): one read in flight, 73 % LDS-busy, half of it conflict cycles
+            // (profiles/r02_accumulate_sq_counters.md)
+            double tmp[SCS_CELLS_DEPTH];
+            const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_dv[nb * DV_LD];
+            SCS_CELLS_ASM(acc, tmp, addr, vn);
+        }
+#endif
         stamp(6);
         // (no barrier here: the record and min-table were last read before the barrier
         // above, and the next expansion of s_dv waits behind the next step's barrier)
@@ -682,20 +696,22 @@ __global__ void k_contract(const double *__restrict__ w, int64_t ld, int old_row
                            const int32_t *__restrict__ gstart, int g_begin, int g_end, int n_groups,
                            double *__restrict__ out, int64_t ld_out) {
     const int h = blockIdx.x * blockDim.x + threadIdx.x;  // new column
-    const int g = g_begin + blockIdx.y;                    // new row (global)
-    if (h >= n_groups || g >= g_end) return;
-    double best = 0.0;
-    if (h != g) {
-        const int r0 = gstart[g], r1 = gstart[g + 1];
-        const int c0 = gstart[h], c1 = gstart[h + 1];
-        best = w[(int64_t)(r0 - old_row_begin) * ld + c0];
-        for (int r = r0; r < r1; ++r)
-            for (int c = c0; c < c1; ++c) {
-                const double v = w[(int64_t)(r - old_row_begin) * ld + c];
-                best = v > best ? v : best;
-            }
+    if (h >= n_groups) return;
+    const int c0 = gstart[h], c1 = gstart[h + 1];
+    // new rows (global), grid-stride: grid.y is capped at 65535
+    for (int g = g_begin + blockIdx.y; g < g_end; g += gridDim.y) {
+        double best = 0.0;
+        if (h != g) {
+            const int r0 = gstart[g], r1 = gstart[g + 1];
+            best = w[(int64_t)(r0 - old_row_begin) * ld + c0];
+            for (int r = r0; r < r1; ++r)
+                for (int c = c0; c < c1; ++c) {
+                    const double v = w[(int64_t)(r - old_row_begin) * ld + c];
+                    best = v > best ? v : best;
+                }
+        }
+        out[(int64_t)(g - g_begin) * ld_out + h] = best;
     }
-    out[(int64_t)(g - g_begin) * ld_out + h] = best;
 }
 
 // ---------------------------------------------------------------------------
@@ -1233,10 +1249,11 @@ extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *gro
     }
     hipMemcpyAsync(d_gs, group_start, (size_t)(n_groups + 1) * 4, hipMemcpyHostToDevice,
                    ctx->stream);
-    dim3 grid((unsigned)((n_groups + 255) / 256), (unsigned)(g_end - g_begin));
+    dim3 grid((unsigned)((n_groups + 255) / 256), (unsigned)std::min(g_end - g_begin, 65535));
     k_contract<<<grid, 256, 0, ctx->stream>>>(g->d_w, g->ld, g->row_begin, d_gs, g_begin, g_end,
                                               n_groups, ng->d_w, ng->ld);
-    e = hipStreamSynchronize(ctx->stream);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(d_gs);
     if (e != hipSuccess) {
         scs_graph_free(ctx, ng);

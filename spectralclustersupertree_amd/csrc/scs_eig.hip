@@ -1644,6 +1644,12 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     st->apply_ms_total = tot;
     st->apply_ms_min = sv.n_apply ? mn : 0.0;
     st->apply_bytes = 8.0 * sv.rows * (double)n + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;
+    if (!converged) {
+        // maps_out and stats are filled: the caller decides whether the block is usable
+        scs_set_error("scs_fiedler: residual %.3e above tol %.3e after %d iterations (V = %d, block %d)",
+                      std::max(final_res[0], final_res[1]), tol, iter, n, b);
+        return SCS_ENOCONV;
+    }
     return SCS_OK;
 }
 

@@ -281,6 +281,11 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             child_trees.append(tip_names_to_tree([names[i] for i in component]))
             continue
         sub = arrays.restrict(np.asarray(component, dtype=np.int32))
+        if sub.n_trees == 0:
+            # no source tree keeps two of these taxa: the reference's recursive call receives
+            # an empty list and raises (reference: scs.py:63-65 reached from :158)
+            msg = "There must be at least one tree to make a supertree."
+            raise ValueError(msg)
         child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, bipartition))
         covered = set(int(i) for i in sub.present_taxa())
         child_trees.extend(TreeNode(names[i]) for i in component if i not in covered)
@@ -330,6 +335,9 @@ def _construct_objects(trees, weights, pcg_weighting, contract_edges, random_sta
             child_trees.append(tip_names_to_tree(sorted(component)))
             continue
         sub_trees, sub_weights = _induce(component, trees, weights)
+        if len(sub_trees) == 0:  # reference: scs.py:63-65 reached from :158
+            msg = "There must be at least one tree to make a supertree."
+            raise ValueError(msg)
         child_trees.append(
             _construct_objects(sub_trees, sub_weights, pcg_weighting, contract_edges, random_state,
                                bipartition)
