@@ -22,7 +22,6 @@
 #include <algorithm>
 
 #include "scs_internal.h"
-#include "scs_cells_asm.h"
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
@@ -36,10 +35,7 @@ constexpr int REC_CNT = 1152;     // int32     rows present in the tree
 constexpr int REC_M = 1156;       // int32     gaps of the tree (n_t - 1)
 constexpr int REC_STOFF = 1160;   // int64     offset of the tree's sparse table in the batch
 constexpr int REC_VWOFF = 1168;   // int64     offset of the tree's gaps in the batch vw array
-constexpr int REC_RANK63 = 1184;  // u8[64]    row -> rank with absent rows mapped to 63 (monotone kernel)
-constexpr int REC_SPV = 1248;     // f64[64*7] min-table over the gap values, [rank][level] (monotone kernel)
-constexpr int REC_PIV = 1248 + 64 * 7 * 8;  // int32[8] sorted positions 7, 15, ..., 63 (search pivots)
-constexpr int REC_BYTES = REC_PIV + 32;     // 4864
+constexpr int REC_BYTES = 1184;
 constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------
@@ -111,6 +107,26 @@ __global__ void k_positions(const int64_t *__restrict__ tree_off,
     }
 }
 
+// monotone builds: the range-minimum table is over the gap VALUES themselves (the value of
+// the shallowest LCA of a range is the smallest value in it), level 0 = value * w per gap
+__global__ void k_positions_values(const int64_t *__restrict__ tree_off,
+                                   const int32_t *__restrict__ leaf_taxon,
+                                   const int32_t *__restrict__ adj_depth,
+                                   const double *__restrict__ adj_val,
+                                   const double *__restrict__ tree_w, int t0,
+                                   int32_t *__restrict__ pos, int64_t npad,
+                                   const int64_t *__restrict__ st_off, double *__restrict__ stv) {
+    const int tl = blockIdx.y;
+    const int t = t0 + tl;
+    const int64_t off = tree_off[t];
+    const int n = (int)(tree_off[t + 1] - off);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    pos[(int64_t)tl * npad + leaf_taxon[off + p]] = p;
+    if (p < n - 1)  // one rounded multiply, as the reference's `length * tree_weight`
+        stv[st_off[tl] + p] = adj_depth[off + p] ? adj_val[off + p] * tree_w[t] : 0.0;
+}
+
 // level k >= 1 of every tree's sparse table; grid as k_positions
 template <typename K>
 __global__ void k_sparse_level(const int64_t *__restrict__ tree_off, int t0, int k,
@@ -178,25 +194,10 @@ __global__ __launch_bounds__(64) void k_block_records(
     }
     unsigned char *rec = rec_all + ((int64_t)blk * n_batch + tl) * REC_BYTES;
     ((int *)(rec + REC_SPOS))[lane] = spos;
-    if ((lane & 7) == 7) ((int *)(rec + REC_PIV))[lane >> 3] = spos;
     ((u32 *)(rec + REC_GDEPTH))[lane] = gdepth;
     ((double *)(rec + REC_GVW))[lane] = gvw;
     rec[REC_SORIG + lane] = (unsigned char)orig;
     rec[REC_RANK + orig] = present ? (unsigned char)lane : (unsigned char)255;
-    rec[REC_RANK63 + orig] = present ? (unsigned char)lane : (unsigned char)63;
-    {
-        // min-table over the gap values (0 beyond the last real gap), stored in the LDS
-        // layout of k_accumulate_mono so that staging it is a plain copy
-        double *spv = (double *)(rec + REC_SPV);
-        double key = gvw;
-        spv[lane * 7] = key;
-        for (int j = 1; j < 6; ++j) {
-            const double other = __shfl_down(key, 1 << (j - 1), 64);
-            if (lane + (1 << (j - 1)) < 64) key = other < key ? other : key;
-            spv[lane * 7 + j] = key;
-        }
-        spv[lane * 7 + 6] = 0.0;
-    }
     if (lane == 0) {
         *(int *)(rec + REC_CNT) = cnt;
         *(int *)(rec + REC_M) = m;
@@ -405,258 +406,7 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
     }
 }
 
-// ---------------------------------------------------------------------------
-// tile accumulate, monotone fast path
-// ---------------------------------------------------------------------------
-// When the weighting value never decreases from an ancestor to a descendant
-// (`one`, `depth`, and `branch` with non-negative lengths; the host sets
-// SCS_BUILD_MONOTONE), value(LCA) is itself a monotone image of the LCA depth:
-// the value of the shallower of two nodes on one root path is the smaller one.
-// The row-row table then only needs values, range minima can be taken over
-// values, and a cell is   acc += min(Dv[i][nb(c)], vn(c))   -- one LDS gather,
-// one v_min_f64, one v_add_f64.  Same addends in the same (tree) order as the
-// general kernel, hence the same bits.
-// The kernel is bound by dependent memory latency, not arithmetic: the per-tree record
-// and the column's DFS position are therefore requested one tree ahead (registers) so
-// that only the range-minimum chain of the column step is exposed.
-constexpr int DV_LD = 65;  // leading dimension of the row-row table (doubles): with 65 a
-                           // lane's ds_read_b64 of row nb hits bank pair (nb + i) mod 32
-
-template <bool SYM, bool STAMPED, typename K>
-__global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(acc_params p) {
-    // block record of the current / next tree, staged by LDS-DMA (global_load_lds_dwordx4:
-    // no registers held across the step); same byte layout as in global memory
-    __shared__ __attribute__((aligned(16))) unsigned char s_rec[2][REC_BYTES];
-    __shared__ double s_dv[64 * DV_LD];
-
-    // phase timers of the STAMPED diagnostic build (SCS_ACC_STAMP=1; never timed)
-    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int k) {
-        if (STAMPED) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long tnow;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
-            ts[k] += tnow - tprev;
-            tprev = tnow;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int2 tile = p.tiles[blockIdx.x];
-    const int blk = tile.x;
-    const int row0 = p.row_begin + blk * SCS_TR;
-    const int col = tile.y * SCS_TCW + tid;
-    const int nt = p.n_batch;
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    // a column that is one of the tile's own rows (tiles on the diagonal): its cells are the
-    // row-row table itself, no search or range-minimum needed; W[c][c] stays 0
-    const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
-
-    double acc[SCS_TR];
-#pragma unroll
-    for (int i = 0; i < SCS_TR; ++i) {
-        double v = 0.0;
-        if (p.load_w && p.tile_out)
-            v = p.tile_out[((int64_t)(p.slot_base + blockIdx.x) * SCS_TR + i) * SCS_TCW + tid];
-        else if (p.load_w && col < p.n && row0 + i < p.row_end)
-            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
-        acc[i] = v;
-    }
-
-    const unsigned char *rec_base = p.rec + (int64_t)blk * nt * REC_BYTES;
-    int cpos_next = -1;
-    // request tree tl's record into LDS buffer `b`: wave w copies bytes [1024 w, 1024 w + 1024),
-    // wave 0 also the tail; one 16-byte piece per lane, landing at base + 16 * lane
-    auto issue_record = [&](int tl, int b) {
-        const unsigned char *rec = rec_base + (int64_t)tl * REC_BYTES;
-        typedef __attribute__((address_space(3))) void *lds_ptr;
-        __builtin_amdgcn_global_load_lds((const void *)(rec + tid * 16),
-                                         (lds_ptr)(s_rec[b] + wave * 1024), 16, 0, 0);
-        if (wave == 0 && lane < (REC_BYTES - 4096) / 16)
-            __builtin_amdgcn_global_load_lds((const void *)(rec + 4096 + lane * 16),
-                                             (lds_ptr)(s_rec[b] + 4096), 16, 0, 0);
-        cpos_next = p.pos[(int64_t)tl * p.npad + col];
-    };
-    issue_record(0, 0);
-
-    for (int tl = 0; tl < nt; ++tl) {
-        const unsigned char *rb = s_rec[tl & 1];
-        const int *s_spos = (const int *)(rb + REC_SPOS);
-        const unsigned char *s_sorig = rb + REC_SORIG;
-        const double *s_sp = (const double *)(rb + REC_SPV);
-        const int *s_piv = (const int *)(rb + REC_PIV);
-        // the DMA of this tree's record was issued a whole step ago
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int cpos = cpos_next;
-        stamp(0);
-        __syncthreads();
-        stamp(1);
-
-        // ---- column step, part 1: nearest tile rows in DFS order.  Branch-free, and the
-        // four sparse-table loads of the two range-minimum queries are only ISSUED here
-        // (raw values, combined in part 2) so that they fly while the table is expanded
-        const int cnt = *(const int *)(rb + REC_CNT);
-        const bool present = cpos >= 0 && cnt > 0;
-        int lo;
-        {
-            // count of tile rows before the column: eight pivots (every eighth sorted
-            // position, two independent 16-byte reads) pick the octet, three dependent
-            // reads finish the count
-            const int4 pa = *(const int4 *)&s_piv[0];
-            const int4 pb = *(const int4 *)&s_piv[4];
-            lo = ((pa.x < cpos) + (pa.y < cpos) + (pa.z < cpos) + (pa.w < cpos) + (pb.x < cpos) +
-                  (pb.y < cpos) + (pb.z < cpos) + (pb.w < cpos)) * 8;
-            const int base = min(lo, 56);  // lo == 64: all rows precede; reads stay in range
-            int l2 = base;
-#pragma unroll
-            for (int s = 4; s > 0; s >>= 1)
-                if (s_spos[l2 + s - 1] < cpos) l2 += s;
-            lo = lo == 64 ? 64 : l2;
-        }
-        const bool hasl = present && self < 0 && lo > 0;
-        const bool hasr = present && self < 0 && lo < cnt;
-        K xl, yl, xr, yr;
-        {
-            const int ql = s_spos[max(lo - 1, 0)];
-            const int qr = s_spos[min(lo, 63)];
-            const int m = *(const int *)(rb + REC_M);
-            const K *st = (const K *)p.st + *(const long long *)(rb + REC_STOFF);
-            // left query: gaps [ql, cpos); right query: gaps [cpos, qr); a side that does
-            // not exist reads entry 0 of the tree's level 0 (always there) and is ignored
-            int ol[2], orr[2];
-            rmq_offsets(m, hasl ? ql : 0, hasl ? cpos : 1, ol);
-            rmq_offsets(m, hasr ? cpos : 0, hasr ? qr : 1, orr);
-            xl = st[ol[0]];
-            yl = st[ol[1]];
-            xr = st[orr[0]];
-            yr = st[orr[1]];
-        }
-        stamp(2);
-        // ---- expand the row-row value table in rank space: entry (a, b), a < b, is the running
-        // minimum of the gap values g[a .. b-1] (0 as soon as one of the rows is absent: the
-        // gaps past the last present row are 0), so lane a carries `cur` along b and every step
-        // is one v_min_f64 and two stores (the entry and its mirror image, at the rows' original
-        // indices).  Wave w walks b in [16 w, 16 w + 16); lanes that start inside an earlier
-        // segment take their running minimum at the segment start from the record's min-table.
-        // A lane's first active step (b == a) stores cur = +inf on the diagonal --
-        // min(inf, vn) = vn: the cell (nb, c) itself -- and picks up g[a].
-        {
-            const double g_own = ((const double *)(rb + REC_GVW))[lane];
-            const int so_own = s_sorig[lane];
-            const int b0 = wave * 16;
-            double cur = inf;
-            // (opaque copy of the lane id: keeps the table offsets below from being hoisted
-            // out of the tree loop into registers the accumulators need)
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            if (ln < b0) {
-                const int len = b0 - ln;
-                const int k = 31 - __clz(len);
-                cur = min_f64(s_sp[ln * 7 + k], s_sp[(b0 - (1 << k)) * 7 + k]);
-            }
-            double *row_a = &s_dv[so_own * DV_LD];  // row of this lane's own row
-            double *col_a = &s_dv[so_own];          // its column
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int b = b0 + j;
-                const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_own), b);
-                const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_own), b);
-                const int so_b = __builtin_amdgcn_readlane(so_own, b);
-                const double gb = __hiloint2double(hi32, lo32);
-                if (lane <= b) {
-                    row_a[so_b] = cur;
-                    col_a[so_b * DV_LD] = cur;
-                    cur = min_f64(cur, gb);
-                }
-            }
-        }
-        stamp(3);
-        // ---- column step, part 2: combine the loads; the neighbour with the deeper LCA
-        // and that LCA's value
-        int nb = 0;
-        double vn = 0.0;
-        if (hasl || hasr) {
-            const int pos_bits = p.pos_bits;
-            const K gl = hasl ? (xl < yl ? xl : yl) : 0;
-            const K gr = hasr ? (xr < yr ? xr : yr) : 0;
-            const bool left = hasl && (!hasr || key_depth<K>(gl, pos_bits) >= key_depth<K>(gr, pos_bits));
-            const K g = left ? gl : gr;
-            nb = s_sorig[left ? lo - 1 : lo];
-            if (key_depth<K>(g, pos_bits))
-                vn = p.vw[*(const long long *)(rb + REC_VWOFF) + key_pos<K>(g, pos_bits)];
-        } else if (present && self >= 0) {
-            // cell (i, c) = table entry (self, i); the diagonal entry is +inf and makes
-            // acc[self] meaningless -- it is reset after the last tree
-            nb = self;
-            vn = inf;
-        }
-        if (STAMPED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(4);
-        __syncthreads();
-        stamp(5);
-        // request the next tree's record now: the cell loop below only reads s_dv, so no
-        // wait on this DMA is needed until the top of the next step (the compiler orders
-        // every read of s_rec behind pending DMA into s_rec); the other buffer was last
-        // read before the barrier above
-        if (tl + 1 < nt) issue_record(tl + 1, (tl + 1) & 1);
-
-        // ---- 64 cells of this column: row nb of the (symmetric) table is contiguous:
-        // one conflict-free ds_read_b64, one v_min_f64, one v_add_f64 per cell
-#ifdef SCS_CELLS_C
-        const double *dv = &s_dv[nb * DV_LD];
-#pragma unroll
-        for (int i0 = 0; i0 < SCS_TR; i0 += 8) {
-#pragma unroll
-            for (int i = i0; i < i0 + 8; ++i) acc[i] += min_f64(dv[i], vn);
-            __builtin_amdgcn_sched_barrier(0);  // at most eight reads in flight
-        }
-#else
-        {
-            // hand-scheduled (scs_cells_asm.h): eight plain ds_read_b64 in flight, each waited
-            // for just before its use.  Left to the compiler the loop became ds_read2_b64
-            // pairs (half the LDS rate, 4-way bank conflicts on this pattern), each followed
-            // by lgkmcnt(0): one read in flight, 73 % LDS-busy, half of it conflict cycles
-            // (profiles/r02_accumulate_sq_counters.md)
-            double tmp[SCS_CELLS_DEPTH];
-            const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_dv[nb * DV_LD];
-            SCS_CELLS_ASM(acc, tmp, addr, vn);
-        }
-#endif
-        stamp(6);
-        // (no barrier here: the record and min-table were last read before the barrier
-        // above, and the next expansion of s_dv waits behind the next step's barrier)
-    }
-
-    if (STAMPED && lane == 0 && p.stamps) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
-        atomicAdd(&p.stamps[7], 1ull);
-    }
-    if (self >= 0) {
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i)
-            if (i == self) acc[i] = 0.0;
-    }
-    if (p.tile_out) {
-        double *tp = p.tile_out + (int64_t)(p.slot_base + blockIdx.x) * SCS_TR * SCS_TCW + tid;
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) tp[i * SCS_TCW] = acc[i];
-    } else if (col < p.n) {
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) {
-            const int r = row0 + i;
-            if (r < p.row_end) {
-                p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
-                if (SYM && ((r / SCS_TCW) + 1) * SCS_TCW <= (col / SCS_TR) * SCS_TR)
-                    p.w[(int64_t)col * p.ld + r] = acc[i];
-            }
-        }
-    }
-}
+#include "scs_mono.h"  // monotone fast path: k_block_tables, k_accumulate_mono
 
 // ---------------------------------------------------------------------------
 // shared multi-rank build: gathered upper-triangle tiles -> this rank's rows of W
@@ -904,19 +654,13 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         }
     } gd{ctx, g};
 
-    // ---- tile lists.  SCS_DIAG_GENERAL=1 (diagnostic) sends the tiles whose column range
-    // overlaps their row range to the general kernel even in a monotone build
-    static const bool diag_general = getenv("SCS_DIAG_GENERAL") && atoi(getenv("SCS_DIAG_GENERAL"));
-    std::vector<int2> tiles, tiles_diag;
+    // ---- tile list
+    std::vector<int2> tiles;
     tiles.reserve((size_t)n_blocks * n_cgroups);
     for (int b = 0; b < n_blocks; ++b)
         for (int c = 0; c < n_cgroups; ++c) {
             if (upper && (int64_t)(c + 1) * cols_per_tile <= (int64_t)b * SCS_TR) continue;
-            const int64_t r_lo = (int64_t)b_row_begin + (int64_t)b * SCS_TR, r_hi = r_lo + SCS_TR;
-            const int64_t c_lo = (int64_t)c * cols_per_tile, c_hi = c_lo + cols_per_tile;
-            const bool overlap = c_lo < r_hi && r_lo < c_hi;
-            if (monotone && diag_general && overlap) tiles_diag.push_back(make_int2(b, c));
-            else tiles.push_back(make_int2(b, c));
+            tiles.push_back(make_int2(b, c));
         }
     // XCD-aware order: workgroups go to the eight XCDs round-robin by index and all tiles
     // walk the trees at about the same pace.  Handing XCD x the row blocks b = x (mod 8), one
@@ -942,7 +686,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         };
         if (per_xcd && !shared) {
             xcd_reorder(tiles);
-        } else if (per_xcd && tiles_diag.empty()) {
+        } else if (per_xcd) {
             std::vector<std::vector<int2>> share(world);
             for (size_t i = 0; i < tiles.size(); ++i) share[i % world].push_back(tiles[i]);
             for (auto &v : share) xcd_reorder(v);
@@ -950,8 +694,6 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 for (size_t k = 0; k < share[r].size(); ++k) tiles[(size_t)world * k + r] = share[r][k];
         }
     }
-    size_t n_main = tiles.size();
-    tiles.insert(tiles.end(), tiles_diag.begin(), tiles_diag.end());
     // shared: tile i of the job-wide list belongs to rank i % world and lands in slot
     // i / world of that rank's packed buffer
     std::vector<int2> all_tiles;
@@ -959,12 +701,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     size_t chunk_doubles = 0;
     if (shared) {
         all_tiles.swap(tiles);
-        size_t my_main = 0;
-        for (size_t i = rank; i < all_tiles.size(); i += world) {
-            tiles.push_back(all_tiles[i]);
-            if (i < n_main) ++my_main;
-        }
-        n_main = my_main;
+        for (size_t i = rank; i < all_tiles.size(); i += world) tiles.push_back(all_tiles[i]);
         const size_t slots = (all_tiles.size() + world - 1) / world;
         chunk_doubles = slots * SCS_TR * SCS_TCW;
         SCS_TRY(d_all_tiles.alloc(all_tiles.size() * sizeof(int2)));
@@ -1007,8 +744,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
             const int64_t m = nt - 1;
-            size_t need = (size_t)table_entries(m) * key_bytes + (size_t)nt * 8 +
-                          (size_t)npad * 4 + (size_t)n_blocks * REC_BYTES;
+            size_t need = monotone ? (size_t)table_entries(m) * 8 + (size_t)npad * 4 +
+                                         (size_t)n_blocks * R3_BYTES
+                                   : (size_t)table_entries(m) * key_bytes + (size_t)nt * 8 +
+                                         (size_t)npad * 4 + (size_t)n_blocks * REC_BYTES;
             if ((used + need > ctx->ws_limit || t - batch_start.back() >= max_batch_trees) &&
                 t > batch_start.back()) {
                 batch_start.push_back(t);
@@ -1049,10 +788,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             max_n = std::max(max_n, nt);
         }
         const size_t need_pos = (size_t)nb * npad * 4;
-        const size_t need_vw = (size_t)leaves * 8;
-        const size_t need_st = (size_t)st_off[nb] * key_bytes + 64;  // +64: a tree without gaps may be probed at entry 0
+        const size_t need_vw = monotone ? 0 : (size_t)leaves * 8;
+        // +64: a tree without gaps may be probed at entry 0
+        const size_t need_st = (size_t)st_off[nb] * (monotone ? 8 : key_bytes) + 64;
         const size_t need_stoff = (size_t)(nb + 1) * 8;
-        const size_t need_rec = (size_t)n_blocks * nb * REC_BYTES;
+        const size_t need_rec = (size_t)n_blocks * nb * (monotone ? R3_BYTES : REC_BYTES);
         SCS_TRY(d_pos.alloc(need_pos));
         SCS_TRY(d_vw.alloc(need_vw));
         SCS_TRY(d_st.alloc(need_st));
@@ -1077,8 +817,23 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const K *)d_st.p, pos_bits,     \
             b_row_begin, b_row_end, (unsigned char *)d_rec.p);                                   \
     } while (0)
-        if (key64) SCS_PREP(u64);
-        else SCS_PREP(u32);
+        if (monotone) {
+            k_positions_values<<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon,
+                                                      tb->d_adj_depth, tb->d_adj_val, tb->d_tree_w,
+                                                      t0, (int32_t *)d_pos.p, npad,
+                                                      (const int64_t *)d_stoff.p, (double *)d_st.p);
+            for (int k = 1; k < max_levels; ++k)
+                k_sparse_level<double><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
+                                                              (const int64_t *)d_stoff.p,
+                                                              (double *)d_st.p);
+            k_block_records_mono<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
+                tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
+                (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
+        } else if (key64) {
+            SCS_PREP(u64);
+        } else {
+            SCS_PREP(u32);
+        }
 #undef SCS_PREP
         SCS_HIP_CHECK(hipEventRecord(ev_prep.b, s));
 
@@ -1107,49 +862,42 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
         const unsigned nt = (unsigned)tiles.size();
         if (monotone) {
-            const unsigned n_fast = (unsigned)n_main, n_diag = (unsigned)(tiles.size() - n_main);
-            if (n_fast) {
-                static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
-                if (stamp) {
-                    dev_buf d_st8;
-                    SCS_TRY(d_st8.alloc(64));
-                    SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
-                    ap.stamps = (unsigned long long *)d_st8.p;
-                    if (key64) {
-                        if (sym) k_accumulate_mono<true, true, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                        else k_accumulate_mono<false, true, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                    } else {
-                        if (sym) k_accumulate_mono<true, true, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                        else k_accumulate_mono<false, true, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                    }
-                    unsigned long long h[8];
-                    SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
-                    SCS_HIP_CHECK(hipStreamSynchronize(s));
-                    const char *nm[7] = {"record->LDS", "barrier1", "bsearch+rmq issue", "expand", "wait rmq+vw", "barrier2", "cells"};
-                    double tot = 0;
-                    for (int i = 0; i < 7; ++i) tot += (double)h[i];
-                    for (int i = 0; i < 7; ++i)
-                        fprintf(stderr, "[stamp] %-18s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i], 100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
-                    ap.stamps = nullptr;
-                } else if (key64) {
-                    if (sym) k_accumulate_mono<true, false, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                    else k_accumulate_mono<false, false, u64><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                } else {
-                    if (sym) k_accumulate_mono<true, false, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                    else k_accumulate_mono<false, false, u32><<<n_fast, SCS_TCW, 0, s>>>(ap);
-                }
-            }
-            if (n_diag) {
-                acc_params ad = ap;
-                ad.tiles = (const int2 *)d_tiles.p + n_main;
-                ad.slot_base = (int)n_main;
-                if (key64) {
-                    if (sym) k_accumulate<true, u64><<<n_diag, SCS_TCW, 0, s>>>(ad);
-                    else k_accumulate<false, u64><<<n_diag, SCS_TCW, 0, s>>>(ad);
-                } else {
-                    if (sym) k_accumulate<true, u32><<<n_diag, SCS_TCW, 0, s>>>(ad);
-                    else k_accumulate<false, u32><<<n_diag, SCS_TCW, 0, s>>>(ad);
-                }
+            mono_params mp;
+            mp.tiles = (const int2 *)d_tiles.p;
+            mp.rec = (const unsigned char *)d_rec.p;
+            mp.pos = (const int32_t *)d_pos.p;
+            mp.npad = npad;
+            mp.stv = (const double *)d_st.p;
+            mp.n_batch = nb;
+            mp.w = g->d_w;
+            mp.ld = g->ld;
+            mp.n = n;
+            mp.row_begin = b_row_begin;
+            mp.row_end = b_row_end;
+            mp.load_w = bi > 0;
+            mp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
+            mp.stamps = nullptr;
+            static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
+            if (nt && stamp) {
+                dev_buf d_st8;
+                SCS_TRY(d_st8.alloc(64));
+                SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
+                mp.stamps = (unsigned long long *)d_st8.p;
+                if (sym) k_accumulate_mono<true, true><<<nt, SCS_TCW, 0, s>>>(mp);
+                else k_accumulate_mono<false, true><<<nt, SCS_TCW, 0, s>>>(mp);
+                unsigned long long h[8];
+                SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
+                SCS_HIP_CHECK(hipStreamSynchronize(s));
+                const char *nm[7] = {"wait loads+record", "barrier A", "combine", "search + issue",
+                                     "expand", "barrier B", "cells"};
+                double tot = 0;
+                for (int i = 0; i < 7; ++i) tot += (double)h[i];
+                for (int i = 0; i < 7; ++i)
+                    fprintf(stderr, "[stamp] %-24s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i],
+                            100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
+            } else if (nt) {
+                if (sym) k_accumulate_mono<true, false><<<nt, SCS_TCW, 0, s>>>(mp);
+                else k_accumulate_mono<false, false><<<nt, SCS_TCW, 0, s>>>(mp);
             }
         } else {
             if (!nt) {
