@@ -32,7 +32,7 @@ extern "C" {
 #define SCS_EHIP (-2)     /* a HIP runtime call failed                          */
 #define SCS_ENOMEM (-3)   /* device or host allocation failed                   */
 #define SCS_ECOMM (-4)    /* RCCL / communicator failure                        */
-#define SCS_ENOCONV (-5)  /* eigen-solver hit max_iter before reaching tol      */
+#define SCS_ENOCONV (-5)  /* scs_fiedler stopped above tol: maps_out and stats filled   */
 #define SCS_EUNSUP (-6)   /* valid request the library does not support (yet)   */
 
 #define SCS_UNIQUE_ID_BYTES 128
@@ -193,7 +193,10 @@ int scs_graph_free(scs_ctx *ctx, scs_graph *graph);
  *   max_iter LOBPCG iteration cap
  *   block    LOBPCG block width (<= 16); 0 picks the default
  *   maps_out fp64 [V*2] row-major, caller-owned; every rank receives all V rows
- * Collective over the context's communicator when world > 1. */
+ * Collective over the context's communicator when world > 1.
+ * Returns SCS_ENOCONV when the wanted pair(s) stopped above tol (iteration cap, or the
+ * residual stopped improving): maps_out and stats then hold the block that was reached
+ * and the caller decides (the host retries wider, then warns or raises). */
 int scs_fiedler(scs_ctx *ctx, scs_graph *graph, const double *x_init, double tol,
                 int32_t max_iter, int32_t block, double *maps_out, scs_stats *stats);
 

@@ -28,6 +28,18 @@ class ScsError(RuntimeError):
         self.code = code
 
 
+ENOCONV = -5  # SCS_ENOCONV: scs_fiedler stopped above tol (maps and stats are still filled)
+
+
+class ConvergenceError(ScsError):
+    """scs_fiedler returned SCS_ENOCONV; ``maps`` and ``stats`` hold what it reached."""
+
+    def __init__(self, message: str, maps, stats: dict) -> None:
+        super().__init__(ENOCONV, message)
+        self.maps = maps
+        self.stats = stats
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("n_vertices", C.c_int32),

@@ -196,7 +196,11 @@ class DeviceGraph:
 
     def fiedler(self, x_init: np.ndarray | None = None, tol: float = DEFAULT_TOL,
                 max_iter: int = DEFAULT_MAX_ITER, block: int = 0):
-        """V x 2 spectral embedding + solver report (reference: scs.py:252)."""
+        """V x 2 spectral embedding + solver report (reference: scs.py:252).
+
+        Raises ``_native.ConvergenceError`` (carrying the embedding and the report it
+        reached) when the residual target was not met.
+        """
         n = self.shape[0]
         maps = np.empty((n, 2))
         stats = nv.Stats()
@@ -207,6 +211,10 @@ class DeviceGraph:
                 msg = f"x_init must have shape ({n},)"
                 raise ValueError(msg)
             x0 = nv.dptr(x_init)
-        nv.check(self.dev._lib.scs_fiedler(self.dev._ctx, self._h, x0, tol, max_iter, block,
-                                           nv.dptr(maps), C.byref(stats)))
+        rc = self.dev._lib.scs_fiedler(self.dev._ctx, self._h, x0, tol, max_iter, block,
+                                       nv.dptr(maps), C.byref(stats))
+        if rc == nv.ENOCONV:
+            msg = self.dev._lib.scs_last_error()
+            raise nv.ConvergenceError(msg.decode() if msg else "not converged", maps, stats.as_dict())
+        nv.check(rc)
         return maps, stats.as_dict()

@@ -86,6 +86,40 @@ def relabel_for_contraction(tables: fl.TreeTables, groups: np.ndarray):
     return relabelled, order.astype(np.int32), group_start
 
 
+# A Ritz vector this far from an eigenvector is still good enough to cluster (the k-means
+# split moves only when entries move by far more); above it the node is refused, as the
+# reference's ARPACK call would raise ArpackNoConvergence rather than return a guess.
+ACCEPT_RESIDUAL = 1e-8
+
+
+def _fiedler_checked(graph, v0, tol, max_iter, block):
+    """``graph.fiedler`` with the convergence contract of the recursion: an unconverged block
+    is retried once with the widest block and four times the iterations; a residual that is
+    then still above ``tol`` but below ACCEPT_RESIDUAL is used with a warning, anything
+    worse raises (reference behaviour: scipy's eigsh raises, scs.py:252 propagates)."""
+    import warnings
+
+    from spectralclustersupertree_amd._native import ConvergenceError
+
+    try:
+        return graph.fiedler(v0, tol=tol, max_iter=max_iter, block=block)
+    except ConvergenceError as first:
+        try:
+            return graph.fiedler(v0, tol=tol, max_iter=4 * max_iter, block=16)
+        except ConvergenceError as second:
+            best = min((first, second), key=lambda e: max(e.stats["resid"]))
+            resid = max(best.stats["resid"])
+            if not resid <= ACCEPT_RESIDUAL:
+                msg = (f"Fiedler solve did not converge: residual {resid:.3e} "
+                       f"(V = {best.stats['n_vertices']}, lambda2 {best.stats['lambda'][1]:.12g}, "
+                       f"next {best.stats['lambda_next']:.12g})")
+                raise RuntimeError(msg) from second
+            warnings.warn(
+                f"Fiedler solve stopped at residual {resid:.3e} (target {tol:.1e}); "
+                "clustering the block it reached", RuntimeWarning, stacklevel=3)
+            return best.maps, best.stats
+
+
 def spectral_bipartition_device(
     tables: fl.TreeTables,
     random_state: np.random.RandomState,
@@ -127,7 +161,7 @@ def spectral_bipartition_device(
             graph = graph.contract(group_start)
         # the reference's ARPACK start vector is the first draw from the stream
         v0 = random_state.uniform(-1, 1, n_groups)
-        maps, stats = graph.fiedler(v0, tol=tol, max_iter=max_iter, block=block)
+        maps, stats = _fiedler_checked(graph, v0, tol, max_iter, block)
         if report is not None:
             report.update(stats)
             report["build"] = graph.build_stats

@@ -13,3 +13,29 @@ sys.setrecursionlimit(10000)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes on the GPU box (configs[4], 80 GB of W); "
+                                       "deselect with -m 'gpu and not slow'")
+
+
+def _gpu_available() -> bool:
+    try:
+        from spectralclustersupertree_amd import _native
+
+        return _native.load_library().scs_device_count() > 0
+    except (ImportError, OSError, AttributeError):
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` on a box without a device (or without the built library) skips instead of
+    erroring; the product path itself still fails loudly (tests/test_boundary_cpu.py)."""
+    import pytest
+
+    if not any("gpu" in item.keywords for item in items):
+        return
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device / libscs_hip.so not built")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)

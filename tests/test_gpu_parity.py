@@ -230,6 +230,7 @@ def _fiedler_case(dev, tables, block=0):
     info = dict(stats, err_maps=err_maps, err_unit=err_unit, err_col0=err_col0, true_res=true_res)
     print("FIEDLER", tables.n_taxa, tables.n_trees, info)
     assert err_maps <= FIEDLER_TOL, info
+    assert err_unit <= FIEDLER_TOL, info  # the unit-norm eigenvector ARPACK returns: the stricter scale
     assert err_col0 <= FIEDLER_TOL, info
     assert true_res <= 1e-11, info
     return maps, stats, w_ref
