@@ -315,6 +315,125 @@ def test_labels_match_spectral_clustering(dev):
         assert np.array_equal(got, want), f"{int(np.sum(got != want))} labels differ"
 
 
+def test_two_vertices_after_contraction(dev):
+    # V == 2 after contraction (SURVEY.md 8a edge cases): scipy's eigsh falls back to a dense
+    # eigh with a RuntimeWarning and the two vertices end up in different parts
+    import warnings
+
+    from spectralclustersupertree_amd import construct_supertree
+    from spectralclustersupertree_amd.scs import spectral_bipartition_device
+
+    trees = [make_tree(s) for s in ["(((a,b),(c,d)));", "((a,b),(c,d));"]]
+    names = sorted(so._all_tips(trees))
+    tables = fl.flatten_trees(trees, [1.0, 1.0], "branch", names)
+    assert int(fl.pcg_components(tables).max()) == 0
+    groups = fl.contraction_groups(tables)
+    assert int(groups.max()) + 1 == 2
+    report = {}
+    members, labels = spectral_bipartition_device(tables, np.random.RandomState(3), contract_edges=True,
+                                                  device=dev, report=report)
+    assert sorted(sorted(int(i) for i in mm) for mm in members) == [[0, 1], [2, 3]]
+    assert labels[0] != labels[1]
+    assert report["n_vertices"] == 2 and report["block"] == 0
+    # the embedding itself against scikit-learn on the contracted 2 x 2 matrix
+    work, perm, group_start = relabel_for_contraction(tables, groups)
+    dtab = dev.upload(work)
+    g = dtab.build().contract(group_start)
+    w2 = g.download()
+    maps, _ = g.fiedler(None)
+    g.free()
+    dtab.free()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = to.sign_flip_columns(so.spectral_maps(w2, np.random.RandomState(0)))
+    assert np.max(np.abs(maps - ref)) <= FIEDLER_TOL, (maps, ref)
+    for seed in range(3):
+        got = construct_supertree(trees, pcg_weighting="branch", random_state=np.random.RandomState(seed))
+        assert got.sorted().same_shape(make_tree("((a,b),(c,d));").sorted())
+
+
+def test_two_squares_repeated_eigenvalue_partition():
+    # lambda2 is repeated for this input (reference: tests/test_spectral_cluster_supertree.py:80-106):
+    # the Fiedler vector is not unique, only the partition is -- every seed must give the
+    # reference's topology and the solver must report convergence
+    from spectralclustersupertree_amd import construct_supertree
+
+    case = next(c for c in INLINE_CASES if c.name == "two_squares")
+    trees = [make_tree(s) for s in case.trees]
+    expected = make_tree(case.expected)
+    for seed in range(8):
+        got = construct_supertree(trees, weights=case.weights, pcg_weighting=case.pcg_weighting,
+                                  contract_edges=case.contract_edges,
+                                  random_state=np.random.RandomState(seed))
+        assert got.sorted().same_shape(expected.sorted()), seed
+
+
+def test_unconverged_solve_is_reported_not_clustered(dev):
+    # scs_fiedler stops above tol -> SCS_ENOCONV with the block it reached; the recursion's
+    # wrapper retries wider, then refuses a residual that is still far off
+    import warnings
+
+    from spectralclustersupertree_amd._native import ConvergenceError
+    from spectralclustersupertree_amd.scs import _fiedler_checked, spectral_bipartition_device
+
+    tables = synthetic.make_tables(12, 600, 20, "branch")
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    v0 = np.random.RandomState(0).uniform(-1, 1, 600)
+    with pytest.raises(ConvergenceError) as ei:
+        g.fiedler(v0, max_iter=2)
+    assert ei.value.code == nv.ENOCONV and ei.value.stats["converged"] == 0
+    assert ei.value.maps.shape == (600, 2) and ei.value.stats["resid"][1] > 1e-13
+    # a target below the floating-point floor: the solver stagnates around 1e-14, the wrapper
+    # retries, then accepts the block with a warning
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        maps, stats = _fiedler_checked(g, v0, 1e-30, 300, 0)
+    assert any(issubclass(w.category, RuntimeWarning) for w in caught)
+    assert stats["converged"] == 0 and max(stats["resid"]) <= 1e-11
+    maps_ok, _ = g.fiedler(v0)
+    assert np.max(np.abs(maps - maps_ok)) <= 1e-9
+    g.free()
+    dtab.free()
+    # far from converged even after the retry (1 and then 4 iterations): refused
+    with pytest.raises(RuntimeError, match="did not converge"):
+        spectral_bipartition_device(tables, np.random.RandomState(0), contract_edges=False, device=dev,
+                                    max_iter=1)
+
+
+def test_contract_more_groups_than_a_grid_dimension(dev):
+    # > 65 535 contracted rows: the row index of k_contract is a grid-stride loop (a grid.y of
+    # that size is not launchable); groups of one or two taxa, checked against numpy on samples
+    n = 70000
+    tables = synthetic.make_tables(4, n, 2, "depth", leaves_per_tree=300)
+    gs = [0]
+    rs = np.random.RandomState(1)
+    while gs[-1] < n:
+        gs.append(min(n, gs[-1] + (2 if rs.rand() < 0.05 else 1)))
+    group_start = np.asarray(gs, dtype=np.int32)
+    n_groups = len(group_start) - 1
+    assert n_groups > 65536
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    rows_old = {int(r): g.download_rows(int(r), 1)[0] for r in range(0, 8)}
+    first_pair = int(np.argmax(np.diff(group_start) == 2))
+    for r in (group_start[first_pair], group_start[first_pair] + 1, group_start[-2], n - 1):
+        rows_old[int(r)] = g.download_rows(int(r), 1)[0]
+    c = g.contract(group_start)
+    assert c.shape == (n_groups, 0, n_groups)
+    for grp in (0, first_pair, n_groups - 1, 65535, 65536, 66000):
+        got = c.download_rows(grp, 1)[0]
+        lo, hi = int(group_start[grp]), int(group_start[grp + 1])
+        if not all(r in rows_old for r in range(lo, hi)):
+            continue
+        member_rows = np.vstack([rows_old[r] for r in range(lo, hi)])
+        want = np.maximum.reduceat(member_rows.max(axis=0), group_start[:-1])
+        want[grp] = 0.0
+        assert np.array_equal(got, want), grp
+    c.free()
+    dtab.free()
+
+
 def _run_local_group(tables, splits, shared, v0):
     """Row-partitioned build + solve on ONE GPU: `world` contexts, one host thread each,
     the in-process communicator instead of RCCL.  Returns [(W rows, maps, stats, build stats)]."""

@@ -335,3 +335,29 @@ def test_host_graph_helpers_on_reference_cases(case):
     tables = fl.flatten_trees(trees, [1.0] * len(trees), "one", names)
     assert np.array_equal(fl.pcg_components(tables), fl.pcg_components_numpy(tables))
     assert np.array_equal(fl.contraction_groups(tables), fl.contraction_groups_numpy(tables))
+
+
+def test_part_without_any_tree_raises_like_the_reference():
+    """A part of more than two taxa of which no source tree keeps two: the reference's
+    recursive call receives an empty list of induced trees and raises
+    (reference: scs.py:63-65 reached from :158) -- no phantom empty leaf in the result."""
+    from spectralclustersupertree_amd.treearrays import TreeArrays
+
+    # unary roots: one root side per tree, so the top-level graph is one component
+    trees = [make_tree(s) for s in ["(((a,b),(c,p)));", "(((d,b),(c,q)));", "(((e,b),(c,r)));"]]
+    taxa = sorted({n for t in trees for n in t.get_tip_names()})
+    lone = {taxa.index(x) for x in "ade"}
+
+    def stub(tables, random_state, *, contract_edges):
+        # vertices in table order; a, d, e together, everything else on the other side
+        members = [np.array([i], dtype=np.int32) for i in range(tables.n_taxa)]
+        names = tables.taxa if tables.taxa is not None else taxa
+        labels = np.array([1 if names[i] in "ade" else 0 for i in range(tables.n_taxa)])
+        return members, labels
+
+    assert len(lone) == 3
+    arrays = TreeArrays.from_trees(trees, [1.0, 1.0, 1.0], taxa)
+    with pytest.raises(ValueError, match="at least one tree"):
+        scs._construct(arrays, "one", True, np.random.RandomState(0), stub)
+    with pytest.raises(ValueError, match="at least one tree"):
+        scs._construct_objects(trees, [1.0, 1.0, 1.0], "one", True, np.random.RandomState(0), stub)
