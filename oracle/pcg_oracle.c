@@ -128,3 +128,98 @@ void scs_oracle_pcg_rows(int32_t n_taxa, int32_t n_trees, const int64_t *tree_of
         }
     }
 }
+
+/* ---- all-core variant (bench.py's cpu_baseline, SURVEY.md 8d "all host cores") -------------
+ * Thread k owns the rows of a contiguous range of taxa and sweeps, for every tree in tree
+ * order, left and right from each of its leaves (as scs_oracle_pcg_rows does): every cell
+ * still receives the reference's addends in the reference's order, from exactly one thread. */
+#include <pthread.h>
+#include <stdlib.h>
+
+typedef struct {
+    int32_t n_taxa, t_begin, t_end, r0, r1;
+    const int64_t *tree_off;
+    const int32_t *leaf_taxon, *adj_depth;
+    const double *adj_val, *tree_w;
+    double *w;
+} mt_job;
+
+static void *mt_worker(void *arg) {
+    const mt_job *j = (const mt_job *)arg;
+    for (int32_t t = j->t_begin; t < j->t_end; ++t) {
+        const int64_t off = j->tree_off[t];
+        const int32_t n = (int32_t)(j->tree_off[t + 1] - off);
+        const int32_t *tax = j->leaf_taxon + off;
+        const int32_t *dep = j->adj_depth + off;
+        const double *val = j->adj_val + off;
+        const double wt = j->tree_w[t];
+        for (int32_t a = 0; a < n; ++a) {
+            if (tax[a] < j->r0 || tax[a] >= j->r1) continue;
+            double *o = j->w + (int64_t)tax[a] * j->n_taxa;
+            if (a + 1 < n) {
+                int32_t md = dep[a];
+                double mv = val[a];
+                for (int32_t b = a + 1; b < n; ++b) {
+                    if (b > a + 1 && dep[b - 1] < md) {
+                        md = dep[b - 1];
+                        mv = val[b - 1];
+                    }
+                    if (md == 0) break;
+                    o[tax[b]] = o[tax[b]] + mv * wt;
+                }
+            }
+            if (a > 0) {
+                int32_t md = dep[a - 1];
+                double mv = val[a - 1];
+                for (int32_t b = a - 1; b >= 0; --b) {
+                    if (b < a - 1 && dep[b] < md) {
+                        md = dep[b];
+                        mv = val[b];
+                    }
+                    if (md == 0) break;
+                    o[tax[b]] = o[tax[b]] + mv * wt;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* w zero-initialised by the caller; returns 0, or -1 when threads cannot be started */
+int scs_oracle_pcg_dense_mt(int32_t n_taxa, int32_t t_begin, int32_t t_end,
+                            const int64_t *tree_off, const int32_t *leaf_taxon,
+                            const int32_t *adj_depth, const double *adj_val,
+                            const double *tree_w, double *w, int32_t n_threads) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > n_taxa) n_threads = n_taxa;
+    mt_job *jobs = (mt_job *)malloc(sizeof(mt_job) * (size_t)n_threads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    if (!jobs || !th) {
+        free(jobs);
+        free(th);
+        return -1;
+    }
+    int started = 0, rc = 0;
+    for (int32_t k = 0; k < n_threads; ++k) {
+        mt_job j = {n_taxa, t_begin, t_end, (int32_t)((int64_t)n_taxa * k / n_threads),
+                    (int32_t)((int64_t)n_taxa * (k + 1) / n_threads), tree_off, leaf_taxon,
+                    adj_depth, adj_val, tree_w, w};
+        jobs[k] = j;
+        if (pthread_create(&th[k], 0, mt_worker, &jobs[k]) != 0) {
+            rc = -1;
+            break;
+        }
+        ++started;
+    }
+    for (int k = 0; k < started; ++k) pthread_join(th[k], 0);
+    if (rc != 0) /* finish the rows nobody took on this thread */
+        for (int32_t k = started; k < n_threads; ++k) {
+            mt_job j = {n_taxa, t_begin, t_end, (int32_t)((int64_t)n_taxa * k / n_threads),
+                        (int32_t)((int64_t)n_taxa * (k + 1) / n_threads), tree_off, leaf_taxon,
+                        adj_depth, adj_val, tree_w, w};
+            mt_worker(&j);
+        }
+    free(jobs);
+    free(th);
+    return 0;
+}

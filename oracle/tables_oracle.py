@@ -25,6 +25,8 @@ def _load():
         ip, dp, lp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)
         lib.scs_oracle_pcg_dense.restype = C.c_int64
         lib.scs_oracle_pcg_dense.argtypes = [C.c_int32, C.c_int32, C.c_int32, lp, ip, ip, dp, dp, dp]
+        lib.scs_oracle_pcg_dense_mt.restype = C.c_int
+        lib.scs_oracle_pcg_dense_mt.argtypes = [C.c_int32, C.c_int32, C.c_int32, lp, ip, ip, dp, dp, dp, C.c_int32]
         lib.scs_oracle_pcg_rows.restype = None
         lib.scs_oracle_pcg_rows.argtypes = [C.c_int32, C.c_int32, lp, ip, ip, dp, dp, C.c_int32, ip, ip, dp]
         lib.scs_oracle_contract.restype = None
@@ -47,6 +49,27 @@ def pcg_dense(tables, t_begin: int = 0, t_end: int | None = None, out: np.ndarra
         tables.tree_w.ctypes.data_as(dp), w.ctypes.data_as(dp),
     )
     return w, int(updates)
+
+
+def pcg_dense_mt(tables, threads: int, t_begin: int = 0, t_end: int | None = None,
+                 out: np.ndarray | None = None) -> np.ndarray:
+    """Dense W on `threads` host threads (rows partitioned, tree order kept per cell): the same
+    bits as ``pcg_dense``."""
+    lib = _load()
+    n = tables.n_taxa
+    if t_end is None:
+        t_end = tables.n_trees
+    w = np.zeros((n, n)) if out is None else out
+    ip, dp, lp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    rc = lib.scs_oracle_pcg_dense_mt(
+        n, t_begin, t_end, tables.tree_off.ctypes.data_as(lp), tables.leaf_taxon.ctypes.data_as(ip),
+        tables.adj_depth.ctypes.data_as(ip), tables.adj_val.ctypes.data_as(dp),
+        tables.tree_w.ctypes.data_as(dp), w.ctypes.data_as(dp), int(threads),
+    )
+    if rc != 0:
+        msg = "scs_oracle_pcg_dense_mt failed"
+        raise RuntimeError(msg)
+    return w
 
 
 def pcg_rows(tables, rows) -> np.ndarray:

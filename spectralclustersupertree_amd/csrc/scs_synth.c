@@ -45,9 +45,84 @@ static void rng_seed(rng_t *r, uint64_t seed, uint64_t tree) {
  * -1 for leaves), length, support; taxon_of_leaf sized k.
  * Returns 0, or -1 on allocation failure / bad arguments.
  */
+static int synth_tree(uint64_t seed, int64_t tree, int32_t n_taxa, int32_t k, int32_t strategy,
+                      int32_t n_spr, int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val,
+                      int32_t *left, int32_t *right, double *length, double *support,
+                      int32_t *taxon_of_leaf);
+
 int scs_synth_tree(uint64_t seed, int64_t tree, int32_t n_taxa, int32_t k, int32_t strategy,
                    int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val, int32_t *left,
                    int32_t *right, double *length, double *support, int32_t *taxon_of_leaf) {
+    return synth_tree(seed, tree, n_taxa, k, strategy, -1, leaf_taxon, adj_depth, adj_val, left,
+                      right, length, support, taxon_of_leaf);
+}
+
+/* random joins over leaves 0..k-1: internal nodes k..2k-2, root = 2k-2 */
+static void random_joins(rng_t *rng, int32_t k, int32_t *lf, int32_t *rt, int32_t *roots) {
+    for (int32_t i = 0; i < k; ++i) roots[i] = i;
+    int32_t cnt = k;
+    for (int32_t step = 0; step < k - 1; ++step) {
+        int32_t i = (int32_t)rng_below(rng, (uint64_t)cnt);
+        int32_t j = (int32_t)rng_below(rng, (uint64_t)(cnt - 1));
+        if (j >= i) ++j;
+        const int32_t v = k + step;
+        lf[v] = roots[i];
+        rt[v] = roots[j];
+        roots[i] = v;
+        roots[j] = roots[cnt - 1];
+        --cnt;
+    }
+}
+
+/* one subtree-prune-and-regraft move that keeps the root node and its two sides' node ids:
+ * prune x (parent p, p != root), close the gap, re-insert p on the edge above y */
+static void spr_move(rng_t *rng, int32_t nn, int32_t *lf, int32_t *rt, int32_t *par) {
+    const int32_t root = nn - 1;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        const int32_t x = (int32_t)rng_below(rng, (uint64_t)(nn - 1));
+        const int32_t p = par[x];
+        if (p == root) continue;
+        const int32_t y = (int32_t)rng_below(rng, (uint64_t)(nn - 1));
+        if (y == x || y == p) continue;
+        int inside = 0; /* y in the subtree of x (or of p: p moves along)? */
+        for (int32_t a = y; a != root; a = par[a])
+            if (a == x || a == p) {
+                inside = 1;
+                break;
+            }
+        const int32_t sib = lf[p] == x ? rt[p] : lf[p];
+        if (inside && y != sib) {
+            int under_x = 0;
+            for (int32_t a = y; a != root; a = par[a])
+                if (a == x) {
+                    under_x = 1;
+                    break;
+                }
+            if (under_x) continue;
+        }
+        if (y == sib) continue; /* re-inserting above the sibling changes nothing */
+        /* close the gap: the sibling takes p's place under g */
+        const int32_t g = par[p];
+        if (lf[g] == p) lf[g] = sib; else rt[g] = sib;
+        par[sib] = g;
+        /* insert p above y */
+        const int32_t q = par[y];
+        if (lf[q] == y) lf[q] = p; else rt[q] = p;
+        par[p] = q;
+        lf[p] = x;
+        rt[p] = y;
+        par[y] = p;
+        return;
+    }
+}
+
+/* n_spr < 0: an independent random-join tree (the iid sets).  n_spr >= 0: the PLANTED sets of
+ * SURVEY.md 8d -- the model tree of the set (random joins drawn from (seed, tree = -1)) with
+ * n_spr random SPR moves, lengths and supports drawn per tree. */
+static int synth_tree(uint64_t seed, int64_t tree, int32_t n_taxa, int32_t k, int32_t strategy,
+                      int32_t n_spr, int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val,
+                      int32_t *left, int32_t *right, double *length, double *support,
+                      int32_t *taxon_of_leaf) {
     if (k < 1 || k > n_taxa || strategy < 0 || strategy > 3) return -1;
     rng_t rng;
     rng_seed(&rng, seed, (uint64_t)tree);
@@ -83,19 +158,26 @@ int scs_synth_tree(uint64_t seed, int64_t tree, int32_t n_taxa, int32_t k, int32
         sup[v] = 50.0 + (double)rng_below(&rng, 51);
         lf[v] = rt[v] = -1;
     }
-    /* random joins */
-    for (int32_t i = 0; i < k; ++i) roots[i] = i;
-    int32_t cnt = k;
-    for (int32_t step = 0; step < k - 1; ++step) {
-        int32_t i = (int32_t)rng_below(&rng, (uint64_t)cnt);
-        int32_t j = (int32_t)rng_below(&rng, (uint64_t)(cnt - 1));
-        if (j >= i) ++j;
-        const int32_t v = k + step;
-        lf[v] = roots[i];
-        rt[v] = roots[j];
-        roots[i] = v;
-        roots[j] = roots[cnt - 1];
-        --cnt;
+    if (n_spr < 0) {
+        random_joins(&rng, k, lf, rt, roots);
+    } else {
+        rng_t model;
+        rng_seed(&model, seed, 0xFFFFFFFFFFFFFFFFull);
+        random_joins(&model, k, lf, rt, roots);
+        int32_t *par = (int32_t *)malloc(sizeof(int32_t) * (size_t)nn);
+        if (!par) {
+            free(lf); free(rt); free(len); free(sup); free(tax); free(roots); free(stack);
+            free(sdepth); free(sval); free(state);
+            return -1;
+        }
+        for (int32_t v = 0; v < nn; ++v) par[v] = -1;
+        for (int32_t v = k; v < nn; ++v) {
+            par[lf[v]] = v;
+            par[rt[v]] = v;
+        }
+        if (nn >= 7)
+            for (int32_t i = 0; i < n_spr; ++i) spr_move(&rng, nn, lf, rt, par);
+        free(par);
     }
     const int32_t root = nn - 1;
     /* depth-first flatten; value carried below a node per weighting strategy
@@ -166,14 +248,36 @@ int scs_synth_tree(uint64_t seed, int64_t tree, int32_t n_taxa, int32_t k, int32
 
 /* A whole set: trees [0, n_trees), tree t written at slot offset t*k.
  * weight_mode 0: all weights 1.0; 1: Uniform(0.5, 2.0) drawn per tree. */
+static int synth_tables(uint64_t seed, int32_t n_taxa, int32_t n_trees, int32_t k,
+                        int32_t strategy, int32_t weight_mode, int32_t n_spr, int64_t *tree_off,
+                        int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val, double *tree_w);
+
 int scs_synth_tables(uint64_t seed, int32_t n_taxa, int32_t n_trees, int32_t k, int32_t strategy,
                      int32_t weight_mode, int64_t *tree_off, int32_t *leaf_taxon,
                      int32_t *adj_depth, double *adj_val, double *tree_w) {
+    return synth_tables(seed, n_taxa, n_trees, k, strategy, weight_mode, -1, tree_off, leaf_taxon,
+                        adj_depth, adj_val, tree_w);
+}
+
+/* The planted sets: every tree = the set's model tree over all n_taxa taxa
+ * + n_spr random SPR moves. */
+int scs_synth_tables_planted(uint64_t seed, int32_t n_taxa, int32_t n_trees, int32_t strategy,
+                             int32_t weight_mode, int32_t n_spr, int64_t *tree_off,
+                             int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val,
+                             double *tree_w) {
+    if (n_spr < 0) return -1;
+    return synth_tables(seed, n_taxa, n_trees, n_taxa, strategy, weight_mode, n_spr, tree_off,
+                        leaf_taxon, adj_depth, adj_val, tree_w);
+}
+
+static int synth_tables(uint64_t seed, int32_t n_taxa, int32_t n_trees, int32_t k,
+                        int32_t strategy, int32_t weight_mode, int32_t n_spr, int64_t *tree_off,
+                        int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val, double *tree_w) {
     for (int32_t t = 0; t < n_trees; ++t) {
         const int64_t off = (int64_t)t * k;
         tree_off[t] = off;
-        if (scs_synth_tree(seed, t, n_taxa, k, strategy, leaf_taxon + off, adj_depth + off,
-                           adj_val + off, 0, 0, 0, 0, 0) != 0)
+        if (synth_tree(seed, t, n_taxa, k, strategy, n_spr, leaf_taxon + off, adj_depth + off,
+                       adj_val + off, 0, 0, 0, 0, 0) != 0)
             return -1;
         if (weight_mode == 1) {
             rng_t rng;

@@ -41,14 +41,34 @@ from spectralclustersupertree_amd.tree import (
 )
 
 _default_device: Device | None = None
+_default_team = None
+_default_team_checked = False
 
 
 def default_device() -> Device:
-    """Process-wide context on GPU 0, created on first use."""
+    """Process-wide single-rank context, created on first use: GPU ``SCS_DEVICE`` (default 0),
+    or this rank's single-device context when the process belongs to a launched job."""
     global _default_device
+    team = default_team()
+    if team is not None:
+        return team.solo
     if _default_device is None:
-        _default_device = Device(0)
+        import os
+
+        _default_device = Device(int(os.environ.get("SCS_DEVICE", "0")))
     return _default_device
+
+
+def default_team():
+    """The team of a job launched with one process per GPU (``torch.distributed.run`` sets
+    RANK / WORLD_SIZE / LOCAL_RANK): created on first use, None in a plain run."""
+    global _default_team, _default_team_checked
+    if not _default_team_checked:
+        from spectralclustersupertree_amd.partition import team_from_env
+
+        _default_team = team_from_env()
+        _default_team_checked = True
+    return _default_team
 
 
 def _make_result_tree(newick: str):
@@ -126,6 +146,7 @@ def spectral_bipartition_device(
     *,
     contract_edges: bool,
     device: Device | None = None,
+    team=None,
     tol: float = DEFAULT_TOL,
     max_iter: int = DEFAULT_MAX_ITER,
     block: int = 0,
@@ -136,10 +157,15 @@ def spectral_bipartition_device(
     Returns ``(groups, labels)``: the member taxa (ids of ``tables``) of every
     vertex in canonical order, and the 0/1 label of every vertex
     (reference: scs.py:125-134, 210-258).
+
+    With a ``team`` of several ranks (one process per GPU, every rank making this call with
+    the same arguments) a node of at least ``team.shard_min`` vertices is solved collectively:
+    W row-partitioned on group-aligned splits, the upper-triangle tiles shared, one RCCL
+    all-gather of the Krylov block per iteration; every rank receives the whole embedding and
+    draws the same labels.  Smaller nodes run on the rank's own single-device context.
     """
     from sklearn.cluster import k_means
 
-    dev = device or default_device()
     n = tables.n_taxa
     if contract_edges:
         groups = fl.contraction_groups(tables)
@@ -151,9 +177,28 @@ def spectral_bipartition_device(
     else:
         work, perm, group_start = tables, np.arange(n, dtype=np.int32), None
 
+    sharded = team is not None and team.world > 1 and n_groups >= team.shard_min
+    splits = None
+    if sharded:
+        from spectralclustersupertree_amd.partition import row_splits
+
+        try:
+            splits = row_splits(n, team.world, group_start)
+        except ValueError:
+            sharded = False  # fewer groups than ranks: every rank solves it alone
+    if sharded:
+        dev = team.device
+    elif team is not None:
+        dev = team.solo
+    else:
+        dev = device or default_device()
+
     dtab = dev.upload(work)
     try:
-        graph = dtab.build()
+        if sharded:
+            graph = dtab.build(splits[team.rank], splits[team.rank + 1], shared=True)
+        else:
+            graph = dtab.build()
     finally:
         dtab.free()
     try:
@@ -165,6 +210,8 @@ def spectral_bipartition_device(
         if report is not None:
             report.update(stats)
             report["build"] = graph.build_stats
+            report["sharded"] = bool(sharded)
+            report["splits"] = splits
     finally:
         graph.free()
     _, labels, _ = k_means(maps, 2, random_state=random_state, n_init=10, verbose=False)
@@ -183,14 +230,22 @@ def construct_supertree(
     *,
     contract_edges: bool = True,
     random_state: np.random.RandomState | None = None,
+    team=None,
 ):
     """Spectral Cluster Supertree (SCS) -- see the reference docstring.
 
     Parameters and return value as in the reference
     (reference: src/sc_supertree/scs.py:18-59).
+
+    Extension (keyword-only): ``team`` -- a ``partition.Team`` when several ranks walk the
+    recursion together (one process per GPU; every rank passes the same trees and a
+    RandomState in the same state).  Left at None a job launched by ``torch.distributed.run``
+    finds its team from the environment, a plain run uses GPU ``SCS_DEVICE`` (default 0).
     """
     if random_state is None:
         random_state = np.random.RandomState()
+    if team is None:
+        team = default_team()
 
     if isinstance(trees, TreeArrays):
         # extension: a forest that was parsed straight into arrays (load.load_tree_arrays)
@@ -210,7 +265,7 @@ def construct_supertree(
         if arrays.n_trees == 0:
             msg = "There must be at least one tree to make a supertree."
             raise ValueError(msg)
-        return _finish(_construct(arrays, pcg_weighting, contract_edges, random_state))
+        return _finish(_construct(arrays, pcg_weighting, contract_edges, random_state, team=team))
 
     if len(trees) == 0:
         msg = "There must be at least one tree to make a supertree."
@@ -239,7 +294,7 @@ def construct_supertree(
 
     taxa = sorted(_all_tip_names(trees))
     arrays = TreeArrays.from_trees(trees, weights, taxa)
-    return _finish(_construct(arrays, pcg_weighting, contract_edges, random_state))
+    return _finish(_construct(arrays, pcg_weighting, contract_edges, random_state, team=team))
 
 
 def _finish(result):
@@ -274,15 +329,26 @@ def _induce(names: set[str], trees, weights):
 
 
 def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
-               bipartition=None) -> TreeNode:
+               bipartition=None, team=None) -> TreeNode:
     """One node of the recursion on flat tree arrays (reference: scs.py:96-174).
 
     Same decisions in the same order as the reference -- and therefore the same draws from
     ``random_state`` -- but the induced trees of a child problem come from
     ``TreeArrays.restrict`` instead of ``get_sub_tree`` on objects.
+
+    ``team`` (several ranks walking together): nodes of at least ``team.shard_min`` vertices
+    are solved collectively.  Below it, ``team.child_rng == "shared"`` has every rank solve
+    every child on its own device with the shared stream (the reference's results, bit for
+    bit); ``"forked"`` deals sibling sub-problems to the ranks, one per device, each with a
+    RandomState forked from the parent's stream, and exchanges the subtrees.
     """
+    given = bipartition  # a caller's own routine (tests) is handed down unchanged
     if bipartition is None:
-        bipartition = spectral_bipartition_device
+        if team is not None:
+            def bipartition(tables, rs, *, contract_edges):
+                return spectral_bipartition_device(tables, rs, contract_edges=contract_edges, team=team)
+        else:
+            bipartition = spectral_bipartition_device
     names = arrays.taxa
     if arrays.n_trees == 1:  # reference: scs.py:96-98
         return arrays.to_tree(0)
@@ -306,7 +372,9 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         for i, c in enumerate(comp):
             parts[int(c)].append(int(present[i]))
 
-    child_trees: list[TreeNode] = []
+    forked = (team is not None and team.world > 1 and team.child_rng == "forked")
+    child_trees: list = []
+    dealt: list[tuple[int, int, TreeArrays, np.random.RandomState]] = []  # (slot, owner, sub, rng)
     for component in parts:
         if len(component) == 0:
             continue
@@ -320,9 +388,24 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             # an empty list and raises (reference: scs.py:63-65 reached from :158)
             msg = "There must be at least one tree to make a supertree."
             raise ValueError(msg)
-        child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, bipartition))
+        if forked and len(component) < team.shard_min:
+            # one sub-problem per device: its own stream, forked here, in order, on every rank
+            rng = np.random.RandomState(random_state.randint(0, 2**31 - 1))
+            dealt.append((len(child_trees), len(dealt) % team.world, sub, rng))
+            child_trees.append(None)
+        else:
+            child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, given, team))
         covered = set(int(i) for i in sub.present_taxa())
         child_trees.extend(TreeNode(names[i]) for i in component if i not in covered)
+    if dealt:
+        from spectralclustersupertree_amd.partition import Team
+
+        alone = Team(rank=0, world=1, device=team.solo, solo=team.solo)
+        mine = {slot: _construct(sub, pcg_weighting, contract_edges, rng, given, alone)
+                for slot, owner, sub, rng in dealt if owner == team.rank}
+        for part in team.allgather(mine):
+            for slot, tree in part.items():
+                child_trees[slot] = tree
     return connect_trees(child_trees)
 
 

@@ -35,6 +35,9 @@ def _load() -> C.CDLL:
         lib.scs_synth_tables.restype = C.c_int
         lib.scs_synth_tables.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, lp, ip, ip, dp, dp]
+        lib.scs_synth_tables_planted.restype = C.c_int
+        lib.scs_synth_tables_planted.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.c_int32, lp, ip, ip, dp, dp]
         _lib = lib
     return _lib
 
@@ -51,10 +54,19 @@ def make_tables(
     strategy: str,
     leaves_per_tree: int | None = None,
     random_weights: bool = False,
+    planted_spr: int | None = None,
 ) -> TreeTables:
-    """Flattened tables of the synthetic set ``(seed, n_taxa, n_trees)``."""
+    """Flattened tables of the synthetic set ``(seed, n_taxa, n_trees)``.
+
+    ``planted_spr`` (the planted variant): every tree is the set's
+    model tree over all taxa plus that many random SPR moves, instead of an independent
+    random-join tree.
+    """
     lib = _load()
     k = n_taxa if leaves_per_tree is None else int(leaves_per_tree)
+    if planted_spr is not None and k != n_taxa:
+        msg = "planted sets cover all taxa in every tree"
+        raise ValueError(msg)
     total = n_trees * k
     tree_off = np.empty(n_trees + 1, dtype=np.int64)
     leaf_taxon = np.empty(total, dtype=np.int32)
@@ -62,11 +74,18 @@ def make_tables(
     adj_val = np.empty(total, dtype=np.float64)
     tree_w = np.empty(n_trees, dtype=np.float64)
     ip, dp, lp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)
-    rc = lib.scs_synth_tables(
-        seed, n_taxa, n_trees, k, STRATEGIES_INDEX[strategy], 1 if random_weights else 0,
-        tree_off.ctypes.data_as(lp), leaf_taxon.ctypes.data_as(ip), adj_depth.ctypes.data_as(ip),
-        adj_val.ctypes.data_as(dp), tree_w.ctypes.data_as(dp),
-    )
+    if planted_spr is None:
+        rc = lib.scs_synth_tables(
+            seed, n_taxa, n_trees, k, STRATEGIES_INDEX[strategy], 1 if random_weights else 0,
+            tree_off.ctypes.data_as(lp), leaf_taxon.ctypes.data_as(ip), adj_depth.ctypes.data_as(ip),
+            adj_val.ctypes.data_as(dp), tree_w.ctypes.data_as(dp),
+        )
+    else:
+        rc = lib.scs_synth_tables_planted(
+            seed, n_taxa, n_trees, STRATEGIES_INDEX[strategy], 1 if random_weights else 0,
+            int(planted_spr), tree_off.ctypes.data_as(lp), leaf_taxon.ctypes.data_as(ip),
+            adj_depth.ctypes.data_as(ip), adj_val.ctypes.data_as(dp), tree_w.ctypes.data_as(dp),
+        )
     if rc != 0:
         msg = "scs_synth_tables failed (bad arguments or out of memory)"
         raise RuntimeError(msg)

@@ -1,0 +1,147 @@
+"""The multi-rank path behind the public API (needs an MI355X): several ranks walking one
+recursion, nodes above the threshold solved collectively on group-aligned row splits
+(SURVEY.md 8e, 8f-1), children below it on single devices.  The ranks here are threads of
+one process on one GPU (libscs_hip's in-process communicator stands in for RCCL; the
+collective code path above it is the same) -- a real job has one process per GPU."""
+
+import numpy as np
+import pytest
+from reference_cases import DATA_DIR, FILE_CASES
+
+from oracle import scs_oracle as so
+from oracle import tables_oracle as to
+from spectralclustersupertree_amd import construct_supertree, synthetic
+from spectralclustersupertree_amd import flatten as fl
+from spectralclustersupertree_amd.backend import Device
+from spectralclustersupertree_amd.load import load_tree_arrays
+from spectralclustersupertree_amd.partition import LocalTeams, group_splits, row_splits
+from spectralclustersupertree_amd.scs import relabel_for_contraction, spectral_bipartition_device
+from spectralclustersupertree_amd.tree import TreeNode, load_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_twins(tree: TreeNode, twinned: set[str]) -> TreeNode:
+    """A copy of the tree in which every tip named in `twinned` is a cherry (x, x_twin): the
+    two always travel together, so contraction merges them."""
+    if tree.is_tip():
+        if tree.name in twinned:
+            return TreeNode(None, [TreeNode(tree.name, None, 0.01), TreeNode(tree.name + "_twin", None, 0.02)],
+                            tree.length, 90.0)
+        return TreeNode(tree.name, None, tree.length, tree.support)
+    return TreeNode(tree.name, [_with_twins(c, twinned) for c in tree.children], tree.length, tree.support)
+
+
+def _twin_tables(n, m, k, n_twins, strategy="branch"):
+    trees = synthetic.tree_objects(21, n, m, leaves_per_tree=k)
+    rs = np.random.RandomState(2)
+    twinned = {synthetic.taxon_name(int(i)) for i in rs.choice(n, size=n_twins, replace=False)}
+    trees = [_with_twins(t, twinned) for t in trees]
+    names = sorted(so._all_tips(trees))
+    weights = [1.0 + 0.25 * (i % 3) for i in range(m)]
+    return fl.flatten_trees(trees, weights, strategy, names), trees, weights
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_build_contract_fiedler_matches_single_rank(world):
+    # build -> contract -> fiedler on group-aligned row splits vs the single-rank result
+    # (reference: scs.py:261-387 contraction, then :210-258)
+    tables, _, _ = _twin_tables(640, 14, 600, 150)
+    assert tables.monotone
+    groups = fl.contraction_groups(tables)
+    n_groups = int(groups.max()) + 1
+    assert n_groups < tables.n_taxa - 100  # the twins (present in every tree they share) merge
+    work, perm, group_start = relabel_for_contraction(tables, groups)
+    splits = row_splits(tables.n_taxa, world, group_start)
+    gsp = group_splits(splits, group_start)
+
+    with Device(0) as dev:
+        dtab = dev.upload(work)
+        g = dtab.build().contract(group_start)
+        w_single = g.download()
+        v0 = np.random.RandomState(0).uniform(-1, 1, n_groups)
+        maps_single, _ = g.fiedler(v0)
+        g.free()
+        dtab.free()
+    w_ref, _ = to.pcg_dense(work)
+    assert np.array_equal(w_single, to.contract_dense(w_ref, group_start))
+
+    teams = LocalTeams(world)
+
+    def rank_work(team):
+        dtab = team.device.upload(work)
+        g = dtab.build(splits[team.rank], splits[team.rank + 1], shared=True).contract(group_start)
+        assert g.shape == (n_groups, gsp[team.rank], gsp[team.rank + 1])
+        w = g.download()
+        maps, stats = g.fiedler(v0)
+        g.free()
+        dtab.free()
+        return w, maps, stats
+
+    try:
+        out = teams.run(rank_work)
+    finally:
+        teams.close()
+    assert np.array_equal(np.vstack([o[0] for o in out]), w_single)
+    for w, maps, stats in out:
+        assert stats["converged"] == 1
+        assert np.array_equal(maps, out[0][1])
+        assert np.max(np.abs(maps - maps_single)) <= 1e-10
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bipartition_through_a_team_equals_single_device(world):
+    tables, _, _ = _twin_tables(500, 12, 470, 90, strategy="depth")
+    with Device(0) as dev:
+        want_members, want_labels = spectral_bipartition_device(
+            tables, np.random.RandomState(5), contract_edges=True, device=dev)
+    teams = LocalTeams(world, shard_min=100)
+
+    def rank_work(team):
+        report = {}
+        rs = np.random.RandomState(5)
+        members, labels = spectral_bipartition_device(tables, rs, contract_edges=True, team=team,
+                                                      report=report)
+        return members, labels, report, rs.randint(1 << 30)
+
+    try:
+        out = teams.run(rank_work)
+    finally:
+        teams.close()
+    for members, labels, report, draw in out:
+        assert report["sharded"] and len(report["splits"]) == world + 1
+        assert [m.tolist() for m in members] == [m.tolist() for m in want_members]
+        assert np.array_equal(labels, want_labels)
+        assert draw == out[0][3]  # every rank left the stream in the same state
+
+
+def test_construct_supertree_with_a_team_shared_stream():
+    # the whole recursion walked by two ranks: big nodes collectively, small ones on each
+    # rank's own device with the shared stream -> the single-device result, exactly
+    tables, trees, weights = _twin_tables(420, 10, 400, 60)
+    want = construct_supertree(trees, weights, "branch", random_state=np.random.RandomState(1))
+    teams = LocalTeams(2, shard_min=120)
+    try:
+        out = teams.run(lambda team: construct_supertree(trees, weights, "branch",
+                                                         random_state=np.random.RandomState(1), team=team))
+    finally:
+        teams.close()
+    for got in out:
+        assert got.sorted().get_newick() == want.sorted().get_newick()
+
+
+def test_construct_supertree_with_a_team_children_one_per_device():
+    # "forked" streams: sibling sub-problems below the threshold are dealt to the ranks and the
+    # subtrees exchanged; the reference's fixture has a seed-independent answer
+    name, src, exp, weighting = next(c for c in FILE_CASES if "supertriplets" in c[0])
+    arrays = load_tree_arrays(DATA_DIR / src)
+    expected = load_tree(DATA_DIR / exp)
+    teams = LocalTeams(3, shard_min=60, child_rng="forked")
+    try:
+        out = teams.run(lambda team: construct_supertree(arrays, pcg_weighting=weighting,
+                                                         random_state=np.random.RandomState(0), team=team))
+    finally:
+        teams.close()
+    for got in out:
+        assert got.sorted().same_shape(expected.sorted())
+    assert len({g.sorted().get_newick() for g in out}) == 1

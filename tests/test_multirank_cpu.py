@@ -1,5 +1,7 @@
-"""World-size-2 gloo tests (CPU) of the N > 1 host logic: the row-partition plan,
-the unique-id/barrier/max rendezvous bench.py performs, and the slice-gather
+"""World-size-2 gloo tests (CPU) of the N > 1 host logic: the row-partition plan
+(tile- and group-aligned), the product's own rendezvous (partition.rendezvous_host, as
+bench.py and construct_supertree use it) up to the GPU call, the recursion walked by two
+ranks with sibling sub-problems dealt one per rank, and the slice-gather
 order the device path relies on (rank r contributes rows [split_r, split_{r+1})
 of S @ X; concatenating the gathered slices in rank order must equal the full
 product).  The arithmetic here is the oracle's numpy restatement -- the device
@@ -24,21 +26,25 @@ def _free_port() -> int:
 
 def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     sys.path.insert(0, str(ROOT))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import torch
-    import torch.distributed as dist
 
     import bench
     from oracle import tables_oracle as to
-    from spectralclustersupertree_amd import synthetic
+    from spectralclustersupertree_amd import partition, synthetic
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    # 1. unique-id style broadcast (128 bytes from rank 0)
-    buf = torch.zeros(128, dtype=torch.uint8)
-    if rank == 0:
-        buf = torch.arange(128, dtype=torch.uint8)
-    dist.broadcast(buf, 0)
-    assert buf.tolist() == list(range(128))
+    # 1. the product's own rendezvous (partition.rendezvous_host: process group + broadcast of
+    # rank 0's 128-byte id), everything up to -- not including -- the GPU context
+    made = []
+
+    def make_id():
+        made.append(rank)
+        return bytes(range(128))
+
+    dist, uid = partition.rendezvous_host(rank, world, make_id)
+    assert uid == bytes(range(128)) and made == ([0] if rank == 0 else [])
     # 2. row-partitioned operator apply, slices gathered in rank order
     n, b = 333, 8
     tables = synthetic.make_tables(3, n, 12, "branch", leaves_per_tree=300)
@@ -59,6 +65,29 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     t = torch.tensor([1.0 + rank], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     assert t.item() == float(world)
+    # 4. the recursion walked by two ranks, sibling sub-problems dealt one per rank ("forked"
+    # streams) and the subtrees exchanged through the process group; the bipartition itself
+    # is the CPU oracle's here (the device one is covered by the -m gpu tests)
+    from reference_cases import DATA_DIR, FILE_CASES
+    from test_treearrays import cpu_bipartition
+
+    from spectralclustersupertree_amd import scs
+    from spectralclustersupertree_amd.load import load_tree_arrays
+    from spectralclustersupertree_amd.tree import load_tree
+
+    def allgather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    team = partition.Team(rank=rank, world=world, device=None, solo=None, allgather=allgather,
+                          shard_min=10**9, child_rng="forked")
+    name, src, exp, weighting = next(c for c in FILE_CASES if "supertriplets" in c[0])
+    arrays = load_tree_arrays(DATA_DIR / src)
+    got = scs._construct(arrays, weighting, True, np.random.RandomState(0), cpu_bipartition, team)
+    assert got.sorted().same_shape(load_tree(DATA_DIR / exp).sorted())
+    newicks = allgather(got.sorted().get_newick())
+    assert newicks[0] == newicks[1]
     dist.barrier()
     dist.destroy_process_group()
     Path(out_dir, f"ok{rank}").write_text("ok")
@@ -70,12 +99,37 @@ def test_even_splits_tile_aligned_and_cover():
 
     for n in (64, 65, 333, 1000, 10000, 50000):
         for world in (1, 2, 4, 8):
+            if (n + 63) // 64 < world:
+                with pytest.raises(ValueError):
+                    bench.even_splits(n, world)
+                continue
             sp = bench.even_splits(n, world)
             assert sp[0] == 0 and sp[-1] == n and len(sp) == world + 1
-            assert all(a <= b for a, b in zip(sp, sp[1:]))
+            assert all(a < b for a, b in zip(sp, sp[1:]))
             assert all(x % 64 == 0 for x in sp[1:-1])
-            if n >= 64 * world:
-                assert all(a < b for a, b in zip(sp, sp[1:]))
+
+
+def test_group_aligned_splits():
+    # contraction under row partitioning: every split is a group boundary,
+    # every rank gets at least one group, splits stay near the even ones
+    from spectralclustersupertree_amd.partition import group_splits, row_splits
+
+    rs = np.random.RandomState(0)
+    for n, world in ((700, 2), (700, 3), (5000, 8), (64, 4), (9, 3)):
+        sizes = []
+        while sum(sizes) < n:
+            sizes.append(min(n - sum(sizes), int(rs.choice([1, 1, 1, 2, 3, 40]))))
+        gs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+        sp = row_splits(n, world, gs)
+        assert sp[0] == 0 and sp[-1] == n and all(a < b for a, b in zip(sp, sp[1:]))
+        assert set(sp) <= set(gs.tolist())
+        gsp = group_splits(sp, gs)
+        assert gsp[0] == 0 and gsp[-1] == len(gs) - 1 and all(a < b for a, b in zip(gsp, gsp[1:]))
+        assert max(abs(sp[r] - n * r / world) for r in range(1, world)) <= 64 + 40
+    with pytest.raises(ValueError):
+        row_splits(10, 4, [0, 5, 10])
+    with pytest.raises(ValueError):
+        group_splits([0, 3, 10], [0, 5, 10])
 
 
 def test_two_rank_gloo_rendezvous_and_gather(tmp_path):

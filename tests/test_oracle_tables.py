@@ -80,3 +80,31 @@ def test_contraction_merges_planted():
     # a and b always together; c, d always together in the trees holding them
     trees = [make_tree(s) for s in ["(((a,b),(c,d)),(e,f))", "((a,b),((c,d),g))", "(((a,b),e),(c,d))"]]
     _check(trees, [1.0, 1.0, 1.0], "depth")
+
+
+@pytest.mark.parametrize("strategy", ["depth", "bootstrap"])
+def test_all_core_oracle_build_gives_the_same_bits(strategy):
+    # bench.py's all-core cpu_baseline leg: rows partitioned over threads, tree order per cell
+    from spectralclustersupertree_amd import synthetic
+
+    tables = synthetic.make_tables(9, 257, 12, strategy, leaves_per_tree=200, random_weights=True)
+    w1, _ = to.pcg_dense(tables)
+    for threads in (1, 3, 8):
+        assert np.array_equal(to.pcg_dense_mt(tables, threads), w1)
+
+
+def test_planted_sets_are_model_tree_plus_moves():
+    # SURVEY.md 8d planted variant: same model tree behind every source tree of a set
+    from spectralclustersupertree_amd import synthetic
+
+    a = synthetic.make_tables(5, 200, 6, "depth", planted_spr=0)
+    # no moves: every tree IS the model tree (same leaf order, same LCA depths)
+    k = 200
+    for t in range(1, 6):
+        assert np.array_equal(a.leaf_taxon[:k], a.leaf_taxon[t * k:(t + 1) * k])
+        assert np.array_equal(a.adj_depth[:k], a.adj_depth[t * k:(t + 1) * k])
+    b = synthetic.make_tables(5, 200, 6, "depth", planted_spr=4)
+    b.validate()
+    assert sorted(b.leaf_taxon[:k].tolist()) == list(range(k))
+    assert not np.array_equal(b.adj_depth[:k], b.adj_depth[k:2 * k])
+    assert int(fl.pcg_components(b).max()) == 0
