@@ -563,8 +563,8 @@ int levels_for(int64_t m) {
 
 }  // namespace
 
-static int graph_alloc(int32_t n, int32_t row_begin, int32_t row_end, hipStream_t stream,
-                       scs_graph **out) {
+static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_end,
+                       hipStream_t stream, scs_graph **out) {
     auto *g = new scs_graph();
     g->n = n;
     g->row_begin = row_begin;
@@ -573,14 +573,31 @@ static int graph_alloc(int32_t n, int32_t row_begin, int32_t row_end, hipStream_
     g->ld = scs_round_up(n, SCS_LD_ALIGN);
     const size_t rows = (size_t)(row_end - row_begin);
     size_t bytes = rows * (size_t)g->ld * sizeof(double);
-    hipError_t e = hipMalloc((void **)&g->d_w, bytes ? bytes : 16);
-    if (e != hipSuccess) {
-        delete g;
-        scs_set_error("cannot allocate %zu bytes for W: %s", bytes, hipGetErrorString(e));
-        return SCS_ENOMEM;
+    if (bytes < 16) bytes = 16;
+    // the cached buffer fits when it is large enough and at most twice the need (+1 MiB)
+    if (ctx->w_cache && ctx->w_cache_bytes >= bytes && ctx->w_cache_bytes <= 2 * bytes + (1u << 20)) {
+        g->d_w = ctx->w_cache;
+        g->w_bytes = ctx->w_cache_bytes;
+        ctx->w_cache = nullptr;
+        ctx->w_cache_bytes = 0;
+    } else {
+        hipError_t e = hipMalloc((void **)&g->d_w, bytes);
+        if (e != hipSuccess && ctx->w_cache) {  // make room and try once more
+            (void)hipGetLastError();
+            hipFree(ctx->w_cache);
+            ctx->w_cache = nullptr;
+            ctx->w_cache_bytes = 0;
+            e = hipMalloc((void **)&g->d_w, bytes);
+        }
+        if (e != hipSuccess) {
+            delete g;
+            scs_set_error("cannot allocate %zu bytes for W: %s", bytes, hipGetErrorString(e));
+            return SCS_ENOMEM;
+        }
+        g->w_bytes = bytes;
     }
     if (g->ld > n) {
-        e = hipMemset2DAsync(g->d_w + n, (size_t)g->ld * 8, 0, (size_t)(g->ld - n) * 8, rows, stream);
+        hipError_t e = hipMemset2DAsync(g->d_w + n, (size_t)g->ld * 8, 0, (size_t)(g->ld - n) * 8, rows, stream);
         if (e != hipSuccess) {
             hipFree(g->d_w);
             delete g;
@@ -595,7 +612,19 @@ static int graph_alloc(int32_t n, int32_t row_begin, int32_t row_end, hipStream_
 extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
     if (!g) return SCS_OK;
     if (ctx) hipSetDevice(ctx->device);
-    hipFree(g->d_w);
+    if (ctx && g->d_w) {
+        // keep the larger of the two buffers for the next graph; the kernels that used this
+        // one are ordered before any later use by the context's stream
+        if (!ctx->w_cache || g->w_bytes >= ctx->w_cache_bytes) {
+            if (ctx->w_cache) hipFree(ctx->w_cache);
+            ctx->w_cache = g->d_w;
+            ctx->w_cache_bytes = g->w_bytes;
+        } else {
+            hipFree(g->d_w);
+        }
+    } else {
+        hipFree(g->d_w);
+    }
     hipFree(g->d_deg);
     hipFree(g->d_dinv);
     delete g;
@@ -645,7 +674,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     const int n_blocks = (b_row_end - b_row_begin + SCS_TR - 1) / SCS_TR;
 
     scs_graph *g = nullptr;
-    SCS_TRY(graph_alloc(n, row_begin, row_end, s, &g));
+    SCS_TRY(graph_alloc(ctx, n, row_begin, row_end, s, &g));
     struct guard {
         scs_ctx *c;
         scs_graph *g;
@@ -987,7 +1016,7 @@ extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *gro
                 g->row_begin, g->row_end);
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     scs_graph *ng = nullptr;
-    SCS_TRY(graph_alloc(n_groups, g_begin, g_end, ctx->stream, &ng));
+    SCS_TRY(graph_alloc(ctx, n_groups, g_begin, g_end, ctx->stream, &ng));
     int32_t *d_gs = nullptr;
     hipError_t e = hipMalloc((void **)&d_gs, (size_t)(n_groups + 1) * 4);
     if (e != hipSuccess) {

@@ -290,6 +290,9 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
         if (sl.p) hipFree(sl.p);
     for (auto &e : ctx->build_events)
         if (e) hipEventDestroy(e);
+    for (auto &e : ctx->solve_events)
+        if (e) hipEventDestroy(e);
+    if (ctx->w_cache) hipFree(ctx->w_cache);
     delete ctx;
     return SCS_OK;
 }

@@ -1309,16 +1309,11 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     memset(st, 0, sizeof(*st));
     st->n_vertices = n;
 
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    SCS_HIP_CHECK(hipEventCreate(&ev_a));
-    SCS_HIP_CHECK(hipEventCreate(&ev_b));
-    struct evg {
-        hipEvent_t a, b;
-        ~evg() {
-            hipEventDestroy(a);
-            hipEventDestroy(b);
-        }
-    } evguard{ev_a, ev_b};
+    // timing events live in the context (created once: this call is made thousands of times
+    // per recursion)
+    for (auto &e : ctx->solve_events)
+        if (!e) SCS_HIP_CHECK(hipEventCreate(&e));
+    hipEvent_t ev_a = ctx->solve_events[0], ev_b = ctx->solve_events[1];
     SCS_HIP_CHECK(hipEventRecord(ev_a, s));
 
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));

@@ -85,6 +85,12 @@ struct scs_ctx {
         size_t cap = 0;
     } scratch[8];
     hipEvent_t build_events[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t solve_events[2] = {nullptr, nullptr};
+    // the W buffer of the graph freed last: the next graph of about that size takes it over
+    // instead of a hipFree / hipMalloc pair (a step of the benchmark re-builds the same 20 GB
+    // matrix; the recursion makes thousands of small ones).  One buffer at most.
+    double *w_cache = nullptr;
+    size_t w_cache_bytes = 0;
 };
 
 struct scs_tables {
@@ -107,6 +113,7 @@ struct scs_graph {
     int32_t row_end = 0;
     int64_t ld = 0;         // leading dimension (doubles) of d_w
     double *d_w = nullptr;  // (row_end-row_begin) x ld, row-major
+    size_t w_bytes = 0;     // size of the d_w allocation (may exceed the need: reused buffer)
     // degree data for all V vertices (filled lazily by scs_graph_prepare_degrees)
     bool have_deg = false;
     double *d_deg = nullptr;   // [V] row sums
