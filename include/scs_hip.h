@@ -200,6 +200,30 @@ int scs_graph_free(scs_ctx *ctx, scs_graph *graph);
 int scs_fiedler(scs_ctx *ctx, scs_graph *graph, const double *x_init, double tol,
                 int32_t max_iter, int32_t block, double *maps_out, scs_stats *stats);
 
+/* ---- batched small nodes ----------------------------------------------- */
+
+/* Deep recursion levels (reference: scs.py:110-134 at depth): K
+ * independent nodes of at most 64 taxa each, one workgroup per node, one launch.  Every node
+ * goes from its flattened tables to the V x 2 embedding in LDS: proper-cluster-graph weights
+ * (bit-identical to scs_pcg_build's W), contraction of consecutive id ranges (max over member
+ * pairs, scs.py:336-387), scipy's degree scaling, full Jacobi eigen-decomposition,
+ * scikit-learn's embedding conventions (as scs_fiedler).  Replaces, per node,
+ * scs_tables_upload + scs_pcg_build + scs_graph_contract + scs_fiedler.
+ *   n_taxa, n_trees, n_groups  int32 [K]   (2 <= n_groups <= n_taxa <= 64)
+ *   tree_off    int32, per node n_trees+1 leaf offsets starting at 0, nodes concatenated
+ *   leaf_taxon / adj_depth / adj_val       the nodes' tables, concatenated (taxon ids 0..n_taxa-1,
+ *                                          numbered so that every contraction group is a
+ *                                          consecutive range)
+ *   tree_w      fp64, n_trees per node, concatenated
+ *   group_start int32, per node n_groups+1 entries 0 .. n_taxa, concatenated
+ *   maps_out    fp64 [sum n_groups][2]     lambda_out fp64 [K][3] (three largest eigenvalues of S)
+ *   w_out       fp64, per node n_groups^2 (row-major), concatenated, or NULL */
+int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa, const int32_t *n_trees,
+                    const int32_t *n_groups, const int32_t *tree_off, const int32_t *leaf_taxon,
+                    const int32_t *adj_depth, const double *adj_val, const double *tree_w,
+                    const int32_t *group_start, double *maps_out, double *lambda_out,
+                    double *w_out);
+
 /* ---- diagnostics used by the parity tests ------------------------------ */
 
 /* Eigen-decomposition of a dense symmetric n x n matrix (n <= 64) by the

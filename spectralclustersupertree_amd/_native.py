@@ -116,6 +116,7 @@ SIGNATURES = {
     "scs_graph_degrees": (C.c_int, [_P, _P, _DP]),
     "scs_graph_free": (C.c_int, [_P, _P]),
     "scs_fiedler": (C.c_int, [_P, _P, _DP, C.c_double, _I32, _I32, _DP, C.POINTER(Stats)]),
+    "scs_small_solve": (C.c_int, [_P, _I32, _IP, _IP, _IP, _IP, _IP, _IP, _DP, _DP, _IP, _DP, _DP, _DP]),
     "scs_debug_jacobi": (C.c_int, [_P, _DP, _I32, _DP, _DP]),
     "scs_debug_gram": (C.c_int, [_P, _DP, _DP, _I32, _I32, _I32, _I32, _DP]),
     "scs_debug_apply": (C.c_int, [_P, _P, _DP, _I32, _DP]),

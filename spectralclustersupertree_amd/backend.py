@@ -78,6 +78,58 @@ class Device:
         )
         return DeviceTables(self, handle, tables.n_taxa, tables.n_trees, bool(tables.monotone))
 
+    # -- batched small nodes --------------------------------------------------
+    SMALL_MAX_TAXA = 64  # MAXS of the device Jacobi kernel
+
+    def small_solve(self, nodes, want_w: bool = False):
+        """K small recursion nodes in one launch (``scs_small_solve``; reference: scs.py:110-134
+        at depth).  ``nodes``: list of ``(tables, group_start or None)`` with at most
+        ``SMALL_MAX_TAXA`` taxa each, taxa numbered so that contraction groups are consecutive
+        ranges.  Returns one ``(maps, lambdas)`` -- or ``(maps, lambdas, W)`` -- per node."""
+        k = len(nodes)
+        if k == 0:
+            return []
+        n_taxa = np.empty(k, dtype=np.int32)
+        n_trees = np.empty(k, dtype=np.int32)
+        n_groups = np.empty(k, dtype=np.int32)
+        toff, gstart, lt, ad, av, tw = [], [], [], [], [], []
+        for i, (tables, group_start) in enumerate(nodes):
+            n_taxa[i], n_trees[i] = tables.n_taxa, tables.n_trees
+            gs = (np.arange(tables.n_taxa + 1, dtype=np.int32) if group_start is None
+                  else np.ascontiguousarray(group_start, dtype=np.int32))
+            n_groups[i] = len(gs) - 1
+            toff.append(np.asarray(tables.tree_off, dtype=np.int32))
+            gstart.append(gs)
+            lt.append(tables.leaf_taxon)
+            ad.append(tables.adj_depth)
+            av.append(tables.adj_val)
+            tw.append(tables.tree_w)
+        cat = np.concatenate
+        toff_a = np.ascontiguousarray(cat(toff), dtype=np.int32)
+        gs_a = np.ascontiguousarray(cat(gstart), dtype=np.int32)
+        lt_a = np.ascontiguousarray(cat(lt), dtype=np.int32)
+        ad_a = np.ascontiguousarray(cat(ad), dtype=np.int32)
+        av_a = np.ascontiguousarray(cat(av), dtype=np.float64)
+        tw_a = np.ascontiguousarray(cat(tw), dtype=np.float64)
+        total_v = int(n_groups.sum())
+        maps = np.empty((total_v, 2))
+        lam = np.empty((k, 3))
+        w = np.empty(int((n_groups.astype(np.int64) ** 2).sum())) if want_w else None
+        nv.check(self._lib.scs_small_solve(
+            self._ctx, k, nv.iptr(n_taxa), nv.iptr(n_trees), nv.iptr(n_groups), nv.iptr(toff_a),
+            nv.iptr(lt_a), nv.iptr(ad_a), nv.dptr(av_a), nv.dptr(tw_a), nv.iptr(gs_a), nv.dptr(maps),
+            nv.dptr(lam), nv.dptr(w) if want_w else None))
+        out, at, wat = [], 0, 0
+        for i in range(k):
+            v = int(n_groups[i])
+            item = (maps[at:at + v].copy(), lam[i].copy())
+            if want_w:
+                item += (w[wat:wat + v * v].reshape(v, v).copy(),)
+                wat += v * v
+            out.append(item)
+            at += v
+        return out
+
     # -- building blocks exposed for the parity tests -----------------------
     def debug_jacobi(self, a: np.ndarray):
         a = np.ascontiguousarray(a, dtype=np.float64)

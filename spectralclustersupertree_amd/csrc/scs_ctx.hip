@@ -293,6 +293,8 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     for (auto &e : ctx->solve_events)
         if (e) hipEventDestroy(e);
     if (ctx->w_cache) hipFree(ctx->w_cache);
+    if (ctx->small_dev) hipFree(ctx->small_dev);
+    if (ctx->small_host) hipHostFree(ctx->small_host);
     delete ctx;
     return SCS_OK;
 }

@@ -1649,6 +1649,257 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 }
 
 // ---------------------------------------------------------------------------
+// batched small nodes: tables -> W -> contraction -> S -> Jacobi -> maps
+// ---------------------------------------------------------------------------
+// Deep levels of the recursion are thousands of nodes of a few to a few dozen taxa
+// (reference: scs.py:110-134 at depth; 47 spectral calls with V <= 100 in the reference's
+// supertriplets fixture).  One workgroup takes one such node from its flattened tables to the
+// V x 2 embedding without leaving LDS: the proper-cluster-graph weights (same addends, same
+// tree order as scs_pcg_build: bit-identical W), the contraction max-reduce over consecutive
+// id ranges, scipy's degree scaling, the full Jacobi eigen-decomposition and scikit-learn's
+// embedding conventions.  K nodes = K workgroups = one launch, one upload, one download.
+struct small_batch {
+    const int32_t *n_taxa;      // [K] taxa of the node (<= MAXS)
+    const int32_t *n_trees;     // [K]
+    const int32_t *n_groups;    // [K] vertices after contraction (>= 2)
+    const int32_t *tree_ptr;    // [K+1] first tree of node k in tree_w; its tree_off starts at tree_ptr[k] + k
+    const int64_t *leaf_ptr;    // [K+1] first leaf slot of node k
+    const int32_t *vertex_ptr;  // [K+1] first vertex of node k in maps; its group_start at vertex_ptr[k] + k
+    const int32_t *tree_off;    // per node: n_trees + 1 leaf offsets relative to the node's first slot
+    const int32_t *leaf_taxon;
+    const int32_t *adj_depth;
+    const double *adj_val;
+    const double *tree_w;
+    const int32_t *group_start;  // per node: n_groups + 1 entries, 0 .. n_taxa
+    double *maps;                // [total vertices][2]
+    double *lambda;              // [K][3]
+    double *w_out;               // per node n_groups^2 doubles at w_ptr[k], or null
+    const int64_t *w_ptr;
+};
+
+__global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
+    __shared__ jacobi_lds s;
+    __shared__ double s_dd[MAXS];
+    __shared__ double s_val[MAXS];
+    __shared__ int s_tax[MAXS], s_dep[MAXS], s_gs[MAXS + 1];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x;
+    const int v0 = p.n_taxa[k], m = p.n_trees[k], v = p.n_groups[k];
+    const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
+    const int64_t lbase = p.leaf_ptr[k];
+    double(*w0)[SLD] = s.e;  // the uncontracted weights live where Jacobi later keeps its vectors
+
+    for (int e = tid; e < MAXS * SLD; e += 256) (&s.e[0][0])[e] = 0.0;
+    if (tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
+    __syncthreads();
+    // ---- W0: every tree in order; thread a sweeps the leaves to its right with the running
+    // shallowest LCA (reference: scs.py:644-658; one rounded multiply, one rounded add: FMA
+    // contraction is switched off for that statement)
+    for (int t = 0; t < m; ++t) {
+        const int off = toff[t], n = toff[t + 1] - off;
+        if (tid < n) {
+            s_tax[tid] = p.leaf_taxon[lbase + off + tid];
+            s_dep[tid] = p.adj_depth[lbase + off + tid];
+            s_val[tid] = p.adj_val[lbase + off + tid];
+        }
+        __syncthreads();
+        const double wt = p.tree_w[p.tree_ptr[k] + t];
+        if (tid + 1 < n) {
+            const int a = tid, ta = s_tax[a];
+            int md = s_dep[a];
+            double mv = s_val[a];
+            for (int b = a + 1; b < n; ++b) {
+                if (b > a + 1 && s_dep[b - 1] < md) {
+                    md = s_dep[b - 1];
+                    mv = s_val[b - 1];
+                }
+                if (md == 0) break;  // the root separates a from every later leaf
+                const int tb = s_tax[b];
+                double sum;
+                {
+#pragma clang fp contract(off)
+                    const double add = mv * wt;  // rounded on its own, never fused into the add
+                    sum = w0[ta][tb] + add;
+                }
+                w0[ta][tb] = sum;
+                w0[tb][ta] = sum;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- contraction: vertex g = taxa [gs[g], gs[g+1]); weight = max over member pairs
+    // (reference: scs.py:336-387), diagonal 0
+    for (int e = tid; e < v * v; e += 256) {
+        const int g = e / v, h = e - g * v;
+        double best = 0.0;
+        if (g != h) {
+            best = w0[s_gs[g]][s_gs[h]];
+            for (int r = s_gs[g]; r < s_gs[g + 1]; ++r)
+                for (int c = s_gs[h]; c < s_gs[h + 1]; ++c) best = w0[r][c] > best ? w0[r][c] : best;
+        }
+        s.a[g][h] = best;
+    }
+    __syncthreads();
+    if (p.w_out)
+        for (int e = tid; e < v * v; e += 256) p.w_out[p.w_ptr[k] + e] = s.a[e / v][e % v];
+    // ---- degrees as scipy takes them (column sums, rows in order; isolated -> 1)
+    if (tid < v) {
+        double d = 0.0;
+        for (int i = 0; i < v; ++i) d = d + s.a[i][tid];
+        s_dd[tid] = d == 0.0 ? 1.0 : sqrt(d);
+    }
+    __syncthreads();
+    // S = (W / dd) / dd^T: two successive divisions (scipy/sparse/csgraph/_laplacian.py:552-557),
+    // then the symmetric part (the two orders of division may differ in the last bit)
+    double keep[(MAXS * MAXS + 255) / 256];
+    {
+        int q = 0;
+        for (int e = tid; e < v * v; e += 256, ++q) {
+            const int g = e / v, h = e - g * v;
+            const double x = (s.a[g][h] / s_dd[h]) / s_dd[g];
+            const double y = (s.a[h][g] / s_dd[g]) / s_dd[h];
+            keep[q] = g == h ? 0.0 : 0.5 * (x + y);
+        }
+        __syncthreads();
+        q = 0;
+        for (int e = tid; e < v * v; e += 256, ++q) s.a[e / v][e % v] = keep[q];
+    }
+    __syncthreads();
+    jacobi_eig(s, v);
+    // ---- embedding: unit eigenvectors / dd, largest |entry| of each column positive, column 0
+    // <-> the largest eigenvalue (sklearn/manifold/_spectral_embedding.py:373-376, 463)
+    if (tid < 2) {
+        const int col = s.perm[tid];
+        int arg = 0;
+        double best = -1.0;
+        for (int i = 0; i < v; ++i) {
+            const double x = fabs(s.e[i][col] / s_dd[i]);
+            if (x > best) {
+                best = x;
+                arg = i;
+            }
+        }
+        const double sg = s.e[arg][col] < 0.0 ? -1.0 : 1.0;
+        double *out = p.maps + (int64_t)p.vertex_ptr[k] * 2 + tid;
+        for (int i = 0; i < v; ++i) out[2 * i] = sg * (s.e[i][col] / s_dd[i]);
+    }
+    if (tid < 3) p.lambda[k * 3 + tid] = tid < v ? s.w[tid] : 0.0;
+}
+
+extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
+                               const int32_t *n_trees, const int32_t *n_groups,
+                               const int32_t *tree_off, const int32_t *leaf_taxon,
+                               const int32_t *adj_depth, const double *adj_val,
+                               const double *tree_w, const int32_t *group_start, double *maps_out,
+                               double *lambda_out, double *w_out) {
+    SCS_REQUIRE(ctx && n_taxa && n_trees && n_groups && tree_off && leaf_taxon && adj_depth &&
+                    adj_val && tree_w && group_start && maps_out && lambda_out,
+                "scs_small_solve: null argument");
+    SCS_REQUIRE(n_nodes >= 1, "scs_small_solve: need at least one node");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int K = n_nodes;
+    // ---- layout of the one staging block: [pointers | tree_off | group_start | leaf arrays |
+    // tree_w], 8-byte aligned pieces
+    std::vector<int32_t> tree_ptr(K + 1, 0), vertex_ptr(K + 1, 0);
+    std::vector<int64_t> leaf_ptr(K + 1, 0), w_ptr(K + 1, 0);
+    int64_t toff_at = 0;
+    for (int k = 0; k < K; ++k) {
+        SCS_REQUIRE(n_taxa[k] >= 2 && n_taxa[k] <= MAXS, "scs_small_solve: node %d has %d taxa (2..%d)",
+                    k, n_taxa[k], MAXS);
+        SCS_REQUIRE(n_groups[k] >= 2 && n_groups[k] <= n_taxa[k], "scs_small_solve: node %d: bad group count %d",
+                    k, n_groups[k]);
+        SCS_REQUIRE(n_trees[k] >= 1, "scs_small_solve: node %d has no tree", k);
+        const int32_t *to = tree_off + toff_at;
+        SCS_REQUIRE(to[0] == 0, "scs_small_solve: node %d: tree_off must start at 0", k);
+        for (int t = 0; t < n_trees[k]; ++t)
+            SCS_REQUIRE(to[t + 1] >= to[t] && to[t + 1] - to[t] <= n_taxa[k],
+                        "scs_small_solve: node %d tree %d: bad leaf range", k, t);
+        const int32_t *gs = group_start + vertex_ptr[k] + k;
+        SCS_REQUIRE(gs[0] == 0 && gs[n_groups[k]] == n_taxa[k], "scs_small_solve: node %d: group_start must span the taxa", k);
+        for (int g = 0; g < n_groups[k]; ++g)
+            SCS_REQUIRE(gs[g] < gs[g + 1], "scs_small_solve: node %d: empty group %d", k, g);
+        tree_ptr[k + 1] = tree_ptr[k] + n_trees[k];
+        leaf_ptr[k + 1] = leaf_ptr[k] + to[n_trees[k]];
+        vertex_ptr[k + 1] = vertex_ptr[k] + n_groups[k];
+        w_ptr[k + 1] = w_ptr[k] + (int64_t)n_groups[k] * n_groups[k];
+        toff_at += n_trees[k] + 1;
+    }
+    const int64_t n_toff = toff_at, n_gs = vertex_ptr[K] + K, n_leaf = leaf_ptr[K], n_tree = tree_ptr[K];
+    auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+    size_t at = 0;
+    const size_t o_nt = at; at += up8((size_t)K * 4);
+    const size_t o_nm = at; at += up8((size_t)K * 4);
+    const size_t o_ng = at; at += up8((size_t)K * 4);
+    const size_t o_tp = at; at += up8((size_t)(K + 1) * 4);
+    const size_t o_vp = at; at += up8((size_t)(K + 1) * 4);
+    const size_t o_lp = at; at += (size_t)(K + 1) * 8;
+    const size_t o_wp = at; at += (size_t)(K + 1) * 8;
+    const size_t o_to = at; at += up8((size_t)n_toff * 4);
+    const size_t o_gs = at; at += up8((size_t)n_gs * 4);
+    const size_t o_lt = at; at += up8((size_t)n_leaf * 4);
+    const size_t o_ad = at; at += up8((size_t)n_leaf * 4);
+    const size_t o_av = at; at += (size_t)n_leaf * 8;
+    const size_t o_tw = at; at += (size_t)n_tree * 8;
+    const size_t in_bytes = at;
+    const size_t o_maps = at; at += (size_t)vertex_ptr[K] * 16;
+    const size_t o_lam = at; at += (size_t)K * 24;
+    const size_t o_w = at; if (w_out) at += (size_t)w_ptr[K] * 8;
+    const size_t total = at;
+    if (ctx->small_cap < total) {
+        if (ctx->small_dev) hipFree(ctx->small_dev);
+        if (ctx->small_host) hipHostFree(ctx->small_host);
+        ctx->small_dev = nullptr;
+        ctx->small_host = nullptr;
+        ctx->small_cap = 0;
+        const size_t cap = std::max<size_t>(total * 2, (size_t)1 << 20);
+        SCS_HIP_CHECK(hipMalloc((void **)&ctx->small_dev, cap));
+        SCS_HIP_CHECK(hipHostMalloc((void **)&ctx->small_host, cap, hipHostMallocDefault));
+        ctx->small_cap = cap;
+    }
+    unsigned char *h = ctx->small_host, *d = ctx->small_dev;
+    memcpy(h + o_nt, n_taxa, (size_t)K * 4);
+    memcpy(h + o_nm, n_trees, (size_t)K * 4);
+    memcpy(h + o_ng, n_groups, (size_t)K * 4);
+    memcpy(h + o_tp, tree_ptr.data(), (size_t)(K + 1) * 4);
+    memcpy(h + o_vp, vertex_ptr.data(), (size_t)(K + 1) * 4);
+    memcpy(h + o_lp, leaf_ptr.data(), (size_t)(K + 1) * 8);
+    memcpy(h + o_wp, w_ptr.data(), (size_t)(K + 1) * 8);
+    memcpy(h + o_to, tree_off, (size_t)n_toff * 4);
+    memcpy(h + o_gs, group_start, (size_t)n_gs * 4);
+    memcpy(h + o_lt, leaf_taxon, (size_t)n_leaf * 4);
+    memcpy(h + o_ad, adj_depth, (size_t)n_leaf * 4);
+    memcpy(h + o_av, adj_val, (size_t)n_leaf * 8);
+    memcpy(h + o_tw, tree_w, (size_t)n_tree * 8);
+    SCS_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    small_batch sb;
+    sb.n_taxa = (const int32_t *)(d + o_nt);
+    sb.n_trees = (const int32_t *)(d + o_nm);
+    sb.n_groups = (const int32_t *)(d + o_ng);
+    sb.tree_ptr = (const int32_t *)(d + o_tp);
+    sb.vertex_ptr = (const int32_t *)(d + o_vp);
+    sb.leaf_ptr = (const int64_t *)(d + o_lp);
+    sb.w_ptr = (const int64_t *)(d + o_wp);
+    sb.tree_off = (const int32_t *)(d + o_to);
+    sb.group_start = (const int32_t *)(d + o_gs);
+    sb.leaf_taxon = (const int32_t *)(d + o_lt);
+    sb.adj_depth = (const int32_t *)(d + o_ad);
+    sb.adj_val = (const double *)(d + o_av);
+    sb.tree_w = (const double *)(d + o_tw);
+    sb.maps = (double *)(d + o_maps);
+    sb.lambda = (double *)(d + o_lam);
+    sb.w_out = w_out ? (double *)(d + o_w) : nullptr;
+    k_small_nodes<<<K, 256, 0, s>>>(sb);
+    SCS_HIP_CHECK(hipGetLastError());
+    SCS_HIP_CHECK(hipMemcpyAsync(h + o_maps, d + o_maps, total - o_maps, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(maps_out, h + o_maps, (size_t)vertex_ptr[K] * 16);
+    memcpy(lambda_out, h + o_lam, (size_t)K * 24);
+    if (w_out) memcpy(w_out, h + o_w, (size_t)w_ptr[K] * 8);
+    return SCS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // debug entry points (parity tests of the building blocks)
 // ---------------------------------------------------------------------------
 extern "C" int scs_debug_jacobi(scs_ctx *ctx, const double *a, int32_t n, double *w, double *v) {

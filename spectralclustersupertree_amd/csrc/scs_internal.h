@@ -91,6 +91,10 @@ struct scs_ctx {
     // matrix; the recursion makes thousands of small ones).  One buffer at most.
     double *w_cache = nullptr;
     size_t w_cache_bytes = 0;
+    // staging of scs_small_solve (one pinned host block, one device block), grown on demand
+    unsigned char *small_host = nullptr;
+    unsigned char *small_dev = nullptr;
+    size_t small_cap = 0;
 };
 
 struct scs_tables {

@@ -151,6 +151,7 @@ def spectral_bipartition_device(
     max_iter: int = DEFAULT_MAX_ITER,
     block: int = 0,
     report: dict | None = None,
+    presolved=None,
 ):
     """One recursion node's device work: build, contract, Fiedler, labels.
 
@@ -163,19 +164,21 @@ def spectral_bipartition_device(
     W row-partitioned on group-aligned splits, the upper-triangle tiles shared, one RCCL
     all-gather of the Krylov block per iteration; every rank receives the whole embedding and
     draws the same labels.  Smaller nodes run on the rank's own single-device context.
-    """
-    from sklearn.cluster import k_means
 
+    A node of at most 64 taxa goes through ``scs_small_solve`` (one fused launch);
+    ``presolved`` carries the embedding of a node whose device work was already done in a
+    batch with its siblings (``_construct``).
+    """
     n = tables.n_taxa
-    if contract_edges:
-        groups = fl.contraction_groups(tables)
-    else:
-        groups = np.arange(n, dtype=np.int32)
-    n_groups = int(groups.max()) + 1
-    if n_groups < n:
-        work, perm, group_start = relabel_for_contraction(tables, groups)
-    else:
-        work, perm, group_start = tables, np.arange(n, dtype=np.int32), None
+    if presolved is not None:
+        work, perm, group_start, n_groups, maps = presolved
+        # the reference's ARPACK start vector is still the first draw from the stream
+        random_state.uniform(-1, 1, n_groups)
+        if report is not None:
+            report.update({"n_vertices": n_groups, "block": 0, "presolved": True})
+        return _labels_and_members(maps, random_state, n, perm, group_start, n_groups)
+
+    work, perm, group_start, n_groups = prepare_node(tables, contract_edges)
 
     sharded = team is not None and team.world > 1 and n_groups >= team.shard_min
     splits = None
@@ -192,6 +195,18 @@ def spectral_bipartition_device(
         dev = team.solo
     else:
         dev = device or default_device()
+
+    if not sharded and n <= dev.SMALL_MAX_TAXA and tol == DEFAULT_TOL and block == 0 and _small_path():
+        # a small node: tables -> W -> contraction -> Jacobi -> embedding in ONE launch
+        # (scs_small_solve)
+        v0 = random_state.uniform(-1, 1, n_groups)  # the stream position of the reference
+        del v0
+        maps, lam = dev.small_solve([(work, group_start)])[0]
+        if report is not None:
+            report.update({"n_vertices": n_groups, "block": 0, "iterations": 0, "converged": 1,
+                           "lambda": [float(lam[0]), float(lam[1])], "lambda_next": float(lam[2]),
+                           "sharded": False, "splits": None, "small_path": True})
+        return _labels_and_members(maps, random_state, n, perm, group_start, n_groups)
 
     dtab = dev.upload(work)
     try:
@@ -214,8 +229,39 @@ def spectral_bipartition_device(
             report["splits"] = splits
     finally:
         graph.free()
-    _, labels, _ = k_means(maps, 2, random_state=random_state, n_init=10, verbose=False)
+    return _labels_and_members(maps, random_state, n, perm, group_start, n_groups)
 
+
+def _small_path() -> bool:
+    """SCS_NO_SMALL_PATH=1 (diagnostic) sends small nodes through the general per-node path
+    (tables upload, build, contract, solve) instead of ``scs_small_solve``."""
+    import os
+
+    return not int(os.environ.get("SCS_NO_SMALL_PATH", "0") or 0)
+
+
+def prepare_node(tables: fl.TreeTables, contract_edges: bool):
+    """Contraction groups of a node and its tables renumbered so that every group is a
+    consecutive id range: ``(work, perm, group_start or None, n_groups)``."""
+    n = tables.n_taxa
+    if contract_edges:
+        groups = fl.contraction_groups(tables)
+    else:
+        groups = np.arange(n, dtype=np.int32)
+    n_groups = int(groups.max()) + 1
+    if n_groups < n:
+        work, perm, group_start = relabel_for_contraction(tables, groups)
+    else:
+        work, perm, group_start = tables, np.arange(n, dtype=np.int32), None
+    return work, perm, group_start, n_groups
+
+
+def _labels_and_members(maps, random_state, n, perm, group_start, n_groups):
+    """k_means on the embedding exactly as ``SpectralClustering.fit`` calls it
+    (sklearn/cluster/_spectral.py:759-766), and the member taxa of every vertex."""
+    from sklearn.cluster import k_means
+
+    _, labels, _ = k_means(maps, 2, random_state=random_state, n_init=10, verbose=False)
     if group_start is None:
         members = [np.array([i], dtype=np.int32) for i in range(n)]
     else:
@@ -329,12 +375,18 @@ def _induce(names: set[str], trees, weights):
 
 
 def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
-               bipartition=None, team=None) -> TreeNode:
+               bipartition=None, team=None, pre=None) -> TreeNode:
     """One node of the recursion on flat tree arrays (reference: scs.py:96-174).
 
     Same decisions in the same order as the reference -- and therefore the same draws from
     ``random_state`` -- but the induced trees of a child problem come from
     ``TreeArrays.restrict`` instead of ``get_sub_tree`` on objects.
+
+    Siblings are scheduled together: once a node's parts are known, the
+    device work of every small single-component child (tables -> W -> contraction -> Jacobi ->
+    embedding, ``scs_small_solve``) runs as ONE batched launch; it depends on no random
+    draw, so each child later consumes the stream exactly where the reference does and only
+    finds its embedding ready (``pre``).
 
     ``team`` (several ranks walking together): nodes of at least ``team.shard_min`` vertices
     are solved collectively.  Below it, ``team.child_rng == "shared"`` has every rank solve
@@ -343,27 +395,30 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     RandomState forked from the parent's stream, and exchanges the subtrees.
     """
     given = bipartition  # a caller's own routine (tests) is handed down unchanged
-    if bipartition is None:
-        if team is not None:
-            def bipartition(tables, rs, *, contract_edges):
-                return spectral_bipartition_device(tables, rs, contract_edges=contract_edges, team=team)
-        else:
-            bipartition = spectral_bipartition_device
     names = arrays.taxa
     if arrays.n_trees == 1:  # reference: scs.py:96-98
         return arrays.to_tree(0)
 
-    present = arrays.present_taxa()
+    if pre is not None:
+        present, tables, comp, presolved = pre
+    else:
+        present = arrays.present_taxa()
+        if len(present) <= 2:
+            return tip_names_to_tree([names[int(i)] for i in present])
+        # a node numbers its taxa by sorted name: global ids are ranks of the sorted names
+        tables = arrays.flatten(pcg_weighting, local_ids=present)
+        comp = fl.pcg_components(tables)
+        presolved = None
     if len(present) <= 2:
         return tip_names_to_tree([names[int(i)] for i in present])
-
-    # a node numbers its taxa by sorted name: global ids are ranks of the sorted names
-    tables = arrays.flatten(pcg_weighting, local_ids=present)
-    comp = fl.pcg_components(tables)
     n_comp = int(comp.max()) + 1
 
     if n_comp == 1:
-        members, labels = bipartition(tables, random_state, contract_edges=contract_edges)
+        if given is not None:
+            members, labels = given(tables, random_state, contract_edges=contract_edges)
+        else:
+            members, labels = spectral_bipartition_device(tables, random_state, contract_edges=contract_edges,
+                                                          team=team, presolved=presolved)
         parts: list[list[int]] = [[], []]
         for ids, lab in zip(members, labels):
             parts[int(lab)].extend(int(present[int(i)]) for i in ids)
@@ -373,14 +428,14 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             parts[int(c)].append(int(present[i]))
 
     forked = (team is not None and team.world > 1 and team.child_rng == "forked")
-    child_trees: list = []
-    dealt: list[tuple[int, int, TreeArrays, np.random.RandomState]] = []  # (slot, owner, sub, rng)
+    # ---- the children: restriction first (host), then one batched launch for the small ones
+    children: list = []  # ("tips", names) | ("sub", component, sub, pre)
     for component in parts:
         if len(component) == 0:
             continue
         component = sorted(component)
         if len(component) <= 2:
-            child_trees.append(tip_names_to_tree([names[i] for i in component]))
+            children.append(("tips", component))
             continue
         sub = arrays.restrict(np.asarray(component, dtype=np.int32))
         if sub.n_trees == 0:
@@ -388,13 +443,25 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             # an empty list and raises (reference: scs.py:63-65 reached from :158)
             msg = "There must be at least one tree to make a supertree."
             raise ValueError(msg)
+        children.append(["sub", component, sub, None])
+    if given is None and not forked and _small_path():
+        _presolve_small_children(children, pcg_weighting, contract_edges, team)
+
+    child_trees: list = []
+    dealt: list[tuple[int, int, TreeArrays, np.random.RandomState]] = []  # (slot, owner, sub, rng)
+    for child in children:
+        if child[0] == "tips":
+            child_trees.append(tip_names_to_tree([names[i] for i in child[1]]))
+            continue
+        _, component, sub, child_pre = child
         if forked and len(component) < team.shard_min:
             # one sub-problem per device: its own stream, forked here, in order, on every rank
             rng = np.random.RandomState(random_state.randint(0, 2**31 - 1))
             dealt.append((len(child_trees), len(dealt) % team.world, sub, rng))
             child_trees.append(None)
         else:
-            child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, given, team))
+            child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, given, team,
+                                          child_pre))
         covered = set(int(i) for i in sub.present_taxa())
         child_trees.extend(TreeNode(names[i]) for i in component if i not in covered)
     if dealt:
@@ -407,6 +474,37 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             for slot, tree in part.items():
                 child_trees[slot] = tree
     return connect_trees(child_trees)
+
+
+def _presolve_small_children(children, pcg_weighting, contract_edges, team) -> None:
+    """Flatten every child problem, and run the device work of those that are one component of
+    at most 64 taxa as ONE ``scs_small_solve`` launch; fills the ``pre`` slot of each child
+    (present taxa, tables, components, embedding-or-None)."""
+    batch, where = [], []
+    for child in children:
+        if child[0] != "sub":
+            continue
+        sub = child[2]
+        if sub.n_trees == 1:
+            continue  # grafted as it is (reference: scs.py:96-98)
+        present = sub.present_taxa()
+        if len(present) <= 2:
+            child[3] = (present, None, None, None)
+            continue
+        tables = sub.flatten(pcg_weighting, local_ids=present)
+        comp = fl.pcg_components(tables)
+        child[3] = [present, tables, comp, None]
+        if int(comp.max()) == 0 and tables.n_taxa <= Device.SMALL_MAX_TAXA:
+            work, perm, group_start, n_groups = prepare_node(tables, contract_edges)
+            batch.append((work, group_start))
+            where.append((child, work, perm, group_start, n_groups))
+    if batch:  # (a recursion that never reaches the spectral step never touches the device)
+        dev = team.solo if team is not None else default_device()
+        for (child, work, perm, group_start, n_groups), (maps, _) in zip(where, dev.small_solve(batch)):
+            child[3][3] = (work, perm, group_start, n_groups, maps)
+    for child in children:
+        if child[0] == "sub" and isinstance(child[3], list):
+            child[3] = tuple(child[3])
 
 
 def _construct_objects(trees, weights, pcg_weighting, contract_edges, random_state,

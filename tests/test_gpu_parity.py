@@ -565,3 +565,89 @@ def test_reference_not_completed_end_to_end():
     case = NOT_COMPLETED_CASE
     trees = [make_tree(s) for s in case.trees] + [NotCompleted("ERROR", "local", "Example NotCompleted")]
     _scs(trees, make_tree(case.expected), weights=case.weights)
+
+
+# ---------------------------------------------------------------------------
+# batched small nodes
+# ---------------------------------------------------------------------------
+def _supertriplets_spectral_nodes():
+    """Every node of the reference's supertriplets fixture at which the reference calls
+    SpectralClustering (47 of them, V = 100 ... 3), as (tables, group_start) in the
+    recursion's own numbering, by walking the recursion with the oracle's bipartition."""
+    from tests.test_treearrays import cpu_bipartition
+
+    from spectralclustersupertree_amd import scs
+    from spectralclustersupertree_amd.load import load_tree_arrays
+
+    name, src, exp, weighting = next(c for c in FILE_CASES if "supertriplets" in c[0])
+    nodes = []
+
+    def spy(tables, random_state, *, contract_edges):
+        groups = fl.contraction_groups(tables) if contract_edges else np.arange(tables.n_taxa, dtype=np.int32)
+        if int(groups.max()) + 1 < tables.n_taxa:
+            work, _, group_start = relabel_for_contraction(tables, groups)
+        else:
+            work, group_start = tables, None
+        nodes.append((work, group_start))
+        return cpu_bipartition(tables, random_state, contract_edges=contract_edges)
+
+    scs._construct(load_tree_arrays(DATA_DIR / src), weighting, True, np.random.RandomState(0), spy)
+    return nodes
+
+
+def test_small_solve_batch_matches_sklearn_on_the_supertriplets_nodes(dev):
+    import warnings
+
+    nodes = _supertriplets_spectral_nodes()
+    assert len(nodes) == 47
+    small = [nd for nd in nodes if nd[0].n_taxa <= dev.SMALL_MAX_TAXA]
+    assert len(small) >= 40
+    out = dev.small_solve(small, want_w=True)
+    worst = 0.0
+    for (tables, gs), (maps, lam, w) in zip(small, out):
+        w_ref, _ = to.pcg_dense(tables)
+        if gs is not None:
+            w_ref = to.contract_dense(w_ref, gs)
+        assert np.array_equal(w, w_ref)  # W bit-exact, contraction included
+        s_ref, _ = to.normalized_operator(w_ref)
+        ev = np.sort(np.linalg.eigvalsh(s_ref))[::-1]
+        assert np.max(np.abs(lam[: min(3, len(ev))] - ev[:3])) <= 1e-12
+        if len(ev) > 2 and ev[1] - ev[2] < 1e-6:
+            continue  # repeated lambda2: only the partition is defined, covered end to end
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+        # the sign rule is ill-defined when the two largest |entries| tie: accept either sign
+        for c in range(2):
+            err = float(np.max(np.abs(maps[:, c] - ref[:, c])))
+            mags = np.sort(np.abs(ref[:, c]))[::-1]
+            if mags[0] - mags[1] <= 1e-9 * mags[0]:
+                err = min(err, float(np.max(np.abs(maps[:, c] + ref[:, c]))))
+            worst = max(worst, err)
+            assert err <= FIEDLER_TOL, (tables.n_taxa, c, err)
+    print("SMALL BATCH nodes", len(small), "worst |maps - sklearn|", worst)
+
+
+def test_small_solve_equals_the_per_node_path(dev):
+    # the fused kernel against build + contract + fiedler on the same nodes, one at a time
+    rs = np.random.RandomState(4)
+    nodes = []
+    for i in range(12):
+        n = int(rs.randint(3, 65))
+        nodes.append((synthetic.make_tables(500 + i, n, int(rs.randint(2, 30)), ["one", "depth", "branch", "bootstrap"][i % 4],
+                                            leaves_per_tree=max(2, n - int(rs.randint(0, 3))),
+                                            random_weights=bool(i % 2)), None))
+    out = dev.small_solve(nodes, want_w=True)
+    for (tables, _), (maps, lam, w) in zip(nodes, out):
+        dtab = dev.upload(tables)
+        g = dtab.build()
+        assert np.array_equal(g.download(), w)
+        ref, stats = g.fiedler(None)
+        g.free()
+        dtab.free()
+        deg = w.sum(axis=0)
+        s_ref, _ = to.normalized_operator(w)
+        ev = np.sort(np.linalg.eigvalsh(s_ref))[::-1]
+        if np.all(deg > 0) and len(ev) > 2 and ev[1] - ev[2] > 1e-6 and ev[0] - ev[1] > 1e-6:
+            assert np.max(np.abs(maps - ref)) <= FIEDLER_TOL, tables.n_taxa
+        assert abs(lam[1] - stats["lambda"][1]) <= 1e-12

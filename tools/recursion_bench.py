@@ -27,14 +27,25 @@ device_s = [0.0]
 calls = [0]
 sizes = []
 real = scs.spectral_bipartition_device
+real_presolve = scs._presolve_small_children
+presolve_s = [0.0]
 
-def timed(tables, rs, *, contract_edges):
+def timed(tables, rs, *, contract_edges, **kw):
     t0 = time.perf_counter()
-    out = real(tables, rs, contract_edges=contract_edges)
+    out = real(tables, rs, contract_edges=contract_edges, **kw)
     device_s[0] += time.perf_counter() - t0
     calls[0] += 1
     sizes.append(tables.n_taxa)
     return out
+
+def timed_presolve(*a, **kw):
+    t0 = time.perf_counter()
+    real_presolve(*a, **kw)
+    presolve_s[0] += time.perf_counter() - t0
+
+# the product path: no hook handed down (the recursion then batches the small siblings)
+scs.spectral_bipartition_device = timed
+scs._presolve_small_children = timed_presolve
 
 warnings.simplefilter("ignore")
 scs.default_device()  # context creation outside the timings
@@ -44,13 +55,17 @@ names = sorted(scs._all_tip_names(trees))
 arrays = TreeArrays.from_trees(trees, weights, names)
 t_conv = time.perf_counter() - t0
 t0 = time.perf_counter()
-got = scs._construct(arrays, args.strategy, True, np.random.RandomState(0), timed)
+got = scs._construct(arrays, args.strategy, True, np.random.RandomState(0))
 t_arr = time.perf_counter() - t0
 res["arrays"] = {"total_s": round(t_arr + t_conv, 3), "convert_once_s": round(t_conv, 3),
                  "device_calls": calls[0], "in_bipartition_s": round(device_s[0], 3),
-                 "host_recursion_s": round(t_arr - device_s[0], 3), "largest_problems": sorted(sizes, reverse=True)[:5]}
+                 "presolve_batches_s": round(presolve_s[0], 3),
+                 "per_node_ms": round(1e3 * (device_s[0] + presolve_s[0]) / max(calls[0], 1), 3),
+                 "host_recursion_s": round(t_arr - device_s[0] - presolve_s[0], 3),
+                 "small_path": scs._small_path(), "largest_problems": sorted(sizes, reverse=True)[:5]}
 if not args.skip_objects:
     device_s[0], calls[0] = 0.0, 0
+    scs.spectral_bipartition_device = real
     t0 = time.perf_counter()
     want = scs._construct_objects(trees, weights, args.strategy, True, np.random.RandomState(0), timed)
     t_obj = time.perf_counter() - t0
