@@ -17,6 +17,7 @@
 
 #include "scs_internal.h"
 #include "scs_symm.h"
+#include "scs_symm_tri.h"
 #include "scs_panel.h"
 
 constexpr int MAXB = 16;      // widest LOBPCG block
@@ -1037,9 +1038,41 @@ struct solver {
 
     int last_nseg = 1;  // column segments of the most recent k_symm launch
 
+    // symmetric schedule (k_symm_tri): the whole matrix on this device, streamed by upper tiles
+    bool tri = false;
+    int tri_ct = 2, tri_nct = 0, tri_ntiles = 0;
+    dbuf tri_tiles, tri_pdir, tri_ptr;
+    double w_bytes_per_apply = 0.0;  // bytes of W one application streams
+
+    int launch_symm_tri(const double *zin, double *yout) {
+        const int tw = tri_ct * 128;
+#define TRI(B_, CT_, RPW_, D_)                                                                       \
+    k_symm_tri<B_, CT_, RPW_, D_><<<tri_ntiles, 256, 0, s>>>(g->d_w, g->ld, n, zin,                  \
+                                                             (const int2 *)tri_tiles.p, tri_pdir.d(), \
+                                                             tri_ptr.d())
+        if (b == 4) {
+            if (tri_ct == 4) TRI(4, 4, 2, 3);
+            else if (tri_ct == 1) TRI(4, 1, 4, 4);
+            else TRI(4, 2, 4, 3);
+        } else {
+            if (tri_ct == 1) TRI(8, 1, 2, 6);
+            else TRI(8, 2, 2, 4);
+        }
+#undef TRI
+        SCS_HIP_CHECK(hipGetLastError());
+        // one segment: scaled into yout, or unscaled into ypart for k_gram_qaq to fold in
+        k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), tri_ptr.d(), n, b, tw, tri_nct,
+                                                              yout ? g->d_dinv : nullptr,
+                                                              yout ? yout : ypart.d());
+        SCS_HIP_CHECK(hipGetLastError());
+        last_nseg = 1;
+        return SCS_OK;
+    }
+
     // yout (rows x b) = dinv (.) (W_local * Z), Z given k-major in zin (b x ld);
     // yout == null leaves the column segments in ypart for the caller to combine
     int launch_symm(const double *zin, double *yout) {
+        if (tri) return launch_symm_tri(zin, yout);
         const int64_t ld = g->ld;
         int rpw = 4, sdepth = 2;
         if (b == 16) rpw = 2;
@@ -1086,6 +1119,29 @@ struct solver {
         SCS_TRY(ypart.alloc(ypart_cap * 8));
         SCS_TRY(z.alloc((size_t)b * g->ld * 8));
         SCS_HIP_CHECK(hipMemsetAsync(z.p, 0, (size_t)b * g->ld * 8, s));
+        w_bytes_per_apply = 8.0 * rows * (double)n;
+        // W is symmetric: with all of it on this device only the tiles on and above the
+        // diagonal need streaming (small matrices keep k_symm, whose column segments fill the
+        // chip better).  SCS_NO_TRI=1 keeps the full stream.
+        static const bool no_tri = getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"));
+        tri = !no_tri && world == 1 && rows == n && g->row_begin == 0 && n >= 4096 && (b == 4 || b == 8);
+        if (tri) {
+            if (getenv("SCS_TRI_CT")) tri_ct = atoi(getenv("SCS_TRI_CT"));
+            const int tw = tri_ct * 128;
+            const int n_rb = (n + TRI_TH - 1) / TRI_TH;
+            tri_nct = (n + tw - 1) / tw;
+            std::vector<int2> tiles;
+            for (int i = 0; i < n_rb; ++i)
+                for (int j = i * TRI_TH / tw; j < tri_nct; ++j) tiles.push_back(make_int2(i, j));
+            tri_ntiles = (int)tiles.size();
+            SCS_TRY(tri_tiles.alloc(tiles.size() * sizeof(int2)));
+            SCS_HIP_CHECK(hipMemcpyAsync(tri_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
+                                         hipMemcpyHostToDevice, s));
+            SCS_HIP_CHECK(hipStreamSynchronize(s));  // `tiles` goes out of scope
+            SCS_TRY(tri_pdir.alloc((size_t)tri_nct * n * b * 8));
+            SCS_TRY(tri_ptr.alloc((size_t)n_rb * n * b * 8));
+            w_bytes_per_apply = 8.0 * (double)tri_ntiles * TRI_TH * tw;
+        }
         return SCS_OK;
     }
 
@@ -1638,7 +1694,9 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     if (n_timed > 0) tot *= (double)sv.n_apply / n_timed;
     st->apply_ms_total = tot;
     st->apply_ms_min = sv.n_apply ? mn : 0.0;
-    st->apply_bytes = 8.0 * sv.rows * (double)n + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;
+    // W bytes one application streams (all of this rank's rows, or the upper tiles of the
+    // symmetric schedule) + the block in and out
+    st->apply_bytes = sv.w_bytes_per_apply + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;
     if (!converged) {
         // maps_out and stats are filled: the caller decides whether the block is usable
         scs_set_error("scs_fiedler: residual %.3e above tol %.3e after %d iterations (V = %d, block %d)",
