@@ -76,6 +76,7 @@ typedef struct scs_build_stats {
     double total_ms;            /* whole call, device time                           */
     double bytes_w;             /* algorithmic bytes: W written once (8 * rows * V)  */
     double bytes_tables;        /* algorithmic bytes: tables read once               */
+    double exchange_bytes;      /* shared build: bytes of packed tiles this rank received */
 } scs_build_stats;
 
 int scs_version(void);
@@ -142,8 +143,11 @@ int scs_tables_free(scs_ctx *ctx, scs_tables *tables);
  * off-diagonal cell twice across the job -- the ranks split the upper-triangle
  * tiles of the whole matrix round-robin, all-gather the packed tiles and unpack
  * their own rows (direct cells and mirror images).  Same bits, half the
- * evaluations, one exchange of ~4 V^2 bytes per rank; falls back to the plain row
- * build when the packed triangle would exceed 96 GiB.  stats may be NULL. */
+ * evaluations.  The exchange is point to point: a tile travels only to the ranks whose rows
+ * it touches (one grouped round of RCCL send/recv, ~8 V^2 / world bytes received per rank;
+ * SCS_EXCHANGE=allgather selects one all-gather of the whole packed triangle instead).  Falls
+ * back to the plain row build when the packed triangle would exceed 96 GiB.  stats may be
+ * NULL. */
 #define SCS_BUILD_MONOTONE 1
 #define SCS_BUILD_SHARED 2
 int scs_pcg_build(scs_ctx *ctx, const scs_tables *tables, int32_t row_begin, int32_t row_end,

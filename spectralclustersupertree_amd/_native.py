@@ -82,6 +82,7 @@ class BuildStats(C.Structure):
         ("total_ms", C.c_double),
         ("bytes_w", C.c_double),
         ("bytes_tables", C.c_double),
+        ("exchange_bytes", C.c_double),
     ]
 
     def as_dict(self) -> dict:

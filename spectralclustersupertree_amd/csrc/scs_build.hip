@@ -439,6 +439,39 @@ __global__ __launch_bounds__(256) void k_unpack_tiles(const double *__restrict__
     }
 }
 
+// targeted exchange: copy the tiles a peer needs into its contiguous share of the send buffer
+// (entry e: slot src_slot[e] of this rank's packed tiles -> position e of the send buffer)
+__global__ __launch_bounds__(256) void k_pack_tiles(const double *__restrict__ tile_out,
+                                                    const int32_t *__restrict__ src_slot,
+                                                    double *__restrict__ sendbuf) {
+    const double2 *src = (const double2 *)(tile_out + (int64_t)src_slot[blockIdx.x] * SCS_TR * SCS_TCW);
+    double2 *dst = (double2 *)(sendbuf + (int64_t)blockIdx.x * SCS_TR * SCS_TCW);
+    for (int q = threadIdx.x; q < SCS_TR * SCS_TCW / 2; q += 256) dst[q] = src[q];
+}
+
+// received tiles (entry e of recvbuf is tile tiles[e]) -> this rank's rows of W: the cells of
+// a tile that fall into its rows and the mirror image of the cells whose COLUMN does
+__global__ __launch_bounds__(256) void k_unpack_received(const double *__restrict__ recvbuf,
+                                                         const int2 *__restrict__ tiles, int n,
+                                                         int row_begin, int row_end,
+                                                         double *__restrict__ w, int64_t ld) {
+    const int2 tile = tiles[blockIdx.x];
+    const double *src = recvbuf + (int64_t)blockIdx.x * SCS_TR * SCS_TCW;
+    const int c = tile.y * SCS_TCW + threadIdx.x;  // global column of this thread
+    if (c >= n) return;
+    const int r0 = tile.x * SCS_TR;
+    const bool col_is_my_row = c >= row_begin && c < row_end;
+    for (int i = 0; i < SCS_TR; ++i) {
+        const int r = r0 + i;
+        if (r >= n) break;
+        const double v = src[i * SCS_TCW + threadIdx.x];
+        if (r >= row_begin && r < row_end) w[(int64_t)(r - row_begin) * ld + c] = v;
+        // cell (c, r) has no tile of its own iff its column group ends at or before its row block
+        if (col_is_my_row && ((r / SCS_TCW) + 1) * SCS_TCW <= (c / SCS_TR) * SCS_TR)
+            w[(int64_t)(c - row_begin) * ld + r] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // contraction: consecutive index ranges -> one vertex, weight = max over members
 // ---------------------------------------------------------------------------
@@ -486,6 +519,16 @@ __global__ __launch_bounds__(256) void k_degrees(const double *__restrict__ w, i
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) deg_full[row_begin + r] = s;
+}
+
+// row-partitioned graphs: the gathered per-rank degree vectors (zero outside a rank's rows)
+__global__ void k_combine_degrees(const double *__restrict__ gathered, int world, int n,
+                                  double *__restrict__ deg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d = 0.0;
+    for (int r = 0; r < world; ++r) d += gathered[(int64_t)r * n + i];
+    deg[i] = d;
 }
 
 __global__ void k_dinv(const double *__restrict__ deg, int n, double *__restrict__ dinv) {
@@ -639,6 +682,33 @@ extern "C" int scs_graph_shape(const scs_graph *g, int32_t *n, int32_t *rb, int3
     return SCS_OK;
 }
 
+int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int32_t n,
+                          std::vector<int32_t> &splits) {
+    const int world = ctx->comm.world;
+    splits.assign(world + 1, 0);
+    if (world == 1) {
+        splits[0] = row_begin;
+        splits[1] = row_end;
+        return SCS_OK;
+    }
+    dev_buf send, recv;
+    SCS_TRY(send.alloc(8));
+    SCS_TRY(recv.alloc(8 * (size_t)world));
+    double v = (double)row_begin;
+    SCS_HIP_CHECK(hipMemcpyAsync(send.p, &v, 8, hipMemcpyHostToDevice, ctx->stream));
+    SCS_TRY(scs_comm_allgather_f64(&ctx->comm, (const double *)send.p, (double *)recv.p, 1, ctx->stream));
+    std::vector<double> h(world);
+    SCS_HIP_CHECK(hipMemcpyAsync(h.data(), recv.p, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < world; ++r) splits[r] = (int32_t)h[r];
+    splits[world] = n;
+    for (int r = 0; r < world; ++r)
+        SCS_REQUIRE(splits[r] < splits[r + 1], "row partition is not contiguous by rank");
+    SCS_REQUIRE(splits[0] == 0 && splits[ctx->comm.rank] == row_begin && splits[ctx->comm.rank + 1] == row_end,
+                "row partition does not tile [0, V)");
+    return SCS_OK;
+}
+
 extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_begin,
                              int32_t row_end, int32_t flags, scs_graph **out,
                              scs_build_stats *stats) {
@@ -728,6 +798,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     std::vector<int2> all_tiles;
     dev_buf d_all_tiles, d_tile_out, d_gathered;
     size_t chunk_doubles = 0;
+    // the exchange of a shared build: point to point by default, one all-gather on request
+    const bool exchange_allgather =
+        getenv("SCS_EXCHANGE") && std::string(getenv("SCS_EXCHANGE")) == "allgather";
     if (shared) {
         all_tiles.swap(tiles);
         for (size_t i = rank; i < all_tiles.size(); i += world) tiles.push_back(all_tiles[i]);
@@ -737,7 +810,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_HIP_CHECK(hipMemcpyAsync(d_all_tiles.p, all_tiles.data(),
                                      all_tiles.size() * sizeof(int2), hipMemcpyHostToDevice, s));
         SCS_TRY(d_tile_out.alloc(chunk_doubles * 8));
-        SCS_TRY(d_gathered.alloc(chunk_doubles * 8 * world));
+        if (exchange_allgather) SCS_TRY(d_gathered.alloc(chunk_doubles * 8 * world));
         if (tiles.size() < slots)  // the unused last slot is gathered too: keep it defined
             SCS_HIP_CHECK(hipMemsetAsync((double *)d_tile_out.p + (slots - 1) * SCS_TR * SCS_TCW,
                                          0, (size_t)SCS_TR * SCS_TCW * 8, s));
@@ -953,7 +1026,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         }
     }
     float exch_ms = 0.f;
-    if (shared) {
+    double exch_bytes = 0.0;
+    if (shared && exchange_allgather) {
         ev_pair ev_x;
         SCS_TRY(ev_x.init());
         SCS_HIP_CHECK(hipEventRecord(ev_x.a, s));
@@ -966,6 +1040,57 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_HIP_CHECK(hipEventRecord(ev_x.b, s));
         SCS_HIP_CHECK(hipEventSynchronize(ev_x.b));
         SCS_HIP_CHECK(hipEventElapsedTime(&exch_ms, ev_x.a, ev_x.b));
+        exch_bytes = (double)chunk_doubles * 8.0 * (world - 1);
+    } else if (shared) {
+        // ---- point-to-point exchange: a tile travels only to the ranks whose rows it touches
+        // (directly: its row block; mirrored: its columns).  Every rank derives the same plan
+        // from the job-wide tile list and the row splits.
+        std::vector<int32_t> splits;
+        SCS_TRY(scs_gather_row_splits(ctx, row_begin, row_end, n, splits));
+        auto needs = [&](int dst, const int2 &t) {
+            const int64_t lo = splits[dst], hi = splits[dst + 1];
+            const int64_t r_lo = (int64_t)t.x * SCS_TR, r_hi = std::min<int64_t>(r_lo + SCS_TR, n);
+            const int64_t c_lo = (int64_t)t.y * SCS_TCW, c_hi = std::min<int64_t>(c_lo + SCS_TCW, n);
+            return (r_lo < hi && lo < r_hi) || (c_lo < hi && lo < c_hi);
+        };
+        std::vector<int64_t> send_off(world + 1, 0), recv_off(world + 1, 0);
+        std::vector<int32_t> send_slots;  // per destination, in slot order
+        std::vector<int2> recv_tiles;     // per source, in the source's slot order
+        for (int p = 0; p < world; ++p) {
+            for (size_t i = rank; i < all_tiles.size(); i += world)
+                if (needs(p, all_tiles[i])) send_slots.push_back((int32_t)(i / world));
+            send_off[p + 1] = (int64_t)send_slots.size() * SCS_TR * SCS_TCW;
+            for (size_t i = p; i < all_tiles.size(); i += world)
+                if (needs(rank, all_tiles[i])) recv_tiles.push_back(all_tiles[i]);
+            recv_off[p + 1] = (int64_t)recv_tiles.size() * SCS_TR * SCS_TCW;
+        }
+        dev_buf d_send, d_recv, d_slots, d_rtiles;
+        SCS_TRY(d_send.alloc((size_t)send_off[world] * 8));
+        SCS_TRY(d_recv.alloc((size_t)recv_off[world] * 8));
+        SCS_TRY(d_slots.alloc(send_slots.size() * 4));
+        SCS_TRY(d_rtiles.alloc(recv_tiles.size() * sizeof(int2)));
+        ev_pair ev_x;
+        SCS_TRY(ev_x.init());
+        SCS_HIP_CHECK(hipEventRecord(ev_x.a, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(d_slots.p, send_slots.data(), send_slots.size() * 4,
+                                     hipMemcpyHostToDevice, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(d_rtiles.p, recv_tiles.data(), recv_tiles.size() * sizeof(int2),
+                                     hipMemcpyHostToDevice, s));
+        if (!send_slots.empty())
+            k_pack_tiles<<<(unsigned)send_slots.size(), 256, 0, s>>>(
+                (const double *)d_tile_out.p, (const int32_t *)d_slots.p, (double *)d_send.p);
+        SCS_HIP_CHECK(hipGetLastError());
+        SCS_TRY(scs_comm_alltoallv_f64(&ctx->comm, (const double *)d_send.p, send_off.data(),
+                                       (double *)d_recv.p, recv_off.data(), s));
+        if (!recv_tiles.empty())
+            k_unpack_received<<<(unsigned)recv_tiles.size(), SCS_TCW, 0, s>>>(
+                (const double *)d_recv.p, (const int2 *)d_rtiles.p, n, row_begin, row_end, g->d_w,
+                g->ld);
+        SCS_HIP_CHECK(hipGetLastError());
+        SCS_HIP_CHECK(hipEventRecord(ev_x.b, s));
+        SCS_HIP_CHECK(hipEventSynchronize(ev_x.b));  // (also keeps the host vectors alive long enough)
+        SCS_HIP_CHECK(hipEventElapsedTime(&exch_ms, ev_x.a, ev_x.b));
+        exch_bytes = (double)(recv_off[world] - (recv_off[rank + 1] - recv_off[rank])) * 8.0;
     }
     SCS_HIP_CHECK(hipEventRecord(ev_total.b, s));
     SCS_HIP_CHECK(hipEventSynchronize(ev_total.b));
@@ -984,6 +1109,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         stats->row_end = row_end;
         stats->symmetric = shared ? 2 : (sym ? 1 : 0);
         stats->exchange_ms = exch_ms;
+        stats->exchange_bytes = exch_bytes;
         stats->n_tiles = (int32_t)tiles.size();
         stats->n_batches = n_batches;
         stats->cell_trees = (double)tiles.size() * SCS_TR * cols_per_tile * (double)M;
@@ -1089,14 +1215,10 @@ int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
                                                  (double *)send.p);
         SCS_TRY(scs_comm_allgather_f64(&ctx->comm, (const double *)send.p, (double *)recv.p,
                                        (size_t)n, s));
-        std::vector<double> h((size_t)n * world), d((size_t)n, 0.0);
-        SCS_HIP_CHECK(hipMemcpyAsync(h.data(), recv.p, h.size() * 8, hipMemcpyDeviceToHost, s));
-        SCS_HIP_CHECK(hipStreamSynchronize(s));
-        for (int r = 0; r < world; ++r)
-            for (int i = 0; i < n; ++i)
-                if (h[(size_t)r * n + i] != 0.0) d[i] = h[(size_t)r * n + i];
-        SCS_HIP_CHECK(hipMemcpyAsync(g->d_deg, d.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
-        SCS_HIP_CHECK(hipStreamSynchronize(s));
+        // every index is non-zero in its owner's slice only: the sum in rank order is exact
+        k_combine_degrees<<<(n + 255) / 256, 256, 0, s>>>((const double *)recv.p, world, n, g->d_deg);
+        SCS_HIP_CHECK(hipGetLastError());
+        SCS_HIP_CHECK(hipStreamSynchronize(s));  // send / recv go out of scope
     }
     k_dinv<<<(n + 255) / 256, 256, 0, s>>>(g->d_deg, n, g->d_dinv);
     std::vector<double> deg((size_t)n);

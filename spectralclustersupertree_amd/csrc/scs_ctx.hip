@@ -47,6 +47,9 @@ typedef int (*fn_get_uid)(rccl_uid *);
 typedef int (*fn_init_rank)(void **, int, rccl_uid, int);
 typedef int (*fn_destroy)(void *);
 typedef int (*fn_allgather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_group)(void);
 typedef const char *(*fn_errstr)(int);
 
 struct rccl_api {
@@ -55,6 +58,9 @@ struct rccl_api {
     fn_init_rank init_rank = nullptr;
     fn_destroy destroy = nullptr;
     fn_allgather allgather = nullptr;
+    fn_send send = nullptr;
+    fn_recv recv = nullptr;
+    fn_group group_start = nullptr, group_end = nullptr;
     fn_errstr errstr = nullptr;
 };
 
@@ -78,6 +84,10 @@ int load_rccl() {
     g_rccl.init_rank = (fn_init_rank)dlsym(h, "ncclCommInitRank");
     g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
     g_rccl.allgather = (fn_allgather)dlsym(h, "ncclAllGather");
+    g_rccl.send = (fn_send)dlsym(h, "ncclSend");
+    g_rccl.recv = (fn_recv)dlsym(h, "ncclRecv");
+    g_rccl.group_start = (fn_group)dlsym(h, "ncclGroupStart");
+    g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
     if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allgather) {
         scs_set_error("librccl lacks an expected symbol");
@@ -132,6 +142,7 @@ struct scs_local_group {
     int arrived = 0;
     uint64_t generation = 0;
     std::vector<const double *> send;
+    std::vector<const int64_t *> send_off;  // all-to-all-v: every rank's offsets into its send buffer
     void barrier() {
         std::unique_lock<std::mutex> lock(m);
         uint64_t gen = generation;
@@ -151,6 +162,7 @@ extern "C" int scs_local_group_create(int world, scs_local_group **out) {
     auto *g = new scs_local_group();
     g->world = world;
     g->send.assign(world, nullptr);
+    g->send_off.assign(world, nullptr);
     *out = g;
     return SCS_OK;
 }
@@ -187,6 +199,75 @@ int scs_comm_allgather_f64(scs_comm *comm, const double *sendbuf, double *recvbu
                                      count * sizeof(double), hipMemcpyDeviceToDevice, stream));
     SCS_HIP_CHECK(hipStreamSynchronize(stream));
     g->barrier();
+    return SCS_OK;
+}
+
+// all-to-all-v of fp64: this rank sends doubles [send_off[p], send_off[p+1]) of sendbuf to
+// rank p and receives rank p's share for it at recvbuf + recv_off[p] (recv_off[p+1] -
+// recv_off[p] doubles, which must be what p sends).  Offsets are host arrays of world + 1.
+int scs_comm_alltoallv_f64(scs_comm *comm, const double *sendbuf, const int64_t *send_off,
+                           double *recvbuf, const int64_t *recv_off, hipStream_t stream) {
+    const int world = comm->world, rank = comm->rank;
+    if (world == 1 || comm->kind == 0) {
+        const int64_t cnt = send_off[1] - send_off[0];
+        if (cnt > 0)
+            SCS_HIP_CHECK(hipMemcpyAsync(recvbuf + recv_off[0], sendbuf + send_off[0], (size_t)cnt * 8,
+                                         hipMemcpyDeviceToDevice, stream));
+        return SCS_OK;
+    }
+    if (comm->kind == 1) {
+        if (!g_rccl.send || !g_rccl.recv || !g_rccl.group_start || !g_rccl.group_end) {
+            scs_set_error("librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+            return SCS_ECOMM;
+        }
+        // own share: a device copy; the peers: one grouped round of point-to-point transfers
+        // (xGMI is point to point: every pair has its own link)
+        const int64_t own = send_off[rank + 1] - send_off[rank];
+        if (own > 0)
+            SCS_HIP_CHECK(hipMemcpyAsync(recvbuf + recv_off[rank], sendbuf + send_off[rank],
+                                         (size_t)own * 8, hipMemcpyDeviceToDevice, stream));
+        int rc = g_rccl.group_start();
+        for (int p = 0; p < world && rc == 0; ++p) {
+            if (p == rank) continue;
+            const int64_t ns = send_off[p + 1] - send_off[p], nr = recv_off[p + 1] - recv_off[p];
+            if (ns > 0) rc = g_rccl.send(sendbuf + send_off[p], (size_t)ns, /*ncclFloat64*/ 8, p,
+                                         comm->rccl_comm, stream);
+            if (rc == 0 && nr > 0)
+                rc = g_rccl.recv(recvbuf + recv_off[p], (size_t)nr, /*ncclFloat64*/ 8, p,
+                                 comm->rccl_comm, stream);
+        }
+        const int rc_end = g_rccl.group_end();
+        if (rc == 0) rc = rc_end;
+        if (rc != 0) {
+            scs_set_error("RCCL send/recv exchange failed: %s", rccl_err(rc));
+            return SCS_ECOMM;
+        }
+        return SCS_OK;
+    }
+    // local group: publish, meet, pull every peer's share, meet again
+    scs_local_group *g = comm->group;
+    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    g->send[rank] = sendbuf;
+    g->send_off[rank] = send_off;
+    g->barrier();
+    int bad = 0;
+    for (int p = 0; p < world; ++p) {
+        const int64_t *po = g->send_off[p];
+        const int64_t cnt = po[rank + 1] - po[rank];
+        if (cnt != recv_off[p + 1] - recv_off[p]) {
+            bad = 1;
+            continue;
+        }
+        if (cnt > 0)
+            SCS_HIP_CHECK(hipMemcpyAsync(recvbuf + recv_off[p], g->send[p] + po[rank], (size_t)cnt * 8,
+                                         hipMemcpyDeviceToDevice, stream));
+    }
+    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    g->barrier();
+    if (bad) {
+        scs_set_error("all-to-all-v: a peer sends a different count than this rank expects");
+        return SCS_ECOMM;
+    }
     return SCS_OK;
 }
 

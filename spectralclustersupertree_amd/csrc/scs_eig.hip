@@ -1291,32 +1291,7 @@ void sign_flip_and_store(const std::vector<double> &col0, const std::vector<doub
 }  // namespace
 
 static int gather_full_rows(scs_ctx *ctx, scs_graph *g, std::vector<int32_t> &splits) {
-    // row splits of every rank (the partition is contiguous and ordered by rank)
-    const int world = ctx->comm.world;
-    splits.assign(world + 1, 0);
-    if (world == 1) {
-        splits[0] = g->row_begin;
-        splits[1] = g->row_end;
-        return SCS_OK;
-    }
-    dbuf send, recv;
-    SCS_TRY(send.alloc(8));
-    SCS_TRY(recv.alloc(8 * (size_t)world));
-    double v = (double)g->row_begin;
-    SCS_HIP_CHECK(hipMemcpyAsync(send.p, &v, 8, hipMemcpyHostToDevice, ctx->stream));
-    SCS_TRY(scs_comm_allgather_f64(&ctx->comm, send.d(), recv.d(), 1, ctx->stream));
-    std::vector<double> h(world);
-    SCS_HIP_CHECK(hipMemcpyAsync(h.data(), recv.p, 8 * (size_t)world, hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    for (int r = 0; r < world; ++r) splits[r] = (int32_t)h[r];
-    splits[world] = g->n;
-    for (int r = 0; r < world; ++r)
-        SCS_REQUIRE(splits[r] < splits[r + 1], "row partition is not contiguous by rank");
-    SCS_REQUIRE(splits[0] == 0 && splits[ctx->comm.rank] == g->row_begin &&
-                    splits[ctx->comm.rank + 1] == g->row_end,
-                "row partition does not tile [0, V)");
-    return SCS_OK;
+    return scs_gather_row_splits(ctx, g->row_begin, g->row_end, g->n, splits);
 }
 
 // small-V path: dense S on the device, full Jacobi, top two eigenvectors

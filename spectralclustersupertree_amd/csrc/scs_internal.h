@@ -62,6 +62,9 @@ struct scs_comm {
 // world*count doubles (device pointers), enqueued on `stream`.
 int scs_comm_allgather_f64(scs_comm *comm, const double *sendbuf, double *recvbuf, size_t count,
                            hipStream_t stream);
+// all-to-all-v of fp64 (host offset arrays of world + 1, in doubles): see scs_ctx.hip
+int scs_comm_alltoallv_f64(scs_comm *comm, const double *sendbuf, const int64_t *send_off,
+                           double *recvbuf, const int64_t *recv_off, hipStream_t stream);
 int scs_comm_init_rccl(scs_comm *comm, int rank, int world, const void *uid);
 int scs_comm_destroy(scs_comm *comm);
 
@@ -128,6 +131,9 @@ struct scs_graph {
 
 // build.hip
 int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g);
+// row splits of every rank (contiguous, ordered by rank): collective, world + 1 entries
+int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int32_t n,
+                          std::vector<int32_t> &splits);
 
 // eig.hip helpers used by debug entry points are declared in scs_hip.h
 

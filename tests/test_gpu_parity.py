@@ -497,6 +497,26 @@ def test_multi_rank_row_partition_matches_single(dev, splits, shared, strategy):
         single.free()
 
 
+@pytest.mark.parametrize("mode", ["p2p", "allgather"])
+def test_shared_build_exchange_modes(dev, monkeypatch, mode):
+    # the point-to-point exchange (a tile goes only to the ranks whose rows it touches) and the
+    # all-gather of the whole packed triangle give the same rows; the former moves fewer bytes
+    if mode == "allgather":
+        monkeypatch.setenv("SCS_EXCHANGE", "allgather")
+    tables = synthetic.make_tables(31, 1500, 8, "branch", leaves_per_tree=1400)
+    w_ref, _ = to.pcg_dense(tables)
+    splits = [0, 320, 700, 1100, 1500]
+    out = _run_local_group(tables, splits, True, None)
+    assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
+    received = [o[3]["exchange_bytes"] for o in out]
+    n_tiles_all = sum(o[3]["n_tiles"] for o in out)
+    tile_bytes = 64 * 256 * 8
+    if mode == "allgather":
+        assert all(rb >= 0.7 * n_tiles_all * tile_bytes for rb in received)
+    else:
+        assert all(0 < rb < 0.75 * n_tiles_all * tile_bytes for rb in received), received
+
+
 def test_shared_build_multi_batch(dev, monkeypatch):
     # a workspace small enough to force several tree batches: the packed tiles carry the
     # running sums between batches
