@@ -1,0 +1,44 @@
+"""``scs`` command line front-end with the reference's options
+(reference: src/sc_supertree/cli.py:8-39): default weighting ``branch`` (the library call
+defaults to ``one``), no tree weights, no seed.  The source trees are read straight into flat
+arrays by the C Newick loader -- no tree object is built for the input."""
+
+from __future__ import annotations
+
+import click
+
+from spectralclustersupertree_amd import __version__
+
+
+@click.command(no_args_is_help=True)
+@click.version_option(__version__)
+@click.option("-i", "--in-file", required=True, help="File containing source trees.")
+@click.option("-o", "--out-file", required=True, help="Output file.")
+@click.option(
+    "-p",
+    "--pcg-weighting",
+    help="Proper cluster graph weighting strategy.",
+    default="branch",
+    type=click.Choice(["one", "depth", "branch", "bootstrap"], case_sensitive=False),
+)
+@click.option(
+    "--disable-contraction",
+    help="Disable edge contraction (not recommended).",
+    default=False,
+    is_flag=True,
+)
+def scs(in_file: str, out_file: str, pcg_weighting: str, *, disable_contraction: bool) -> None:
+    """Run spectral cluster supertree over the given set of source trees."""
+    from spectralclustersupertree_amd import construct_supertree
+    from spectralclustersupertree_amd.load import load_tree_arrays
+
+    supertree = construct_supertree(
+        load_tree_arrays(in_file),
+        pcg_weighting=pcg_weighting.lower(),
+        contract_edges=not disable_contraction,
+    )
+    supertree.write(out_file)
+
+
+if __name__ == "__main__":
+    scs()

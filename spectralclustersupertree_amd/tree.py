@@ -219,6 +219,52 @@ class TreeNode:
         """Same rooted topology over the same tip names (branch data ignored)."""
         return self._shape_key() == other._shape_key()
 
+    def rooted(self, edge_name: str) -> "TreeNode":
+        """A copy re-rooted on the branch above the node named ``edge_name`` (outgroup
+        rooting, as cogent3's ``PhyloNode.rooted``): the new root has that node and the rest of
+        the tree as its two children; the old root, left with one child, is spliced out."""
+        new = self.copy()
+        target = None
+        stack = [new]
+        while stack:
+            node = stack.pop()
+            if node.name == edge_name and node is not new:
+                target = node
+                break
+            stack.extend(node.children)
+        if target is None:
+            msg = f"no node named {edge_name!r} below the root"
+            raise ValueError(msg)
+        if target.parent is new and len(new.children) == 2:
+            return new  # already rooted on that branch
+        # reverse the parent links on the path from the target's parent up to the old root
+        half = None if target.length is None else target.length / 2
+        root = TreeNode(None, None, None, None)
+        up, up_len = target.parent, half
+        up.children.remove(target)
+        target.parent = None
+        target.length = half
+        root.append(target)
+        prev = root
+        while up is not None:
+            nxt, nxt_len = up.parent, up.length
+            if nxt is not None:
+                nxt.children.remove(up)
+            up.parent = None
+            up.length = up_len
+            prev.append(up)
+            prev, up, up_len = up, nxt, nxt_len
+        # the old root may be left with a single child: splice it out
+        if len(prev.children) == 1 and prev is not root:
+            only = prev.children[0]
+            parent = prev.parent
+            idx = parent.children.index(prev)
+            if only.length is not None or prev.length is not None:
+                only.length = (only.length or 0.0) + (prev.length or 0.0)
+            only.parent = parent
+            parent.children[idx] = only
+        return root
+
     # -- Newick ------------------------------------------------------------
     def get_newick(self, with_distances: bool = False, with_node_names: bool = False) -> str:
         pieces: dict[int, str] = {}
