@@ -358,6 +358,63 @@ extern "C" int scs_ctx_create_local(int device, int rank, scs_local_group *group
     return SCS_OK;
 }
 
+int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
+    if (bytes < 256) bytes = 256;
+    for (auto &b : ctx->blocks)
+        if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096) {
+            b.in_use = true;
+            *out = b.p;
+            return SCS_OK;
+        }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // make room: drop every free block (and the cached W buffer) and try once more
+        (void)hipGetLastError();
+        for (size_t i = 0; i < ctx->blocks.size();) {
+            if (!ctx->blocks[i].in_use) {
+                hipFree(ctx->blocks[i].p);
+                ctx->blocks.erase(ctx->blocks.begin() + i);
+            } else {
+                ++i;
+            }
+        }
+        if (ctx->w_cache) {
+            hipFree(ctx->w_cache);
+            ctx->w_cache = nullptr;
+            ctx->w_cache_bytes = 0;
+        }
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            scs_set_error("cannot allocate %zu bytes of device memory: %s", bytes, hipGetErrorString(e));
+            return SCS_ENOMEM;
+        }
+    }
+    ctx->blocks.push_back({p, bytes, true});
+    *out = p;
+    return SCS_OK;
+}
+
+void scs_block_release(scs_ctx *ctx, void *p) {
+    if (!p) return;
+    size_t free_bytes = 0;
+    for (auto &b : ctx->blocks) {
+        if (b.p == p) b.in_use = false;
+        if (!b.in_use) free_bytes += b.bytes;
+    }
+    // keep at most SCS_BLOCK_KEEP bytes of free blocks: release the largest ones first
+    while (free_bytes > SCS_BLOCK_KEEP) {
+        size_t pick = ctx->blocks.size();
+        for (size_t i = 0; i < ctx->blocks.size(); ++i)
+            if (!ctx->blocks[i].in_use && (pick == ctx->blocks.size() || ctx->blocks[i].bytes > ctx->blocks[pick].bytes))
+                pick = i;
+        if (pick == ctx->blocks.size()) break;
+        free_bytes -= ctx->blocks[pick].bytes;
+        hipFree(ctx->blocks[pick].p);
+        ctx->blocks.erase(ctx->blocks.begin() + pick);
+    }
+}
+
 extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     if (!ctx) return SCS_OK;
     hipSetDevice(ctx->device);
@@ -374,6 +431,8 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     for (auto &e : ctx->solve_events)
         if (e) hipEventDestroy(e);
     if (ctx->w_cache) hipFree(ctx->w_cache);
+    for (auto &b : ctx->blocks) hipFree(b.p);
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->small_dev) hipFree(ctx->small_dev);
     if (ctx->small_host) hipHostFree(ctx->small_host);
     delete ctx;

@@ -1003,12 +1003,22 @@ __global__ void k_dense_s(const double *__restrict__ w, int64_t ld, int n,
 // ---------------------------------------------------------------------------
 namespace {
 
+// a device block from the calling context's cache (scs_block_alloc): the entry points below
+// name their context in t_ctx before the first allocation
+thread_local scs_ctx *t_ctx = nullptr;
+
 struct dbuf {
     void *p = nullptr;
+    scs_ctx *owner = nullptr;
     ~dbuf() {
-        if (p) hipFree(p);
+        if (p && owner) scs_block_release(owner, p);
+        else if (p) hipFree(p);
     }
     int alloc(size_t bytes) {
+        if (t_ctx) {
+            owner = t_ctx;
+            return scs_block_alloc(t_ctx, bytes, &p);
+        }
         SCS_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
         return SCS_OK;
     }
@@ -1031,7 +1041,17 @@ struct solver {
     int n_apply = 0;
 
     ~solver() {
-        for (auto e : ev) hipEventDestroy(e);
+        if (ctx) ctx->event_pool.insert(ctx->event_pool.end(), ev.begin(), ev.end());
+        else for (auto e : ev) hipEventDestroy(e);
+    }
+    int new_event(hipEvent_t *e) {
+        if (ctx && !ctx->event_pool.empty()) {
+            *e = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+            return SCS_OK;
+        }
+        SCS_HIP_CHECK(hipEventCreate(e));
+        return SCS_OK;
     }
 
     double *small_at(int off) const { return small.d() + off; }
@@ -1151,8 +1171,8 @@ struct solver {
         k_scale_rows<<<(nb + 255) / 256, 256, 0, s>>>(src, 3 * b, c0s, b, n, g->d_dinv, z.d(),
                                                       g->ld);
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        SCS_HIP_CHECK(hipEventCreate(&e0));
-        SCS_HIP_CHECK(hipEventCreate(&e1));
+        SCS_TRY(new_event(&e0));
+        SCS_TRY(new_event(&e1));
         ev.push_back(e0);
         ev.push_back(e1);
         SCS_HIP_CHECK(hipEventRecord(e0, s));
@@ -1228,8 +1248,8 @@ struct solver {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = (n_apply & 3) == 0;
         if (timed) {
-            SCS_HIP_CHECK(hipEventCreate(&e0));
-            SCS_HIP_CHECK(hipEventCreate(&e1));
+            SCS_TRY(new_event(&e0));
+            SCS_TRY(new_event(&e1));
             ev.push_back(e0);
             ev.push_back(e1);
         }
@@ -1333,6 +1353,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_REQUIRE(block >= 0 && block <= MAXB, "scs_fiedler: block must be in [0, %d]", MAXB);
     SCS_REQUIRE(tol > 0.0 && max_iter >= 1, "scs_fiedler: tol must be > 0 and max_iter >= 1");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    t_ctx = ctx;
     hipStream_t s = ctx->stream;
     const int n = g->n;
     scs_stats st_local;
@@ -1939,6 +1960,7 @@ extern "C" int scs_debug_jacobi(scs_ctx *ctx, const double *a, int32_t n, double
     SCS_REQUIRE(ctx && a && w && v, "scs_debug_jacobi: null argument");
     SCS_REQUIRE(n >= 1 && n <= MAXS, "scs_debug_jacobi: n must be in [1, %d]", MAXS);
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    t_ctx = ctx;
     dbuf da, dw, dv;
     SCS_TRY(da.alloc((size_t)n * n * 8));
     SCS_TRY(dw.alloc((size_t)n * 8));
@@ -1956,6 +1978,7 @@ extern "C" int scs_debug_gram(scs_ctx *ctx, const double *a, const double *b, in
     SCS_REQUIRE(ctx && a && b && out, "scs_debug_gram: null argument");
     SCS_REQUIRE(n >= 1 && ka >= 1 && ka <= 48 && kb >= 1 && kb <= 48, "scs_debug_gram: bad shape");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    t_ctx = ctx;
     solver sv;
     sv.ctx = ctx;
     sv.s = ctx->stream;
@@ -1978,6 +2001,7 @@ extern "C" int scs_debug_apply(scs_ctx *ctx, scs_graph *g, const double *x, int3
     SCS_REQUIRE(ctx && g && x && y, "scs_debug_apply: null argument");
     SCS_REQUIRE(b == 4 || b == 8 || b == 12 || b == 16, "scs_debug_apply: b must be 4, 8, 12 or 16");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    t_ctx = ctx;
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));
     solver sv;
     sv.ctx = ctx;

@@ -46,6 +46,12 @@ constexpr int SCS_NPAD = 512; // position tables are padded to a multiple of thi
 constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_symm.h
 
 constexpr size_t SCS_SCRATCH_KEEP = (size_t)64 << 20;
+constexpr size_t SCS_BLOCK_KEEP = (size_t)4 << 30;
+
+struct scs_ctx;
+// cached device blocks of a context (scs_ctx.hip)
+int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out);
+void scs_block_release(scs_ctx *ctx, void *p);
 
 // ---- communicator -----------------------------------------------------------
 struct scs_local_group;  // in-process barrier + exchange slots
@@ -94,6 +100,17 @@ struct scs_ctx {
     // matrix; the recursion makes thousands of small ones).  One buffer at most.
     double *w_cache = nullptr;
     size_t w_cache_bytes = 0;
+    // device blocks of the solver, kept between calls (scs_fiedler needs a dozen buffers per
+    // call; the recursion calls it thousands of times): a block is handed out again when it is
+    // large enough and at most twice the request.  Free blocks beyond SCS_BLOCK_KEEP bytes in
+    // total are released.
+    struct cached_block {
+        void *p;
+        size_t bytes;
+        bool in_use;
+    };
+    std::vector<cached_block> blocks;
+    std::vector<hipEvent_t> event_pool;  // events of the timed SYMM launches, reused
     // staging of scs_small_solve (one pinned host block, one device block), grown on demand
     unsigned char *small_host = nullptr;
     unsigned char *small_dev = nullptr;
