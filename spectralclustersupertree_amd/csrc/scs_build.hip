@@ -977,6 +977,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.row_begin = b_row_begin;
             mp.row_end = b_row_end;
             mp.load_w = bi > 0;
+            mp.mirror = (sym && bi == n_batches - 1) ? 1 : 0;
             mp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
             mp.stamps = nullptr;
             static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));

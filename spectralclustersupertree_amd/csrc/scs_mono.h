@@ -154,6 +154,7 @@ struct mono_params {
     int n;                       // V
     int row_begin, row_end;
     int load_w;                  // 1: continue a sum started by an earlier batch
+    int mirror;                  // 1: last batch of a symmetric build: write the mirror image too
     double *tile_out;            // shared multi-rank build: packed 64 x 256 tiles (else null)
     unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
 };
@@ -380,14 +381,37 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
         double *tp = p.tile_out + (int64_t)blockIdx.x * SCS_TR * SCS_TCW + tid;
 #pragma unroll
         for (int i = 0; i < SCS_TR; ++i) tp[i * SCS_TCW] = acc[i];
-    } else if (col < p.n) {
+        return;
+    }
+    if (col < p.n) {
 #pragma unroll
         for (int i = 0; i < SCS_TR; ++i) {
             const int r = row0 + i;
-            if (r < p.row_end) {
-                p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
-                if (SYM && ((r / SCS_TCW) + 1) * SCS_TCW <= (col / SCS_TR) * SCS_TR)
-                    p.w[(int64_t)col * p.ld + r] = acc[i];
+            if (r < p.row_end) p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
+        }
+    }
+    if (SYM && p.mirror) {
+        // The mirror image W[c][r] of the tile (cells no tile of the schedule owns; only the last
+        // batch writes it -- earlier batches are re-read through the direct cells).  Stored
+        // straight from the accumulators every lane would write 8 bytes into a different row;
+        // instead eight rows at a time go through LDS ([column][8 rows], the table's space) and
+        // come out as 64-byte runs along the rows of W.
+        double *t = s_dv;  // 256 x 9 doubles
+        const bool wave_mirrors = ((row0 / SCS_TCW) + 1) * SCS_TCW <= ((tile.y * SCS_TCW + wave * 64) / SCS_TR) * SCS_TR;
+#pragma unroll
+        for (int q = 0; q < SCS_TR / 8; ++q) {
+            SCS_BARE_BARRIER();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[tid * 9 + j] = acc[q * 8 + j];
+            SCS_BARE_BARRIER();
+            if (wave_mirrors) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int cl = wave * 64 + it * 8 + (lane >> 3);  // column within the tile
+                    const int c = tile.y * SCS_TCW + cl;
+                    const int r = row0 + q * 8 + (lane & 7);
+                    if (c < p.n && r < p.row_end) p.w[(int64_t)c * p.ld + r] = t[cl * 9 + (lane & 7)];
+                }
             }
         }
     }
