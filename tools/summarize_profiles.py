@@ -1,96 +1,169 @@
 """Turn gpurun_out/profiles_raw/ (tools/collect_profiles.sh) into the committed files under
-profiles/: kernel-time table, PMC traffic per launch, bench lines, pmc_traffic.json.
+profiles/: kernel-time table, PMC traffic per launch, SQ counters and phase stamps of the
+accumulate kernel, bench lines, pmc_traffic.json.
 
-    python tools/summarize_profiles.py r01
+    python tools/summarize_profiles.py r02
 """
-import csv, glob, json, shutil, sys
+import csv
+import glob
+import json
+import shutil
+import sys
 from collections import defaultdict
 from pathlib import Path
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 root = Path(__file__).resolve().parent.parent
 raw = root / "gpurun_out" / "profiles_raw"
 out = root / "profiles"
 
-stats_csv = glob.glob(str(raw / "kt" / "*" / "*kernel_stats.csv"))[0]
+
+def newest(pattern, must_contain=None):
+    files = sorted(glob.glob(str(raw / pattern)), key=lambda f: Path(f).stat().st_mtime, reverse=True)
+    for f in files:
+        if must_contain is None or must_contain in Path(f).read_text(errors="ignore"):
+            return f
+    raise FileNotFoundError(pattern)
+
+
+stats_csv = newest("kt/*/*kernel_stats.csv", "k_symm")
 shutil.copy(stats_csv, out / f"{tag}_bench_cfg2_kernel_stats.csv")
 shutil.copy(raw / "bench_under_rocprof.json", out / f"{tag}_bench_cfg2_under_rocprof.json")
 shutil.copy(raw / "bench_default.json", out / f"{tag}_bench_default_run.json")
+if (raw / "bench_cfg4.json").exists():
+    shutil.copy(raw / "bench_cfg4.json", out / f"{tag}_bench_cfg4_single_gpu.json")
 stamps = (raw / "stamps.txt").read_text()
 (out / f"{tag}_accumulate_phase_stamps.txt").write_text(
     "In-kernel s_memtime phase shares of k_accumulate_mono (SCS_ACC_STAMP=1 diagnostic variant, configs[2]);\n"
-    "cycles are per wave per (tile, tree) step, three waves per SIMD interleaved.\n\n" + stamps)
+    "cycles are per wave per (tile, tree) step, three waves per SIMD interleaved; two tree batches.\n\n" + stamps)
 
 rows = list(csv.DictReader(open(stats_csv)))
 bench = json.load(open(raw / "bench_under_rocprof.json"))
 default = json.load(open(raw / "bench_default.json"))
 
+
 def pmc(kind):
-    f = glob.glob(str(raw / kind / "*" / "*counter_collection.csv"))[0]
-    acc = defaultdict(lambda: [0, 0.0])
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    f = newest(f"{kind}/*/*counter_collection.csv", "k_accumulate_mono")
     for r in csv.DictReader(open(f)):
-        a = acc[r["Kernel_Name"].split("(")[0]]
+        a = acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
     return acc
 
-fetch, write = pmc("fetch"), pmc("write")
-n, b = bench["config"]["n_taxa"], bench["config"]["lobpcg_block"]
-symm_name = next(k for k in fetch if k.startswith("void k_symm<"))
-alg = {symm_name: (8.0 * n * n + 16.0 * n * b, f"8 V^2 + 8 V b + 8 V b, b = {b}"),
-       "k_degrees": (8.0 * n * n, "8 V^2"),
-       next(k for k in fetch if "k_accumulate_mono" in k): (8.0 * n * n + 16.0 * bench["config"]["n_trees"] * n, "W written once + tables read once")}
 
-lines = [f"# Round-{tag[1:]} profile: `python3 bench.py --steps 5 --no-cpu-baseline --no-extra` (BASELINE.json configs[2]: "
-         f"{n} taxa / {bench['config']['n_trees']} trees / {bench['config']['pcg_weighting']}), one MI355X", "",
+fetch, write = pmc("fetch"), pmc("write")
+n, m, b = bench["config"]["n_taxa"], bench["config"]["n_trees"], bench["config"]["lobpcg_block"]
+
+
+def key_of(acc, needle):
+    return next(k for k in acc if needle in k)
+
+
+k_symm = key_of(fetch, "k_symm")
+k_acc = key_of(fetch, "k_accumulate_mono")
+roofs = {r["kernel"].split(" ")[0].split("<")[0]: r for r in (bench["roofline"], bench["roofline_other"])}
+symm_alg = roofs["k_symm"]["bytes_per_launch"]
+acc_alg = roofs["k_accumulate_mono"]["bytes_per_launch"]
+alg = {k_symm: (symm_alg, "bytes of W tiles streamed + block in/out"),
+       "k_degrees": (8.0 * n * n, "8 V^2"),
+       k_acc: (acc_alg, "per tree batch: W tile sums written once + tables read once")}
+
+lines = [f"# Round-{tag[1:]} profile: `python3 bench.py --steps 5 --no-cpu-baseline --no-extra --no-parity` "
+         f"(BASELINE.json configs[2]: {n} taxa / {m} trees / {bench['config']['pcg_weighting']}), one MI355X", "",
          "Collected by `tools/collect_profiles.sh` with `rocprofv3 --kernel-trace --stats --output-format csv` (kernel times) and, in "
-         "separate runs with `--kernel-trace` only, `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (bench with --steps 2 --warmup 0); "
-         "summarised by `tools/summarize_profiles.py`.  Files: "
+         "separate runs with `--kernel-trace` only, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` and three SQ counter passes (bench with "
+         "--steps 2 --warmup 0); summarised by `tools/summarize_profiles.py`.  Files: "
          f"`{tag}_bench_cfg2_kernel_stats.csv` (raw stats), `{tag}_bench_cfg2_under_rocprof.json` (bench line printed under the "
-         f"profiler), `{tag}_bench_default_run.json` (un-profiled default `python bench.py` line incl. cpu_baseline and the "
-         f"configs[1]/configs[3] reference passes), `{tag}_accumulate_phase_stamps.txt` (in-kernel phase shares of the accumulate "
-         f"kernel), `{tag}_bench_cfg4_single_gpu.json` (configs[4], 100 000 taxa / 5 000 trees, on ONE device).", "",
-         "## Kernel time (7 passes of the hot path: 1 warm-up + 5 timed + 1 parity pass)", "",
+         f"profiler), `{tag}_bench_default_run.json` (un-profiled default `python bench.py` line incl. parity gates, cpu_baseline, "
+         f"seeds, planted input and the configs[1]/configs[3] reference passes), `{tag}_accumulate_phase_stamps.txt`, "
+         f"`{tag}_accumulate_sq_counters_*.txt` (SQ counters of the accumulate kernel: round-1 structure, with the hand-scheduled "
+         f"cell loop, final structure), `{tag}_bench_cfg4_single_gpu.json` (configs[4] on ONE device).", "",
+         "## Kernel time (6 passes of the hot path: 1 warm-up + 5 timed)", "",
          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
-for r in rows[:18]:
+for r in rows[:16]:
     lines.append(f"| `{r['Name'].split('(')[0]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | "
                  f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
-rl = bench["roofline"]
-lines += ["", f"Live measurement inside bench.py in the same run (HIP events on the library's stream around k_symm): "
-          f"{rl['avg_launch_ms']*1e3:.1f} us per launch, {rl['achieved']:.1f} GB/s.", "",
-          "## HBM-side traffic per launch (PMC; FETCH_SIZE / WRITE_SIZE count KB: x 1024)", "",
+lines += ["", "Live measurement inside bench.py in the same run (HIP events on the library's stream):"]
+for name, r in roofs.items():
+    lines.append(f"* `{name}`: {r['avg_launch_ms']*1e3:.1f} us per launch x {r['launches_per_step']:.0f} launches per step, "
+                 f"{r['achieved']:.1f} GB/s of algorithmic bytes (frac {r['frac']}).")
+lines += ["", "## HBM-side traffic per launch (PMC; FETCH_SIZE / WRITE_SIZE count KB: x 1024)", "",
           "gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly half of the bytes of a wide coalesced "
-          "streaming read, so k_symm and k_degrees are doubled before comparing with the algorithmic byte count; other access "
-          "widths are uncalibrated and quoted raw.", "",
+          "streaming read, so the SYMM kernel and k_degrees are doubled before comparing with the algorithmic byte count; the "
+          "accumulate kernel's fetches are random 8-byte gathers (uncalibrated width) and are quoted raw.", "",
           "| kernel | launches | FETCH_SIZE raw bytes | corrected | WRITE_SIZE bytes | algorithmic bytes per launch |",
           "|---|---|---|---|---|---|"]
 traffic = {}
 for k, (ab, note) in alg.items():
-    fr = fetch[k][1] / fetch[k][0] * 1024
-    wr = write[k][1] / write[k][0] * 1024
+    fr = fetch[k]["FETCH_SIZE"][1] / fetch[k]["FETCH_SIZE"][0] * 1024
+    wr = write[k]["WRITE_SIZE"][1] / write[k]["WRITE_SIZE"][0] * 1024
     corr = fr * 2 if ("k_symm" in k or k == "k_degrees") else fr
-    lines.append(f"| `{k}` | {fetch[k][0]} | {fr:,.0f} | {corr:,.0f} | {wr:,.0f} | {ab:,.0f} ({note}) |")
+    lines.append(f"| `{k}` | {fetch[k]['FETCH_SIZE'][0]} | {fr:,.0f} | {corr:,.0f} | {wr:,.0f} | {ab:,.0f} ({note}) |")
     traffic[k] = (fr, corr, wr)
-fr, corr, wr = traffic[symm_name]
-lines += ["", f"Reading: k_symm moves {(corr + wr)/1e6:.0f} MB per launch against {alg[symm_name][0]/1e6:.0f} MB algorithmic (the "
-          "difference is the zero padding of the leading dimension to a multiple of 512 doubles) -- no wasted re-reads.  The "
-          "accumulate kernel's fetch traffic is L2-miss gathers into the per-tree range-minimum tables plus block records, far "
-          "above its algorithmic bytes: it is not HBM-bound (see the phase stamps).", "",
-          "## Default bench line (un-profiled)", "",
-          f"configs[2]: {default['value']*1e3:.1f} ms per step (build {default['stages']['build_ms']:.1f} ms, solve "
-          f"{default['stages']['fiedler_ms']:.1f} ms, {default['stages']['lobpcg_iterations']:.0f} LOBPCG iterations, k_symm "
-          f"{default['roofline']['achieved']:.0f} GB/s = {default['roofline']['frac']:.3f} of 8 TB/s); cpu_baseline "
-          f"{default['cpu_baseline']['value']:.1f} s ({default['cpu_baseline']['kind']}).", ""]
+fr, corr, wr = traffic[k_symm]
+afr, acorr, awr = traffic[k_acc]
+lines += ["", f"Reading: the SYMM kernel moves {(corr + wr)/1e6:.0f} MB per launch against {symm_alg/1e6:.0f} MB algorithmic "
+          "(upper tiles of W + partial sums) -- no wasted re-reads.  The accumulate kernel fetches "
+          f"{afr/1e9:.1f} GB per launch against {acc_alg/1e9:.2f} GB algorithmic: range-minimum gathers that miss the L2 "
+          "(each 8-byte gather moves a whole line) and block records; it is bound by L2 line traffic, LDS and VALU, not by HBM "
+          "(see the SQ counters and the phase stamps).", ""]
+
+# SQ counters of the accumulate kernel from this collection
+try:
+    sq = defaultdict(lambda: [0, 0.0])
+    for kind in ("sq1", "sq2", "sq3"):
+        f = newest(f"{kind}/*/*counter_collection.csv", "k_accumulate_mono")
+        for r in csv.DictReader(open(f)):
+            if "k_accumulate_mono" in r["Kernel_Name"]:
+                a = sq[r["Counter_Name"]]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+    per = {k: v[1] / v[0] for k, v in sq.items()}
+    cu_cycles = per["GRBM_GUI_ACTIVE"] / 8 * 256
+    lines += ["## SQ counters of `k_accumulate_mono` (per launch)", "",
+              f"CU cycles (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs): {cu_cycles:.3e}; LDS busy (SQ_LDS_IDX_ACTIVE): "
+              f"{per['SQ_LDS_IDX_ACTIVE'] / cu_cycles:.2f} of them, bank-conflict cycles (SQ_LDS_BANK_CONFLICT): "
+              f"{per['SQ_LDS_BANK_CONFLICT'] / cu_cycles:.2f}; VALU busy (4 x SQ_ACTIVE_INST_VALU / (4 SIMDs x CU cycles)): "
+              f"{per['SQ_ACTIVE_INST_VALU'] * 4 / (cu_cycles * 4):.2f}; VALU instructions per wave: "
+              f"{per['SQ_INSTS_VALU'] / per['SQ_WAVES']:.0f}, LDS instructions per wave: {per['SQ_INSTS_LDS'] / per['SQ_WAVES']:.0f}, "
+              f"waves: {per['SQ_WAVES']:.0f}.", ""]
+    (out / f"{tag}_accumulate_sq_counters_final.txt").write_text(
+        "\n".join(f"{k:28s} per launch {v:.6g}" for k, v in sorted(per.items())) + "\n")
+except (FileNotFoundError, KeyError, ZeroDivisionError) as e:
+    lines += [f"(SQ counter summary unavailable: {e})", ""]
+
+st = default["stages"]
+lines += ["## Default bench line (un-profiled)", "",
+          f"configs[2]: {default['value']*1e3:.1f} ms per step (build {st['build_ms']:.1f} ms of which accumulate "
+          f"{st['build_accumulate_ms']:.1f}, solve {st['fiedler_ms']:.1f} ms of which SYMM {st['fiedler_symm_ms']:.1f}, "
+          f"{st['lobpcg_iterations']:.0f} LOBPCG iterations); including the tables' upload {default['value_incl_h2d_d2h']*1e3:.1f} ms; "
+          f"dominant kernel {default['roofline']['kernel'].split(' ')[0]} (frac {default['roofline']['frac']}); path figure "
+          f"{default['roofline_path']['achieved']:.0f} GB/s = {default['roofline_path']['frac']} of spec; cpu_baseline "
+          f"{default['cpu_baseline']['value']:.1f} s ({default['cpu_baseline']['sample'][:60]}...).", "",
+          f"Parity gates at full size: {json.dumps(default['parity'])}", "",
+          f"Seeds: {json.dumps(default.get('seeds', {}))}", "",
+          f"Planted input: {default['planted'].get('value')} s, lambda2 {default['planted']['stages']['lambda2']:.4f}, "
+          f"lambda3 {default['planted']['stages']['lambda3']:.4f}, {default['planted']['stages']['lobpcg_iterations']:.0f} iterations.", ""]
 for k, v in default.get("other_workloads", {}).items():
     if "value" in v:
         lines.append(f"{k}: {v['value']:.4f} s per step (build {v['stages']['build_ms']:.1f} ms, solve {v['stages']['fiedler_ms']:.1f} ms, "
-                     f"k_symm frac {v['roofline']['frac']:.3f}), W rows mismatched: {v['parity']['w_cells_mismatched']}.")
+                     f"{v['stages']['lobpcg_iterations']:.0f} iterations), W rows mismatched: {v['parity']['w_cells_mismatched']}.")
+if (raw / "bench_cfg4.json").exists():
+    c4 = json.load(open(raw / "bench_cfg4.json"))
+    lines.append(f"cfg4 (own run): {c4['value']:.3f} s per step (build {c4['stages']['build_ms']:.0f} ms, solve "
+                 f"{c4['stages']['fiedler_ms']:.0f} ms, {c4['stages']['lobpcg_iterations']:.0f} iterations), W rows mismatched: "
+                 f"{c4.get('parity', {}).get('w_cells_mismatched')}.")
 (out / f"{tag}_bench_cfg2_summary.md").write_text("\n".join(lines) + "\n")
 
-pj = {"_comment": "HBM-side bytes per launch of k_symm from committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 "
-                  "correction for wide coalesced reads, + WRITE_SIZE), keyed by workload name; bench.py quotes the matching entry "
-                  "as roofline.traffic",
-      "cfg2": {"kernel": symm_name.replace("void ", ""), "fetch_raw": round(fr), "fetch_corrected": round(corr), "write": round(wr),
-               "traffic": round(corr + wr), "source": f"profiles/{tag}_bench_cfg2_summary.md"}}
+pj = {"_comment": "HBM-side bytes per launch from committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction "
+                  "for wide coalesced reads where that applies, + WRITE_SIZE), keyed by workload name; bench.py quotes the "
+                  "matching entry as roofline.traffic",
+      "cfg2": [
+          {"kernel": k_symm.replace("void ", "").split("<")[0], "fetch_raw": round(fr), "fetch_corrected": round(corr),
+           "write": round(wr), "traffic": round(corr + wr), "source": f"profiles/{tag}_bench_cfg2_summary.md"},
+          {"kernel": "k_accumulate_mono", "fetch_raw": round(afr), "fetch_corrected": round(acorr), "write": round(awr),
+           "traffic": round(acorr + awr), "source": f"profiles/{tag}_bench_cfg2_summary.md (fetches are 8-byte gathers: "
+                                                     "uncalibrated width, quoted raw)"}]}
 (out / "pmc_traffic.json").write_text(json.dumps(pj, indent=1))
-print("\n".join(lines[:40]))
+print("\n".join(lines[:60]))
