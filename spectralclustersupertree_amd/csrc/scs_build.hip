@@ -556,6 +556,22 @@ struct dev_buf {
     }
 };
 
+// a device block from the context's cache (scs_block_alloc): the multi-GB exchange buffers of a
+// shared build are reused from step to step instead of a hipMalloc / hipFree pair each
+struct cached_buf {
+    scs_ctx *ctx;
+    void *p = nullptr;
+    explicit cached_buf(scs_ctx *c) : ctx(c) {}
+    ~cached_buf() {
+        if (p) scs_block_release(ctx, p);
+    }
+    int alloc(size_t bytes) {
+        if (p) scs_block_release(ctx, p);
+        p = nullptr;
+        return scs_block_alloc(ctx, bytes, &p);
+    }
+};
+
 // a scratch buffer that lives in the context between calls (see scs_ctx::scratch)
 struct pooled_buf {
     scs_ctx *ctx = nullptr;
@@ -796,7 +812,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // shared: tile i of the job-wide list belongs to rank i % world and lands in slot
     // i / world of that rank's packed buffer
     std::vector<int2> all_tiles;
-    dev_buf d_all_tiles, d_tile_out, d_gathered;
+    dev_buf d_all_tiles;
+    cached_buf d_tile_out(ctx), d_gathered(ctx);
     size_t chunk_doubles = 0;
     // the exchange of a shared build: point to point by default, one all-gather on request
     const bool exchange_allgather =
@@ -1065,7 +1082,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 if (needs(rank, all_tiles[i])) recv_tiles.push_back(all_tiles[i]);
             recv_off[p + 1] = (int64_t)recv_tiles.size() * SCS_TR * SCS_TCW;
         }
-        dev_buf d_send, d_recv, d_slots, d_rtiles;
+        cached_buf d_send(ctx), d_recv(ctx);
+        dev_buf d_slots, d_rtiles;
         SCS_TRY(d_send.alloc((size_t)send_off[world] * 8));
         SCS_TRY(d_recv.alloc((size_t)recv_off[world] * 8));
         SCS_TRY(d_slots.alloc(send_slots.size() * 4));

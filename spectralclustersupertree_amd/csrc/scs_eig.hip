@@ -1221,8 +1221,12 @@ struct solver {
     }
 
     // ---- fused iteration (scs_panel.h), block widths 4 and 8 ----
-    int panel_blocks16() const { return std::max(1, std::min(PANEL_BLOCKS_MAX, ((n + 15) / 16 + 3) / 4)); }
-    int panel_blocks4() const { return std::max(1, std::min(PANEL_BLOCKS_MAX, ((n + 3) / 4 + 3) / 4)); }
+    static int panel_cap() {
+        static const int cap = getenv("SCS_PANEL_BLOCKS") ? std::max(1, std::min(512, atoi(getenv("SCS_PANEL_BLOCKS")))) : PANEL_BLOCKS_MAX;
+        return cap;
+    }
+    int panel_blocks16() const { return std::max(1, std::min(panel_cap(), ((n + 15) / 16 + 3) / 4)); }
+    int panel_blocks4() const { return std::max(1, std::min(panel_cap(), ((n + 3) / 4 + 3) / 4)); }
 
     template <int B>
     int fused_front(const double *uvec, const double *c, const double *d, const double *theta,

@@ -46,7 +46,7 @@ constexpr int SCS_NPAD = 512; // position tables are padded to a multiple of thi
 constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_symm.h
 
 constexpr size_t SCS_SCRATCH_KEEP = (size_t)64 << 20;
-constexpr size_t SCS_BLOCK_KEEP = (size_t)4 << 30;
+constexpr size_t SCS_BLOCK_KEEP = (size_t)32 << 30;  // free cached blocks kept per context (of 288 GB)
 
 struct scs_ctx;
 // cached device blocks of a context (scs_ctx.hip)

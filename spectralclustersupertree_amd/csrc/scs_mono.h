@@ -121,21 +121,19 @@ __global__ __launch_bounds__(64) void k_block_records_mono(
         *(int64_t *)(rec + R3_STOFF) = st_off[tl];
     }
     // seeds of the table expansion: wave w of the tile kernel walks b in [16w, 16w + 16) and
-    // needs, for every lane a < 16w, the running minimum of g[a .. 16w - 1]
+    // needs, for every lane a < 16w, the running minimum of g[a .. 16w - 1]: a suffix minimum
+    // cut off at 16w, by doubling steps across the wave
     {
         const double inf = __longlong_as_double(0x7FF0000000000000ll);
         double *seed = (double *)(rec + R3_SEED);
-        double run = inf, mine = inf;
-        for (int w = 3; w >= 1; --w) {
-            // after this pass `mine` = min g[lane .. 16w-1] for lane < 16w (suffix minimum
-            // taken from 16w - 1 downwards; `run` is wave-uniform)
-            run = inf;
-            mine = inf;
-            for (int j = 16 * w - 1; j >= 0; --j) {
-                const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g), j);
-                const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g), j);
-                run = min_f64(run, __hiloint2double(hi32, lo32));
-                if (lane == j) mine = run;
+#pragma unroll
+        for (int w = 1; w <= 3; ++w) {
+            const int end = 16 * w;
+            double mine = lane < end ? g : inf;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const double other = __shfl_down(mine, off, 64);
+                if (lane + off < end) mine = min_f64(mine, other);
             }
             seed[(w - 1) * 64 + lane] = mine;
         }

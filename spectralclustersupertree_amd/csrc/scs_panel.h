@@ -30,7 +30,7 @@
 
 typedef double panel_v4d __attribute__((ext_vector_type(4)));
 
-constexpr int PANEL_BLOCKS_MAX = 64;   // workgroups of a tall panel kernel (partials per output)
+constexpr int PANEL_BLOCKS_MAX = 128;  // workgroups of a tall panel kernel (partials per output; 64 -> 128: -3 % of the solve)
 
 // outputs per workgroup partial: [x p]^T r (2B x B), then [r | u]^T r ((B + 1) x B)
 template <int B>

@@ -21,7 +21,7 @@ warnings.simplefilter("ignore")
 rng = np.random.RandomState(args.seed)
 dev = Device(0)
 t_end = time.time() + args.seconds
-n_cases = n_fiedler = n_multi = 0
+n_cases = n_fiedler = n_multi = n_small = 0
 worst = 0.0
 fails = []
 while time.time() < t_end:
@@ -40,6 +40,15 @@ while time.time() < t_end:
     if not np.array_equal(w, w_ref):
         fails.append(f"W mismatch: {tag}: {int(np.sum(w != w_ref))} cells")
     n_cases += 1
+    if n <= dev.SMALL_MAX_TAXA:
+        # the fused small-node kernel on the same input: same W, same embedding as the general path
+        (maps_s, lam_s, w_s), = dev.small_solve([(tables, None)], want_w=True)
+        n_small += 1
+        if not np.array_equal(w_s, w_ref):
+            fails.append(f"small-path W mismatch: {tag}: {int(np.sum(w_s != w_ref))} cells")
+        ev = np.sort(np.linalg.eigvalsh(to.normalized_operator(w_ref)[0]))[::-1]
+        if np.max(np.abs(lam_s[: min(3, n)] - ev[:3])) > 1e-11:
+            fails.append(f"small-path eigenvalues: {tag}: {lam_s} vs {ev[:3]}")
     if n_cases % 200 == 0:
         print(f"... {n_cases} cases, {len(fails)} failures", flush=True)
     deg = w_ref.sum(axis=1)
@@ -109,7 +118,7 @@ while time.time() < t_end:
                     fails.append(f"multi-rank maps differ between ranks: {tag} splits={splits} rank {r}")
 dev.close()
 print(f"fuzz: {n_cases} builds bit-exact checked, {n_fiedler} Fiedler comparisons, worst |diff| {worst:.2e}, "
-      f"{n_multi} multi-rank shared builds + solves, {len(fails)} failures")
+      f"{n_multi} multi-rank shared builds + solves, {n_small} fused small-node solves, {len(fails)} failures")
 for f in fails[:20]:
     print("  ", f)
 sys.exit(1 if fails else 0)
