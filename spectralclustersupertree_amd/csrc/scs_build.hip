@@ -415,26 +415,28 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
 // t / world of that rank's chunk of `gathered`.  A rank copies the cells of every tile
 // that fall into its rows, and -- for cells no tile owns directly -- the transposed
 // image of the tile's cells whose COLUMN falls into its rows.
-__global__ __launch_bounds__(256) void k_unpack_tiles(const double *__restrict__ gathered,
+// (blockDim.x = tcw, the tile width of the build: 256, or 384 for the monotone kernel)
+__global__ __launch_bounds__(1024) void k_unpack_tiles(const double *__restrict__ gathered,
                                                       const int2 *__restrict__ tiles, int world,
                                                       int64_t chunk_doubles, int n, int row_begin,
                                                       int row_end, double *__restrict__ w,
                                                       int64_t ld) {
+    const int tcw = blockDim.x;
     const int t = blockIdx.x;
     const int2 tile = tiles[t];
     const double *src = gathered + (int64_t)(t % world) * chunk_doubles +
-                        (int64_t)(t / world) * SCS_TR * SCS_TCW;
-    const int c = tile.y * SCS_TCW + threadIdx.x;  // global column of this thread
+                        (int64_t)(t / world) * SCS_TR * tcw;
+    const int c = tile.y * tcw + threadIdx.x;  // global column of this thread
     if (c >= n) return;
     const int r0 = tile.x * SCS_TR;
     const bool col_is_my_row = c >= row_begin && c < row_end;
     for (int i = 0; i < SCS_TR; ++i) {
         const int r = r0 + i;
         if (r >= n) break;
-        const double v = src[i * SCS_TCW + threadIdx.x];
+        const double v = src[i * tcw + threadIdx.x];
         if (r >= row_begin && r < row_end) w[(int64_t)(r - row_begin) * ld + c] = v;
         // cell (c, r) has no tile of its own iff its column group ends at or before its row block
-        if (col_is_my_row && ((r / SCS_TCW) + 1) * SCS_TCW <= (c / SCS_TR) * SCS_TR)
+        if (col_is_my_row && ((r / tcw) + 1) * tcw <= (c / SCS_TR) * SCS_TR)
             w[(int64_t)(c - row_begin) * ld + r] = v;
     }
 }
@@ -442,32 +444,33 @@ __global__ __launch_bounds__(256) void k_unpack_tiles(const double *__restrict__
 // targeted exchange: copy the tiles a peer needs into its contiguous share of the send buffer
 // (entry e: slot src_slot[e] of this rank's packed tiles -> position e of the send buffer)
 __global__ __launch_bounds__(256) void k_pack_tiles(const double *__restrict__ tile_out,
-                                                    const int32_t *__restrict__ src_slot,
+                                                    const int32_t *__restrict__ src_slot, int tcw,
                                                     double *__restrict__ sendbuf) {
-    const double2 *src = (const double2 *)(tile_out + (int64_t)src_slot[blockIdx.x] * SCS_TR * SCS_TCW);
-    double2 *dst = (double2 *)(sendbuf + (int64_t)blockIdx.x * SCS_TR * SCS_TCW);
-    for (int q = threadIdx.x; q < SCS_TR * SCS_TCW / 2; q += 256) dst[q] = src[q];
+    const double2 *src = (const double2 *)(tile_out + (int64_t)src_slot[blockIdx.x] * SCS_TR * tcw);
+    double2 *dst = (double2 *)(sendbuf + (int64_t)blockIdx.x * SCS_TR * tcw);
+    for (int q = threadIdx.x; q < SCS_TR * tcw / 2; q += 256) dst[q] = src[q];
 }
 
 // received tiles (entry e of recvbuf is tile tiles[e]) -> this rank's rows of W: the cells of
 // a tile that fall into its rows and the mirror image of the cells whose COLUMN does
-__global__ __launch_bounds__(256) void k_unpack_received(const double *__restrict__ recvbuf,
+__global__ __launch_bounds__(1024) void k_unpack_received(const double *__restrict__ recvbuf,
                                                          const int2 *__restrict__ tiles, int n,
                                                          int row_begin, int row_end,
                                                          double *__restrict__ w, int64_t ld) {
+    const int tcw = blockDim.x;
     const int2 tile = tiles[blockIdx.x];
-    const double *src = recvbuf + (int64_t)blockIdx.x * SCS_TR * SCS_TCW;
-    const int c = tile.y * SCS_TCW + threadIdx.x;  // global column of this thread
+    const double *src = recvbuf + (int64_t)blockIdx.x * SCS_TR * tcw;
+    const int c = tile.y * tcw + threadIdx.x;  // global column of this thread
     if (c >= n) return;
     const int r0 = tile.x * SCS_TR;
     const bool col_is_my_row = c >= row_begin && c < row_end;
     for (int i = 0; i < SCS_TR; ++i) {
         const int r = r0 + i;
         if (r >= n) break;
-        const double v = src[i * SCS_TCW + threadIdx.x];
+        const double v = src[i * tcw + threadIdx.x];
         if (r >= row_begin && r < row_end) w[(int64_t)(r - row_begin) * ld + c] = v;
         // cell (c, r) has no tile of its own iff its column group ends at or before its row block
-        if (col_is_my_row && ((r / SCS_TCW) + 1) * SCS_TCW <= (c / SCS_TR) * SCS_TR)
+        if (col_is_my_row && ((r / tcw) + 1) * tcw <= (c / SCS_TR) * SCS_TR)
             w[(int64_t)(c - row_begin) * ld + r] = v;
     }
 }
@@ -739,9 +742,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int world = ctx->comm.world, rank = ctx->comm.rank;
-    const int cols_per_tile = SCS_TCW;
+    const int cols_per_tile = monotone ? MONO_TCW : SCS_TCW;
     const int n_cgroups = (n + cols_per_tile - 1) / cols_per_tile;
-    const int64_t npad = scs_round_up(n, SCS_NPAD);
+    // (the last column group may reach past n: its threads read "absent" positions)
+    const int64_t npad = scs_round_up((int64_t)n_cgroups * cols_per_tile, SCS_NPAD);
     // Shared build (world > 1): the ranks split the upper-triangle tiles of the WHOLE matrix
     // round-robin, all-gather them and each unpacks its own rows -- every cell is computed
     // once across the job, as in the single-GPU symmetric schedule.  The decision depends
@@ -749,7 +753,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     bool shared = (flags & SCS_BUILD_SHARED) != 0 && world > 1;
     if (shared) {
         const int64_t nb_all = (n + SCS_TR - 1) / SCS_TR;
-        const double tile_bytes = 0.5 * (double)nb_all * n_cgroups * SCS_TR * SCS_TCW * 8.0;
+        const double tile_bytes = 0.5 * (double)nb_all * n_cgroups * SCS_TR * cols_per_tile * 8.0;
         if (tile_bytes * (1.0 + 1.0 / world) > 96.0 * 1024 * 1024 * 1024) shared = false;
     }
     // rows the accumulate kernels see: the whole matrix when shared
@@ -822,15 +826,15 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         all_tiles.swap(tiles);
         for (size_t i = rank; i < all_tiles.size(); i += world) tiles.push_back(all_tiles[i]);
         const size_t slots = (all_tiles.size() + world - 1) / world;
-        chunk_doubles = slots * SCS_TR * SCS_TCW;
+        chunk_doubles = slots * SCS_TR * cols_per_tile;
         SCS_TRY(d_all_tiles.alloc(all_tiles.size() * sizeof(int2)));
         SCS_HIP_CHECK(hipMemcpyAsync(d_all_tiles.p, all_tiles.data(),
                                      all_tiles.size() * sizeof(int2), hipMemcpyHostToDevice, s));
         SCS_TRY(d_tile_out.alloc(chunk_doubles * 8));
         if (exchange_allgather) SCS_TRY(d_gathered.alloc(chunk_doubles * 8 * world));
         if (tiles.size() < slots)  // the unused last slot is gathered too: keep it defined
-            SCS_HIP_CHECK(hipMemsetAsync((double *)d_tile_out.p + (slots - 1) * SCS_TR * SCS_TCW,
-                                         0, (size_t)SCS_TR * SCS_TCW * 8, s));
+            SCS_HIP_CHECK(hipMemsetAsync((double *)d_tile_out.p + (slots - 1) * SCS_TR * cols_per_tile,
+                                         0, (size_t)SCS_TR * cols_per_tile * 8, s));
     }
     pooled_buf d_tiles(ctx, 0);
     SCS_TRY(d_tiles.alloc(std::max<size_t>(tiles.size(), 1) * sizeof(int2)));
@@ -1003,8 +1007,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 SCS_TRY(d_st8.alloc(64));
                 SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
                 mp.stamps = (unsigned long long *)d_st8.p;
-                if (sym) k_accumulate_mono<true, true><<<nt, SCS_TCW, 0, s>>>(mp);
-                else k_accumulate_mono<false, true><<<nt, SCS_TCW, 0, s>>>(mp);
+                if (sym) k_accumulate_mono<true, true><<<nt, MONO_TCW, 0, s>>>(mp);
+                else k_accumulate_mono<false, true><<<nt, MONO_TCW, 0, s>>>(mp);
                 unsigned long long h[8];
                 SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
                 SCS_HIP_CHECK(hipStreamSynchronize(s));
@@ -1016,8 +1020,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                     fprintf(stderr, "[stamp] %-24s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i],
                             100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
             } else if (nt) {
-                if (sym) k_accumulate_mono<true, false><<<nt, SCS_TCW, 0, s>>>(mp);
-                else k_accumulate_mono<false, false><<<nt, SCS_TCW, 0, s>>>(mp);
+                if (sym) k_accumulate_mono<true, false><<<nt, MONO_TCW, 0, s>>>(mp);
+                else k_accumulate_mono<false, false><<<nt, MONO_TCW, 0, s>>>(mp);
             }
         } else {
             if (!nt) {
@@ -1051,7 +1055,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_HIP_CHECK(hipEventRecord(ev_x.a, s));
         SCS_TRY(scs_comm_allgather_f64(&ctx->comm, (const double *)d_tile_out.p,
                                        (double *)d_gathered.p, chunk_doubles, s));
-        k_unpack_tiles<<<(unsigned)all_tiles.size(), SCS_TCW, 0, s>>>(
+        k_unpack_tiles<<<(unsigned)all_tiles.size(), cols_per_tile, 0, s>>>(
             (const double *)d_gathered.p, (const int2 *)d_all_tiles.p, world,
             (int64_t)chunk_doubles, n, row_begin, row_end, g->d_w, g->ld);
         SCS_HIP_CHECK(hipGetLastError());
@@ -1068,7 +1072,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         auto needs = [&](int dst, const int2 &t) {
             const int64_t lo = splits[dst], hi = splits[dst + 1];
             const int64_t r_lo = (int64_t)t.x * SCS_TR, r_hi = std::min<int64_t>(r_lo + SCS_TR, n);
-            const int64_t c_lo = (int64_t)t.y * SCS_TCW, c_hi = std::min<int64_t>(c_lo + SCS_TCW, n);
+            const int64_t c_lo = (int64_t)t.y * cols_per_tile, c_hi = std::min<int64_t>(c_lo + cols_per_tile, n);
             return (r_lo < hi && lo < r_hi) || (c_lo < hi && lo < c_hi);
         };
         std::vector<int64_t> send_off(world + 1, 0), recv_off(world + 1, 0);
@@ -1077,10 +1081,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         for (int p = 0; p < world; ++p) {
             for (size_t i = rank; i < all_tiles.size(); i += world)
                 if (needs(p, all_tiles[i])) send_slots.push_back((int32_t)(i / world));
-            send_off[p + 1] = (int64_t)send_slots.size() * SCS_TR * SCS_TCW;
+            send_off[p + 1] = (int64_t)send_slots.size() * SCS_TR * cols_per_tile;
             for (size_t i = p; i < all_tiles.size(); i += world)
                 if (needs(rank, all_tiles[i])) recv_tiles.push_back(all_tiles[i]);
-            recv_off[p + 1] = (int64_t)recv_tiles.size() * SCS_TR * SCS_TCW;
+            recv_off[p + 1] = (int64_t)recv_tiles.size() * SCS_TR * cols_per_tile;
         }
         cached_buf d_send(ctx), d_recv(ctx);
         dev_buf d_slots, d_rtiles;
@@ -1097,12 +1101,12 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                                      hipMemcpyHostToDevice, s));
         if (!send_slots.empty())
             k_pack_tiles<<<(unsigned)send_slots.size(), 256, 0, s>>>(
-                (const double *)d_tile_out.p, (const int32_t *)d_slots.p, (double *)d_send.p);
+                (const double *)d_tile_out.p, (const int32_t *)d_slots.p, cols_per_tile, (double *)d_send.p);
         SCS_HIP_CHECK(hipGetLastError());
         SCS_TRY(scs_comm_alltoallv_f64(&ctx->comm, (const double *)d_send.p, send_off.data(),
                                        (double *)d_recv.p, recv_off.data(), s));
         if (!recv_tiles.empty())
-            k_unpack_received<<<(unsigned)recv_tiles.size(), SCS_TCW, 0, s>>>(
+            k_unpack_received<<<(unsigned)recv_tiles.size(), cols_per_tile, 0, s>>>(
                 (const double *)d_recv.p, (const int2 *)d_rtiles.p, n, row_begin, row_end, g->d_w,
                 g->ld);
         SCS_HIP_CHECK(hipGetLastError());

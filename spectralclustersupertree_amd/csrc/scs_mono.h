@@ -41,15 +41,29 @@ constexpr int DT_DOUBLES = 64 * DV_LD;
 // per-(row block, tree) record of the monotone path
 constexpr int R3_SPOS = 0;       // int32[64]  sorted DFS positions (INT_MAX beyond cnt)
 constexpr int R3_G = 256;        // f64[64]    value of LCA(sorted k, sorted k+1); 0 beyond cnt-1
-constexpr int R3_SEED = 768;     // f64[3][64] seed[w-1][a] = min g[a .. 16w-1] for a < 16w
-constexpr int R3_ARGPOS = 2304;  // int32[64]  a position where gap k attains its minimum g[k]
-constexpr int R3_SORIG = 2560;   // u8[64]     row (0..63) at sorted rank k
-constexpr int R3_RANK = 2624;    // u8[64]     sorted rank of row i (absent rows: the ranks >= cnt)
-constexpr int R3_PIV = 2688;     // int32[8]   sorted positions 7, 15, ..., 63 (search pivots)
-constexpr int R3_CNT = 2720;     // int32      rows present in the tree
-constexpr int R3_M = 2724;       // int32      gaps of the tree (n_t - 1)
-constexpr int R3_STOFF = 2728;   // int64      offset of the tree's value table in the batch
-constexpr int R3_BYTES = 2752;   // 4 waves x 43 lanes x 16 B
+// The tile of the monotone kernel is 64 rows x MONO_TCW columns, one column per thread.  Wider
+// tiles would share the table expansion (per tile and tree, independent of the width) among
+// more columns, but measured slower: 384 columns (six waves) leave a CU with ONE workgroup --
+// two six-wave workgroups need a (2,2,1,1) + (1,1,2,2) placement over the four SIMDs at three
+// waves per SIMD, which the dispatcher does not find (+40 %); 768 columns (twelve waves, one
+// workgroup per CU) serialise the step's phases behind its two barriers (+22 %).  Four waves,
+// three workgroups per CU it is.  Wave w walks the expansion steps b in
+// [mono_seg(w), mono_seg(w + 1)).
+constexpr int MONO_WAVES = 4;
+constexpr int MONO_TCW = 64 * MONO_WAVES;
+__host__ __device__ constexpr int mono_seg(int w) { return 64 * w / MONO_WAVES; }
+constexpr int MONO_MAXSEG = (64 + MONO_WAVES - 1) / MONO_WAVES;  // longest segment: 11 steps
+constexpr int R3_SEED = 768;     // f64[5][64] seed[w-1][a] = min g[a .. mono_seg(w)-1] for a < mono_seg(w)
+constexpr int R3_ARGPOS = R3_SEED + (MONO_WAVES - 1) * 512;  // int32[64] a position where gap k attains its minimum g[k]
+constexpr int R3_SORIG = R3_ARGPOS + 256;  // u8[64]     row (0..63) at sorted rank k
+constexpr int R3_RANK = R3_SORIG + 64;     // u8[64]     sorted rank of row i (absent rows: the ranks >= cnt)
+constexpr int R3_PIV = R3_RANK + 64;       // int32[8]   sorted positions 7, 15, ..., 63 (search pivots)
+constexpr int R3_CNT = R3_PIV + 32;        // int32      rows present in the tree
+constexpr int R3_M = R3_CNT + 4;           // int32      gaps of the tree (n_t - 1)
+constexpr int R3_STOFF = R3_M + 4;         // int64      offset of the tree's value table in the batch
+constexpr int R3_PIECE = (R3_STOFF + 8 + MONO_WAVES * 16 - 1) / (MONO_WAVES * 16) * 16;  // bytes of a record one wave stages
+constexpr int R3_BYTES = R3_PIECE * MONO_WAVES;
+static_assert(R3_STOFF + 8 <= R3_BYTES && R3_PIECE <= 1024, "record layout");
 
 // s_barrier without the fences of __syncthreads(): those make the compiler drain vmcnt in
 // front of it, and with it the range-minimum loads that are meant to stay in flight across
@@ -120,15 +134,15 @@ __global__ __launch_bounds__(64) void k_block_records_mono(
         *(int *)(rec + R3_M) = m;
         *(int64_t *)(rec + R3_STOFF) = st_off[tl];
     }
-    // seeds of the table expansion: wave w of the tile kernel walks b in [16w, 16w + 16) and
-    // needs, for every lane a < 16w, the running minimum of g[a .. 16w - 1]: a suffix minimum
-    // cut off at 16w, by doubling steps across the wave
+    // seeds of the table expansion: wave w of the tile kernel walks b from mono_seg(w) and needs,
+    // for every lane a below that, the running minimum of g[a .. mono_seg(w) - 1]: a suffix
+    // minimum cut off there, by doubling steps across the wave
     {
         const double inf = __longlong_as_double(0x7FF0000000000000ll);
         double *seed = (double *)(rec + R3_SEED);
 #pragma unroll
-        for (int w = 1; w <= 3; ++w) {
-            const int end = 16 * w;
+        for (int w = 1; w < MONO_WAVES; ++w) {
+            const int end = mono_seg(w);
             double mine = lane < end ? g : inf;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -158,7 +172,7 @@ struct mono_params {
 };
 
 template <bool SYM, bool STAMPED>
-__global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
+__global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mono_params p) {
     __shared__ __attribute__((aligned(16))) double s_dv[DT_DOUBLES];
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[2][R3_BYTES];
     typedef __attribute__((address_space(3))) void *lds_ptr;
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
     const int2 tile = p.tiles[blockIdx.x];
     const int blk = tile.x;
     const int row0 = p.row_begin + blk * SCS_TR;
-    const int col = tile.y * SCS_TCW + tid;
+    const int col = tile.y * MONO_TCW + tid;
     const int nt = p.n_batch;
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     // a column that is one of the tile's own rows (tiles on the diagonal): its cells are the
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
     for (int i = 0; i < SCS_TR; ++i) {
         double v = 0.0;
         if (p.load_w && p.tile_out)
-            v = p.tile_out[((int64_t)blockIdx.x * SCS_TR + i) * SCS_TCW + tid];
+            v = p.tile_out[((int64_t)blockIdx.x * SCS_TR + i) * MONO_TCW + tid];
         else if (p.load_w && col < p.n && row0 + i < p.row_end)
             v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
         acc[i] = v;
@@ -211,11 +225,11 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
     const int col4 = col * 4;
     // every wave issues the same number of vector-memory operations per step (1 record piece,
     // 2 table loads, 1 position), so the counted vmcnt waits below hold for all of them;
-    // wave w copies bytes [688 w, 688 w + 688) of a record with 43 lanes
+    // wave w copies bytes [640 w, 640 w + 640) of a record with 40 lanes
     auto issue_record = [&](int tl, int b) {
-        if (lane < 43)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rec, (lds_ptr)(s_rec[b] + wave * 688), 16,
-                                                     lane16, tl * R3_BYTES + wave * 688, 0, 0);
+        if (lane < R3_PIECE / 16)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rec, (lds_ptr)(s_rec[b] + wave * R3_PIECE), 16,
+                                                     lane16, tl * R3_BYTES + wave * R3_PIECE, 0, 0);
     };
 
     // ---- column state of the tree whose range-minimum loads are in flight
@@ -282,13 +296,13 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
     // indices.  Lane = original row index i (rank rho_i): both stores are then free of bank
     // conflicts -- the mirror store writes row so_b contiguously, the other one has stride
     // DV_LD over consecutive lanes (with lane = rank they conflicted three ways).  Wave w walks
-    // b in [16 w, 16 w + 16); lanes whose rank lies in an earlier segment take their running
+    // b in [mono_seg(w), mono_seg(w + 1)); lanes whose rank lies in an earlier segment take their running
     // minimum at the segment start from the record's seeds.  A lane's first active step
     // (b == rho) stores cur = +inf on the diagonal -- min(inf, vn) = vn: the cell (nb, c)
     // itself -- and picks up g[rho].
     auto expand = [&](int tl) {
         const unsigned char *rb = s_rec[tl & 1];
-        const int b0 = wave * 16;
+        const int b0 = mono_seg(wave), b1 = mono_seg(wave + 1);
         const double g_rank = ((const double *)(rb + R3_G))[lane];  // lane b holds g[b]
         const int so_rank = rb[R3_SORIG + lane];                    // lane b holds the row of rank b
         const int rho = rb[R3_RANK + lane];
@@ -297,8 +311,9 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
         double *row_a = &s_dv[lane * DV_LD];
         double *col_a = &s_dv[lane];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < MONO_MAXSEG; ++j) {
             const int b = b0 + j;
+            if (b >= b1) break;  // uniform over the wave: segments are 10 or 11 steps long
             const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_rank), b);
             const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_rank), b);
             const int so_b = __builtin_amdgcn_readlane(so_rank, b);
@@ -376,9 +391,9 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
             if (i == self) acc[i] = 0.0;
     }
     if (p.tile_out) {
-        double *tp = p.tile_out + (int64_t)blockIdx.x * SCS_TR * SCS_TCW + tid;
+        double *tp = p.tile_out + (int64_t)blockIdx.x * SCS_TR * MONO_TCW + tid;
 #pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) tp[i * SCS_TCW] = acc[i];
+        for (int i = 0; i < SCS_TR; ++i) tp[i * MONO_TCW] = acc[i];
         return;
     }
     if (col < p.n) {
@@ -394,8 +409,10 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
         // straight from the accumulators every lane would write 8 bytes into a different row;
         // instead eight rows at a time go through LDS ([column][8 rows], the table's space) and
         // come out as 64-byte runs along the rows of W.
-        double *t = s_dv;  // 256 x 9 doubles
-        const bool wave_mirrors = ((row0 / SCS_TCW) + 1) * SCS_TCW <= ((tile.y * SCS_TCW + wave * 64) / SCS_TR) * SCS_TR;
+        // (in the table's space when it fits, as it does at 256 columns)
+        __shared__ double t_own[MONO_TCW * 9 > DT_DOUBLES ? MONO_TCW * 9 : 1];
+        double *t = MONO_TCW * 9 > DT_DOUBLES ? t_own : s_dv;
+        const bool wave_mirrors = ((row0 / MONO_TCW) + 1) * MONO_TCW <= ((tile.y * MONO_TCW + wave * 64) / SCS_TR) * SCS_TR;
 #pragma unroll
         for (int q = 0; q < SCS_TR / 8; ++q) {
             SCS_BARE_BARRIER();
@@ -406,7 +423,7 @@ __global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate_mono(mono_params p) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
                     const int cl = wave * 64 + it * 8 + (lane >> 3);  // column within the tile
-                    const int c = tile.y * SCS_TCW + cl;
+                    const int c = tile.y * MONO_TCW + cl;
                     const int r = row0 + q * 8 + (lane & 7);
                     if (c < p.n && r < p.row_end) p.w[(int64_t)c * p.ld + r] = t[cl * 9 + (lane & 7)];
                 }

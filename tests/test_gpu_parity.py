@@ -510,7 +510,7 @@ def test_shared_build_exchange_modes(dev, monkeypatch, mode):
     assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
     received = [o[3]["exchange_bytes"] for o in out]
     n_tiles_all = sum(o[3]["n_tiles"] for o in out)
-    tile_bytes = 64 * 256 * 8
+    tile_bytes = out[0][3]["cell_trees"] / out[0][3]["n_tiles"] / tables.n_trees * 8  # cells per tile x 8
     if mode == "allgather":
         assert all(rb >= 0.7 * n_tiles_all * tile_bytes for rb in received)
     else:
