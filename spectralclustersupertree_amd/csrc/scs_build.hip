@@ -855,14 +855,24 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     const int M = tb->n_trees;
     std::vector<int> batch_start{0};
     {
-        // A batch is also capped at 256 trees.  All tiles of a launch start at the batch's first
-        // tree and drift apart as they walk the trees; the gathers into a tree's tables hit the
-        // L2 only while the workgroups of an XCD are within a few trees of each other.  A new
-        // launch re-synchronises them for the price of re-reading the tile sums (measured at
-        // 50 000 / 2 000: 2.10 s in one batch, 1.31 s in batches of 256; 64 -> 1.67 s, 512 ->
-        // 1.55 s; at 100 000 / 5 000: 25.3 s -> 14.3 s).  SCS_BATCH_TREES overrides.
+        // A batch is also capped in trees.  All tiles of a launch start at the batch's first tree
+        // and drift apart as they walk the trees; the gathers into a tree's range-minimum table
+        // hit the L2 (or at least the Infinity Cache) only while the workgroups are within a few
+        // trees of each other.  A new launch re-synchronises them for the price of re-reading
+        // and re-writing the tile sums (the mirror image is only written by the last batch), so
+        // the bigger a tree's table, the shorter the batch: about 600 MB of tables per batch,
+        // between 64 and 256 trees (measured: 10 000 leaves 256 trees -- 128 within 1 %;
+        // 50 000 leaves: 96 / 80 trees 682 ms, 256 trees 720 ms, 32 trees 761 ms; 100 000
+        // leaves: 48-96 trees 7.5 s, 256 trees 8.4 s).  SCS_BATCH_TREES overrides.
         static const int batch_trees_env = getenv("SCS_BATCH_TREES") ? atoi(getenv("SCS_BATCH_TREES")) : 0;
-        const int max_batch_trees = batch_trees_env > 0 ? batch_trees_env : 256;
+        int max_batch_trees = 256;
+        {
+            const double avg_leaves = (double)tb->n_leaves / std::max(M, 1);
+            const double table_bytes = (double)table_entries((int64_t)std::max(avg_leaves - 1.0, 1.0)) *
+                                       (monotone ? 8.0 : (double)key_bytes);
+            max_batch_trees = (int)std::min(256.0, std::max(64.0, 600e6 / std::max(table_bytes, 1.0)));
+        }
+        if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
         size_t used = 0;
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
