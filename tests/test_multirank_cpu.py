@@ -138,3 +138,112 @@ def test_two_rank_gloo_rendezvous_and_gather(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def _bench_worker(rank: int, world: int, port: int, out_dir: str) -> None:
+    """bench.py's N > 1 control flow end to end (rendezvous, timed loop, max over ranks, parity
+    gate, the one-GPU reference pass, the JSON line) with the device replaced by a stand-in that
+    answers from the oracle: no GPU here, and every key the real library reports is present."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import contextlib
+    import io
+    import json
+
+    from oracle import scs_oracle as so
+    from oracle import tables_oracle as to
+    from spectralclustersupertree_amd import backend
+
+    class FakeGraph:
+        def __init__(self, dev, tables, rb, re_, shared):
+            self.w, _ = to.pcg_dense(tables)
+            self.rb, self.re = rb, re_
+            n, m = tables.n_taxa, tables.n_trees
+            self.build_stats = {
+                "n_taxa": n, "n_trees": m, "row_begin": rb, "row_end": re_, "symmetric": 2 if shared else 0,
+                "n_tiles": 3, "n_batches": 1, "cell_trees": 1.0 * n * n * m, "prep_ms": 0.1,
+                "accumulate_ms": 1.0, "exchange_ms": 0.2 if shared else 0.0, "total_ms": 1.4,
+                "bytes_w": 8.0 * (re_ - rb) * n, "bytes_tables": 16.0 * tables.n_taxa * m,
+                "exchange_bytes": 1e6 if shared else 0.0}
+
+        def fiedler(self, v0, tol=1e-13, max_iter=2000, block=0):
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                maps = to.sign_flip_columns(so.spectral_maps(self.w, np.random.RandomState(0)))
+            n = self.w.shape[0]
+            return maps, {"n_vertices": n, "block": 4, "iterations": 7, "n_apply": 8, "converged": 1,
+                          "used_constraint": 1, "lambda": [1.0, 0.5], "resid": [0.0, 1e-14], "lambda_next": 0.4,
+                          "apply_ms_total": 0.8, "apply_ms_min": 0.1, "solve_ms": 2.0,
+                          "apply_bytes": 8.0 * (self.re - self.rb) * n}
+
+        def download_rows(self, first, count):
+            return self.w[first:first + count].copy()
+
+        def free(self):
+            pass
+
+    class FakeTables:
+        def __init__(self, dev, tables):
+            self.dev, self.tables = dev, tables
+
+        def build(self, rb=0, re_=None, shared=None):
+            re_ = self.tables.n_taxa if re_ is None else re_
+            return FakeGraph(self.dev, self.tables, rb, re_, bool(shared))
+
+        def free(self):
+            pass
+
+    class FakeDevice:
+        SMALL_MAX_TAXA = 64
+
+        def __init__(self, device=0, rank=0, world=1, unique_id=None, **kw):
+            assert world == 1 or (unique_id is not None and len(unique_id) == 128)
+            self.rank, self.world = rank, world
+
+        @staticmethod
+        def unique_id():
+            return bytes(range(128))
+
+        def upload(self, tables):
+            return FakeTables(self, tables)
+
+        def synchronize(self):
+            pass
+
+        def close(self):
+            pass
+
+    backend.Device = FakeDevice
+    import bench
+
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "custom",
+                "--taxa", "200", "--trees", "5", "--strategy", "depth"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.main()
+    assert rc == 0
+    if rank == 0:
+        line = json.loads(buf.getvalue().strip().splitlines()[-1])
+        assert line["n_gpus"] == world and line["steps"] == 2 and line["unit"] == "s"
+        assert line["higher_is_better"] is False and line["scaling"] == "strong"
+        for key in ("metric", "value", "ms_per_step", "config", "roofline", "roofline_other", "roofline_path",
+                    "stages", "parity", "same_workload_on_one_gpu"):
+            assert key in line, key
+        assert line["parity"]["w_cells_mismatched"] == 0
+        assert line["stages"]["build_exchange_ms"] > 0 and line["stages"]["build_exchange_bytes_received"] > 0
+        assert "workload" in line["config"] and "parallelism" in line["config"]
+    else:
+        assert buf.getvalue().strip() == ""
+    Path(out_dir, f"bench_ok{rank}").write_text("ok")
+
+
+def test_bench_two_rank_control_flow(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "bench_ok0").exists() and (tmp_path / "bench_ok1").exists()
