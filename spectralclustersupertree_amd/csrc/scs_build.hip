@@ -11,13 +11,15 @@
 // reference's order and the sum is bit-identical.
 //
 // LCA depth is an ultrametric.  For a tile's 64 rows Y and a column c in tree t:
-//   d(i,c) = min( D[i][nb(c)], dn(c) ),  nb(c) = the row nearest to c in DFS
-//   order with the deeper LCA, dn(c) = depth(LCA(nb(c), c)),
-// where D is the 64 x 64 row-row LCA table of the tile in that tree.  D is
-// expanded in LDS from a 1.1 KB per-(row block, tree) record (rows sorted by
-// DFS position + the 63 LCAs between neighbours); nb/dn cost two range-minimum
-// queries per column on the tree's sparse table.  The inner loop is then one
-// LDS gather of (depth, value), a compare/select and one fp64 add per cell.
+//   d(i,c) = min( D[i][nb(c)], dn(c) ),  nb(c) = the row next to c in DFS order with the
+//   deeper LCA, dn(c) = depth(LCA(nb(c), c)),
+// where D is the 64 x 64 row-row LCA table of the tile in that tree.  D is expanded in LDS
+// from a per-(row block, tree) record (rows sorted by DFS position + the 63 LCAs between
+// neighbours); nb/dn cost ONE range-minimum query (two independent loads) per column on the
+// tree's sparse table.  The inner loop is one ds_read_b64 per cell plus
+//   * a v_min_f64 and a v_add_f64 when the value is monotone in the depth (scs_mono.h: the
+//     table and the range-minimum tables then hold values), or
+//   * a rank compare, a select and a v_add_f64 otherwise (scs_gen.h: (depth, value) pairs).
 
 #include <algorithm>
 
@@ -26,16 +28,6 @@
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-constexpr int REC_SPOS = 0;       // int32[64] sorted DFS positions (INT_MAX beyond cnt)
-constexpr int REC_GDEPTH = 256;   // u32[64]   depth of LCA(sorted k, sorted k+1)
-constexpr int REC_GVW = 512;      // f64[64]   value*w of that LCA (0 where depth 0)
-constexpr int REC_SORIG = 1024;   // u8[64]    row (0..63) at sorted rank k
-constexpr int REC_RANK = 1088;    // u8[64]    sorted rank of row i (255 = absent)
-constexpr int REC_CNT = 1152;     // int32     rows present in the tree
-constexpr int REC_M = 1156;       // int32     gaps of the tree (n_t - 1)
-constexpr int REC_STOFF = 1160;   // int64     offset of the tree's sparse table in the batch
-constexpr int REC_VWOFF = 1168;   // int64     offset of the tree's gaps in the batch vw array
-constexpr int REC_BYTES = 1184;
 constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
 
 // ---------------------------------------------------------------------------
@@ -43,29 +35,13 @@ constexpr u32 DEPTH_INF = 0xFFFFFFFFu;
 // ---------------------------------------------------------------------------
 
 // ---- range-minimum tables ---------------------------------------------------
-// A gap p of a tree (the LCA of leaves p and p + 1) is keyed (depth << pos_bits) | p, so
-// the minimum key over a range of gaps names the shallowest LCA in it, i.e. the LCA of
-// the range's end leaves.  Keys are 32-bit when depth and position fit together (K = u32,
-// pos_bits = bits of the largest tree), else 64-bit with pos_bits = 32: half the table
-// bytes of a (depth, position) pair of words, which is what the gathers of the accumulate
-// kernels miss the L2 on.  Per tree with m gaps: a plain sparse table, level k at
-// [k m, (k + 1) m), entry p = min over [p, p + 2^k); a query is two independent loads.
+// Per tree with m gaps (gap p = the LCA of leaves p and p + 1 in DFS order): a plain sparse
+// table, level k at [k m, (k + 1) m), entry p = the minimum over gaps [p, p + 2^k); a query is
+// two independent loads.  Entries are the gap VALUES when the weighting is monotone in the
+// depth (scs_mono.h), else (depth, value) pairs ordered by depth (scs_gen.h).
 // (A blocked table -- in-block prefix/suffix minima plus a sparse table over block minima,
 // 6.75 m entries -- was measured slower: twice the gathers per query cost more than the
 // smaller footprint saved.)
-template <typename K>
-__device__ __forceinline__ K key_make(u32 depth, u32 pos, int pos_bits) {
-    return ((K)depth << pos_bits) | (K)pos;
-}
-template <typename K>
-__device__ __forceinline__ u32 key_depth(K k, int pos_bits) {
-    return (u32)(k >> pos_bits);
-}
-template <typename K>
-__device__ __forceinline__ u32 key_pos(K k, int pos_bits) {
-    return (u32)(k & (((K)1 << pos_bits) - 1));
-}
-
 // offsets (entries from the tree's table base) of the two loads of a query over gaps
 // [a, b), 0 <= a < b <= m
 __device__ __forceinline__ void rmq_offsets(int m, int a, int b, int (&o)[2]) {
@@ -80,31 +56,6 @@ __device__ __forceinline__ K rmq_min(const K *__restrict__ base, int m, int a, i
     rmq_offsets(m, a, b, o);
     const K x = base[o[0]], y = base[o[1]];
     return x < y ? x : y;
-}
-
-// grid (ceil(max_leaves/256), trees in batch): positions, leaf values, level-0 keys
-template <typename K>
-__global__ void k_positions(const int64_t *__restrict__ tree_off,
-                            const int32_t *__restrict__ leaf_taxon,
-                            const int32_t *__restrict__ adj_depth,
-                            const double *__restrict__ adj_val,
-                            const double *__restrict__ tree_w, int t0, int64_t leaf_base,
-                            int32_t *__restrict__ pos, int64_t npad, double *__restrict__ vw,
-                            const int64_t *__restrict__ st_off, K *__restrict__ st,
-                            int pos_bits) {
-    const int tl = blockIdx.y;
-    const int t = t0 + tl;
-    const int64_t off = tree_off[t];
-    const int n = (int)(tree_off[t + 1] - off);
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    pos[(int64_t)tl * npad + leaf_taxon[off + p]] = p;
-    if (p < n - 1) {
-        const u32 d = (u32)adj_depth[off + p];
-        // one rounded multiply, as the reference's `length * tree_weight`
-        vw[off - leaf_base + p] = d ? adj_val[off + p] * tree_w[t] : 0.0;
-        st[st_off[tl] + p] = key_make<K>(d, (u32)p, pos_bits);
-    }
 }
 
 // monotone builds: the range-minimum table is over the gap VALUES themselves (the value of
@@ -152,261 +103,8 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 #endif
 }
 
-// one wave per (local row block, tree): grid (n_blocks, trees in batch), 64 threads
-template <typename K>
-__global__ __launch_bounds__(64) void k_block_records(
-    const int64_t *__restrict__ tree_off, int t0, int n_batch, int64_t leaf_base,
-    const int32_t *__restrict__ pos, int64_t npad, const double *__restrict__ vw,
-    const int64_t *__restrict__ st_off, const K *__restrict__ st, int pos_bits, int row_begin,
-    int row_end, unsigned char *__restrict__ rec_all) {
-    const int blk = blockIdx.x;
-    const int tl = blockIdx.y;
-    const int t = t0 + tl;
-    const int lane = threadIdx.x;
-    const int64_t off = tree_off[t];
-    const int m = (int)(tree_off[t + 1] - off) - 1;
-    const int row = row_begin + blk * SCS_TR + lane;
-    int p = -1;
-    if (row < row_end) p = pos[(int64_t)tl * npad + row];
-    const u32 pk = p < 0 ? 0x7FFFFFFFu : (u32)p;
-    u64 key = ((u64)pk << 32) | (u32)lane;
-    // bitonic sort of 64 unique keys across the wave
-    for (int k = 2; k <= 64; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const u64 other = __shfl_xor(key, j, 64);
-            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
-            const u64 lo = key < other ? key : other;
-            const u64 hi = key < other ? other : key;
-            key = take_min ? lo : hi;
-        }
-    }
-    const int spos = (int)(key >> 32);
-    const int orig = (int)(key & 63);
-    const bool present = spos != 0x7FFFFFFF;
-    const int cnt = __popcll(__ballot(present));
-    const int next_pos = __shfl_down(spos, 1, 64);
-    u32 gdepth = 0;
-    double gvw = 0.0;
-    if (lane < cnt - 1) {
-        const K r = rmq_min<K>(st + st_off[tl], m, spos, next_pos);
-        gdepth = key_depth<K>(r, pos_bits);
-        gvw = gdepth ? vw[off - leaf_base + key_pos<K>(r, pos_bits)] : 0.0;
-    }
-    unsigned char *rec = rec_all + ((int64_t)blk * n_batch + tl) * REC_BYTES;
-    ((int *)(rec + REC_SPOS))[lane] = spos;
-    ((u32 *)(rec + REC_GDEPTH))[lane] = gdepth;
-    ((double *)(rec + REC_GVW))[lane] = gvw;
-    rec[REC_SORIG + lane] = (unsigned char)orig;
-    rec[REC_RANK + orig] = present ? (unsigned char)lane : (unsigned char)255;
-    if (lane == 0) {
-        *(int *)(rec + REC_CNT) = cnt;
-        *(int *)(rec + REC_M) = m;
-        *(int64_t *)(rec + REC_STOFF) = st_off[tl];
-        *(int64_t *)(rec + REC_VWOFF) = off - leaf_base;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// tile accumulate
-// ---------------------------------------------------------------------------
-struct acc_params {
-    const int2 *tiles;  // (local row block, column group index)
-    const unsigned char *rec;
-    const int32_t *pos;
-    int64_t npad;
-    const double *vw;
-    const int64_t *st_off;
-    const void *st;  // range-minimum tables, entries of the kernel's key type
-    int pos_bits;    // key = (depth << pos_bits) | position
-    const int64_t *tree_off;
-    int t0;
-    int n_batch;
-    int64_t leaf_base;
-    double *w;   // this rank's rows
-    int64_t ld;
-    int n;       // V
-    int row_begin, row_end;
-    int load_w;  // 1: continue a sum started by an earlier batch
-    double *tile_out;  // shared multi-rank build: packed 64 x 256 tiles instead of W (else null)
-    int slot_base;     // slot of this launch's first tile in tile_out
-    unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
-};
-
-template <bool SYM, typename K>
-__global__ __launch_bounds__(SCS_TCW, 3) void k_accumulate(acc_params p) {
-    constexpr int CPT = 1;  // columns per thread
-    __shared__ int s_spos[64];
-    __shared__ double s_gvw[64];
-    __shared__ unsigned char s_sorig[64];
-    __shared__ unsigned char s_rank[64];
-    __shared__ int s_cnt;
-    __shared__ u64 s_sp[6][64];
-    __shared__ u32 s_dd[64][64];
-    __shared__ double s_dv[64][64];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int2 tile = p.tiles[blockIdx.x];
-    const int blk = tile.x;
-    const int row0 = p.row_begin + blk * SCS_TR;  // global index of the tile's first row
-    int col[CPT];
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) col[q] = (tile.y * CPT + q) * SCS_TCW + tid;
-
-    double acc[CPT][SCS_TR];
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) {
-            double v = 0.0;
-            if (p.load_w && p.tile_out)
-                v = p.tile_out[((int64_t)(p.slot_base + blockIdx.x) * SCS_TR + i) * SCS_TCW + tid];
-            else if (p.load_w && col[q] < p.n && row0 + i < p.row_end)
-                v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col[q]];
-            acc[q][i] = v;
-        }
-    }
-
-    const unsigned char *rec = p.rec + (int64_t)blk * p.n_batch * REC_BYTES;
-    for (int tl = 0; tl < p.n_batch; ++tl, rec += REC_BYTES) {
-        // ---- record -> LDS; wave 0 also builds the sparse table over the 63 gaps
-        if (tid < 64) {
-            s_spos[tid] = ((const int *)(rec + REC_SPOS))[tid];
-            const int cnt = *(const int *)(rec + REC_CNT);
-            const u32 gd = ((const u32 *)(rec + REC_GDEPTH))[tid];
-            u64 key = tid < cnt - 1 ? (((u64)gd << 32) | (u32)tid) : ~0ull;
-            s_sp[0][tid] = key;
-#pragma unroll
-            for (int j = 1; j < 6; ++j) {
-                const u64 other = __shfl_down(key, 1 << (j - 1), 64);
-                if (tid + (1 << (j - 1)) < 64) key = key < other ? key : other;
-                s_sp[j][tid] = key;
-            }
-            if (tid == 0) s_cnt = cnt;
-        } else if (tid < 128) {
-            s_gvw[tid - 64] = ((const double *)(rec + REC_GVW))[tid - 64];
-        } else if (tid < 192) {
-            s_sorig[tid - 128] = rec[REC_SORIG + tid - 128];
-        } else {
-            s_rank[tid - 192] = rec[REC_RANK + tid - 192];
-        }
-        // column positions (global, independent of LDS)
-        int cpos[CPT];
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) cpos[q] = p.pos[(int64_t)tl * p.npad + col[q]];
-        __syncthreads();
-
-        // ---- expand the row-row LCA table: wave w fills rows w, w+4, ...
-        {
-            const int rj = s_rank[lane];
-#pragma unroll 4
-            for (int i = wave; i < SCS_TR; i += 4) {
-                const int ri = s_rank[i];
-                u32 d = 0;
-                double v = 0.0;
-                if (i == lane) {
-                    d = DEPTH_INF;
-                } else if (ri != 255 && rj != 255) {
-                    const int a = ri < rj ? ri : rj;
-                    const int b = ri < rj ? rj : ri;
-                    const int k = 31 - __clz(b - a);
-                    const u64 x = s_sp[k][a];
-                    const u64 y = s_sp[k][b - (1 << k)];
-                    const u64 r = x < y ? x : y;
-                    d = (u32)(r >> 32);
-                    v = s_gvw[(u32)r & 63u];
-                }
-                s_dd[i][lane] = d;
-                s_dv[i][lane] = v;
-            }
-        }
-        // ---- per column: nearest tile row in DFS order and the LCA with it
-        int nb[CPT];
-        u32 dn[CPT];
-        double vn[CPT];
-        {
-            const int t = p.t0 + tl;
-            const int64_t off = p.tree_off[t];
-            const int m = (int)(p.tree_off[t + 1] - off) - 1;
-            const K *st = (const K *)p.st + p.st_off[tl];
-            const int pos_bits = p.pos_bits;
-            const int cnt = s_cnt;
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) {
-                nb[q] = 0;
-                dn[q] = 0;
-                vn[q] = 0.0;
-                const int cp = cpos[q];
-                if (cp >= 0 && cnt > 0) {
-                    int lo = 0;
-#pragma unroll
-                    for (int s = 32; s > 0; s >>= 1)
-                        if (s_spos[lo + s - 1] < cp) lo += s;
-                    if (s_spos[lo] < cp) lo += 1;  // only when all 64 rows precede the column
-                    if (lo < cnt && s_spos[lo] == cp) {
-                        nb[q] = s_sorig[lo];  // the column is one of the tile's rows
-                        dn[q] = DEPTH_INF;
-                    } else {
-                        K gl = 0, gr = 0;
-                        if (lo > 0) gl = rmq_min<K>(st, m, s_spos[lo - 1], cp);
-                        if (lo < cnt) gr = rmq_min<K>(st, m, cp, s_spos[lo]);
-                        const bool left = lo > 0 && (lo >= cnt || key_depth<K>(gl, pos_bits) >=
-                                                                      key_depth<K>(gr, pos_bits));
-                        const K g = left ? gl : gr;
-                        nb[q] = s_sorig[left ? lo - 1 : lo];
-                        dn[q] = key_depth<K>(g, pos_bits);
-                        if (dn[q]) vn[q] = p.vw[off - p.leaf_base + key_pos<K>(g, pos_bits)];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- 64 cells per column: gather, select, add (tree order preserved)
-#pragma unroll
-        for (int q = 0; q < CPT; ++q) {
-            const u32 *dd = &s_dd[0][nb[q]];
-            const double *dv = &s_dv[0][nb[q]];
-            const u32 dnq = dn[q];
-            const double vnq = vn[q];
-#pragma unroll
-            for (int i = 0; i < SCS_TR; ++i) {
-                const u32 ed = dd[i * 64];
-                const double ev = dv[i * 64];
-                acc[q][i] += ed < dnq ? ev : vnq;
-            }
-        }
-    }
-
-    // ---- write the tile once: packed (shared multi-rank build) or straight into W, with
-    // its mirror image in the symmetric schedule
-    if (p.tile_out) {
-        double *tp = p.tile_out + (int64_t)(p.slot_base + blockIdx.x) * SCS_TR * SCS_TCW + tid;
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) tp[i * SCS_TCW] = acc[0][i];
-        return;
-    }
-#pragma unroll
-    for (int q = 0; q < CPT; ++q) {
-        const int c = col[q];
-        if (c >= p.n) continue;
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) {
-            const int r = row0 + i;
-            if (r < p.row_end) {
-                p.w[(int64_t)(r - p.row_begin) * p.ld + c] = acc[q][i];
-                // mirror only into cells that no tile of the schedule owns, so
-                // every cell of W has exactly one writer (needed for batches)
-                constexpr int CT = SCS_TCW * CPT;
-                if (SYM && ((r / CT) + 1) * CT <= (c / SCS_TR) * SCS_TR)
-                    p.w[(int64_t)c * p.ld + r] = acc[q][i];
-            }
-        }
-    }
-}
-
-#include "scs_mono.h"  // monotone fast path: k_block_tables, k_accumulate_mono
+#include "scs_mono.h"  // monotone fast path: k_block_records_mono, k_accumulate_mono
+#include "scs_gen.h"   // general path on the same tile structure: k_block_records_gen, k_accumulate_gen
 
 // ---------------------------------------------------------------------------
 // shared multi-rank build: gathered upper-triangle tiles -> this rank's rows of W
@@ -742,7 +440,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int world = ctx->comm.world, rank = ctx->comm.rank;
-    const int cols_per_tile = monotone ? MONO_TCW : SCS_TCW;
+    // monotone weighting: tables over values (scs_mono.h); else (depth, value) pairs (scs_gen.h)
+    const int cols_per_tile = MONO_TCW;
+    static_assert(MONO_TCW == SCS_TCW, "one tile width for all kernels");
+    const size_t entry_bytes = monotone ? 8 : sizeof(gap_entry);
+    const size_t rec_bytes = monotone ? R3_BYTES : G3_BYTES;
     const int n_cgroups = (n + cols_per_tile - 1) / cols_per_tile;
     // (the last column group may reach past n: its threads read "absent" positions)
     const int64_t npad = scs_round_up((int64_t)n_cgroups * cols_per_tile, SCS_NPAD);
@@ -841,14 +543,6 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                  hipMemcpyHostToDevice, s));
 
-    // ---- key width of the range-minimum tables: 32 bits when depth and position fit
-    // together (SCS_KEY64=1 forces the 64-bit path: tests)
-    int pos_bits = 1;
-    while ((1ll << pos_bits) < std::max<int64_t>(tb->max_leaves, 2)) ++pos_bits;
-    const bool key64 = (int64_t)tb->max_depth >= (1ll << (32 - pos_bits)) ||
-                       (getenv("SCS_KEY64") && atoi(getenv("SCS_KEY64")));
-    if (key64) pos_bits = 32;
-    const size_t key_bytes = key64 ? 8 : 4;
     auto table_entries = [](int64_t m) -> int64_t { return (int64_t)levels_for(m) * m; };
 
     // ---- batch plan: bound range-minimum tables + records + positions by the workspace
@@ -864,12 +558,16 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // between 64 and 256 trees (measured: 10 000 leaves 256 trees -- 128 within 1 %;
         // 50 000 leaves: 96 / 80 trees 682 ms, 256 trees 720 ms, 32 trees 761 ms; 100 000
         // leaves: 48-96 trees 7.5 s, 256 trees 8.4 s).  SCS_BATCH_TREES overrides.
+        // (Preparing batch k + 1 on a second stream while batch k accumulates was tried and is
+        // slower -- 50 000 leaves: 785 ms instead of 697 ms at any stream priority: the
+        // preparation kernels take CU slots a few at a time, the tiles fall out of step and the
+        // new tables push the current ones out of the caches.  The batches stay sequential.)
         static const int batch_trees_env = getenv("SCS_BATCH_TREES") ? atoi(getenv("SCS_BATCH_TREES")) : 0;
         int max_batch_trees = 256;
         {
             const double avg_leaves = (double)tb->n_leaves / std::max(M, 1);
-            const double table_bytes = (double)table_entries((int64_t)std::max(avg_leaves - 1.0, 1.0)) *
-                                       (monotone ? 8.0 : (double)key_bytes);
+            const double table_bytes =
+                (double)table_entries((int64_t)std::max(avg_leaves - 1.0, 1.0)) * (double)entry_bytes;
             max_batch_trees = (int)std::min(256.0, std::max(64.0, 600e6 / std::max(table_bytes, 1.0)));
         }
         if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
@@ -877,10 +575,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
             const int64_t m = nt - 1;
-            size_t need = monotone ? (size_t)table_entries(m) * 8 + (size_t)npad * 4 +
-                                         (size_t)n_blocks * R3_BYTES
-                                   : (size_t)table_entries(m) * key_bytes + (size_t)nt * 8 +
-                                         (size_t)npad * 4 + (size_t)n_blocks * REC_BYTES;
+            const size_t need =
+                (size_t)table_entries(m) * entry_bytes + (size_t)npad * 4 + (size_t)n_blocks * rec_bytes;
             if ((used + need > ctx->ws_limit || t - batch_start.back() >= max_batch_trees) &&
                 t > batch_start.back()) {
                 batch_start.push_back(t);
@@ -904,12 +600,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     float prep_ms = 0.f, acc_ms = 0.f;
     SCS_HIP_CHECK(hipEventRecord(ev_total.a, s));
 
-    pooled_buf d_pos(ctx, 1), d_vw(ctx, 2), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5);
+    pooled_buf d_pos(ctx, 1), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5);
     for (int bi = 0; bi < n_batches; ++bi) {
         const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
         const int nb = t1 - t0;
-        const int64_t leaf_base = tb->h_tree_off[t0];
-        const int64_t leaves = tb->h_tree_off[t1] - leaf_base;
         std::vector<int64_t> st_off(nb + 1);
         int max_levels = 0;
         int64_t max_n = 0;
@@ -921,13 +615,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             max_n = std::max(max_n, nt);
         }
         const size_t need_pos = (size_t)nb * npad * 4;
-        const size_t need_vw = monotone ? 0 : (size_t)leaves * 8;
         // +64: a tree without gaps may be probed at entry 0
-        const size_t need_st = (size_t)st_off[nb] * (monotone ? 8 : key_bytes) + 64;
+        const size_t need_st = (size_t)st_off[nb] * entry_bytes + 64;
         const size_t need_stoff = (size_t)(nb + 1) * 8;
-        const size_t need_rec = (size_t)n_blocks * nb * (monotone ? R3_BYTES : REC_BYTES);
+        const size_t need_rec = (size_t)n_blocks * nb * rec_bytes;
         SCS_TRY(d_pos.alloc(need_pos));
-        SCS_TRY(d_vw.alloc(need_vw));
         SCS_TRY(d_st.alloc(need_st));
         SCS_TRY(d_stoff.alloc(need_stoff));
         SCS_TRY(d_rec.alloc(need_rec));
@@ -936,20 +628,6 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_HIP_CHECK(hipMemcpyAsync(d_stoff.p, st_off.data(), need_stoff, hipMemcpyHostToDevice, s));
         SCS_HIP_CHECK(hipMemsetAsync(d_pos.p, 0xFF, need_pos, s));
         dim3 grid_l((unsigned)((max_n + 255) / 256), (unsigned)nb);
-#define SCS_PREP(K)                                                                              \
-    do {                                                                                         \
-        k_positions<K><<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon, tb->d_adj_depth, \
-                                              tb->d_adj_val, tb->d_tree_w, t0, leaf_base,        \
-                                              (int32_t *)d_pos.p, npad, (double *)d_vw.p,        \
-                                              (const int64_t *)d_stoff.p, (K *)d_st.p, pos_bits); \
-        for (int k = 1; k < max_levels; ++k)                                                     \
-            k_sparse_level<K><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,                      \
-                                                     (const int64_t *)d_stoff.p, (K *)d_st.p);   \
-        k_block_records<K><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(                \
-            tb->d_tree_off, t0, nb, leaf_base, (const int32_t *)d_pos.p, npad,                   \
-            (const double *)d_vw.p, (const int64_t *)d_stoff.p, (const K *)d_st.p, pos_bits,     \
-            b_row_begin, b_row_end, (unsigned char *)d_rec.p);                                   \
-    } while (0)
         if (monotone) {
             k_positions_values<<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon,
                                                       tb->d_adj_depth, tb->d_adj_val, tb->d_tree_w,
@@ -962,36 +640,21 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             k_block_records_mono<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
                 tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
                 (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
-        } else if (key64) {
-            SCS_PREP(u64);
         } else {
-            SCS_PREP(u32);
+            k_positions_pairs<<<grid_l, 256, 0, s>>>(tb->d_tree_off, tb->d_leaf_taxon,
+                                                     tb->d_adj_depth, tb->d_adj_val, tb->d_tree_w,
+                                                     t0, (int32_t *)d_pos.p, npad,
+                                                     (const int64_t *)d_stoff.p, (gap_entry *)d_st.p);
+            for (int k = 1; k < max_levels; ++k)
+                k_sparse_level_pairs<<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
+                                                            (const int64_t *)d_stoff.p,
+                                                            (gap_entry *)d_st.p);
+            k_block_records_gen<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
+                tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
+                (const gap_entry *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
         }
-#undef SCS_PREP
         SCS_HIP_CHECK(hipEventRecord(ev_prep.b, s));
 
-        acc_params ap;
-        ap.tiles = (const int2 *)d_tiles.p;
-        ap.rec = (const unsigned char *)d_rec.p;
-        ap.pos = (const int32_t *)d_pos.p;
-        ap.npad = npad;
-        ap.vw = (const double *)d_vw.p;
-        ap.st_off = (const int64_t *)d_stoff.p;
-        ap.st = d_st.p;
-        ap.pos_bits = pos_bits;
-        ap.tree_off = tb->d_tree_off;
-        ap.t0 = t0;
-        ap.n_batch = nb;
-        ap.leaf_base = leaf_base;
-        ap.w = g->d_w;
-        ap.ld = g->ld;
-        ap.n = n;
-        ap.row_begin = b_row_begin;
-        ap.row_end = b_row_end;
-        ap.load_w = bi > 0;
-        ap.tile_out = shared ? (double *)d_tile_out.p : nullptr;
-        ap.slot_base = 0;
-        ap.stamps = nullptr;
         SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
         const unsigned nt = (unsigned)tiles.size();
         if (monotone) {
@@ -1034,13 +697,24 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 else k_accumulate_mono<false, false><<<nt, MONO_TCW, 0, s>>>(mp);
             }
         } else {
-            if (!nt) {
-            } else if (key64) {
-                if (sym) k_accumulate<true, u64><<<nt, SCS_TCW, 0, s>>>(ap);
-                else k_accumulate<false, u64><<<nt, SCS_TCW, 0, s>>>(ap);
-            } else {
-                if (sym) k_accumulate<true, u32><<<nt, SCS_TCW, 0, s>>>(ap);
-                else k_accumulate<false, u32><<<nt, SCS_TCW, 0, s>>>(ap);
+            gen_params gp;
+            gp.tiles = (const int2 *)d_tiles.p;
+            gp.rec = (const unsigned char *)d_rec.p;
+            gp.pos = (const int32_t *)d_pos.p;
+            gp.npad = npad;
+            gp.ste = (const gap_entry *)d_st.p;
+            gp.n_batch = nb;
+            gp.w = g->d_w;
+            gp.ld = g->ld;
+            gp.n = n;
+            gp.row_begin = b_row_begin;
+            gp.row_end = b_row_end;
+            gp.load_w = bi > 0;
+            gp.mirror = (sym && bi == n_batches - 1) ? 1 : 0;
+            gp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
+            if (nt) {
+                if (sym) k_accumulate_gen<true><<<nt, MONO_TCW, 0, s>>>(gp);
+                else k_accumulate_gen<false><<<nt, MONO_TCW, 0, s>>>(gp);
             }
         }
         SCS_HIP_CHECK(hipGetLastError());

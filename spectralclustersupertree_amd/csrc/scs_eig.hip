@@ -1742,7 +1742,7 @@ __global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
     __shared__ int s_tax[MAXS], s_dep[MAXS], s_gs[MAXS + 1];
     const int tid = threadIdx.x;
     const int k = blockIdx.x;
-    const int v0 = p.n_taxa[k], m = p.n_trees[k], v = p.n_groups[k];
+    const int m = p.n_trees[k], v = p.n_groups[k];
     const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
     const int64_t lbase = p.leaf_ptr[k];
     double(*w0)[SLD] = s.e;  // the uncontracted weights live where Jacobi later keeps its vectors

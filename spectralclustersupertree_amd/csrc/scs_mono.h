@@ -171,6 +171,61 @@ struct mono_params {
     unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
 };
 
+// ---- end of a tile (shared by the monotone and the general tile kernel): write the sums once,
+// packed (shared multi-rank build) or straight into W, plus the mirror image in the last batch
+// of a symmetric build.  s_dv: the workgroup's table space (free once the last tree is done).
+template <bool SYM, typename P>
+__device__ __forceinline__ void tile_store(const P &p, double (&acc)[SCS_TR], const int2 tile,
+                                           const int row0, const int col, const int self,
+                                           const int tid, const int lane, const int wave,
+                                           double *s_dv) {
+    if (self >= 0) {
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i)
+            if (i == self) acc[i] = 0.0;
+    }
+    if (p.tile_out) {
+        double *tp = p.tile_out + (int64_t)blockIdx.x * SCS_TR * MONO_TCW + tid;
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) tp[i * MONO_TCW] = acc[i];
+        return;
+    }
+    if (col < p.n) {
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) {
+            const int r = row0 + i;
+            if (r < p.row_end) p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
+        }
+    }
+    if (SYM && p.mirror) {
+        // The mirror image W[c][r] of the tile (cells no tile of the schedule owns; only the last
+        // batch writes it -- earlier batches are re-read through the direct cells).  Stored
+        // straight from the accumulators every lane would write 8 bytes into a different row;
+        // instead eight rows at a time go through LDS ([column][8 rows], the table's space) and
+        // come out as 64-byte runs along the rows of W.
+        // (in the table's space when it fits, as it does at 256 columns)
+        __shared__ double t_own[MONO_TCW * 9 > DT_DOUBLES ? MONO_TCW * 9 : 1];
+        double *t = MONO_TCW * 9 > DT_DOUBLES ? t_own : s_dv;
+        const bool wave_mirrors = ((row0 / MONO_TCW) + 1) * MONO_TCW <= ((tile.y * MONO_TCW + wave * 64) / SCS_TR) * SCS_TR;
+#pragma unroll
+        for (int q = 0; q < SCS_TR / 8; ++q) {
+            SCS_BARE_BARRIER();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[tid * 9 + j] = acc[q * 8 + j];
+            SCS_BARE_BARRIER();
+            if (wave_mirrors) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int cl = wave * 64 + it * 8 + (lane >> 3);  // column within the tile
+                    const int c = tile.y * MONO_TCW + cl;
+                    const int r = row0 + q * 8 + (lane & 7);
+                    if (c < p.n && r < p.row_end) p.w[(int64_t)c * p.ld + r] = t[cl * 9 + (lane & 7)];
+                }
+            }
+        }
+    }
+}
+
 template <bool SYM, bool STAMPED>
 __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mono_params p) {
     __shared__ __attribute__((aligned(16))) double s_dv[DT_DOUBLES];
@@ -385,49 +440,5 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
         atomicAdd(&p.stamps[7], 1ull);
     }
-    if (self >= 0) {
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i)
-            if (i == self) acc[i] = 0.0;
-    }
-    if (p.tile_out) {
-        double *tp = p.tile_out + (int64_t)blockIdx.x * SCS_TR * MONO_TCW + tid;
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) tp[i * MONO_TCW] = acc[i];
-        return;
-    }
-    if (col < p.n) {
-#pragma unroll
-        for (int i = 0; i < SCS_TR; ++i) {
-            const int r = row0 + i;
-            if (r < p.row_end) p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
-        }
-    }
-    if (SYM && p.mirror) {
-        // The mirror image W[c][r] of the tile (cells no tile of the schedule owns; only the last
-        // batch writes it -- earlier batches are re-read through the direct cells).  Stored
-        // straight from the accumulators every lane would write 8 bytes into a different row;
-        // instead eight rows at a time go through LDS ([column][8 rows], the table's space) and
-        // come out as 64-byte runs along the rows of W.
-        // (in the table's space when it fits, as it does at 256 columns)
-        __shared__ double t_own[MONO_TCW * 9 > DT_DOUBLES ? MONO_TCW * 9 : 1];
-        double *t = MONO_TCW * 9 > DT_DOUBLES ? t_own : s_dv;
-        const bool wave_mirrors = ((row0 / MONO_TCW) + 1) * MONO_TCW <= ((tile.y * MONO_TCW + wave * 64) / SCS_TR) * SCS_TR;
-#pragma unroll
-        for (int q = 0; q < SCS_TR / 8; ++q) {
-            SCS_BARE_BARRIER();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[tid * 9 + j] = acc[q * 8 + j];
-            SCS_BARE_BARRIER();
-            if (wave_mirrors) {
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int cl = wave * 64 + it * 8 + (lane >> 3);  // column within the tile
-                    const int c = tile.y * MONO_TCW + cl;
-                    const int r = row0 + q * 8 + (lane & 7);
-                    if (c < p.n && r < p.row_end) p.w[(int64_t)c * p.ld + r] = t[cl * 9 + (lane & 7)];
-                }
-            }
-        }
-    }
+    tile_store<SYM>(p, acc, tile, row0, col, self, tid, lane, wave, s_dv);
 }
