@@ -105,6 +105,25 @@ def test_config2_full_parity(dev):
     assert mism == 0
 
 
+def test_config2_size_bootstrap_rows_bit_exact(dev):
+    """configs[2]'s shape under the one weighting that is not monotone in the depth
+    (`bootstrap`: the general tile kernel, scs_gen.h): sampled rows bit for bit, symmetry."""
+    n, m = 10000, 500
+    tables = synthetic.make_tables(0, n, m, "bootstrap")
+    assert not tables.monotone
+    dtab = dev.upload(tables)
+    graph = dtab.build()
+    try:
+        assert graph.build_stats["n_batches"] > 1
+        _check_rows_bit_exact(graph, tables, _sample_rows(n, 40, 3))
+        w = graph.download()
+        assert np.array_equal(w, w.T)
+        assert not np.any(np.diag(w))
+    finally:
+        graph.free()
+        dtab.free()
+
+
 def _large_config_properties(dev, n, m, random_weights, n_rows, blocks):
     tables = synthetic.make_tables(0, n, m, "branch", random_weights=random_weights)
     dtab = dev.upload(tables)

@@ -128,6 +128,28 @@ def test_build_negative_lengths_and_weights_take_general_kernel(dev):
     _build_and_compare(dev, t2)
 
 
+def test_build_general_kernel_deep_caterpillars(dev):
+    # values that go up and down along a root path (negative lengths -> the general tile kernel,
+    # scs_gen.h) on trees as deep as they are wide: long runs of rows that share the column's
+    # LCA, depths far beyond the 63 gaps of a tile, taxa missing from some trees
+    rs = np.random.RandomState(5)
+    taxa = [f"t{i}" for i in range(330)]
+    trees = []
+    for k in range(7):
+        order = list(rs.permutation(taxa)[: 330 - 40 * (k % 3)])
+        nwk = f"{order[0]}:1"
+        for name in order[1:]:
+            left = rs.rand() < 0.5
+            ln = float(np.round(rs.uniform(-1.0, 2.0), 3))
+            nwk = f"({name}:1,{nwk}):{ln}" if left else f"({nwk},{name}:1):{ln}"
+        trees.append(make_tree(nwk + ";"))
+    names = sorted(so._all_tips(trees))
+    tables = fl.flatten_trees(trees, list(rs.uniform(0.5, 2.0, len(trees))), "branch", names)
+    assert not tables.monotone
+    _build_and_compare(dev, tables)
+    _build_and_compare(dev, tables, [(0, 130), (130, 330), (64, 129)])
+
+
 def test_build_tiny_and_degenerate_trees(dev):
     trees = [make_tree(s) for s in ["(a,b)", "((a,b),c)", "(d,(e,(f,(g,(h,(a,b))))))", "(a,b,c,d)", "((a,b,c)x,(d,e))"]]
     names = sorted(so._all_tips(trees))
