@@ -31,6 +31,13 @@
 //     accumulators leave no room for 64-bit per-lane addresses.
 // (Staging a precomputed 33 KB table per step by LDS-DMA instead of expanding it was tried:
 // +50 % -- it adds as much L2 traffic as the gathers it sits beside.)
+// (Pacing the workgroups inside a launch was tried too: the workgroups (b >> 3) / 96 of one
+// XCD met on a device-memory counter every 32-96 trees, bounded wait, so that one launch could
+// take 256 trees of 50 000 leaves without drifting apart.  Slower at every interval -- 50 000
+// leaves: 778 / 739 / 718 ms at 32 / 64 / 96 trees against 685 ms for plain launches of 80
+// trees; 10 000 leaves: 8.6 against 7.2 ms.  The workgroups do not drift at random, they run at
+// persistently different speeds (about +-20 % over 64 trees), and a meeting point makes every
+// one of them as slow as the slowest.)
 #pragma once
 
 #include "scs_cells_asm.h"
