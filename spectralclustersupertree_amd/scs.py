@@ -258,10 +258,13 @@ def prepare_node(tables: fl.TreeTables, contract_edges: bool):
 
 def _labels_and_members(maps, random_state, n, perm, group_start, n_groups):
     """k_means on the embedding exactly as ``SpectralClustering.fit`` calls it
-    (sklearn/cluster/_spectral.py:759-766), and the member taxa of every vertex."""
-    from sklearn.cluster import k_means
+    (sklearn/cluster/_spectral.py:759-766) -- through ``kmeans2.labels``, which drives
+    scikit-learn's compiled Lloyd iteration without the per-call validation around it when it
+    has verified that it reproduces ``k_means`` bit for bit -- and the member taxa of every
+    vertex."""
+    from . import kmeans2
 
-    _, labels, _ = k_means(maps, 2, random_state=random_state, n_init=10, verbose=False)
+    labels = kmeans2.labels(maps, random_state)
     if group_start is None:
         members = [np.array([i], dtype=np.int32) for i in range(n)]
     else:
