@@ -247,7 +247,8 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     # one v_add_f64 each) against 8 V^2 bytes written once: its HBM fraction is tiny by
     # construction and is reported as is, next to the fractions of the units that do bound it
     roof_acc = {
-        "kernel": "k_accumulate_mono (PCG weights: tree-ordered sums of LCA values into 64 x 256 tiles)",
+        "kernel": ("k_accumulate_mono" if tables.monotone else "k_accumulate_gen") +
+                  " (PCG weights: tree-ordered sums of LCA values into 64 x 256 tiles)",
         "bound": "hbm",
         "achieved": round(build_gbs, 1),
         "peak": HBM_PEAK_GBS,
@@ -262,8 +263,9 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         "cell_trees_per_s": round(cell_rate, 0),
         "frac_f64_valu": round(2.0 * cell_rate / (F64_VALU_TOPS * 1e12), 4),
         "frac_lds": round(8.0 * cell_rate / (LDS_PEAK_TBS * 1e12), 4),
-        "note": "not HBM-bound: 2 fp64 VALU ops and one 8-byte LDS read per cell-tree, plus one "
-                "range-minimum query (two random 8-byte L2 gathers) per (row block, tree, column); "
+        "note": "not HBM-bound: 2 fp64 VALU ops (monotone weighting; 4 vector ops otherwise) and one "
+                "8-byte LDS read per cell-tree, plus one "
+                "range-minimum query (two random 8- or 12-byte L2 gathers) per (row block, tree, column); "
                 "frac_f64_valu / frac_lds price the cell loop alone against 39.3 Tops/s of "
                 "non-FMA fp64 issue and ~150 TB/s of ds_read_b64",
     }
