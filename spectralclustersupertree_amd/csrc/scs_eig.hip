@@ -1264,7 +1264,7 @@ struct solver {
             SCS_TRY(launch_symm(z.d(), nullptr));
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
-            k_gram_qaq<B, true><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
+            k_gram_qaq<B, 1><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
                                                    g->d_dinv, part.d());
         } else {
             if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
@@ -1272,13 +1272,9 @@ struct solver {
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
             SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
-            const int nbq = n * B;
-            k_unpack<<<(nbq + 255) / 256, 256, 0, s>>>(recv.d(), chunk, B,
-                                                       (const int32_t *)splits_d.p, world, n,
-                                                       yfull.d());
-            k_store_cols<<<(nbq + 255) / 256, 256, 0, s>>>(yfull.d(), B, n, aq.d(), 3 * B, 2 * B);
-            k_gram_qaq<B, false><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, nullptr, 0, g->d_dinv,
-                                                    part.d());
+            // (the gathered slices go straight into AQ's R slot inside the Gram kernel)
+            k_gram_qaq<B, 2><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, part.d(),
+                                                (int64_t)chunk, (const int32_t *)splits_d.p);
         }
         SCS_HIP_CHECK(hipGetLastError());
         return SCS_OK;

@@ -186,14 +186,19 @@ __global__ __launch_bounds__(256) void k_panel_tf(double *q, const double *__res
     if (GRAM) panel_store_partials<B>(g1, g2, partial);
 }
 
-// T = Q^T AQ (3B x 3B) as per-workgroup partials; FINISH: first combine k_symm's column
-// segments into AR = dinv (.) sum_seg ypart[seg] and store it into AQ's R slot (single-rank
-// runs; multi-rank runs gather AR before this kernel).
-template <int B, bool FINISH>
+// T = Q^T AQ (3B x 3B) as per-workgroup partials.  FINISH selects where AR, the R slot of AQ,
+// comes from -- it is stored into AQ on the way:
+//   1  single-rank runs: combine k_symm's column segments, AR = dinv (.) sum_seg ypart[seg];
+//   2  multi-rank runs: the all-gathered row slices (ypart = the receive buffer: `nseg` ranks x
+//      `chunk` doubles, rank r's rows [splits[r], splits[r+1]), already scaled);
+//   0  AR is in place.
+template <int B, int FINISH>
 __global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, double *aq, int n,
                                                    const double *__restrict__ ypart, int nseg,
                                                    const double *__restrict__ dinv,
-                                                   double *__restrict__ partial) {
+                                                   double *__restrict__ partial,
+                                                   int64_t chunk = 0,
+                                                   const int32_t *__restrict__ splits = nullptr) {
     static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
     constexpr int LD = 3 * B;
     constexpr int NT = (LD + 15) / 16;  // 16-column tiles of the panels
@@ -223,7 +228,11 @@ __global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, 
                 fa[uu][t] = (live && col < LD) ? q[(int64_t)row * LD + col] : 0.0;
                 double v = 0.0;
                 if (live && col < LD) {
-                    if (FINISH && col >= 2 * B) {
+                    if (FINISH == 2 && col >= 2 * B) {
+                        int r = 0;
+                        while (r + 1 < nseg && row >= splits[r + 1]) ++r;
+                        v = ypart[(int64_t)r * chunk + (int64_t)(row - splits[r]) * B + (col - 2 * B)];
+                    } else if (FINISH == 1 && col >= 2 * B) {
                         const int64_t idx = (int64_t)row * B + (col - 2 * B);
                         // k_symm uses at most four column segments; the loads are independent
                         double part[4];
