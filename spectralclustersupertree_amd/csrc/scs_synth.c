@@ -290,3 +290,51 @@ static int synth_tables(uint64_t seed, int32_t n_taxa, int32_t n_trees, int32_t 
     tree_off[n_trees] = (int64_t)n_trees * k;
     return 0;
 }
+
+/* Tree t of a set as preorder node arrays, the layout of treearrays.TreeArrays (what
+ * TreeArrays.from_trees makes of synthetic.tree_objects' tree t): 2k-1 nodes; parent = index
+ * within the tree (-1 at the root); taxon = the leaf's taxon id, -1 for internal nodes; length
+ * NaN at the root; support NaN at the leaves.  Children keep their order (left first). */
+int scs_synth_tree_nodes(uint64_t seed, int64_t tree, int32_t n_taxa, int32_t k, int32_t *parent,
+                         int32_t *taxon, double *length, double *support) {
+    if (k < 1) return -1;
+    const int32_t nn = 2 * k - 1;
+    int32_t *lt = malloc(sizeof(int32_t) * (size_t)k), *ad = malloc(sizeof(int32_t) * (size_t)k);
+    double *av = malloc(sizeof(double) * (size_t)k);
+    int32_t *lf = malloc(sizeof(int32_t) * (size_t)nn), *rt = malloc(sizeof(int32_t) * (size_t)nn);
+    double *len = malloc(sizeof(double) * (size_t)nn), *sup = malloc(sizeof(double) * (size_t)nn);
+    int32_t *tax = malloc(sizeof(int32_t) * (size_t)k);
+    int32_t *stack = malloc(sizeof(int32_t) * 2 * (size_t)nn);
+    int rc = -1;
+    if (lt && ad && av && lf && rt && len && sup && tax && stack &&
+        synth_tree(seed, tree, n_taxa, k, 0, -1, lt, ad, av, lf, rt, len, sup, tax) == 0) {
+        int32_t top = 0, out = 0;
+        stack[0] = nn - 1; /* root */
+        stack[1] = -1;
+        top = 1;
+        while (top > 0) {
+            --top;
+            const int32_t v = stack[2 * top], par = stack[2 * top + 1];
+            const int32_t me = out++;
+            parent[me] = par;
+            if (v < k) {
+                taxon[me] = tax[v];
+                length[me] = par < 0 ? NAN : len[v];
+                support[me] = NAN;
+            } else {
+                taxon[me] = -1;
+                length[me] = par < 0 ? NAN : len[v];
+                support[me] = sup[v];
+                stack[2 * top] = rt[v]; /* popped second */
+                stack[2 * top + 1] = me;
+                ++top;
+                stack[2 * top] = lf[v];
+                stack[2 * top + 1] = me;
+                ++top;
+            }
+        }
+        rc = out == nn ? 0 : -1;
+    }
+    free(lt); free(ad); free(av); free(lf); free(rt); free(len); free(sup); free(tax); free(stack);
+    return rc;
+}

@@ -32,6 +32,10 @@ def _load() -> C.CDLL:
         lib.scs_synth_tree.restype = C.c_int
         lib.scs_synth_tree.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                        ip, ip, dp, ip, ip, dp, dp, ip]
+        lib.scs_synth_tree_nodes.restype = C.c_int
+        lib.scs_synth_tree_nodes.argtypes = [C.c_uint64, C.c_int64, C.c_int32, C.c_int32,
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]
         lib.scs_synth_tables.restype = C.c_int
         lib.scs_synth_tables.argtypes = [C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, lp, ip, ip, dp, dp]
@@ -135,3 +139,36 @@ def tree_objects(
         root.length = None
         out.append(root)
     return out
+
+
+def tree_arrays(seed: int, n_taxa: int, n_trees: int, leaves_per_tree: int | None = None,
+                random_weights: bool = False):
+    """The same trees as ``tree_objects`` / ``make_tables`` as flat node arrays
+    (``treearrays.TreeArrays``), built in C without tree objects: the input of whole-recursion
+    runs at sizes where a Python object per node is out of the question."""
+    from .treearrays import TreeArrays
+
+    lib = _load()
+    k = n_taxa if leaves_per_tree is None else int(leaves_per_tree)
+    nn = 2 * k - 1
+    parent = np.empty(n_trees * nn, dtype=np.int32)
+    taxon = np.empty(n_trees * nn, dtype=np.int32)
+    length = np.empty(n_trees * nn, dtype=np.float64)
+    support = np.empty(n_trees * nn, dtype=np.float64)
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    for t in range(n_trees):
+        sl = slice(t * nn, (t + 1) * nn)
+        rc = lib.scs_synth_tree_nodes(seed, t, n_taxa, k, parent[sl].ctypes.data_as(ip),
+                                      taxon[sl].ctypes.data_as(ip), length[sl].ctypes.data_as(dp),
+                                      support[sl].ctypes.data_as(dp))
+        if rc != 0:
+            msg = "scs_synth_tree_nodes failed"
+            raise RuntimeError(msg)
+    weights = np.ones(n_trees, dtype=np.float64)
+    if random_weights:
+        # (a tree's weight depends on (seed, tree) only: take it from a two-leaf table set)
+        weights = make_tables(seed, n_taxa, n_trees, "one", leaves_per_tree=min(2, n_taxa),
+                              random_weights=True).tree_w.copy()
+    return TreeArrays(n_taxa=n_taxa, node_off=np.arange(n_trees + 1, dtype=np.int64) * nn, parent=parent,
+                      taxon=taxon, length=length, support=support, weights=weights,
+                      taxa=[taxon_name(i) for i in range(n_taxa)])

@@ -361,3 +361,27 @@ def test_part_without_any_tree_raises_like_the_reference():
         scs._construct(arrays, "one", True, np.random.RandomState(0), stub)
     with pytest.raises(ValueError, match="at least one tree"):
         scs._construct_objects(trees, [1.0, 1.0, 1.0], "one", True, np.random.RandomState(0), stub)
+
+
+def test_synthetic_tree_arrays_equal_the_object_path():
+    # synthetic.tree_arrays (C, no tree objects) against TreeArrays.from_trees on the same set
+    from spectralclustersupertree_amd import synthetic
+    from spectralclustersupertree_amd.treearrays import TreeArrays
+
+    for n, m, k in ((40, 5, None), (60, 4, 33), (2, 2, None), (1, 1, None)):
+        got = synthetic.tree_arrays(7, n, m, k, random_weights=True)
+        trees = synthetic.tree_objects(7, n, m, k)
+        names = [synthetic.taxon_name(i) for i in range(n)]
+        want = TreeArrays.from_trees(trees, got.weights, names)
+        assert np.array_equal(got.node_off, want.node_off)
+        assert np.array_equal(got.parent, want.parent)
+        assert np.array_equal(got.taxon, want.taxon)
+        assert np.array_equal(got.length, want.length, equal_nan=True)
+        assert np.array_equal(got.support, want.support, equal_nan=True)
+        tabs = synthetic.make_tables(7, n, m, "branch", leaves_per_tree=k, random_weights=True)
+        assert np.array_equal(got.weights, tabs.tree_w)
+        if n >= 2:
+            flat = got.flatten("branch")
+            assert np.array_equal(flat.leaf_taxon, tabs.leaf_taxon)
+            assert np.array_equal(flat.adj_depth, tabs.adj_depth)
+            assert np.array_equal(flat.adj_val, tabs.adj_val)

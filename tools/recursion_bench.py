@@ -19,10 +19,16 @@ ap.add_argument("--trees", type=int, default=50)
 ap.add_argument("--leaves", type=int, default=None)
 ap.add_argument("--strategy", default="branch")
 ap.add_argument("--skip-objects", action="store_true")
+ap.add_argument("--native-arrays", action="store_true",
+                help="build the flat tree arrays in C (synthetic.tree_arrays): no tree objects at all; implies --skip-objects")
 args = ap.parse_args()
 
-trees = synthetic.tree_objects(1, args.taxa, args.trees, args.leaves)
-weights = [1.0] * len(trees)
+if args.native_arrays:
+    args.skip_objects = True
+    trees = None
+else:
+    trees = synthetic.tree_objects(1, args.taxa, args.trees, args.leaves)
+    weights = [1.0] * len(trees)
 device_s = [0.0]
 calls = [0]
 sizes = []
@@ -51,8 +57,11 @@ warnings.simplefilter("ignore")
 scs.default_device()  # context creation outside the timings
 res = {"taxa": args.taxa, "trees": args.trees, "leaves_per_tree": args.leaves or args.taxa, "strategy": args.strategy}
 t0 = time.perf_counter()
-names = sorted(scs._all_tip_names(trees))
-arrays = TreeArrays.from_trees(trees, weights, names)
+if args.native_arrays:
+    arrays = synthetic.tree_arrays(1, args.taxa, args.trees, args.leaves)
+else:
+    names = sorted(scs._all_tip_names(trees))
+    arrays = TreeArrays.from_trees(trees, weights, names)
 t_conv = time.perf_counter() - t0
 t0 = time.perf_counter()
 got = scs._construct(arrays, args.strategy, True, np.random.RandomState(0))
