@@ -23,6 +23,8 @@ def load() -> C.CDLL:
         lib.scs_host_restrict_sizes.argtypes = [C.c_int32, lp, ip, ip, bp, bp, ip]
         lib.scs_host_restrict_fill.restype = C.c_int
         lib.scs_host_restrict_fill.argtypes = [C.c_int32, lp, ip, ip, dp, dp, bp, bp, lp, ip, ip, dp, dp]
+        lib.scs_host_leaf_counts.restype = C.c_int
+        lib.scs_host_leaf_counts.argtypes = [C.c_int32, lp, ip, lp]
         lib.scs_host_flatten.restype = C.c_int
         lib.scs_host_flatten.argtypes = [C.c_int32, lp, ip, ip, dp, dp, C.c_int32, lp, ip, ip, dp, ip]
         lib.scs_host_newick_scan.restype = C.c_int

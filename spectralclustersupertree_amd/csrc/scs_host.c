@@ -24,14 +24,87 @@
  * Plain C, no GPU code; bound with ctypes in spectralclustersupertree_amd/treearrays.py.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #define SCS_HOST_OK 0
 #define SCS_HOST_ENOMEM (-1)
 #define SCS_HOST_EINVAL (-2)
 #define SCS_HOST_ENOSUPPORT (-3) /* bootstrap strategy met an internal node without support */
+
+/*
+ * The trees of a forest are independent in everything below, and a node of the recursion
+ * walks the whole forest of its parent (a child of three taxa split off a parent of 30 000
+ * still visits every node of every tree): forests above SCS_HOST_PAR_NODES nodes are cut over
+ * threads, trees handed out one at a time from a shared counter.  SCS_HOST_THREADS sets the
+ * team size (default: the online cores, at most 16; 1 = serial).
+ */
+#define SCS_HOST_PAR_NODES 200000
+
+typedef int (*tree_fn)(int32_t t, void *scratch, void *ctx);
+typedef struct {
+    int32_t n_trees;
+    int32_t next; /* shared counter (atomic) */
+    tree_fn fn;
+    void *ctx;
+    size_t scratch_bytes;
+    int rc; /* first error (atomic) */
+} tree_team;
+
+static void *tree_team_worker(void *arg) {
+    tree_team *tm = (tree_team *)arg;
+    void *scratch = malloc(tm->scratch_bytes ? tm->scratch_bytes : 1);
+    if (!scratch) {
+        __atomic_store_n(&tm->rc, SCS_HOST_ENOMEM, __ATOMIC_RELAXED);
+        return 0;
+    }
+    for (;;) {
+        const int32_t t = __atomic_fetch_add(&tm->next, 1, __ATOMIC_RELAXED);
+        if (t >= tm->n_trees || __atomic_load_n(&tm->rc, __ATOMIC_RELAXED) != SCS_HOST_OK) break;
+        const int rc = tm->fn(t, scratch, tm->ctx);
+        if (rc != SCS_HOST_OK) __atomic_store_n(&tm->rc, rc, __ATOMIC_RELAXED);
+    }
+    free(scratch);
+    return 0;
+}
+
+static int host_threads(void) {
+    static int cached = 0;
+    if (!cached) {
+        const char *e = getenv("SCS_HOST_THREADS");
+        long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+        if (!e && n > 16) n = 16;
+        if (n < 1) n = 1;
+        if (n > 64) n = 64;
+        cached = (int)n;
+    }
+    return cached;
+}
+
+/* fn(t, scratch, ctx) for every tree t; scratch is a per-thread block of scratch_bytes */
+static int for_each_tree(int32_t n_trees, int64_t total_nodes, size_t scratch_bytes, tree_fn fn,
+                         void *ctx) {
+    tree_team tm = {n_trees, 0, fn, ctx, scratch_bytes, SCS_HOST_OK};
+    int n_thr = host_threads();
+    if (total_nodes < SCS_HOST_PAR_NODES || n_trees < 2) n_thr = 1;
+    if (n_thr > n_trees) n_thr = n_trees;
+    if (n_thr <= 1) {
+        tree_team_worker(&tm);
+        return tm.rc;
+    }
+    pthread_t th[64];
+    int started = 0;
+    for (int i = 0; i < n_thr - 1; ++i) {
+        if (pthread_create(&th[started], 0, tree_team_worker, &tm) != 0) break;
+        ++started;
+    }
+    tree_team_worker(&tm); /* the caller is a member of the team */
+    for (int i = 0; i < started; ++i) pthread_join(th[i], 0);
+    return tm.rc;
+}
 
 /*
  * Pass 1 of a restriction: sizes of the result.
@@ -58,114 +131,150 @@ static int restrict_tree_count(const int32_t *parent, const int32_t *taxon, int3
     return SCS_HOST_OK;
 }
 
+typedef struct {
+    const int64_t *node_off;
+    const int32_t *parent, *taxon;
+    const uint8_t *keep;
+    uint8_t *out_tree_keep;
+    int32_t *out_nodes;
+    int32_t max_k;
+} sizes_ctx;
+
+static int restrict_sizes_tree(int32_t t, void *scratch, void *vctx) {
+    const sizes_ctx *c = (const sizes_ctx *)vctx;
+    int32_t *cnt = (int32_t *)scratch, *nkc = cnt + c->max_k;
+    const int64_t off = c->node_off[t];
+    const int32_t k = (int32_t)(c->node_off[t + 1] - off);
+    const int rc = restrict_tree_count(c->parent + off, c->taxon + off, k, c->keep, cnt, nkc);
+    if (rc != SCS_HOST_OK) return rc;
+    if (cnt[0] < 2) {
+        c->out_tree_keep[t] = 0;
+        c->out_nodes[t] = 0;
+        return SCS_HOST_OK;
+    }
+    int32_t kept = 0;
+    for (int32_t i = 0; i < k; ++i)
+        if ((c->taxon[off + i] >= 0 && cnt[i] == 1) || (c->taxon[off + i] < 0 && nkc[i] >= 2)) ++kept;
+    c->out_tree_keep[t] = 1;
+    c->out_nodes[t] = kept;
+    return SCS_HOST_OK;
+}
+
 int scs_host_restrict_sizes(int32_t n_trees, const int64_t *node_off, const int32_t *parent,
                             const int32_t *taxon, const uint8_t *keep, uint8_t *out_tree_keep,
                             int32_t *out_nodes) {
-    int32_t max_k = 0;
+    int32_t max_k = 1;
     for (int32_t t = 0; t < n_trees; ++t) {
         const int64_t k = node_off[t + 1] - node_off[t];
         if (k < 1 || k > INT32_MAX) return SCS_HOST_EINVAL;
         if (k > max_k) max_k = (int32_t)k;
     }
-    int32_t *cnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)(max_k > 0 ? max_k : 1));
-    int32_t *nkc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(max_k > 0 ? max_k : 1));
-    if (!cnt || !nkc) {
-        free(cnt);
-        free(nkc);
-        return SCS_HOST_ENOMEM;
-    }
-    int rc = SCS_HOST_OK;
-    for (int32_t t = 0; t < n_trees && rc == SCS_HOST_OK; ++t) {
-        const int64_t off = node_off[t];
-        const int32_t k = (int32_t)(node_off[t + 1] - off);
-        rc = restrict_tree_count(parent + off, taxon + off, k, keep, cnt, nkc);
-        if (rc != SCS_HOST_OK) break;
-        if (cnt[0] < 2) {
-            out_tree_keep[t] = 0;
-            out_nodes[t] = 0;
-            continue;
-        }
-        int32_t kept = 0;
-        for (int32_t i = 0; i < k; ++i)
-            if ((taxon[off + i] >= 0 && cnt[i] == 1) || (taxon[off + i] < 0 && nkc[i] >= 2)) ++kept;
-        out_tree_keep[t] = 1;
-        out_nodes[t] = kept;
-    }
-    free(cnt);
-    free(nkc);
-    return rc;
+    sizes_ctx c = {node_off, parent, taxon, keep, out_tree_keep, out_nodes, max_k};
+    return for_each_tree(n_trees, n_trees > 0 ? node_off[n_trees] - node_off[0] : 0,
+                         sizeof(int32_t) * 2 * (size_t)max_k, restrict_sizes_tree, &c);
 }
 
 /*
  * Pass 2: fill the restricted forest.  new_node_off (for the surviving trees, in order)
  * is the exclusive scan of out_nodes over surviving trees, computed by the caller.
  */
+typedef struct {
+    const int64_t *node_off;
+    const int32_t *parent, *taxon;
+    const double *length, *support;
+    const uint8_t *keep, *tree_keep;
+    const int64_t *new_node_off;
+    const int32_t *out_index; /* tree -> its index among the surviving trees */
+    int32_t *new_parent, *new_taxon;
+    double *new_length, *new_support;
+    int32_t max_k;
+} fill_ctx;
+
+static int restrict_fill_tree(int32_t t, void *scratch, void *vctx) {
+    const fill_ctx *c = (const fill_ctx *)vctx;
+    if (!c->tree_keep[t]) return SCS_HOST_OK;
+    int32_t *cnt = (int32_t *)scratch, *nkc = cnt + c->max_k;
+    int32_t *newidx = nkc + c->max_k; /* kept node -> new index */
+    int32_t *anc = newidx + c->max_k; /* nearest kept ancestor-or-self (old index), -1 above the new root */
+    const int64_t off = c->node_off[t];
+    const int32_t k = (int32_t)(c->node_off[t + 1] - off);
+    const int32_t *par = c->parent + off, *tax = c->taxon + off;
+    const double *len = c->length + off, *sup = c->support + off;
+    const int rc = restrict_tree_count(par, tax, k, c->keep, cnt, nkc);
+    if (rc != SCS_HOST_OK) return rc;
+    const int64_t noff = c->new_node_off[c->out_index[t]];
+    int32_t next = 0;
+    /* preorder: a parent is numbered before its children */
+    for (int32_t i = 0; i < k; ++i) {
+        const int kept = (tax[i] >= 0 && cnt[i] == 1) || (tax[i] < 0 && nkc[i] >= 2);
+        const int32_t up = i == 0 ? -1 : anc[par[i]];
+        if (!kept) {
+            anc[i] = up; /* unary, empty, or above the new root: look through */
+            newidx[i] = -1;
+            continue;
+        }
+        anc[i] = i;
+        newidx[i] = next;
+        c->new_parent[noff + next] = up < 0 ? -1 : newidx[up];
+        c->new_taxon[noff + next] = tax[i];
+        c->new_support[noff + next] = sup[i];
+        /* merged length: fold the spliced chain bottom-up, parent's length in front */
+        double acc = len[i];
+        for (int32_t u = i == 0 ? -1 : par[i]; u >= 0 && u != up; u = par[u]) {
+            /* u lies strictly between the node and its kept ancestor: it had one child left */
+            if (!isnan(len[u]) && !isnan(acc)) acc = len[u] + acc;
+        }
+        /* (a node that becomes the root absorbs the chain up to the old root the same way;
+         * a root's length is never used) */
+        c->new_length[noff + next] = acc;
+        ++next;
+    }
+    return SCS_HOST_OK;
+}
+
 int scs_host_restrict_fill(int32_t n_trees, const int64_t *node_off, const int32_t *parent,
                            const int32_t *taxon, const double *length, const double *support,
                            const uint8_t *keep, const uint8_t *tree_keep,
                            const int64_t *new_node_off, int32_t *new_parent, int32_t *new_taxon,
                            double *new_length, double *new_support) {
-    int32_t max_k = 0;
+    int32_t max_k = 1;
     for (int32_t t = 0; t < n_trees; ++t) {
         const int64_t k = node_off[t + 1] - node_off[t];
         if (k > max_k) max_k = (int32_t)k;
     }
-    const size_t cap = (size_t)(max_k > 0 ? max_k : 1);
-    int32_t *cnt = (int32_t *)malloc(sizeof(int32_t) * cap);
-    int32_t *nkc = (int32_t *)malloc(sizeof(int32_t) * cap);
-    int32_t *newidx = (int32_t *)malloc(sizeof(int32_t) * cap); /* kept node -> new index */
-    int32_t *anc = (int32_t *)malloc(sizeof(int32_t) * cap);    /* nearest kept ancestor-or-self (old index), -1 above the new root */
-    if (!cnt || !nkc || !newidx || !anc) {
-        free(cnt);
-        free(nkc);
-        free(newidx);
-        free(anc);
-        return SCS_HOST_ENOMEM;
-    }
-    int rc = SCS_HOST_OK;
+    int32_t *out_index = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n_trees > 0 ? n_trees : 1));
+    if (!out_index) return SCS_HOST_ENOMEM;
     int32_t out_t = 0;
-    for (int32_t t = 0; t < n_trees && rc == SCS_HOST_OK; ++t) {
-        if (!tree_keep[t]) continue;
-        const int64_t off = node_off[t];
-        const int32_t k = (int32_t)(node_off[t + 1] - off);
-        const int32_t *par = parent + off, *tax = taxon + off;
-        const double *len = length + off, *sup = support + off;
-        rc = restrict_tree_count(par, tax, k, keep, cnt, nkc);
-        if (rc != SCS_HOST_OK) break;
-        const int64_t noff = new_node_off[out_t];
-        int32_t next = 0;
-        /* preorder: a parent is numbered before its children */
-        for (int32_t i = 0; i < k; ++i) {
-            const int kept = (tax[i] >= 0 && cnt[i] == 1) || (tax[i] < 0 && nkc[i] >= 2);
-            const int32_t up = i == 0 ? -1 : anc[par[i]];
-            if (!kept) {
-                anc[i] = up; /* unary, empty, or above the new root: look through */
-                newidx[i] = -1;
-                continue;
-            }
-            anc[i] = i;
-            newidx[i] = next;
-            new_parent[noff + next] = up < 0 ? -1 : newidx[up];
-            new_taxon[noff + next] = tax[i];
-            new_support[noff + next] = sup[i];
-            /* merged length: fold the spliced chain bottom-up, parent's length in front */
-            double acc = len[i];
-            for (int32_t u = i == 0 ? -1 : par[i]; u >= 0 && u != up; u = par[u]) {
-                /* u lies strictly between the node and its kept ancestor: it had one child left */
-                if (!isnan(len[u]) && !isnan(acc)) acc = len[u] + acc;
-            }
-            /* (a node that becomes the root absorbs the chain up to the old root the same way;
-             * a root's length is never used) */
-            new_length[noff + next] = acc;
-            ++next;
-        }
-        ++out_t;
-    }
-    free(cnt);
-    free(nkc);
-    free(newidx);
-    free(anc);
+    for (int32_t t = 0; t < n_trees; ++t) out_index[t] = tree_keep[t] ? out_t++ : -1;
+    fill_ctx c = {node_off, parent, taxon, length, support, keep, tree_keep, new_node_off, out_index,
+                  new_parent, new_taxon, new_length, new_support, max_k};
+    const int rc = for_each_tree(n_trees, n_trees > 0 ? node_off[n_trees] - node_off[0] : 0,
+                                 sizeof(int32_t) * 4 * (size_t)max_k, restrict_fill_tree, &c);
+    free(out_index);
     return rc;
+}
+
+/* leaves of every tree (out_counts[t]) */
+typedef struct {
+    const int64_t *node_off;
+    const int32_t *taxon;
+    int64_t *out;
+} count_ctx;
+
+static int leaf_count_tree(int32_t t, void *scratch, void *vctx) {
+    (void)scratch;
+    const count_ctx *c = (const count_ctx *)vctx;
+    int64_t n = 0;
+    for (int64_t i = c->node_off[t]; i < c->node_off[t + 1]; ++i) n += c->taxon[i] >= 0;
+    c->out[t] = n;
+    return SCS_HOST_OK;
+}
+
+int scs_host_leaf_counts(int32_t n_trees, const int64_t *node_off, const int32_t *taxon,
+                         int64_t *out_counts) {
+    count_ctx c = {node_off, taxon, out_counts};
+    return for_each_tree(n_trees, n_trees > 0 ? node_off[n_trees] - node_off[0] : 0, 0,
+                         leaf_count_tree, &c);
 }
 
 /*
@@ -175,107 +284,108 @@ int scs_host_restrict_fill(int32_t n_trees, const int64_t *node_off, const int32
  *   monotone_out: set to 0 if a negative internal length is met under `branch`
  * Outputs sized leaf_off[n_trees].
  */
+typedef struct {
+    const int64_t *node_off;
+    const int32_t *parent, *taxon;
+    const double *length, *support;
+    int32_t strategy;
+    const int64_t *leaf_off;
+    int32_t *leaf_taxon, *adj_depth;
+    double *adj_val;
+    int32_t *monotone_out;
+    int32_t max_k;
+} flatten_ctx;
+
+static int flatten_tree(int32_t t, void *scratch, void *vctx) {
+    const flatten_ctx *c = (const flatten_ctx *)vctx;
+    double *val = (double *)scratch;
+    int32_t *depth = (int32_t *)(val + c->max_k), *nch = depth + c->max_k;
+    const int32_t strategy = c->strategy;
+    int32_t *leaf_taxon = c->leaf_taxon, *adj_depth = c->adj_depth;
+    double *adj_val = c->adj_val;
+    const int64_t off = c->node_off[t];
+    const int32_t k = (int32_t)(c->node_off[t + 1] - off);
+    const int32_t *par = c->parent + off, *tax = c->taxon + off;
+    const double *len = c->length + off, *sup = c->support + off;
+    int64_t slot = c->leaf_off[t];
+    const int64_t slot_end = c->leaf_off[t + 1];
+    int rc = SCS_HOST_OK;
+    for (int32_t i = 0; i < k; ++i) nch[i] = 0;
+    for (int32_t i = 1; i < k; ++i) nch[par[i]] += 1;
+    int first_leaf = 1;
+    int32_t pend_depth = 0;
+    double pend_val = 0.0;
+    depth[0] = 0;
+    val[0] = 0.0;
+    if (tax[0] >= 0) { /* a single-leaf tree */
+        if (slot >= slot_end) return SCS_HOST_EINVAL;
+        leaf_taxon[slot] = tax[0];
+        adj_depth[slot] = 0;
+        adj_val[slot] = 0.0;
+        return SCS_HOST_OK;
+    }
+    for (int32_t i = 1; i < k && rc == SCS_HOST_OK; ++i) {
+        const int32_t u = par[i];
+        if (i != u + 1) { /* not the first child: the next leaf's LCA with the previous one is u */
+            pend_depth = depth[u];
+            pend_val = val[u];
+        }
+        if (tax[i] >= 0) {
+            if (slot >= slot_end) return SCS_HOST_EINVAL;
+            if (!first_leaf) {
+                adj_depth[slot - 1] = pend_depth;
+                adj_val[slot - 1] = pend_val;
+            }
+            first_leaf = 0;
+            leaf_taxon[slot++] = tax[i];
+            continue;
+        }
+        depth[i] = depth[u] + 1;
+        double v;
+        switch (strategy) {
+            case 0:
+                v = 1.0;
+                break;
+            case 1:
+                v = val[u] + 1.0;
+                break;
+            case 2:
+                v = val[u] + (isnan(len[i]) ? 1.0 : len[i]);
+                if (!isnan(len[i]) && len[i] < 0.0) __atomic_store_n(c->monotone_out, 0, __ATOMIC_RELAXED);
+                break;
+            default:
+                v = sup[i];
+                if (isnan(v)) {
+                    if (nch[i] >= 2) rc = SCS_HOST_ENOSUPPORT;
+                    v = 0.0;
+                }
+                break;
+        }
+        val[i] = v;
+    }
+    if (rc != SCS_HOST_OK) return rc;
+    if (slot != slot_end) return SCS_HOST_EINVAL;
+    /* padding slot so adj_* share the offsets of leaf_taxon */
+    adj_depth[slot_end - 1] = 0;
+    adj_val[slot_end - 1] = 0.0;
+    return SCS_HOST_OK;
+}
+
 int scs_host_flatten(int32_t n_trees, const int64_t *node_off, const int32_t *parent,
                      const int32_t *taxon, const double *length, const double *support,
                      int32_t strategy, const int64_t *leaf_off, int32_t *leaf_taxon,
                      int32_t *adj_depth, double *adj_val, int32_t *monotone_out) {
     if (strategy < 0 || strategy > 3) return SCS_HOST_EINVAL;
-    int32_t max_k = 0;
+    int32_t max_k = 1;
     for (int32_t t = 0; t < n_trees; ++t) {
         const int64_t k = node_off[t + 1] - node_off[t];
         if (k < 1 || k > INT32_MAX) return SCS_HOST_EINVAL;
         if (k > max_k) max_k = (int32_t)k;
     }
-    const size_t cap = (size_t)(max_k > 0 ? max_k : 1);
-    int32_t *depth = (int32_t *)malloc(sizeof(int32_t) * cap);
-    double *val = (double *)malloc(sizeof(double) * cap);
-    int32_t *nch = (int32_t *)malloc(sizeof(int32_t) * cap);
-    if (!depth || !val || !nch) {
-        free(depth);
-        free(val);
-        free(nch);
-        return SCS_HOST_ENOMEM;
-    }
-    int rc = SCS_HOST_OK;
-    for (int32_t t = 0; t < n_trees && rc == SCS_HOST_OK; ++t) {
-        const int64_t off = node_off[t];
-        const int32_t k = (int32_t)(node_off[t + 1] - off);
-        const int32_t *par = parent + off, *tax = taxon + off;
-        const double *len = length + off, *sup = support + off;
-        int64_t slot = leaf_off[t];
-        const int64_t slot_end = leaf_off[t + 1];
-        for (int32_t i = 0; i < k; ++i) nch[i] = 0;
-        for (int32_t i = 1; i < k; ++i) nch[par[i]] += 1;
-        int first_leaf = 1;
-        int32_t pend_depth = 0;
-        double pend_val = 0.0;
-        depth[0] = 0;
-        val[0] = 0.0;
-        if (tax[0] >= 0) { /* a single-leaf tree */
-            if (slot >= slot_end) {
-                rc = SCS_HOST_EINVAL;
-                break;
-            }
-            leaf_taxon[slot] = tax[0];
-            adj_depth[slot] = 0;
-            adj_val[slot] = 0.0;
-            continue;
-        }
-        for (int32_t i = 1; i < k && rc == SCS_HOST_OK; ++i) {
-            const int32_t u = par[i];
-            if (i != u + 1) { /* not the first child: the next leaf's LCA with the previous one is u */
-                pend_depth = depth[u];
-                pend_val = val[u];
-            }
-            if (tax[i] >= 0) {
-                if (slot >= slot_end) {
-                    rc = SCS_HOST_EINVAL;
-                    break;
-                }
-                if (!first_leaf) {
-                    adj_depth[slot - 1] = pend_depth;
-                    adj_val[slot - 1] = pend_val;
-                }
-                first_leaf = 0;
-                leaf_taxon[slot++] = tax[i];
-                continue;
-            }
-            depth[i] = depth[u] + 1;
-            double v;
-            switch (strategy) {
-                case 0:
-                    v = 1.0;
-                    break;
-                case 1:
-                    v = val[u] + 1.0;
-                    break;
-                case 2:
-                    v = val[u] + (isnan(len[i]) ? 1.0 : len[i]);
-                    if (!isnan(len[i]) && len[i] < 0.0) *monotone_out = 0;
-                    break;
-                default:
-                    v = sup[i];
-                    if (isnan(v)) {
-                        if (nch[i] >= 2) rc = SCS_HOST_ENOSUPPORT;
-                        v = 0.0;
-                    }
-                    break;
-            }
-            val[i] = v;
-        }
-        if (rc != SCS_HOST_OK) break;
-        if (slot != slot_end) {
-            rc = SCS_HOST_EINVAL;
-            break;
-        }
-        /* padding slot so adj_* share the offsets of leaf_taxon */
-        adj_depth[slot_end - 1] = 0;
-        adj_val[slot_end - 1] = 0.0;
-    }
-    free(depth);
-    free(val);
-    free(nch);
-    return rc;
+    flatten_ctx c = {node_off, parent, taxon, length, support, strategy, leaf_off, leaf_taxon,
+                     adj_depth, adj_val, monotone_out, max_k};
+    return for_each_tree(n_trees, n_trees > 0 ? node_off[n_trees] - node_off[0] : 0,
+                         (sizeof(double) + 2 * sizeof(int32_t)) * (size_t)max_k, flatten_tree, &c);
 }
 
 /* ---------------------------------------------------------------------------

@@ -142,9 +142,11 @@ class TreeArrays:
         return np.flatnonzero(np.bincount(leaves, minlength=self.n_taxa) > 0).astype(np.int32)
 
     def leaf_counts(self) -> np.ndarray:
-        is_leaf = (self.taxon >= 0).astype(np.int64)
-        csum = np.concatenate(([0], np.cumsum(is_leaf)))
-        return csum[self.node_off[1:]] - csum[self.node_off[:-1]]
+        out = np.zeros(self.n_trees, dtype=np.int64)
+        if self.n_trees:
+            _load().scs_host_leaf_counts(self.n_trees, _p(self.node_off, C.c_int64),
+                                         _p(self.taxon, C.c_int32), _p(out, C.c_int64))
+        return out
 
     # ------------------------------------------------------------ restriction
     def restrict(self, keep_ids: np.ndarray) -> "TreeArrays":

@@ -14,11 +14,15 @@ ap.add_argument("--taxa", type=int, default=5000)
 ap.add_argument("--trees", type=int, default=100)
 ap.add_argument("--strategy", default="branch")
 ap.add_argument("--top", type=int, default=45)
+ap.add_argument("--native-arrays", action="store_true")
 args = ap.parse_args()
 warnings.simplefilter("ignore")
-trees = synthetic.tree_objects(1, args.taxa, args.trees, None)
-names = sorted(scs._all_tip_names(trees))
-arrays = TreeArrays.from_trees(trees, [1.0] * len(trees), names)
+if args.native_arrays:
+    arrays = synthetic.tree_arrays(1, args.taxa, args.trees, None)
+else:
+    trees = synthetic.tree_objects(1, args.taxa, args.trees, None)
+    names = sorted(scs._all_tip_names(trees))
+    arrays = TreeArrays.from_trees(trees, [1.0] * len(trees), names)
 scs.default_device()
 from spectralclustersupertree_amd import kmeans2
 kmeans2.fast_path_active()
