@@ -222,7 +222,9 @@ class TreeArrays:
         n_taxa, taxa = self.n_taxa, self.taxa
         if local_ids is not None:
             local_ids = np.asarray(local_ids, dtype=np.int32)
-            leaf_taxon = np.searchsorted(local_ids, leaf_taxon).astype(np.int32)
+            lut = np.zeros(self.n_taxa, dtype=np.int32)  # global id -> position in local_ids
+            lut[local_ids] = np.arange(len(local_ids), dtype=np.int32)
+            leaf_taxon = lut[leaf_taxon]
             n_taxa = len(local_ids)
             taxa = [self.taxa[int(i)] for i in local_ids]
         monotone = (strategy in ("one", "depth", "branch") and bool(mono.value)
