@@ -1734,8 +1734,8 @@ struct small_batch {
 __global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
     __shared__ jacobi_lds s;
     __shared__ double s_dd[MAXS];
-    __shared__ double s_val[MAXS];
-    __shared__ int s_tax[MAXS], s_dep[MAXS], s_gs[MAXS + 1];
+    __shared__ int s_taxb[2][MAXS], s_depb[2][MAXS], s_gs[MAXS + 1];
+    __shared__ double s_valb[2][MAXS];
     const int tid = threadIdx.x;
     const int k = blockIdx.x;
     const int m = p.n_trees[k], v = p.n_groups[k];
@@ -1745,18 +1745,34 @@ __global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
 
     for (int e = tid; e < MAXS * SLD; e += 256) (&s.e[0][0])[e] = 0.0;
     if (tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
-    __syncthreads();
     // ---- W0: every tree in order; thread a sweeps the leaves to its right with the running
     // shallowest LCA (reference: scs.py:644-658; one rounded multiply, one rounded add: FMA
-    // contraction is switched off for that statement)
-    for (int t = 0; t < m; ++t) {
-        const int off = toff[t], n = toff[t + 1] - off;
-        if (tid < n) {
-            s_tax[tid] = p.leaf_taxon[lbase + off + tid];
-            s_dep[tid] = p.adj_depth[lbase + off + tid];
-            s_val[tid] = p.adj_val[lbase + off + tid];
+    // contraction is switched off for that statement).  The leaves of tree t + 1 are fetched
+    // while tree t is swept (registers, then the other half of a double buffer): one barrier
+    // per tree, and the fetch latency off the chain.
+    int f_tax = 0, f_dep = 0, f_n = 0;
+    double f_val = 0.0;
+    auto fetch = [&](int t) {
+        const int off = toff[t];
+        f_n = toff[t + 1] - off;
+        if (tid < f_n) {
+            f_tax = p.leaf_taxon[lbase + off + tid];
+            f_dep = p.adj_depth[lbase + off + tid];
+            f_val = p.adj_val[lbase + off + tid];
         }
-        __syncthreads();
+    };
+    if (m > 0) fetch(0);
+    for (int t = 0; t < m; ++t) {
+        int *s_tax = s_taxb[t & 1], *s_dep = s_depb[t & 1];
+        double *s_val = s_valb[t & 1];
+        const int n = f_n;
+        if (tid < n) {
+            s_tax[tid] = f_tax;
+            s_dep[tid] = f_dep;
+            s_val[tid] = f_val;
+        }
+        __syncthreads();  // tree t is staged; every thread is done with tree t - 1 (w0)
+        if (t + 1 < m) fetch(t + 1);
         const double wt = p.tree_w[p.tree_ptr[k] + t];
         if (tid + 1 < n) {
             const int a = tid, ta = s_tax[a];
@@ -1779,8 +1795,8 @@ __global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
                 w0[tb][ta] = sum;
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     // ---- contraction: vertex g = taxa [gs[g], gs[g+1]); weight = max over member pairs
     // (reference: scs.py:336-387), diagonal 0
     for (int e = tid; e < v * v; e += 256) {
