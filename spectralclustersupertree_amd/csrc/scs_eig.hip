@@ -1734,8 +1734,12 @@ struct small_batch {
 __global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
     __shared__ jacobi_lds s;
     __shared__ double s_dd[MAXS];
-    __shared__ int s_taxb[2][MAXS], s_depb[2][MAXS], s_gs[MAXS + 1];
-    __shared__ double s_valb[2][MAXS];
+    __shared__ int s_gs[MAXS + 1];
+    // per tree, double-buffered: sparse table over the gaps' (depth << 6 | gap) keys, the gaps'
+    // values, the position of every taxon (-1: absent)
+    __shared__ unsigned s_sp[2][6][MAXS];
+    __shared__ double s_val[2][MAXS];
+    __shared__ int s_pos[2][MAXS];
     const int tid = threadIdx.x;
     const int k = blockIdx.x;
     const int m = p.n_trees[k], v = p.n_groups[k];
@@ -1745,11 +1749,18 @@ __global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
 
     for (int e = tid; e < MAXS * SLD; e += 256) (&s.e[0][0])[e] = 0.0;
     if (tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
-    // ---- W0: every tree in order; thread a sweeps the leaves to its right with the running
-    // shallowest LCA (reference: scs.py:644-658; one rounded multiply, one rounded add: FMA
-    // contraction is switched off for that statement).  The leaves of tree t + 1 are fetched
-    // while tree t is swept (registers, then the other half of a double buffer): one barrier
-    // per tree, and the fetch latency off the chain.
+    // ---- W0, output-stationary like the tile kernels: a thread owns the cells (x, y), x < y,
+    // among e = tid + 256 q of the 64 x 64 square and keeps their sums in registers; per tree
+    // it looks the two taxa's positions up, takes the shallowest gap between them from a sparse
+    // table (leftmost on ties, as a left-to-right sweep finds it) and adds value * weight --
+    // every cell sees its addends in tree order (reference: scs.py:644-658; one rounded
+    // multiply, one rounded add: FMA contraction is switched off for that statement; an LCA at
+    // the root adds nothing).  Wave 0 stages a tree (lane = leaf); the next tree's leaves are
+    // fetched while the current one is used.
+    constexpr int CELLS = MAXS * MAXS / 256;
+    double acc[CELLS];
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) acc[q] = 0.0;
     int f_tax = 0, f_dep = 0, f_n = 0;
     double f_val = 0.0;
     auto fetch = [&](int t) {
@@ -1763,37 +1774,59 @@ __global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
     };
     if (m > 0) fetch(0);
     for (int t = 0; t < m; ++t) {
-        int *s_tax = s_taxb[t & 1], *s_dep = s_depb[t & 1];
-        double *s_val = s_valb[t & 1];
+        const int buf = t & 1;
         const int n = f_n;
-        if (tid < n) {
-            s_tax[tid] = f_tax;
-            s_dep[tid] = f_dep;
-            s_val[tid] = f_val;
+        if (tid < 64) {
+            // gap i = the LCA of leaves i and i + 1 (adj_* of leaf i), i < n - 1
+            unsigned key = tid + 1 < n ? ((unsigned)f_dep << 6) | (unsigned)tid : 0xFFFFFFFFu;
+            s_sp[buf][0][tid] = key;
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                const unsigned other = __shfl_down(key, 1 << (j - 1), 64);
+                if (tid + (1 << (j - 1)) < 64) key = other < key ? other : key;
+                s_sp[buf][j][tid] = key;
+            }
+            s_val[buf][tid] = f_val;
+            s_pos[buf][tid] = -1;
+            if (tid < n) s_pos[buf][f_tax] = tid;  // (same wave: after the clearing store)
         }
-        __syncthreads();  // tree t is staged; every thread is done with tree t - 1 (w0)
+        __syncthreads();  // tree t is staged; the other buffer is free again
         if (t + 1 < m) fetch(t + 1);
         const double wt = p.tree_w[p.tree_ptr[k] + t];
-        if (tid + 1 < n) {
-            const int a = tid, ta = s_tax[a];
-            int md = s_dep[a];
-            double mv = s_val[a];
-            for (int b = a + 1; b < n; ++b) {
-                if (b > a + 1 && s_dep[b - 1] < md) {
-                    md = s_dep[b - 1];
-                    mv = s_val[b - 1];
-                }
-                if (md == 0) break;  // the root separates a from every later leaf
-                const int tb = s_tax[b];
-                double sum;
-                {
+        // (branch-free, stage by stage, so that the LDS reads of the sixteen cells overlap:
+        // positions, then the two table entries, then the value; y = tid & 63 for every cell)
+        const int y = tid & 63, x0 = tid >> 6;
+        const int py = s_pos[buf][y];
+        unsigned ka[CELLS], kb[CELLS];
+        bool live[CELLS];
+#pragma unroll
+        for (int q = 0; q < CELLS; ++q) {
+            const int x = x0 + 4 * q;
+            const int px = s_pos[buf][x];
+            live[q] = x < y && px >= 0 && py >= 0;
+            const int lo = live[q] ? (px < py ? px : py) : 0, hi = live[q] ? (px < py ? py : px) : 1;
+            const int lv = 31 - __clz(hi - lo);
+            ka[q] = s_sp[buf][lv][lo];
+            kb[q] = s_sp[buf][lv][hi - (1 << lv)];
+        }
+#pragma unroll
+        for (int q = 0; q < CELLS; ++q) {
+            const unsigned key = kb[q] < ka[q] ? kb[q] : ka[q];
+            const double mv = s_val[buf][key & 63u];
+            // the root (depth 0) separates the two: nothing to add
+            if (live[q] && (key >> 6) != 0) {
 #pragma clang fp contract(off)
-                    const double add = mv * wt;  // rounded on its own, never fused into the add
-                    sum = w0[ta][tb] + add;
-                }
-                w0[ta][tb] = sum;
-                w0[tb][ta] = sum;
+                const double add = mv * wt;  // rounded on its own, never fused into the add
+                acc[q] = acc[q] + add;
             }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CELLS; ++q) {
+        const int e = tid + 256 * q, x = e >> 6, y = e & 63;
+        if (x < y) {
+            w0[x][y] = acc[q];
+            w0[y][x] = acc[q];
         }
     }
     __syncthreads();
