@@ -26,7 +26,9 @@ def load() -> C.CDLL:
         lib.scs_host_leaf_counts.restype = C.c_int
         lib.scs_host_leaf_counts.argtypes = [C.c_int32, lp, ip, lp]
         lib.scs_host_flatten.restype = C.c_int
-        lib.scs_host_flatten.argtypes = [C.c_int32, lp, ip, ip, dp, dp, C.c_int32, lp, ip, ip, dp, ip]
+        lib.scs_host_flatten.argtypes = [C.c_int32, lp, ip, ip, dp, dp, C.c_int32, lp, ip, ip, dp, ip, ip]
+        lib.scs_host_present.restype = C.c_int
+        lib.scs_host_present.argtypes = [C.c_int32, lp, ip, bp]
         lib.scs_host_newick_scan.restype = C.c_int
         lib.scs_host_newick_scan.argtypes = [C.c_char_p, C.c_int64, lp, lp, lp, lp, lp]
         lib.scs_host_newick_parse.restype = C.c_int

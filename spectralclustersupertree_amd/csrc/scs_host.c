@@ -254,6 +254,28 @@ int scs_host_restrict_fill(int32_t n_trees, const int64_t *node_off, const int32
     return rc;
 }
 
+/* mark[x] = 1 for every taxon that is a leaf of some tree (mark zeroed by the caller; the
+ * threads may store the same 1 twice) */
+typedef struct {
+    const int64_t *node_off;
+    const int32_t *taxon;
+    uint8_t *mark;
+} mark_ctx;
+
+static int present_tree(int32_t t, void *scratch, void *vctx) {
+    (void)scratch;
+    const mark_ctx *c = (const mark_ctx *)vctx;
+    for (int64_t i = c->node_off[t]; i < c->node_off[t + 1]; ++i)
+        if (c->taxon[i] >= 0) c->mark[c->taxon[i]] = 1;
+    return SCS_HOST_OK;
+}
+
+int scs_host_present(int32_t n_trees, const int64_t *node_off, const int32_t *taxon, uint8_t *mark) {
+    mark_ctx c = {node_off, taxon, mark};
+    return for_each_tree(n_trees, n_trees > 0 ? node_off[n_trees] - node_off[0] : 0, 0, present_tree,
+                         &c);
+}
+
 /* leaves of every tree (out_counts[t]) */
 typedef struct {
     const int64_t *node_off;
@@ -294,6 +316,7 @@ typedef struct {
     double *adj_val;
     int32_t *monotone_out;
     int32_t max_k;
+    const int32_t *renumber; /* taxon id -> id written to leaf_taxon, or null */
 } flatten_ctx;
 
 static int flatten_tree(int32_t t, void *scratch, void *vctx) {
@@ -319,7 +342,7 @@ static int flatten_tree(int32_t t, void *scratch, void *vctx) {
     val[0] = 0.0;
     if (tax[0] >= 0) { /* a single-leaf tree */
         if (slot >= slot_end) return SCS_HOST_EINVAL;
-        leaf_taxon[slot] = tax[0];
+        leaf_taxon[slot] = c->renumber ? c->renumber[tax[0]] : tax[0];
         adj_depth[slot] = 0;
         adj_val[slot] = 0.0;
         return SCS_HOST_OK;
@@ -337,7 +360,7 @@ static int flatten_tree(int32_t t, void *scratch, void *vctx) {
                 adj_val[slot - 1] = pend_val;
             }
             first_leaf = 0;
-            leaf_taxon[slot++] = tax[i];
+            leaf_taxon[slot++] = c->renumber ? c->renumber[tax[i]] : tax[i];
             continue;
         }
         depth[i] = depth[u] + 1;
@@ -374,7 +397,8 @@ static int flatten_tree(int32_t t, void *scratch, void *vctx) {
 int scs_host_flatten(int32_t n_trees, const int64_t *node_off, const int32_t *parent,
                      const int32_t *taxon, const double *length, const double *support,
                      int32_t strategy, const int64_t *leaf_off, int32_t *leaf_taxon,
-                     int32_t *adj_depth, double *adj_val, int32_t *monotone_out) {
+                     int32_t *adj_depth, double *adj_val, int32_t *monotone_out,
+                     const int32_t *renumber) {
     if (strategy < 0 || strategy > 3) return SCS_HOST_EINVAL;
     int32_t max_k = 1;
     for (int32_t t = 0; t < n_trees; ++t) {
@@ -383,7 +407,7 @@ int scs_host_flatten(int32_t n_trees, const int64_t *node_off, const int32_t *pa
         if (k > max_k) max_k = (int32_t)k;
     }
     flatten_ctx c = {node_off, parent, taxon, length, support, strategy, leaf_off, leaf_taxon,
-                     adj_depth, adj_val, monotone_out, max_k};
+                     adj_depth, adj_val, monotone_out, max_k, renumber};
     return for_each_tree(n_trees, n_trees > 0 ? node_off[n_trees] - node_off[0] : 0,
                          (sizeof(double) + 2 * sizeof(int32_t)) * (size_t)max_k, flatten_tree, &c);
 }
@@ -772,9 +796,10 @@ int scs_host_components(int32_t n_taxa, int32_t n_trees, const int64_t *tree_off
     int32_t *parent = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_taxa);
     if (!parent) return SCS_HOST_ENOMEM;
     for (int32_t x = 0; x < n_taxa; ++x) parent[x] = x;
-    for (int32_t t = 0; t < n_trees; ++t) {
+    int32_t n_sets = n_taxa; /* one set left: every further union is a no-op, stop reading */
+    for (int32_t t = 0; t < n_trees && n_sets > 1; ++t) {
         int32_t rep = -1; /* first leaf of the current root side */
-        for (int64_t p = tree_off[t]; p < tree_off[t + 1]; ++p) {
+        for (int64_t p = tree_off[t]; p < tree_off[t + 1] && n_sets > 1; ++p) {
             const int32_t x = leaf_taxon[p];
             if (rep < 0) {
                 rep = x;
@@ -783,6 +808,7 @@ int scs_host_components(int32_t n_taxa, int32_t n_trees, const int64_t *tree_off
                 if (a != b) {
                     if (a < b) parent[b] = a;
                     else parent[a] = b;
+                    --n_sets;
                 }
             }
             if (adj_depth[p] == 0) rep = -1; /* a root gap (or the tree's padding slot) ends the side */

@@ -138,8 +138,11 @@ class TreeArrays:
     # ---------------------------------------------------------------- queries
     def present_taxa(self) -> np.ndarray:
         """Sorted ids of the taxa that occur in at least one tree."""
-        leaves = self.taxon[self.taxon >= 0]
-        return np.flatnonzero(np.bincount(leaves, minlength=self.n_taxa) > 0).astype(np.int32)
+        mark = np.zeros(max(self.n_taxa, 1), dtype=np.uint8)
+        if self.n_trees:
+            _load().scs_host_present(self.n_trees, _p(self.node_off, C.c_int64), _p(self.taxon, C.c_int32),
+                                     _p(mark, C.c_uint8))
+        return np.flatnonzero(mark[: self.n_taxa]).astype(np.int32)
 
     def leaf_counts(self) -> np.ndarray:
         out = np.zeros(self.n_trees, dtype=np.int64)
@@ -206,12 +209,18 @@ class TreeArrays:
         adj_depth = np.empty(total, dtype=np.int32)
         adj_val = np.empty(total, dtype=np.float64)
         mono = C.c_int32(1)
+        lut = None
+        if local_ids is not None:
+            local_ids = np.asarray(local_ids, dtype=np.int32)
+            lut = np.zeros(max(self.n_taxa, 1), dtype=np.int32)  # global id -> position in local_ids
+            lut[local_ids] = np.arange(len(local_ids), dtype=np.int32)
         if m:
             rc = lib.scs_host_flatten(m, _p(self.node_off, C.c_int64), _p(self.parent, C.c_int32),
                                       _p(self.taxon, C.c_int32), _p(self.length, C.c_double),
                                       _p(self.support, C.c_double), _STRATEGY_CODE[strategy],
                                       _p(leaf_off, C.c_int64), _p(leaf_taxon, C.c_int32),
-                                      _p(adj_depth, C.c_int32), _p(adj_val, C.c_double), C.byref(mono))
+                                      _p(adj_depth, C.c_int32), _p(adj_val, C.c_double), C.byref(mono),
+                                      _p(lut, C.c_int32) if lut is not None else None)
             if rc == -3:
                 # the reference fails in ``length * tree_weight`` with a missing support
                 # (reference: scs.py:656)
@@ -221,10 +230,6 @@ class TreeArrays:
                 raise ValueError(f"scs_host_flatten: {_ERRORS.get(rc, rc)}")
         n_taxa, taxa = self.n_taxa, self.taxa
         if local_ids is not None:
-            local_ids = np.asarray(local_ids, dtype=np.int32)
-            lut = np.zeros(self.n_taxa, dtype=np.int32)  # global id -> position in local_ids
-            lut[local_ids] = np.arange(len(local_ids), dtype=np.int32)
-            leaf_taxon = lut[leaf_taxon]
             n_taxa = len(local_ids)
             taxa = [self.taxa[int(i)] for i in local_ids]
         monotone = (strategy in ("one", "depth", "branch") and bool(mono.value)

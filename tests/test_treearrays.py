@@ -8,7 +8,9 @@ recursion driven by the same (CPU, oracle-based) bipartition.
 
 from __future__ import annotations
 
+import os
 import random
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -385,3 +387,36 @@ def test_synthetic_tree_arrays_equal_the_object_path():
             assert np.array_equal(flat.leaf_taxon, tabs.leaf_taxon)
             assert np.array_equal(flat.adj_depth, tabs.adj_depth)
             assert np.array_equal(flat.adj_val, tabs.adj_val)
+
+
+def test_threaded_host_helpers_equal_serial():
+    # libscs_host.so cuts forests above 200 000 nodes over a team of threads: restriction,
+    # flattening, present taxa and leaf counts must not depend on the team size
+    import hashlib
+    import subprocess
+    import sys
+
+    code = """
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from spectralclustersupertree_amd import synthetic
+a = synthetic.tree_arrays(3, 4000, 60, 3500, random_weights=True)
+assert a.parent.size > 200000
+keep = np.flatnonzero(np.random.RandomState(0).rand(4000) < 0.6).astype(np.int32)
+r = a.restrict(keep)
+present = r.present_taxa()
+f = r.flatten("branch", local_ids=present)
+g = a.flatten("bootstrap")
+h = hashlib.md5()
+for x in (r.node_off, r.parent, r.taxon, r.length, r.support, r.weights, present, r.leaf_counts(),
+          f.tree_off, f.leaf_taxon, f.adj_depth, f.adj_val, g.leaf_taxon, g.adj_depth, g.adj_val):
+    h.update(np.ascontiguousarray(x).tobytes())
+print(h.hexdigest(), int(f.monotone), int(g.monotone))
+""" % str(Path(__file__).resolve().parent.parent)
+    out = []
+    for threads in ("1", "7"):
+        env = dict(os.environ, SCS_HOST_THREADS=threads)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
+        out.append(res.stdout.strip())
+    assert out[0] == out[1] and len(out[0].split()) == 3
