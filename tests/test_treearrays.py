@@ -401,7 +401,7 @@ import hashlib, sys
 import numpy as np
 sys.path.insert(0, %r)
 from spectralclustersupertree_amd import synthetic
-a = synthetic.tree_arrays(3, 4000, 60, 3500, random_weights=True)
+a = synthetic.tree_arrays(3, 4000, 70, 3500, random_weights=True)
 assert a.parent.size > 200000
 keep = np.flatnonzero(np.random.RandomState(0).rand(4000) < 0.6).astype(np.int32)
 r = a.restrict(keep)
