@@ -2,7 +2,7 @@
 oracle and the Fiedler column against scikit-learn on random sizes, strategies, coverage
 and weights.  Prints a summary line; exits non-zero on any failure.
 
-    python tools/fuzz_parity.py [--seconds 120] [--seed 0]
+    python tests/fuzz_parity.py [--seconds 120] [--seed 0]
 """
 import argparse, sys, time, warnings
 from pathlib import Path
