@@ -65,8 +65,9 @@ def _seed_two_centres(x, x_sq, weight, weight_col, cdf, random_state):
     np.minimum(closest, to_cand, out=to_cand)
     cand_pot = to_cand @ weight_col
     best = np.argmin(cand_pot)
-    centres[1] = x[cand[best]]
-    return centres
+    second = cand[best]
+    centres[1] = x[second]
+    return centres, (int(first), int(second))
 
 
 def _fast(maps, random_state):
@@ -87,8 +88,14 @@ def _fast(maps, random_state):
     x -= x.mean(axis=0)
     x_sq = np.einsum("ij,ij->i", x, x)
     best_inertia, best_labels = None, None
+    seen = {}  # (first, second) seed points -> (labels, inertia): the same start, the same run
     for _ in range(10):
-        centres = _seed_two_centres(x, x_sq, weight, weight_col, cdf, random_state)
+        centres, seeds = _seed_two_centres(x, x_sq, weight, weight_col, cdf, random_state)
+        if seeds in seen:
+            lab, inertia = seen[seeds]
+            if best_inertia is None or (inertia < best_inertia and not kc._is_same_clustering(lab, best_labels, 2)):
+                best_labels, best_inertia = lab, inertia
+            continue
         # ---- _kmeans_single_lloyd
         centres_new = np.zeros_like(centres)
         lab = np.full(n, -1, dtype=np.int32)
@@ -109,6 +116,7 @@ def _fast(maps, random_state):
             kl.lloyd_iter_chunked_dense(x, weight, centres, centres, in_clusters, lab, shift, n_threads,
                                         update_centers=False)
         inertia = kc._inertia_dense(x, weight, centres, lab, n_threads)
+        seen[seeds] = (lab, inertia)
         if best_inertia is None or (inertia < best_inertia and not kc._is_same_clustering(lab, best_labels, 2)):
             best_labels, best_inertia = lab, inertia
     if len(set(best_labels)) < 2:

@@ -36,12 +36,21 @@ real = scs.spectral_bipartition_device
 real_presolve = scs._presolve_small_children
 presolve_s = [0.0]
 
+buckets = {}  # size class -> [nodes, seconds inside spectral_bipartition_device]
+
+
 def timed(tables, rs, *, contract_edges, **kw):
     t0 = time.perf_counter()
     out = real(tables, rs, contract_edges=contract_edges, **kw)
-    device_s[0] += time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    device_s[0] += dt
     calls[0] += 1
     sizes.append(tables.n_taxa)
+    n = tables.n_taxa
+    key = "<=64" if n <= 64 else "65-512" if n <= 512 else "513-4096" if n <= 4096 else ">4096"
+    b = buckets.setdefault(key, [0, 0.0])
+    b[0] += 1
+    b[1] += dt
     return out
 
 def timed_presolve(*a, **kw):
@@ -71,7 +80,8 @@ res["arrays"] = {"total_s": round(t_arr + t_conv, 3), "convert_once_s": round(t_
                  "presolve_batches_s": round(presolve_s[0], 3),
                  "per_node_ms": round(1e3 * (device_s[0] + presolve_s[0]) / max(calls[0], 1), 3),
                  "host_recursion_s": round(t_arr - device_s[0] - presolve_s[0], 3),
-                 "small_path": scs._small_path(), "largest_problems": sorted(sizes, reverse=True)[:5]}
+                 "small_path": scs._small_path(), "largest_problems": sorted(sizes, reverse=True)[:5],
+                 "bipartition_by_taxa": {k: {"nodes": v[0], "s": round(v[1], 3)} for k, v in sorted(buckets.items())}}
 if not args.skip_objects:
     device_s[0], calls[0] = 0.0, 0
     scs.spectral_bipartition_device = real
