@@ -574,6 +574,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 (double)table_entries((int64_t)std::max(avg_leaves - 1.0, 1.0)) * (double)entry_bytes;
             max_batch_trees = (int)std::min(256.0, std::max(64.0, 600e6 / std::max(table_bytes, 1.0)));
         }
+        // (a node of the deep recursion -- a few hundred taxa, thousands of tiny trees -- is a
+        // handful of tiles whose tables sit in L2: one batch, one set of launches)
+        if (n <= 2048) max_batch_trees = 4096;
         if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
         size_t used = 0;
         for (int t = 0; t < M; ++t) {

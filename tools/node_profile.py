@@ -8,9 +8,9 @@ from spectralclustersupertree_amd import scs, synthetic, flatten as fl
 from spectralclustersupertree_amd.treearrays import TreeArrays
 warnings.simplefilter("ignore")
 dev = scs.default_device()
-trees = synthetic.tree_objects(1, 5000, 100, 4000)
-names = sorted(scs._all_tip_names(trees))
-arr = TreeArrays.from_trees(trees, [1.0] * 100, names)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+arr = synthetic.tree_arrays(1, 5000, M, 4000)
+from spectralclustersupertree_amd import kmeans2
 rng = np.random.RandomState(0)
 def T(f, n=10):
     f()
@@ -33,5 +33,6 @@ for size in (8, 20, 60, 100, 200, 1000):
     with threadpoolctl.threadpool_limits(1):
         t_km1, _ = T(lambda: k_means(maps, 2, random_state=np.random.RandomState(0), n_init=10))
     t_all, _ = T(lambda: scs.spectral_bipartition_device(tab, np.random.RandomState(0), contract_edges=True))
-    print(f"V={n:5d} trees={sub.n_trees:3d} groups {t_groups:.2f} upload {t_up:.2f} build {t_build:.2f} fiedler {t_fied:.2f} "
+    t_km2, _ = T(lambda: kmeans2.labels(maps, np.random.RandomState(0)))
+    print(f"V={n:5d} trees={sub.n_trees:3d} kmeans2 {t_km2:.2f} groups {t_groups:.2f} upload {t_up:.2f} build {t_build:.2f} fiedler {t_fied:.2f} "
           f"kmeans {t_km:.2f} (1 thread {t_km1:.2f}) | whole node {t_all:.2f} ms")
