@@ -93,7 +93,9 @@ def _build_and_compare(dev, tables, row_ranges=None):
 
 
 @pytest.mark.parametrize("strategy", ["one", "depth", "branch", "bootstrap"])
-# (the last case has more trees than one batch takes: 256)
+# (the last case has more trees than a batch of a large problem takes, 256; a problem this small
+# walks them in one batch -- several batches: test_build_batched_matches_single_batch and the
+# configs[2]-size tests)
 @pytest.mark.parametrize(("n", "m", "k"), [(37, 6, 20), (64, 5, 64), (100, 9, 71), (300, 12, 300), (700, 7, 512),
                                            (330, 600, 200)])
 def test_build_bit_exact_synthetic(dev, strategy, n, m, k):
