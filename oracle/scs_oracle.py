@@ -214,11 +214,20 @@ def spectral_maps(matrix, random_state):
     )
 
 
-def spectral_bipartition(vertices, weight, random_state, vertex_list=None):
-    """Two vertex sets (reference: scs.py:210-258), fixed vertex order."""
+def spectral_bipartition(vertices, weight, random_state, vertex_list=None, trace_entry=None, steer=None):
+    """Two vertex sets, the set of label 0 first (reference: scs.py:210-258), fixed vertex
+    order.  ``trace_entry`` (a dict) receives the label vector and the generator state in
+    front of the call; ``steer(trace_entry, labels) -> labels`` may replace the labels the
+    walk continues with (tests: keep two walks aligned across an exact tie)."""
     if vertex_list is None:
         vertex_list = sorted(vertices)
+    if trace_entry is not None:
+        trace_entry["rng_state"] = random_state.get_state()
     labels = spectral_labels(dense_matrix(vertex_list, weight), random_state)
+    if trace_entry is not None:
+        trace_entry["labels"] = np.asarray(labels).copy()
+    if steer is not None:
+        labels = steer(trace_entry, labels)
     parts = [set(), set()]
     for vertex, lab in zip(vertex_list, labels):
         parts[lab].add(vertex)
@@ -253,11 +262,20 @@ def construct_supertree_oracle(
     contract_edges=True,
     random_state=None,
     trace=None,
+    trace_matrices=True,
+    steer=None,
 ):
     """Whole algorithm on the CPU (reference: scs.py:18-174).
 
     ``trace`` (a list) receives one dict per spectral call -- vertex order,
-    dense matrix -- so tests can harvest golden vectors.
+    dense matrix (dropped again when ``trace_matrices`` is False), label vector -- so
+    tests can harvest golden vectors and compare the recursion node by node.
+
+    Child order: the two parts of a spectral split are visited label 0 first, as the
+    reference's ``partition`` list is (scs.py:254-258, 139) -- the order decides where in the
+    shared RandomState stream each child's draws fall.  The parts of a component split come
+    in set order in the reference (hash-seed dependent, scs.py:458-492); here: by smallest
+    taxon name.  ``steer``: see ``spectral_bipartition`` (needs ``trace``).
     """
     if random_state is None:
         random_state = np.random.RandomState()
@@ -296,14 +314,18 @@ def construct_supertree_oracle(
         if contract_edges:
             contract_pcg(vertices, adjacency, weight, occ, together)
         order = sorted(vertices)
+        entry = None
         if trace is not None:
-            trace.append({"vertices": order, "matrix": dense_matrix(order, weight)})
-        parts = spectral_bipartition(vertices, weight, random_state, order)
+            entry = {"vertices": order}
+            if trace_matrices:
+                entry["matrix"] = dense_matrix(order, weight)
+            trace.append(entry)
+        parts = spectral_bipartition(vertices, weight, random_state, order, entry, steer)
+    else:
+        parts = sorted(parts, key=lambda p: min(p))
 
     children = []
-    # deterministic child order (the reference's is set order; the result is
-    # compared as an unordered topology)
-    for part in sorted(parts, key=lambda p: min(p)):
+    for part in parts:
         taxa = set()
         for vertex in part:
             taxa.update(vertex)
@@ -319,6 +341,8 @@ def construct_supertree_oracle(
                 contract_edges=contract_edges,
                 random_state=random_state,
                 trace=trace,
+                trace_matrices=trace_matrices,
+                steer=steer,
             )
         )
         lost = taxa.difference(_all_tips(sub_trees))

@@ -44,6 +44,26 @@ _default_device: Device | None = None
 _default_team = None
 _default_team_checked = False
 
+# Diagnostic hook: a list here receives one ``(member taxon names per vertex, labels)`` entry
+# per spectral call of the recursion, in call order (``trace_nodes`` sets and clears it); the
+# whole-recursion parity tests compare it with the oracle's trace node by node.
+_node_trace: list | None = None
+
+
+class trace_nodes:
+    """``with trace_nodes() as trace: construct_supertree(...)`` -- every spectral call of the
+    recursion appends ``{"vertices": [tuple of taxon names, ...], "labels": int array}``."""
+
+    def __enter__(self):
+        global _node_trace
+        _node_trace = []
+        return _node_trace
+
+    def __exit__(self, *exc):
+        global _node_trace
+        _node_trace = None
+        return False
+
 
 def default_device() -> Device:
     """Process-wide single-rank context, created on first use: GPU ``SCS_DEVICE`` (default 0),
@@ -425,6 +445,10 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         parts: list[list[int]] = [[], []]
         for ids, lab in zip(members, labels):
             parts[int(lab)].extend(int(present[int(i)]) for i in ids)
+        if _node_trace is not None:
+            _node_trace.append({
+                "vertices": [tuple(names[int(present[int(i)])] for i in ids) for ids in members],
+                "labels": np.asarray(labels).copy()})
     else:
         parts = [[] for _ in range(n_comp)]
         for i, c in enumerate(comp):

@@ -1,0 +1,154 @@
+"""Whole ``construct_supertree`` against the oracle's recursion, node by node (needs an MI355X).
+
+Reference behaviour: src/sc_supertree/scs.py:122-171 -- components, contraction, the
+spectral split, restriction of the trees to each part and the recursive call with the SAME
+RandomState.  The inputs are sized so that one run drives every product path at once: the
+general LOBPCG solve (V in the hundreds to 1 500), contraction inside the recursion (planted
+twins), the fused small-node kernel and its sibling batches, component splits (partial
+coverage), trees dropped by restriction, and the C restriction / flattening of
+``libscs_host.so``.  Checked: the same number of spectral calls, at every call the same
+vertices in the same order and the IDENTICAL label vector (so every later draw falls at the
+same place of the stream), the same topology, and the RandomState left in the same state.
+"""
+
+import numpy as np
+import pytest
+
+from oracle import scs_oracle as so
+from spectralclustersupertree_amd import construct_supertree, synthetic
+from spectralclustersupertree_amd.scs import trace_nodes
+from spectralclustersupertree_amd.tree import TreeNode
+from spectralclustersupertree_amd.treearrays import TreeArrays
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_twins(tree: TreeNode, twinned: set[str], support: float) -> TreeNode:
+    """A copy of the tree in which every tip named in ``twinned`` is a cherry (x, x_twin): the
+    two always travel together, so contraction merges them (reference: scs.py:302-316)."""
+    if tree.is_tip():
+        if tree.name in twinned:
+            return TreeNode(None, [TreeNode(tree.name, None, 0.01), TreeNode(tree.name + "_twin", None, 0.02)],
+                            tree.length, support)
+        return TreeNode(tree.name, None, tree.length, tree.support)
+    return TreeNode(tree.name, [_with_twins(c, twinned, support) for c in tree.children], tree.length,
+                    tree.support)
+
+
+def recursion_input(seed, n_taxa, n_trees, leaves, n_twins, weighted):
+    trees = synthetic.tree_objects(seed, n_taxa, n_trees, leaves_per_tree=leaves)
+    rs = np.random.RandomState(seed)
+    twinned = {synthetic.taxon_name(int(i)) for i in rs.choice(n_taxa, size=n_twins, replace=False)}
+    trees = [_with_twins(t, twinned, 75.0) for t in trees]
+    weights = [0.5 + 0.25 * (i % 5) for i in range(n_trees)] if weighted else None
+    return trees, weights
+
+
+def canonical(tree: TreeNode):
+    """Nested frozensets of tip names: the topology as an unordered rooted tree."""
+    if tree.is_tip():
+        return tree.name
+    return frozenset(canonical(c) for c in tree.children)
+
+
+def _inertia(points, labels):
+    total = 0.0
+    for c in (0, 1):
+        sel = points[labels == c]
+        if len(sel):
+            total += float(np.sum((sel - sel.mean(axis=0)) ** 2))
+    return total
+
+
+def compare_with_oracle(trees, weights, strategy, seed, contract_edges=True, as_arrays=False,
+                        ties_allowed=False):
+    """The product walks first (traced); the oracle then walks with the same seed and is
+    compared call by call.  Integer-valued weightings (`one`, `depth`) produce graphs with
+    automorphisms: an entry of the Fiedler vector that is zero in exact arithmetic puts a
+    point exactly between the two k-means centres, and which side it lands on is decided by
+    rounding noise at 1e-17 -- in the reference as well (its own vertex order is hash-seed
+    dependent).  With ``ties_allowed`` such a node is accepted when it is PROVEN to be a tie --
+    both label vectors have the same k-means inertia on scikit-learn's embedding of the
+    oracle's matrix (or lambda2 == lambda3) -- and the oracle continues with the product's
+    labels so that the two walks stay aligned; otherwise any difference fails."""
+    from oracle import tables_oracle as to
+
+    rs = np.random.RandomState(seed)
+    given = trees
+    if as_arrays:
+        names = sorted(so._all_tips(trees))
+        given = TreeArrays.from_trees(trees, weights or [1.0] * len(trees), names)
+    with trace_nodes() as trace:
+        got = construct_supertree(given, None if as_arrays else weights, strategy,
+                                  contract_edges=contract_edges, random_state=rs)
+    trace = list(trace)
+
+    oracle_trace: list = []
+    ties: list = []
+
+    def steer(entry, labels):
+        k = len(oracle_trace) - 1
+        assert k < len(trace), "the oracle makes more spectral calls than the product"
+        mine = trace[k]
+        assert mine["vertices"] == entry["vertices"], f"spectral call {k}: vertex lists differ"
+        if np.array_equal(mine["labels"], labels):
+            return labels
+        assert ties_allowed, f"spectral call {k} (V = {len(labels)}): labels differ"
+        assert not np.array_equal(mine["labels"], 1 - np.asarray(labels)), (
+            f"spectral call {k}: same split with the labels swapped -- not a tie, the k-means draws differ")
+        matrix = entry["matrix"]
+        state = np.random.RandomState()
+        state.set_state(entry["rng_state"])
+        points = so.spectral_maps(matrix, state)
+        lam = np.sort(np.linalg.eigvalsh(to.normalized_operator(matrix)[0]))[::-1]
+        i_ref, i_mine = _inertia(points, np.asarray(labels)), _inertia(points, mine["labels"])
+        scale = float(np.sum((points - points.mean(axis=0)) ** 2))
+        tie = abs(i_ref - i_mine) <= 1e-9 * scale or (len(lam) > 2 and lam[1] - lam[2] <= 1e-9)
+        assert tie, (f"spectral call {k} (V = {len(labels)}): labels differ and it is no tie "
+                     f"(inertia {i_ref:.17g} vs {i_mine:.17g}, lambda {lam[:3]})")
+        ties.append((k, len(labels)))
+        return mine["labels"]
+
+    rs_oracle = np.random.RandomState(seed)
+    want = so.construct_supertree_oracle(trees, weights, strategy, contract_edges=contract_edges,
+                                         random_state=rs_oracle, trace=oracle_trace,
+                                         trace_matrices=ties_allowed, steer=steer)
+    assert len(trace) == len(oracle_trace)
+    assert canonical(got) == canonical(want)
+    assert rs.randint(1 << 30) == rs_oracle.randint(1 << 30)  # the stream ended at the same place
+    return trace, ties
+
+
+def test_whole_recursion_branch_partial_coverage_twins():
+    # 1 500 (+ 120 twins) taxa / 40 weighted trees of 900 leaves, `branch`
+    trees, weights = recursion_input(5, 1500, 40, 900, 120, weighted=True)
+    trace, ties = compare_with_oracle(trees, weights, "branch", seed=3)
+    assert not ties
+    sizes = [len(e["vertices"]) for e in trace]
+    assert max(sizes) >= 1400  # the general LOBPCG path ...
+    assert sum(1 for s in sizes if 64 < s <= 1400) >= 5  # ... at several sizes ...
+    assert sum(1 for s in sizes if s <= 64) >= 50  # ... and the fused small-node kernel
+    assert any(len(v) > 1 for e in trace for v in e["vertices"])  # contraction inside the recursion
+
+
+def test_whole_recursion_bootstrap():
+    # 600 taxa / 25 trees of 400 leaves, `bootstrap` (the general accumulate kernel)
+    trees, weights = recursion_input(9, 600, 25, 400, 40, weighted=False)
+    _, ties = compare_with_oracle(trees, weights, "bootstrap", seed=11)
+    assert not ties
+
+
+@pytest.mark.parametrize("strategy", ["one", "depth"])
+def test_whole_recursion_integer_strategies_from_tree_arrays(strategy):
+    trees, weights = recursion_input(2, 400, 16, 300, 30, weighted=True)
+    # integer-valued weights: exact ties happen (see compare_with_oracle) -- proven, then followed
+    trace, ties = compare_with_oracle(trees, weights, strategy, seed=1, as_arrays=True, ties_allowed=True)
+    assert len(ties) <= len(trace) // 10
+    assert all(v <= 16 for _, v in ties)  # symmetric little graphs, never a big node
+
+
+def test_whole_recursion_without_contraction():
+    trees, weights = recursion_input(4, 500, 20, 350, 50, weighted=False)
+    trace, ties = compare_with_oracle(trees, weights, "branch", seed=7, contract_edges=False)
+    assert not ties
+    assert all(len(v) == 1 for e in trace for v in e["vertices"])
