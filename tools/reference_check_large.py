@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""The reference's OWN eigen-solve at BASELINE.json configs[3] / [4] size, beside ``scs_fiedler``.
+
+    python tools/reference_check_large.py --taxa 50000 --trees 2000 [--weights] [--out FILE]
+
+Builds W on the device, solves with ``scs_fiedler`` and draws the labels; downloads W and runs
+scikit-learn's ``spectral_embedding`` (ARPACK shift-invert on a dense LU, ``tol = 0`` -- the
+call the reference makes, scs.py:235-252 -> sklearn/cluster/_spectral.py:748-766) followed by
+``k_means`` on the same RandomState stream, on the host: about 5 copies of the V x V matrix in
+RAM (100 GB at 50 000 taxa, 400 GB at 100 000) and 2/3 V^3 LU flops.  Reports the measured --
+not bounded -- entrywise difference of the Fiedler column on both scales and the number of
+differing labels.  This is a checker (it imports the oracle's scikit-learn wrappers); nothing
+in the product path calls it.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def run(n: int, m: int, random_weights: bool, seed: int = 0, log=print) -> dict:
+    from sklearn.cluster import k_means
+
+    from oracle import scs_oracle as so
+    from oracle import tables_oracle as to
+    from spectralclustersupertree_amd import synthetic
+    from spectralclustersupertree_amd.backend import Device
+
+    t0 = time.perf_counter()
+    tables = synthetic.make_tables(seed, n, m, "branch", random_weights=random_weights)
+    log(f"tables generated in {time.perf_counter() - t0:.1f} s")
+    out: dict = {"n_taxa": n, "n_trees": m, "pcg_weighting": "branch", "per_tree_weights": random_weights}
+    with Device(0) as dev:
+        dtab = dev.upload(tables)
+        graph = dtab.build()
+        dtab.free()
+        rs = np.random.RandomState(0)
+        v0 = rs.uniform(-1, 1, n)
+        t0 = time.perf_counter()
+        maps, stats = graph.fiedler(v0)
+        out["device_fiedler_s"] = time.perf_counter() - t0
+        _, labels, _ = k_means(maps, 2, random_state=rs, n_init=10, verbose=False)
+        t0 = time.perf_counter()
+        w = np.empty((n, n))
+        step = 4096
+        for a in range(0, n, step):
+            k = min(step, n - a)
+            w[a:a + k] = graph.download_rows(a, k)
+        out["download_s"] = time.perf_counter() - t0
+        graph.free()
+    out.update({"build_ms": None, "lambda2": stats["lambda"][1], "lambda3": stats["lambda_next"],
+                "gap": stats["lambda"][1] - stats["lambda_next"], "solver_residual": stats["resid"][1],
+                "iterations": stats["iterations"], "block": stats["block"]})
+    log(f"device: lambda2 {out['lambda2']:.12f} gap {out['gap']:.3e} residual {out['solver_residual']:.3e} "
+        f"({out['iterations']} iterations); W downloaded in {out['download_s']:.1f} s")
+
+    t0 = time.perf_counter()
+    rs_ref = np.random.RandomState(0)
+    ref = to.sign_flip_columns(so.spectral_maps(w, rs_ref))
+    out["sklearn_spectral_embedding_s"] = time.perf_counter() - t0
+    log(f"scikit-learn spectral_embedding: {out['sklearn_spectral_embedding_s']:.1f} s")
+    _, labels_ref, _ = k_means(ref, 2, random_state=rs_ref, n_init=10, verbose=False)
+    deg = w.sum(axis=0)
+    del w
+    dd = np.sqrt(deg)
+    mism = int(np.count_nonzero(labels != labels_ref))
+    out.update({
+        "err_maps": float(np.max(np.abs(maps[:, 1] - ref[:, 1]))),
+        "err_unit": float(np.max(np.abs((maps[:, 1] - ref[:, 1]) * dd))),
+        "err_col0": float(np.max(np.abs(maps[:, 0] - ref[:, 0]))),
+        "labels_mismatched": min(mism, n - mism),
+        "labels_identical_as_drawn": mism == 0,
+        "stream_position_equal": int(rs.randint(1 << 30)) == int(rs_ref.randint(1 << 30)),
+    })
+    try:
+        import scipy
+        import sklearn
+        import threadpoolctl
+
+        out["versions"] = f"scikit-learn {sklearn.__version__}, scipy {scipy.__version__}, numpy {np.__version__}"
+        out["blas_threads"] = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except ImportError:
+        pass
+    return out
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--taxa", type=int, default=50000)
+    ap.add_argument("--trees", type=int, default=2000)
+    ap.add_argument("--weights", action="store_true")
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    res = run(args.taxa, args.trees, args.weights, log=lambda s: print(s, flush=True))
+    text = json.dumps(res, indent=1)
+    print(text, flush=True)
+    if args.out:
+        Path(args.out).write_text(text + "\n")
+    ok = res["err_maps"] <= 1e-10 and res["err_unit"] <= 1e-10 and res["labels_mismatched"] == 0
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
