@@ -66,7 +66,20 @@ def run(n: int, m: int, random_weights: bool, seed: int = 0, log=print) -> dict:
 
     t0 = time.perf_counter()
     rs_ref = np.random.RandomState(0)
-    ref = to.sign_flip_columns(so.spectral_maps(w, rs_ref))
+    # (a line a minute while LAPACK runs: a silent job looks hung to the GPU pool's watchdog)
+    import threading
+
+    done = threading.Event()
+
+    def heartbeat():
+        while not done.wait(60.0):
+            log(f"  ... scikit-learn still solving ({time.perf_counter() - t0:.0f} s)")
+
+    threading.Thread(target=heartbeat, daemon=True).start()
+    try:
+        ref = to.sign_flip_columns(so.spectral_maps(w, rs_ref))
+    finally:
+        done.set()
     out["sklearn_spectral_embedding_s"] = time.perf_counter() - t0
     log(f"scikit-learn spectral_embedding: {out['sklearn_spectral_embedding_s']:.1f} s")
     _, labels_ref, _ = k_means(ref, 2, random_state=rs_ref, n_init=10, verbose=False)
