@@ -3,9 +3,12 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
-A *step* is one pass of the hot path over one synthetic input whose flattened
-tree tables are already resident in HBM: ``scs_pcg_build`` (W rows of this rank)
-followed by ``scs_fiedler`` (degrees + LOBPCG).  N = 1 runs BASELINE.json
+A *step* is one pass of the hot path over one synthetic input by the protocol of
+SURVEY.md 8d / BASELINE.md 3.3: the flattened tree tables go host -> HBM
+(``scs_tables_upload`` from page-locked memory), ``scs_pcg_build`` (W rows of this
+rank), ``scs_fiedler`` (degrees + LOBPCG) and the V x 2 embedding comes back to the
+host.  The same pass on tables already resident in HBM is reported beside it as
+``value_tables_resident``.  N = 1 runs BASELINE.json
 configs[2] (10 000 taxa / 500 trees / branch), the largest configuration
 BASELINE.json assigns to a single MI355X; N > 1 runs configs[3] (50 000 taxa /
 2 000 trees, row-partitioned W, RCCL all-gather of the Krylov block), one
@@ -18,12 +21,12 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
                       library's stream inside the timed region), `roofline_other` the other one
                       of the two that matter (k_accumulate_mono, k_symm), `roofline_path` the
                       path-level figure (B_A + B_C) / t of SURVEY.md 8d;
-  value_incl_h2d_d2h  the SURVEY.md 8d protocol (tables host -> HBM, build, solve, embedding
-                      back) -- `value` itself starts with the tables resident in HBM;
+  value_tables_resident  the same step without the tables' upload (`value` includes it);
   parity              the gates of SURVEY.md 8d at FULL size: rows of W vs the C oracle, the
                       embedding vs scikit-learn on both scales, labels;
   cpu_baseline        the CPU path timed on this box: all-core C restatement of the build +
-                      scikit-learn's eigen-solve on the full matrix;
+                      scikit-learn's eigen-solve on the full matrix, and a bounded sample of
+                      the reference's literal dict-based build (oracle/scs_oracle.build_pcg);
   seeds / planted     seeds 0, 1, 2 (median) and the planted input, with lambda2 / lambda3.
 """
 
@@ -92,6 +95,7 @@ def even_splits(n: int, world: int) -> list[int]:
 
 
 def make_input(name, args, seed, planted):
+    """Synthetic tables in page-locked host memory (the upload inside a step is then a DMA)."""
     from spectralclustersupertree_amd import synthetic
 
     if name == "custom":
@@ -100,7 +104,13 @@ def make_input(name, args, seed, planted):
         n, m, strategy, rw, cfg_idx = WORKLOADS[name]
     t0 = time.perf_counter()
     spr = int(np.ceil(0.02 * n)) if planted else None
-    tables = synthetic.make_tables(seed, n, m, strategy, random_weights=rw, planted_spr=spr)
+    try:
+        tables = synthetic.make_tables(seed, n, m, strategy, random_weights=rw, planted_spr=spr, pinned=True)
+        tables.pinned = True
+    except (RuntimeError, OSError):
+        # no HIP device to pin memory on (the CPU-only control-flow tests): pageable arrays
+        tables = synthetic.make_tables(seed, n, m, strategy, random_weights=rw, planted_spr=spr)
+        tables.pinned = False
     return tables, (n, m, strategy, rw, cfg_idx), time.perf_counter() - t0
 
 
@@ -130,6 +140,28 @@ def sklearn_gates(w, maps, labels_dev):
         "col0_max_abs": float(np.max(np.abs(maps[:, 0] - ref[:, 0]))),
         "labels_mismatched": min(mism, n - mism),  # label names are arbitrary
     }, t_eig, int(blas)
+
+
+def reference_style_leg(n, m, strategy, sample_taxa=300, sample_trees=30):
+    """The reference's LITERAL loop structure -- dicts keyed by tuples of names, one Python
+    update per leaf pair (scs.py:569-658, restated in oracle/scs_oracle.build_pcg) -- on a
+    bounded sample (300 taxa / 30 trees, a second or two), with its cost per pair update and
+    what that extrapolates to at the workload's 0.336 N^2 M pair updates."""
+    from oracle import scs_oracle as so
+    from spectralclustersupertree_amd import synthetic
+
+    trees = synthetic.tree_objects(0, sample_taxa, sample_trees)
+    names = sorted(so._all_tips(trees))
+    t0 = time.perf_counter()
+    _, weight, _, together = so.build_pcg({(x,) for x in names}, trees, [1.0] * sample_trees, strategy)
+    secs = time.perf_counter() - t0
+    updates = int(sum(together.values()))
+    per = secs / max(updates, 1)
+    return {"kind": "reference-style (oracle/scs_oracle.build_pcg: the reference's dict-of-tuples loops)",
+            "sample": f"{sample_taxa} taxa / {sample_trees} trees / {strategy}, one thread (CPython)",
+            "seconds": round(secs, 3), "pair_updates": updates, "us_per_pair_update": round(per * 1e6, 3),
+            "extrapolated_s_at_workload": round(per * 0.336 * n * n * m, 0),
+            "extrapolation": "us_per_pair_update x 0.336 N^2 M pair updates of the full workload"}
 
 
 def cpu_build_legs(tables, args, n, m):
@@ -165,7 +197,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     t_up0 = time.perf_counter()
     dtab = dev.upload(tables)
     dev.synchronize()
-    t_upload = time.perf_counter() - t_up0
+    t_upload_first = time.perf_counter() - t_up0
     v0 = np.random.RandomState(seed).uniform(-1, 1, n)
 
     def barrier():
@@ -174,6 +206,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
             dist.barrier()
 
     def one_step(keep=False, tab=None):
+        """build + solve on resident tables (`tab`, default the set uploaded above)"""
         graph = (tab or dtab).build(rb, re_, shared=(world > 1 and not args.no_shared))
         maps, stats = graph.fiedler(v0, tol=args.tol, max_iter=args.max_iter, block=args.block)
         bstats = graph.build_stats
@@ -182,8 +215,16 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         graph.free()
         return None, maps, stats, bstats
 
+    def protocol_step(keep=False):
+        """tables host -> HBM, build, solve, embedding to the host"""
+        tab = dev.upload(tables)
+        try:
+            return one_step(keep=keep, tab=tab)
+        finally:
+            tab.free()
+
     for _ in range(warmup):
-        one_step()
+        protocol_step()
 
     acc = {"apply_ms": 0.0, "n_apply": 0, "iters": 0, "build_ms": 0.0, "acc_ms": 0.0, "prep_ms": 0.0,
            "solve_ms": 0.0, "exch_ms": 0.0}
@@ -193,7 +234,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     kept = None
     for i in range(steps):
         # multi-rank runs keep the last graph for the parity gate (no extra collective step)
-        kept, maps, stats, bstats = one_step(keep=(world > 1 and i == steps - 1))
+        kept, maps, stats, bstats = protocol_step(keep=(world > 1 and i == steps - 1))
         acc["apply_ms"] += stats["apply_ms_total"]
         acc["n_apply"] += stats["n_apply"]
         acc["iters"] += stats["iterations"]
@@ -224,14 +265,18 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     build_gbs = build_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
     symm_ms_step = acc["apply_ms"] / steps
     n_apply_step = acc["n_apply"] / steps
-    # B_C = n_apply (8 rows V + 16 V b) + n_iter 72 V b ; B_A as bytes_w + tables
-    b_c = n_apply_step * (8.0 * (re_ - rb) * n + 16.0 * n * stats["block"]) + \
-        (acc["iters"] / steps) * 72.0 * n * stats["block"]
+    # B_C = n_apply (W bytes of one apply + 16 V b) + n_iter 72 V b with the W
+    # bytes the SELECTED kernel must stream -- 4 V^2 (upper tiles) when the symmetric SYMM ran,
+    # 8 rows V otherwise: stats["apply_bytes"] is exactly that; B_A = bytes_w + tables
+    symm_tri = stats["apply_bytes"] < 6.0 * (re_ - rb) * n
+    b_c = n_apply_step * stats["apply_bytes"] + (acc["iters"] / steps) * 72.0 * n * stats["block"]
     path_gbs = (build_bytes + b_c) / sec_per_step / 1e9
 
     roof_symm = {
-        "kernel": f"k_symm<{stats['block']}> (S*X: streams this rank's rows of the N x N matrix once per "
-                  "LOBPCG iteration)",
+        "kernel": (f"k_symm_tri<{stats['block']}> (S*X from the upper-triangle tiles of the symmetric "
+                   "N x N matrix: 4 V^2 bytes per LOBPCG iteration)" if symm_tri else
+                   f"k_symm<{stats['block']}> (S*X: streams this rank's rows of the N x N matrix once per "
+                   "LOBPCG iteration, 8 rows V bytes)"),
         "bound": "hbm",
         "achieved": round(symm_gbs, 1),
         "peak": HBM_PEAK_GBS,
@@ -246,15 +291,21 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     # the PCG accumulation does 0.5 V^2 M cell-tree evaluations (one ds_read_b64, one v_min_f64,
     # one v_add_f64 each) against 8 V^2 bytes written once: its HBM fraction is tiny by
     # construction and is reported as is, next to the fractions of the units that do bound it
+    lds_gbs = 8.0 * cell_rate / 1e9
     roof_acc = {
         "kernel": ("k_accumulate_mono" if tables.monotone else "k_accumulate_gen") +
                   " (PCG weights: tree-ordered sums of LCA values into 64 x 256 tiles)",
-        "bound": "hbm",
-        "achieved": round(build_gbs, 1),
-        "peak": HBM_PEAK_GBS,
+        # the binding unit: every cell-tree evaluation is one 8-byte ds_read_b64 of the tile's
+        # row-row table (plus one v_min_f64 and one v_add_f64); HBM sees W once
+        "bound": "lds",
+        "achieved": round(lds_gbs, 1),
+        "peak": LDS_PEAK_TBS * 1e3,
         "unit": "GB/s",
-        "frac": round(build_gbs / HBM_PEAK_GBS, 5),
+        "frac": round(lds_gbs / (LDS_PEAK_TBS * 1e3), 4),
         "traffic": None,
+        "hbm": {"achieved": round(build_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(build_gbs / HBM_PEAK_GBS, 5),
+                "bytes_per_launch": build_bytes / n_batches},
         "bytes_per_launch": build_bytes / n_batches,
         "avg_launch_ms": round(acc_ms / n_batches, 4),
         "launches_per_step": n_batches,
@@ -263,11 +314,12 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         "cell_trees_per_s": round(cell_rate, 0),
         "frac_f64_valu": round(2.0 * cell_rate / (F64_VALU_TOPS * 1e12), 4),
         "frac_lds": round(8.0 * cell_rate / (LDS_PEAK_TBS * 1e12), 4),
-        "note": "not HBM-bound: 2 fp64 VALU ops (monotone weighting; 4 vector ops otherwise) and one "
-                "8-byte LDS read per cell-tree, plus one "
-                "range-minimum query (two random 8- or 12-byte L2 gathers) per (row block, tree, column); "
-                "frac_f64_valu / frac_lds price the cell loop alone against 39.3 Tops/s of "
-                "non-FMA fp64 issue and ~150 TB/s of ds_read_b64",
+        "note": "not HBM-bound by construction (SURVEY.md 8d): 0.5 V^2 M cell-tree evaluations against "
+                "8 V^2 bytes of W written once.  frac = LDS bytes of the cell loop (8 per cell-tree, "
+                "ds_read_b64) over ~150 TB/s; the reads are 2-way bank-conflicted by construction (64 "
+                "table rows over 32 eight-byte bank pairs), so 0.5 is the ceiling of this fraction; "
+                "frac_f64_valu prices the 2 fp64 VALU ops per cell-tree against 39.3 Tops/s; hbm.* is the "
+                "algorithmic HBM figure (W + tables once per build)",
     }
     dominant, other = (roof_acc, roof_symm) if acc_ms >= symm_ms_step else (roof_symm, roof_acc)
     report = {
@@ -297,7 +349,9 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         "roofline": dominant,
         "roofline_other": other,
         "roofline_path": {
-            "what": "(B_A + B_C) / t of SURVEY.md 8d: algorithmic bytes of build + solve over the step time",
+            "what": "(B_A + B_C) / t of SURVEY.md 8d: algorithmic bytes of build + solve over the step time; "
+                    + ("B_C counts 4 V^2 bytes per apply (symmetric SYMM, upper tiles only)" if symm_tri
+                       else "B_C counts 8 rows V bytes per apply"),
             "bound": "hbm",
             "achieved": round(path_gbs, 1),
             "peak": HBM_PEAK_GBS * world,
@@ -318,7 +372,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
             "lambda2": stats["lambda"][1],
             "lambda3": stats["lambda_next"],
             "residual": stats["resid"][1],
-            "tables_upload_s": round(t_upload, 4),
+            "tables_upload_first_s": round(t_upload_first, 4),
             "tables_generate_s": round(t_gen, 3),
         },
     }
@@ -336,17 +390,22 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     except (OSError, ValueError, KeyError, AttributeError):
         pass
 
-    if full and world == 1:
-        # SURVEY.md 8d timing protocol: tables host -> HBM, build, solve, embedding to the host
+    if full:
+        # the same step on tables that are already resident in HBM, and the upload alone
         k = min(steps, 5)
-        dev.synchronize()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(k):
-            tab = dev.upload(tables)
-            one_step(tab=tab)
-            tab.free()
+            one_step()
+        barrier()
+        report["value_tables_resident"] = round((time.perf_counter() - t0) / k, 6)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            dev.upload(tables).free()
         dev.synchronize()
-        report["value_incl_h2d_d2h"] = round((time.perf_counter() - t0) / k, 6)
+        report["stages"]["tables_upload_ms"] = round((time.perf_counter() - t0) / k * 1e3, 3)
+        report["stages"]["tables_bytes"] = int(16 * tables.n_leaves + 16 * m + 8)
+        report["stages"]["tables_in_pinned_host_memory"] = bool(getattr(tables, "pinned", False))
 
     if rank == 0 and world == 1 and not args.no_parity:
         from oracle import tables_oracle as to
@@ -380,6 +439,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
             report["parity"]["w_symmetric"] = bool(np.array_equal(w, w.T))
             del w
             legs = cpu_build_legs(tables, args, n, m)
+            ref_leg = reference_style_leg(n, m, strategy)
             report["cpu_baseline"] = {
                 "value": round(legs["all_core_s"] + t_eig, 3),
                 "unit": "s",
@@ -397,6 +457,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
                 "build_one_thread_scaled_s": round(legs["one_thread_scaled_s"], 2),
                 "eig_s": round(t_eig, 3),
                 "blas_threads": blas,
+                "reference_style_build": ref_leg,
             }
         graph.free()
     if world > 1:
@@ -457,8 +518,17 @@ def main() -> int:
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "value_definition": "SURVEY.md 8d / BASELINE.md 3.3 protocol: tables host -> HBM (page-locked source), "
+                            "scs_pcg_build, scs_fiedler, V x 2 embedding to the host; the same step on "
+                            "HBM-resident tables is value_tables_resident",
     }
-    for key in ("config", "roofline", "roofline_other", "roofline_path", "value_incl_h2d_d2h", "stages",
+    try:
+        from spectralclustersupertree_amd import kmeans2
+
+        result["kmeans2_fast_path_active"] = bool(kmeans2.fast_path_active())
+    except Exception as exc:  # noqa: BLE001 - a report field, never fatal
+        result["kmeans2_fast_path_active"] = f"error: {exc}"
+    for key in ("config", "roofline", "roofline_other", "roofline_path", "value_tables_resident", "stages",
                 "parity", "cpu_baseline"):
         if key in main_rep:
             result[key] = main_rep[key]

@@ -21,6 +21,7 @@
 #ifndef SCS_HIP_H
 #define SCS_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -111,6 +112,13 @@ int scs_ctx_synchronize(scs_ctx *ctx);
 
 /* ---- tables ------------------------------------------------------------ */
 
+/* Page-locked host memory (hipHostMalloc) for callers that want scs_tables_upload to run at
+ * the full PCIe rate: tables that live in such a block are copied by DMA straight from it, a
+ * pageable source is staged by the runtime at a fraction of that.  Optional -- any host
+ * pointer is accepted by scs_tables_upload.  Free with scs_host_free. */
+int scs_host_alloc(size_t bytes, void **out);
+int scs_host_free(void *p);
+
 /* Host -> HBM copy of the flattened trees (layout: DESIGN.md "Tables").
  * Replaces the reference's in-memory cogent3 trees as the input of
  * _proper_cluster_graph_edges (scs.py:495-583); the weighting strategy
@@ -119,7 +127,10 @@ int scs_ctx_synchronize(scs_ctx *ctx);
  *   leaf_taxon int32 [L]           taxon id of each leaf in DFS order
  *   adj_depth  int32 [L]           depth of LCA(leaf p, leaf p+1); last slot of a tree unused
  *   adj_val    fp64  [L]           strategy value at that LCA
- *   tree_w     fp64  [n_trees]     tree weights                                  */
+ *   tree_w     fp64  [n_trees]     tree weights
+ * Shapes are checked on the host, the ranges of leaf_taxon / adj_depth by a kernel on the
+ * uploaded copy (SCS_EINVAL, nothing is kept).  The arrays share ONE device block taken from
+ * the context's block cache.                                                     */
 int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, const int64_t *tree_off,
                       const int32_t *leaf_taxon, const int32_t *adj_depth, const double *adj_val,
                       const double *tree_w, scs_tables **out);

@@ -28,6 +28,7 @@ class ScsError(RuntimeError):
         self.code = code
 
 
+EINVAL = -1  # SCS_EINVAL
 ENOCONV = -5  # SCS_ENOCONV: scs_fiedler stopped above tol (maps and stats are still filled)
 
 
@@ -107,6 +108,8 @@ SIGNATURES = {
     "scs_ctx_create_local": (C.c_int, [C.c_int, C.c_int, _P, _PP]),
     "scs_ctx_destroy": (C.c_int, [_P]),
     "scs_ctx_synchronize": (C.c_int, [_P]),
+    "scs_host_alloc": (C.c_int, [C.c_size_t, _PP]),
+    "scs_host_free": (C.c_int, [_P]),
     "scs_tables_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _PP]),
     "scs_tables_free": (C.c_int, [_P, _P]),
     "scs_pcg_build": (C.c_int, [_P, _P, _I32, _I32, _I32, _PP, C.POINTER(BuildStats)]),
@@ -150,6 +153,35 @@ def check(rc: int) -> None:
     if rc != 0:
         msg = load_library().scs_last_error()
         raise ScsError(rc, msg.decode() if msg else "unknown error")
+
+
+class _PinnedBlock:
+    """Owner of one scs_host_alloc block; freed when the last array viewing it goes away."""
+
+    def __init__(self, nbytes: int) -> None:
+        self._lib = load_library()
+        self.ptr = C.c_void_p()
+        check(self._lib.scs_host_alloc(nbytes, C.byref(self.ptr)))
+        self.nbytes = nbytes
+
+    def __del__(self) -> None:
+        try:
+            if self.ptr:
+                self._lib.scs_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+def pinned_empty(shape, dtype) -> np.ndarray:
+    """An uninitialised numpy array in page-locked host memory (``scs_host_alloc``): tables
+    built in such arrays are uploaded by DMA at the full PCIe rate.  Needs a HIP device."""
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    block = _PinnedBlock(max(count * dt.itemsize, 1))
+    buf = (C.c_char * block.nbytes).from_address(block.ptr.value)
+    buf._scs_owner = block  # keeps the block alive as long as any view of the buffer lives
+    return np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
 
 
 def dptr(a: np.ndarray):

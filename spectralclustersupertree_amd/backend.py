@@ -67,15 +67,17 @@ class Device:
 
     # -- tables ------------------------------------------------------------
     def upload(self, tables: TreeTables) -> "DeviceTables":
-        tables.validate()
+        tables.validate(ranges=False)  # (ranges: checked by a kernel on the uploaded copy)
         handle = C.c_void_p()
-        nv.check(
-            self._lib.scs_tables_upload(
-                self._ctx, tables.n_taxa, tables.n_trees, nv.lptr(tables.tree_off),
-                nv.iptr(tables.leaf_taxon), nv.iptr(tables.adj_depth), nv.dptr(tables.adj_val),
-                nv.dptr(tables.tree_w), C.byref(handle),
-            )
+        rc = self._lib.scs_tables_upload(
+            self._ctx, tables.n_taxa, tables.n_trees, nv.lptr(tables.tree_off),
+            nv.iptr(tables.leaf_taxon), nv.iptr(tables.adj_depth), nv.dptr(tables.adj_val),
+            nv.dptr(tables.tree_w), C.byref(handle),
         )
+        if rc == nv.EINVAL:
+            msg = self._lib.scs_last_error()
+            raise ValueError(msg.decode() if msg else "scs_tables_upload: invalid tables")
+        nv.check(rc)
         return DeviceTables(self, handle, tables.n_taxa, tables.n_trees, bool(tables.monotone))
 
     # -- batched small nodes --------------------------------------------------

@@ -12,6 +12,8 @@
 
 #include "scs_internal.h"
 
+#include <algorithm>
+
 // ---------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------
@@ -435,6 +437,7 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     if (ctx->small_dev) hipFree(ctx->small_dev);
     if (ctx->small_host) hipHostFree(ctx->small_host);
+    if (ctx->h_flags) hipHostFree(ctx->h_flags);
     delete ctx;
     return SCS_OK;
 }
@@ -449,23 +452,51 @@ extern "C" int scs_ctx_synchronize(scs_ctx *ctx) {
 // ---------------------------------------------------------------------------
 // tables
 // ---------------------------------------------------------------------------
-template <typename T>
-static int upload(T **dst, const T *src, size_t count, hipStream_t stream) {
-    size_t bytes = (count ? count : 1) * sizeof(T);
-    SCS_HIP_CHECK(hipMalloc((void **)dst, bytes));
-    if (count)
-        SCS_HIP_CHECK(hipMemcpyAsync(*dst, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+// Range checks of the leaf arrays, on the device (the arrays are there anyway; a host loop over
+// 5 * 10^6 leaves cost as much as the copy): bit 0 of *flags: a taxon id outside [0, n_taxa),
+// bit 1: a negative LCA depth.
+__global__ __launch_bounds__(256) void k_validate_tables(const int32_t *__restrict__ leaf_taxon,
+                                                          const int32_t *__restrict__ adj_depth,
+                                                          int64_t n_leaves, int32_t n_taxa,
+                                                          unsigned *__restrict__ flags) {
+    unsigned bad = 0;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_leaves;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t tx = leaf_taxon[p];
+        if (tx < 0 || tx >= n_taxa) bad |= 1u;
+        if (adj_depth[p] < 0) bad |= 2u;
+    }
+    if (bad) atomicOr(flags, bad);
+}
+
+// Page-locked host memory for callers that want their tables to travel at the full PCIe rate
+// (a pageable source is staged by the runtime at a fraction of it).
+extern "C" int scs_host_alloc(size_t bytes, void **out) {
+    SCS_REQUIRE(out != nullptr, "scs_host_alloc: null output");
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        scs_set_error("scs_host_alloc: cannot pin %zu bytes: %s", bytes, hipGetErrorString(e));
+        return SCS_ENOMEM;
+    }
+    *out = p;
+    return SCS_OK;
+}
+
+extern "C" int scs_host_free(void *p) {
+    if (p) SCS_HIP_CHECK(hipHostFree(p));
     return SCS_OK;
 }
 
 extern "C" int scs_tables_free(scs_ctx *ctx, scs_tables *t) {
     if (!t) return SCS_OK;
-    if (ctx) hipSetDevice(ctx->device);
-    hipFree(t->d_tree_off);
-    hipFree(t->d_leaf_taxon);
-    hipFree(t->d_adj_depth);
-    hipFree(t->d_adj_val);
-    hipFree(t->d_tree_w);
+    if (ctx) {
+        hipSetDevice(ctx->device);
+        scs_block_release(ctx, t->d_block);
+    } else if (t->d_block) {
+        hipFree(t->d_block);
+    }
     delete t;
     return SCS_OK;
 }
@@ -480,7 +511,6 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
                 "scs_tables_upload: null table pointer");
     SCS_REQUIRE(tree_off[0] == 0, "scs_tables_upload: tree_off[0] must be 0");
     int64_t max_leaves = 0;
-    int32_t max_depth = 0;
     for (int32_t t = 0; t < n_trees; ++t) {
         int64_t n = tree_off[t + 1] - tree_off[t];
         SCS_REQUIRE(n >= 1, "scs_tables_upload: tree %d has %lld leaves", t, (long long)n);
@@ -489,40 +519,58 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
         if (n > max_leaves) max_leaves = n;
     }
     const int64_t L = tree_off[n_trees];
-    // every leaf id must be in range: an out-of-range id would index past the
-    // position table on the device
-    for (int64_t p = 0; p < L; ++p) {
-        SCS_REQUIRE(leaf_taxon[p] >= 0 && leaf_taxon[p] < n_taxa,
-                    "scs_tables_upload: leaf_taxon[%lld] = %d out of range", (long long)p,
-                    leaf_taxon[p]);
-        SCS_REQUIRE(adj_depth[p] >= 0, "scs_tables_upload: adj_depth[%lld] negative",
-                    (long long)p);
-        if (adj_depth[p] > max_depth) max_depth = adj_depth[p];
-    }
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (!ctx->h_flags) SCS_HIP_CHECK(hipHostMalloc((void **)&ctx->h_flags, 64, hipHostMallocDefault));
+    // one device block for the five arrays (from the context's cache: the recursion uploads
+    // thousands of table sets), 256-byte aligned pieces, 4 trailing bytes for the check flags
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_off = 0;
+    const size_t o_tax = o_off + up256(((size_t)n_trees + 1) * 8);
+    const size_t o_dep = o_tax + up256((size_t)L * 4);
+    const size_t o_val = o_dep + up256((size_t)L * 4);
+    const size_t o_w = o_val + up256((size_t)L * 8);
+    const size_t o_flag = o_w + up256((size_t)n_trees * 8);
+    void *block = nullptr;
+    SCS_TRY(scs_block_alloc(ctx, o_flag + 256, &block));
     auto *t = new scs_tables();
     t->n_taxa = n_taxa;
     t->n_trees = n_trees;
     t->n_leaves = L;
     t->max_leaves = (int32_t)max_leaves;
-    t->max_depth = max_depth;
     t->h_tree_off.assign(tree_off, tree_off + n_trees + 1);
-    int rc = SCS_OK;
-    if ((rc = upload(&t->d_tree_off, tree_off, (size_t)n_trees + 1, ctx->stream)) != SCS_OK ||
-        (rc = upload(&t->d_leaf_taxon, leaf_taxon, (size_t)L, ctx->stream)) != SCS_OK ||
-        (rc = upload(&t->d_adj_depth, adj_depth, (size_t)L, ctx->stream)) != SCS_OK ||
-        (rc = upload(&t->d_adj_val, adj_val, (size_t)L, ctx->stream)) != SCS_OK ||
-        (rc = upload(&t->d_tree_w, tree_w, (size_t)n_trees, ctx->stream)) != SCS_OK) {
-        std::string keep = g_last_error;
-        scs_tables_free(ctx, t);
-        g_last_error = keep;
-        return rc;
+    t->d_block = block;
+    char *base = (char *)block;
+    t->d_tree_off = (int64_t *)(base + o_off);
+    t->d_leaf_taxon = (int32_t *)(base + o_tax);
+    t->d_adj_depth = (int32_t *)(base + o_dep);
+    t->d_adj_val = (double *)(base + o_val);
+    t->d_tree_w = (double *)(base + o_w);
+    unsigned *d_flags = (unsigned *)(base + o_flag);
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemsetAsync(d_flags, 0, 4, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_tree_off, tree_off, ((size_t)n_trees + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_leaf_taxon, leaf_taxon, (size_t)L * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_depth, adj_depth, (size_t)L * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_val, adj_val, (size_t)L * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_tree_w, tree_w, (size_t)n_trees * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<int64_t>((L + 255) / 256 + 1, 4096);
+        k_validate_tables<<<grid, 256, 0, s>>>(t->d_leaf_taxon, t->d_adj_depth, L, n_taxa, d_flags);
+        e = hipGetLastError();
     }
-    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_flags, d_flags, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         scs_tables_free(ctx, t);
         scs_set_error("table upload failed: %s", hipGetErrorString(e));
-        return SCS_EHIP;
+        return e == hipErrorOutOfMemory ? SCS_ENOMEM : SCS_EHIP;
+    }
+    const unsigned bad = *ctx->h_flags;
+    if (bad) {
+        scs_tables_free(ctx, t);
+        scs_set_error("scs_tables_upload: %s", (bad & 1u) ? "a leaf_taxon entry is out of range [0, n_taxa)"
+                                                          : "an adj_depth entry is negative");
+        return SCS_EINVAL;
     }
     *out = t;
     return SCS_OK;

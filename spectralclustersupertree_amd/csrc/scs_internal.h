@@ -112,6 +112,7 @@ struct scs_ctx {
     std::vector<cached_block> blocks;
     std::vector<hipEvent_t> event_pool;  // events of the timed SYMM launches, reused
     // staging of scs_small_solve (one pinned host block, one device block), grown on demand
+    unsigned *h_flags = nullptr;  // 64 pinned bytes: results of device-side argument checks
     unsigned char *small_host = nullptr;
     unsigned char *small_dev = nullptr;
     size_t small_cap = 0;
@@ -122,8 +123,8 @@ struct scs_tables {
     int32_t n_trees = 0;
     int64_t n_leaves = 0;
     int32_t max_leaves = 0;            // largest tree
-    int32_t max_depth = 0;             // deepest LCA of adjacent leaves in any tree
     std::vector<int64_t> h_tree_off;   // host copy (batch planning)
+    void *d_block = nullptr;           // the one cached device block the five arrays live in
     int64_t *d_tree_off = nullptr;     // [n_trees+1]
     int32_t *d_leaf_taxon = nullptr;   // [L]
     int32_t *d_adj_depth = nullptr;    // [L]

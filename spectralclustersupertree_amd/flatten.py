@@ -56,8 +56,10 @@ class TreeTables:
     def n_leaves(self) -> int:
         return int(self.tree_off[-1])
 
-    def validate(self) -> None:
-        """Shape/dtype/range checks done on the host before any native call."""
+    def validate(self, ranges: bool = True) -> None:
+        """Shape/dtype checks done on the host before any native call; ``ranges`` adds the
+        O(leaves) range checks (``Device.upload`` leaves those to the kernel that checks the
+        uploaded copy)."""
         m = self.n_trees
         if self.tree_off.dtype != np.int64 or self.tree_off.shape != (m + 1,):
             raise ValueError("tree_off must be int64 of length n_trees + 1")
@@ -73,6 +75,8 @@ class TreeTables:
                 raise ValueError(f"{name} must be C-contiguous {np.dtype(dt).name} of length {total}")
         if self.tree_w.dtype != np.float64 or not self.tree_w.flags.c_contiguous:
             raise ValueError("tree_w must be C-contiguous float64")
+        if not ranges:
+            return
         if total and (self.leaf_taxon.min() < 0 or self.leaf_taxon.max() >= self.n_taxa):
             raise ValueError("leaf_taxon out of range")
         if total and self.adj_depth.min() < 0:

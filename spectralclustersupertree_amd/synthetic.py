@@ -59,12 +59,14 @@ def make_tables(
     leaves_per_tree: int | None = None,
     random_weights: bool = False,
     planted_spr: int | None = None,
+    pinned: bool = False,
 ) -> TreeTables:
     """Flattened tables of the synthetic set ``(seed, n_taxa, n_trees)``.
 
     ``planted_spr`` (the planted variant): every tree is the set's
     model tree over all taxa plus that many random SPR moves, instead of an independent
-    random-join tree.
+    random-join tree.  ``pinned``: the arrays live in page-locked host memory
+    (``_native.pinned_empty``; needs a HIP device) so that ``Device.upload`` moves them by DMA.
     """
     lib = _load()
     k = n_taxa if leaves_per_tree is None else int(leaves_per_tree)
@@ -72,11 +74,14 @@ def make_tables(
         msg = "planted sets cover all taxa in every tree"
         raise ValueError(msg)
     total = n_trees * k
-    tree_off = np.empty(n_trees + 1, dtype=np.int64)
-    leaf_taxon = np.empty(total, dtype=np.int32)
-    adj_depth = np.empty(total, dtype=np.int32)
-    adj_val = np.empty(total, dtype=np.float64)
-    tree_w = np.empty(n_trees, dtype=np.float64)
+    empty = np.empty
+    if pinned:
+        from spectralclustersupertree_amd._native import pinned_empty as empty
+    tree_off = empty(n_trees + 1, dtype=np.int64)
+    leaf_taxon = empty(total, dtype=np.int32)
+    adj_depth = empty(total, dtype=np.int32)
+    adj_val = empty(total, dtype=np.float64)
+    tree_w = empty(n_trees, dtype=np.float64)
     ip, dp, lp = C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64)
     if planted_spr is None:
         rc = lib.scs_synth_tables(
