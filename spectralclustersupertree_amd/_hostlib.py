@@ -23,6 +23,13 @@ def load() -> C.CDLL:
         lib.scs_host_restrict_sizes.argtypes = [C.c_int32, lp, ip, ip, bp, bp, ip]
         lib.scs_host_restrict_fill.restype = C.c_int
         lib.scs_host_restrict_fill.argtypes = [C.c_int32, lp, ip, ip, dp, dp, bp, bp, lp, ip, ip, dp, dp]
+        lib.scs_host_split_begin.restype = C.c_int
+        lib.scs_host_split_begin.argtypes = [C.c_int32, lp, ip, ip, dp, dp, ip, ip, C.c_int32,
+                                             C.POINTER(C.c_void_p), lp, lp]
+        lib.scs_host_split_fill.restype = C.c_int
+        lib.scs_host_split_fill.argtypes = [C.c_void_p, C.c_int32, lp, ip, lp, ip, ip, dp, dp, bp]
+        lib.scs_host_split_end.restype = None
+        lib.scs_host_split_end.argtypes = [C.c_void_p]
         lib.scs_host_leaf_counts.restype = C.c_int
         lib.scs_host_leaf_counts.argtypes = [C.c_int32, lp, ip, lp]
         lib.scs_host_flatten.restype = C.c_int

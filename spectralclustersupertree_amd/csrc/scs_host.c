@@ -40,7 +40,7 @@
  * walks the whole forest of its parent (a child of three taxa split off a parent of 30 000
  * still visits every node of every tree): forests above SCS_HOST_PAR_NODES nodes are cut over
  * threads, trees handed out one at a time from a shared counter.  SCS_HOST_THREADS sets the
- * team size (default: the online cores, at most 16; 1 = serial).
+ * team size (default: the online cores, at most 32; 1 = serial).
  */
 #define SCS_HOST_PAR_NODES 200000
 
@@ -56,7 +56,7 @@ typedef struct {
 
 static void *tree_team_worker(void *arg) {
     tree_team *tm = (tree_team *)arg;
-    void *scratch = malloc(tm->scratch_bytes ? tm->scratch_bytes : 1);
+    void *scratch = calloc(tm->scratch_bytes ? tm->scratch_bytes : 1, 1); /* zeroed: split_tree relies on it */
     if (!scratch) {
         __atomic_store_n(&tm->rc, SCS_HOST_ENOMEM, __ATOMIC_RELAXED);
         return 0;
@@ -76,7 +76,7 @@ static int host_threads(void) {
     if (!cached) {
         const char *e = getenv("SCS_HOST_THREADS");
         long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
-        if (!e && n > 16) n = 16;
+        if (!e && n > 32) n = 32;
         if (n < 1) n = 1;
         if (n > 64) n = 64;
         cached = (int)n;
@@ -826,5 +826,321 @@ int scs_host_components(int32_t n_taxa, int32_t n_trees, const int64_t *tree_off
         else labels[x] = labels[r];
     }
     free(parent);
+    return SCS_HOST_OK;
+}
+
+/* ---------------------------------------------------------------------------
+ * One-pass multi-way restriction (reference: scs.py:139-155 with :411-455 -- the recursion
+ * restricts the trees to EVERY part of a split).  scs_host_restrict_* walk the whole parent
+ * forest once per child; here one sweep per tree serves all parts at once and the work per
+ * part is proportional to the part, not to the parent:
+ *   - a preorder sweep keeps the current root path on a stack; for a leaf y of part c whose
+ *     previous leaf of the same part was x, LCA(x, y) is the deepest entry of the stack with
+ *     preorder index <= x (binary search: the stack's indices increase with depth);
+ *   - the restricted tree of part c consists of c's leaves and those LCAs (exactly the
+ *     internal nodes left with two or more non-empty children); in preorder they are simply
+ *     sorted by their old index, and a node's new parent is its nearest ancestor in that
+ *     list (interval test with the end of the old subtree);
+ *   - merged branch lengths fold the spliced chain bottom-up with the parent's length in
+ *     front, as scs_host_restrict_fill and tree.py:get_sub_tree do: same bits.
+ * Trees left with fewer than two leaves of a part are dropped for that part.  Taxa are
+ * renumbered through new_id[] (the recursion numbers a child's taxa 0..k-1), so nothing a
+ * child does later is proportional to the number of taxa of the whole input.
+ * The plan holds every part's trees (thread-local arenas); scs_host_split_fill copies one
+ * part out in tree order.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+    int32_t tree, part, n_nodes, n_leaves, arena;
+    int64_t off;
+} split_entry;
+
+typedef struct {
+    int32_t *parent, *taxon;
+    double *length, *support;
+    int64_t used, cap;
+    split_entry *entries;
+    int64_t n_entries, cap_entries;
+} split_arena;
+
+typedef struct scs_split_plan {
+    int32_t n_trees, n_parts, n_arenas, arenas_used;
+    split_arena *arenas;
+    split_entry *sorted;
+    int64_t n_sorted;
+    int64_t *part_first; /* [n_parts + 1] */
+} scs_split_plan;
+
+typedef struct {
+    const int64_t *node_off;
+    const int32_t *parent, *taxon;
+    const double *length, *support;
+    const int32_t *part_of, *new_id;
+    int32_t n_parts, max_k;
+    scs_split_plan *plan;
+} split_ctx;
+
+static int arena_reserve(split_arena *a, int64_t extra_nodes) {
+    if (a->used + extra_nodes > a->cap) {
+        int64_t cap = a->cap ? a->cap : 4096;
+        while (cap < a->used + extra_nodes) cap *= 2;
+        int32_t *p = (int32_t *)realloc(a->parent, sizeof(int32_t) * (size_t)cap);
+        if (!p) return SCS_HOST_ENOMEM;
+        a->parent = p;
+        int32_t *x = (int32_t *)realloc(a->taxon, sizeof(int32_t) * (size_t)cap);
+        if (!x) return SCS_HOST_ENOMEM;
+        a->taxon = x;
+        double *l = (double *)realloc(a->length, sizeof(double) * (size_t)cap);
+        if (!l) return SCS_HOST_ENOMEM;
+        a->length = l;
+        double *s = (double *)realloc(a->support, sizeof(double) * (size_t)cap);
+        if (!s) return SCS_HOST_ENOMEM;
+        a->support = s;
+        a->cap = cap;
+    }
+    if (a->n_entries + 1 > a->cap_entries) {
+        int64_t cap = a->cap_entries ? a->cap_entries * 2 : 256;
+        split_entry *e = (split_entry *)realloc(a->entries, sizeof(split_entry) * (size_t)cap);
+        if (!e) return SCS_HOST_ENOMEM;
+        a->entries = e;
+        a->cap_entries = cap;
+    }
+    return SCS_HOST_OK;
+}
+
+static int cmp_i32(const void *a, const void *b) {
+    const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+/* scratch of a worker: [int32 arena_plus1][pad] then the per-tree arrays (see split_tree) */
+static int split_tree(int32_t t, void *scratch, void *vctx) {
+    const split_ctx *c = (const split_ctx *)vctx;
+    scs_split_plan *plan = c->plan;
+    int32_t *hdr = (int32_t *)scratch;
+    if (hdr[0] == 0) hdr[0] = 1 + __atomic_fetch_add(&plan->arenas_used, 1, __ATOMIC_RELAXED);
+    if (hdr[0] > plan->n_arenas) return SCS_HOST_EINVAL;
+    split_arena *ar = &plan->arenas[hdr[0] - 1];
+    const int32_t mk = c->max_k, np = c->n_parts;
+    int32_t *sub_end = hdr + 4;
+    int32_t *stack = sub_end + mk;
+    int32_t *ev_part = stack + mk;          /* up to 2 mk events */
+    int32_t *ev_node = ev_part + 2 * (size_t)mk;
+    int32_t *sorted_node = ev_node + 2 * (size_t)mk;
+    int32_t *touched = sorted_node + 2 * (size_t)mk; /* mk */
+    int32_t *vstack = touched + mk;                  /* mk: positions in the part's node list */
+    int32_t *last = vstack + mk;                     /* np: 1 + index of the part's latest leaf in this tree, 0 = none (kept clean) */
+    int32_t *cnt = last + np;                        /* np leaves of the part in this tree */
+    int32_t *fill = cnt + np;                        /* np write cursor of the bucket sort */
+
+    const int64_t off = c->node_off[t];
+    const int32_t k = (int32_t)(c->node_off[t + 1] - off);
+    const int32_t *par = c->parent + off, *tax = c->taxon + off;
+    const double *len = c->length + off, *sup = c->support + off;
+
+    for (int32_t i = 0; i < k; ++i) sub_end[i] = i;
+    for (int32_t i = k - 1; i > 0; --i) {
+        const int32_t p = par[i];
+        if (p < 0 || p >= i) return SCS_HOST_EINVAL; /* not preorder */
+        if (sub_end[i] > sub_end[p]) sub_end[p] = sub_end[i];
+    }
+    int32_t sp = 0, n_ev = 0, n_touched = 0;
+    for (int32_t i = 0; i < k; ++i) {
+        while (sp > 0 && i > sub_end[stack[sp - 1]]) --sp;
+        if (tax[i] < 0) {
+            stack[sp++] = i;
+            continue;
+        }
+        const int32_t pc = c->part_of[tax[i]];
+        if (pc < 0) continue;
+        const int32_t x = last[pc] - 1;
+        if (x < 0) {
+            touched[n_touched++] = pc;
+            cnt[pc] = 0;
+        } else {
+            /* deepest ancestor of i whose index is <= x: the LCA of x and i */
+            int32_t lo = 0, hi = sp - 1; /* stack[0] = root <= x */
+            while (lo < hi) {
+                const int32_t mid = (lo + hi + 1) >> 1;
+                if (stack[mid] <= x) lo = mid;
+                else hi = mid - 1;
+            }
+            ev_part[n_ev] = pc;
+            ev_node[n_ev++] = stack[lo];
+        }
+        ev_part[n_ev] = pc;
+        ev_node[n_ev++] = i;
+        last[pc] = i + 1;
+        cnt[pc] += 1;
+    }
+    /* bucket the events by part (parts with >= 2 leaves only) */
+    int32_t total = 0;
+    for (int32_t q = 0; q < n_touched; ++q) {
+        const int32_t pc = touched[q];
+        fill[pc] = total;
+        if (cnt[pc] >= 2) total += 2 * cnt[pc] - 1;
+    }
+    for (int32_t e = 0; e < n_ev; ++e) {
+        const int32_t pc = ev_part[e];
+        if (cnt[pc] >= 2) sorted_node[fill[pc]++] = ev_node[e];
+    }
+    int rc = SCS_HOST_OK;
+    int32_t at = 0;
+    for (int32_t q = 0; q < n_touched && rc == SCS_HOST_OK; ++q) {
+        const int32_t pc = touched[q];
+        const int32_t leaves = cnt[pc];
+        last[pc] = 0; /* leave the per-part state clean for the next tree */
+        if (leaves < 2) continue;
+        const int32_t ne = 2 * leaves - 1;
+        int32_t *nodes = sorted_node + at;
+        at += ne;
+        qsort(nodes, (size_t)ne, sizeof(int32_t), cmp_i32);
+        int32_t nv = 0;
+        for (int32_t j = 0; j < ne; ++j)
+            if (nv == 0 || nodes[j] != nodes[nv - 1]) nodes[nv++] = nodes[j];
+        rc = arena_reserve(ar, nv);
+        if (rc != SCS_HOST_OK) break;
+        const int64_t base = ar->used;
+        int32_t vs = 0;
+        for (int32_t j = 0; j < nv; ++j) {
+            const int32_t v = nodes[j];
+            while (vs > 0 && v > sub_end[nodes[vstack[vs - 1]]]) --vs;
+            const int32_t upj = vs > 0 ? vstack[vs - 1] : -1;
+            const int32_t up = upj < 0 ? -1 : nodes[upj];
+            ar->parent[base + j] = upj;
+            ar->taxon[base + j] = tax[v] >= 0 ? c->new_id[tax[v]] : -1;
+            ar->support[base + j] = sup[v];
+            double acc = len[v];
+            for (int32_t u = v == 0 ? -1 : par[v]; u >= 0 && u != up; u = par[u])
+                if (!isnan(len[u]) && !isnan(acc)) acc = len[u] + acc;
+            ar->length[base + j] = acc;
+            if (tax[v] < 0) vstack[vs++] = j;
+        }
+        split_entry *en = &ar->entries[ar->n_entries++];
+        en->tree = t;
+        en->part = pc;
+        en->n_nodes = nv;
+        en->n_leaves = leaves;
+        en->arena = hdr[0] - 1;
+        en->off = base;
+        ar->used += nv;
+    }
+    /* (on an error the remaining touched parts still have to be cleaned) */
+    for (int32_t q = 0; q < n_touched; ++q) last[touched[q]] = 0;
+    return rc;
+}
+
+static int cmp_entry(const void *a, const void *b) {
+    const split_entry *x = (const split_entry *)a, *y = (const split_entry *)b;
+    if (x->part != y->part) return (x->part > y->part) - (x->part < y->part);
+    return (x->tree > y->tree) - (x->tree < y->tree);
+}
+
+void scs_host_split_end(scs_split_plan *plan) {
+    if (!plan) return;
+    for (int32_t i = 0; i < plan->n_arenas; ++i) {
+        free(plan->arenas[i].parent);
+        free(plan->arenas[i].taxon);
+        free(plan->arenas[i].length);
+        free(plan->arenas[i].support);
+        free(plan->arenas[i].entries);
+    }
+    free(plan->arenas);
+    free(plan->sorted);
+    free(plan->part_first);
+    free(plan);
+}
+
+/*
+ *   part_of[x]   part of taxon x (0 .. n_parts-1) or -1: the taxon is dropped
+ *   new_id[x]    id of taxon x inside its part
+ *   part_trees[c], part_nodes[c]  (out) surviving trees / nodes of part c
+ */
+int scs_host_split_begin(int32_t n_trees, const int64_t *node_off, const int32_t *parent,
+                         const int32_t *taxon, const double *length, const double *support,
+                         const int32_t *part_of, const int32_t *new_id, int32_t n_parts,
+                         scs_split_plan **out_plan, int64_t *part_trees, int64_t *part_nodes) {
+    if (n_parts < 1 || !out_plan) return SCS_HOST_EINVAL;
+    int32_t max_k = 1;
+    for (int32_t t = 0; t < n_trees; ++t) {
+        const int64_t k = node_off[t + 1] - node_off[t];
+        if (k < 1 || k > INT32_MAX / 4) return SCS_HOST_EINVAL;
+        if (k > max_k) max_k = (int32_t)k;
+    }
+    scs_split_plan *plan = (scs_split_plan *)calloc(1, sizeof(scs_split_plan));
+    if (!plan) return SCS_HOST_ENOMEM;
+    plan->n_trees = n_trees;
+    plan->n_parts = n_parts;
+    plan->n_arenas = 64; /* for_each_tree runs at most 64 threads */
+    plan->arenas = (split_arena *)calloc((size_t)plan->n_arenas, sizeof(split_arena));
+    plan->part_first = (int64_t *)calloc((size_t)n_parts + 1, sizeof(int64_t));
+    if (!plan->arenas || !plan->part_first) {
+        scs_host_split_end(plan);
+        return SCS_HOST_ENOMEM;
+    }
+    split_ctx c = {node_off, parent, taxon, length, support, part_of, new_id, n_parts, max_k, plan};
+    /* scratch: header + 10 max_k + 3 n_parts ints, zeroed by the worker (header: no arena
+     * yet; last[]: no leaf seen) */
+    const size_t ints = 4 + (size_t)10 * max_k + (size_t)3 * n_parts;
+    int rc = for_each_tree(n_trees, n_trees > 0 ? node_off[n_trees] - node_off[0] : 0,
+                           sizeof(int32_t) * ints, split_tree, &c);
+    if (rc != SCS_HOST_OK) {
+        scs_host_split_end(plan);
+        return rc;
+    }
+    int64_t n = 0;
+    for (int32_t i = 0; i < plan->n_arenas; ++i) n += plan->arenas[i].n_entries;
+    plan->sorted = (split_entry *)malloc(sizeof(split_entry) * (size_t)(n ? n : 1));
+    if (!plan->sorted) {
+        scs_host_split_end(plan);
+        return SCS_HOST_ENOMEM;
+    }
+    int64_t w = 0;
+    for (int32_t i = 0; i < plan->n_arenas; ++i) {
+        memcpy(plan->sorted + w, plan->arenas[i].entries, sizeof(split_entry) * (size_t)plan->arenas[i].n_entries);
+        w += plan->arenas[i].n_entries;
+    }
+    plan->n_sorted = n;
+    qsort(plan->sorted, (size_t)n, sizeof(split_entry), cmp_entry);
+    for (int32_t p = 0; p < n_parts; ++p) {
+        part_trees[p] = 0;
+        part_nodes[p] = 0;
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        part_trees[plan->sorted[i].part] += 1;
+        part_nodes[plan->sorted[i].part] += plan->sorted[i].n_nodes;
+    }
+    plan->part_first[0] = 0;
+    for (int32_t p = 0; p < n_parts; ++p) plan->part_first[p + 1] = plan->part_first[p] + part_trees[p];
+    *out_plan = plan;
+    return SCS_HOST_OK;
+}
+
+/* Part `part` in tree order: node_off_out [trees + 1], tree_index_out [trees] (index of the
+ * tree in the parent forest), leaf_count_out [trees], the node arrays, and present_out[id] = 1
+ * for every (new) taxon id that occurs (zeroed by the caller). */
+int scs_host_split_fill(const scs_split_plan *plan, int32_t part, int64_t *node_off_out,
+                        int32_t *tree_index_out, int64_t *leaf_count_out, int32_t *parent_out,
+                        int32_t *taxon_out, double *length_out, double *support_out,
+                        uint8_t *present_out) {
+    if (!plan || part < 0 || part >= plan->n_parts) return SCS_HOST_EINVAL;
+    int64_t at = 0, j = 0;
+    node_off_out[0] = 0;
+    for (int64_t i = plan->part_first[part]; i < plan->part_first[part + 1]; ++i, ++j) {
+        const split_entry *e = &plan->sorted[i];
+        const split_arena *a = &plan->arenas[e->arena];
+        memcpy(parent_out + at, a->parent + e->off, sizeof(int32_t) * (size_t)e->n_nodes);
+        memcpy(taxon_out + at, a->taxon + e->off, sizeof(int32_t) * (size_t)e->n_nodes);
+        memcpy(length_out + at, a->length + e->off, sizeof(double) * (size_t)e->n_nodes);
+        memcpy(support_out + at, a->support + e->off, sizeof(double) * (size_t)e->n_nodes);
+        if (present_out)
+            for (int32_t q = 0; q < e->n_nodes; ++q) {
+                const int32_t x = a->taxon[e->off + q];
+                if (x >= 0) present_out[x] = 1;
+            }
+        tree_index_out[j] = e->tree;
+        leaf_count_out[j] = e->n_leaves;
+        at += e->n_nodes;
+        node_off_out[j + 1] = at;
+    }
     return SCS_HOST_OK;
 }

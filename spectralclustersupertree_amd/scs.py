@@ -402,8 +402,9 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     """One node of the recursion on flat tree arrays (reference: scs.py:96-174).
 
     Same decisions in the same order as the reference -- and therefore the same draws from
-    ``random_state`` -- but the induced trees of a child problem come from
-    ``TreeArrays.restrict`` instead of ``get_sub_tree`` on objects.
+    ``random_state`` -- but the induced trees of the child problems come from ONE sweep of
+    this node's forest (``TreeArrays.split``) instead of a ``get_sub_tree`` per tree and
+    part on objects, and every child numbers its own taxa 0..k-1.
 
     Siblings are scheduled together: once a node's parts are known, the
     device work of every small single-component child (tables -> W -> contraction -> Jacobi ->
@@ -418,7 +419,7 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     RandomState forked from the parent's stream, and exchanges the subtrees.
     """
     given = bipartition  # a caller's own routine (tests) is handed down unchanged
-    names = arrays.taxa
+    name = arrays.name
     if arrays.n_trees == 1:  # reference: scs.py:96-98
         return arrays.to_tree(0)
 
@@ -427,13 +428,13 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     else:
         present = arrays.present_taxa()
         if len(present) <= 2:
-            return tip_names_to_tree([names[int(i)] for i in present])
-        # a node numbers its taxa by sorted name: global ids are ranks of the sorted names
+            return tip_names_to_tree([name(i) for i in present])
+        # a node numbers its taxa by sorted name: ids are ranks of the sorted names
         tables = arrays.flatten(pcg_weighting, local_ids=present)
         comp = fl.pcg_components(tables)
         presolved = None
     if len(present) <= 2:
-        return tip_names_to_tree([names[int(i)] for i in present])
+        return tip_names_to_tree([name(i) for i in present])
     n_comp = int(comp.max()) + 1
 
     if n_comp == 1:
@@ -447,7 +448,7 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             parts[int(lab)].extend(int(present[int(i)]) for i in ids)
         if _node_trace is not None:
             _node_trace.append({
-                "vertices": [tuple(names[int(present[int(i)])] for i in ids) for ids in members],
+                "vertices": [tuple(name(present[int(i)]) for i in ids) for ids in members],
                 "labels": np.asarray(labels).copy()})
     else:
         parts = [[] for _ in range(n_comp)]
@@ -455,8 +456,10 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             parts[int(c)].append(int(present[i]))
 
     forked = (team is not None and team.world > 1 and team.child_rng == "forked")
-    # ---- the children: restriction first (host), then one batched launch for the small ones
-    children: list = []  # ("tips", names) | ("sub", component, sub, pre)
+    # ---- the children: ONE sweep of this node's forest restricts it to every part (host),
+    # then one batched launch for the small ones
+    children: list = []  # ("tips", ids) | ["sub", ids, sub, pre]
+    to_split = []
     for component in parts:
         if len(component) == 0:
             continue
@@ -464,13 +467,18 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         if len(component) <= 2:
             children.append(("tips", component))
             continue
-        sub = arrays.restrict(np.asarray(component, dtype=np.int32))
-        if sub.n_trees == 0:
+        children.append(["sub", component, None, None])
+        to_split.append(np.asarray(component, dtype=np.int32))
+    subs = iter(arrays.split(to_split))
+    for child in children:
+        if child[0] != "sub":
+            continue
+        child[2] = next(subs)  # taxa renumbered 0 .. k-1 in the order of child[1]
+        if child[2].n_trees == 0:
             # no source tree keeps two of these taxa: the reference's recursive call receives
             # an empty list and raises (reference: scs.py:63-65 reached from :158)
             msg = "There must be at least one tree to make a supertree."
             raise ValueError(msg)
-        children.append(["sub", component, sub, None])
     if given is None and not forked and _small_path():
         _presolve_small_children(children, pcg_weighting, contract_edges, team)
 
@@ -478,7 +486,7 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     dealt: list[tuple[int, int, TreeArrays, np.random.RandomState]] = []  # (slot, owner, sub, rng)
     for child in children:
         if child[0] == "tips":
-            child_trees.append(tip_names_to_tree([names[i] for i in child[1]]))
+            child_trees.append(tip_names_to_tree([name(i) for i in child[1]]))
             continue
         _, component, sub, child_pre = child
         if forked and len(component) < team.shard_min:
@@ -489,8 +497,9 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         else:
             child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, given, team,
                                           child_pre))
-        covered = set(int(i) for i in sub.present_taxa())
-        child_trees.extend(TreeNode(names[i]) for i in component if i not in covered)
+        if len(sub.present_taxa()) < len(component):  # taxa no surviving tree holds (scs.py:166-170)
+            covered = set(int(i) for i in sub.present_taxa())  # (ids of the child: positions in component)
+            child_trees.extend(TreeNode(name(x)) for j, x in enumerate(component) if j not in covered)
     if dealt:
         from spectralclustersupertree_amd.partition import Team
 

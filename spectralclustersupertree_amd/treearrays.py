@@ -44,11 +44,21 @@ class TreeArrays:
     length: np.ndarray  # float64, NaN = None
     support: np.ndarray  # float64, NaN = None
     weights: np.ndarray  # float64 [M]
-    taxa: list[str]  # id -> name (ids are ranks of the names in sorted order)
+    taxa: list[str]  # name table (ids are ranks of the names in sorted order)
+    # taxon id of THIS forest -> index into ``taxa``; None = identity.  A child produced by
+    # ``split`` numbers its taxa 0..k-1 (in the order of the parent's ids, i.e. by name), so
+    # nothing a deep recursion node does is proportional to the size of the whole input.
+    ids: np.ndarray | None = None
+    _present: np.ndarray | None = None  # cached result of present_taxa (filled by split)
+    _leaf_counts: np.ndarray | None = None
 
     @property
     def n_trees(self) -> int:
         return len(self.weights)
+
+    def name(self, i: int) -> str:
+        """Name of taxon ``i`` of this forest."""
+        return self.taxa[int(i) if self.ids is None else int(self.ids[int(i)])]
 
     # ------------------------------------------------------------------ build
     @classmethod
@@ -138,6 +148,8 @@ class TreeArrays:
     # ---------------------------------------------------------------- queries
     def present_taxa(self) -> np.ndarray:
         """Sorted ids of the taxa that occur in at least one tree."""
+        if self._present is not None:
+            return self._present
         mark = np.zeros(max(self.n_taxa, 1), dtype=np.uint8)
         if self.n_trees:
             _load().scs_host_present(self.n_trees, _p(self.node_off, C.c_int64), _p(self.taxon, C.c_int32),
@@ -145,6 +157,8 @@ class TreeArrays:
         return np.flatnonzero(mark[: self.n_taxa]).astype(np.int32)
 
     def leaf_counts(self) -> np.ndarray:
+        if self._leaf_counts is not None:
+            return self._leaf_counts
         out = np.zeros(self.n_trees, dtype=np.int64)
         if self.n_trees:
             _load().scs_host_leaf_counts(self.n_trees, _p(self.node_off, C.c_int64),
@@ -179,6 +193,7 @@ class TreeArrays:
             support=np.empty(total, dtype=np.float64),
             weights=self.weights[kept].copy(),
             taxa=self.taxa,
+            ids=self.ids,
         )
         if len(kept):
             rc = lib.scs_host_restrict_fill(
@@ -188,6 +203,61 @@ class TreeArrays:
                 _p(out.taxon, C.c_int32), _p(out.length, C.c_double), _p(out.support, C.c_double))
             if rc:
                 raise ValueError(f"scs_host_restrict_fill: {_ERRORS.get(rc, rc)}")
+        return out
+
+    def split(self, parts: Sequence[np.ndarray]) -> list["TreeArrays"]:
+        """The forests induced on each of the disjoint taxon sets ``parts`` (sorted id arrays),
+        all from ONE sweep of this forest (``scs_host_split_*``; reference: the loop over the
+        parts at scs.py:139-155 with the restriction of :411-455).  Child ``c`` numbers its taxa
+        ``0..len(parts[c])-1`` in the order of ``parts[c]``; its ``present_taxa`` and
+        ``leaf_counts`` come for free."""
+        lib = _load()
+        n_parts = len(parts)
+        if n_parts == 0:
+            return []
+        part_of = np.full(max(self.n_taxa, 1), -1, dtype=np.int32)
+        new_id = np.zeros(max(self.n_taxa, 1), dtype=np.int32)
+        parts = [np.asarray(p, dtype=np.int32) for p in parts]
+        for c, ids in enumerate(parts):
+            part_of[ids] = c
+            new_id[ids] = np.arange(len(ids), dtype=np.int32)
+        plan = C.c_void_p()
+        part_trees = np.zeros(n_parts, dtype=np.int64)
+        part_nodes = np.zeros(n_parts, dtype=np.int64)
+        rc = lib.scs_host_split_begin(self.n_trees, _p(self.node_off, C.c_int64), _p(self.parent, C.c_int32),
+                                      _p(self.taxon, C.c_int32), _p(self.length, C.c_double),
+                                      _p(self.support, C.c_double), _p(part_of, C.c_int32),
+                                      _p(new_id, C.c_int32), n_parts, C.byref(plan),
+                                      _p(part_trees, C.c_int64), _p(part_nodes, C.c_int64))
+        if rc:
+            raise ValueError(f"scs_host_split_begin: {_ERRORS.get(rc, rc)}")
+        out = []
+        try:
+            for c, ids in enumerate(parts):
+                m, total = int(part_trees[c]), int(part_nodes[c])
+                node_off = np.zeros(m + 1, dtype=np.int64)
+                tree_index = np.empty(max(m, 1), dtype=np.int32)
+                leaf_counts = np.zeros(max(m, 1), dtype=np.int64)
+                present = np.zeros(max(len(ids), 1), dtype=np.uint8)
+                child = TreeArrays(
+                    n_taxa=len(ids), node_off=node_off,
+                    parent=np.empty(total, dtype=np.int32), taxon=np.empty(total, dtype=np.int32),
+                    length=np.empty(total, dtype=np.float64), support=np.empty(total, dtype=np.float64),
+                    weights=np.empty(0, dtype=np.float64), taxa=self.taxa,
+                    ids=ids if self.ids is None else self.ids[ids])
+                if m:
+                    rc = lib.scs_host_split_fill(plan, c, _p(node_off, C.c_int64), _p(tree_index, C.c_int32),
+                                                 _p(leaf_counts, C.c_int64), _p(child.parent, C.c_int32),
+                                                 _p(child.taxon, C.c_int32), _p(child.length, C.c_double),
+                                                 _p(child.support, C.c_double), _p(present, C.c_uint8))
+                    if rc:
+                        raise ValueError(f"scs_host_split_fill: {_ERRORS.get(rc, rc)}")
+                    child.weights = self.weights[tree_index[:m]].copy()
+                child._present = np.flatnonzero(present[: len(ids)]).astype(np.int32)
+                child._leaf_counts = leaf_counts[:m]
+                out.append(child)
+        finally:
+            lib.scs_host_split_end(plan)
         return out
 
     # -------------------------------------------------------------- flattening
@@ -228,10 +298,11 @@ class TreeArrays:
                 raise TypeError(msg)
             if rc:
                 raise ValueError(f"scs_host_flatten: {_ERRORS.get(rc, rc)}")
-        n_taxa, taxa = self.n_taxa, self.taxa
+        n_taxa = self.n_taxa
+        taxa = self.taxa if self.ids is None else [self.name(i) for i in range(n_taxa)]
         if local_ids is not None:
             n_taxa = len(local_ids)
-            taxa = [self.taxa[int(i)] for i in local_ids]
+            taxa = [self.name(i) for i in local_ids]
         monotone = (strategy in ("one", "depth", "branch") and bool(mono.value)
                     and bool(np.all(self.weights >= 0)))
         return TreeTables(n_taxa=n_taxa, tree_off=leaf_off, leaf_taxon=leaf_taxon, adj_depth=adj_depth,
@@ -245,7 +316,7 @@ class TreeArrays:
         for i in range(lo, hi):
             tx = int(self.taxon[i])
             ln, sp = float(self.length[i]), float(self.support[i])
-            node = TreeNode(self.taxa[tx] if tx >= 0 else "", None,
+            node = TreeNode(self.name(tx) if tx >= 0 else "", None,
                             None if ln != ln else ln, None if sp != sp else sp)
             nodes.append(node)
             par = int(self.parent[i])

@@ -420,3 +420,57 @@ print(h.hexdigest(), int(f.monotone), int(g.monotone))
         res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True)
         out.append(res.stdout.strip())
     assert out[0] == out[1] and len(out[0].split()) == 3
+
+
+# ---- one-pass multi-way restriction (scs_host_split_*) against the per-part restriction
+
+def _same_bits(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.int64) if a.dtype == np.float64 else a,
+                                                 b.view(np.int64) if b.dtype == np.float64 else b)
+
+
+def _check_split(arrays, parts):
+    kids = arrays.split(parts)
+    assert len(kids) == len(parts)
+    for ids, kid in zip(parts, kids):
+        ref = arrays.restrict(ids)
+        assert kid.n_trees == ref.n_trees
+        assert _same_bits(kid.node_off, ref.node_off)
+        assert _same_bits(kid.parent, ref.parent)
+        mapped = np.where(kid.taxon >= 0, np.asarray(ids, dtype=np.int32)[np.maximum(kid.taxon, 0)], -1)
+        assert _same_bits(mapped.astype(np.int32), ref.taxon)
+        assert _same_bits(kid.length, ref.length)  # merged lengths: same additions in the same order
+        assert _same_bits(kid.support, ref.support)
+        assert _same_bits(kid.weights, ref.weights)
+        assert np.array_equal(np.asarray(ids)[kid.present_taxa()], ref.present_taxa())
+        assert np.array_equal(kid.leaf_counts(), ref.leaf_counts())
+        assert all(kid.name(i) == arrays.name(ids[i]) for i in range(len(ids)))
+
+
+@pytest.mark.parametrize("seed,n,m,k", [(1, 60, 7, 40), (2, 300, 12, 200), (3, 1000, 30, 1000), (4, 5000, 60, 3000)])
+def test_split_equals_restrict_per_part(seed, n, m, k):
+    # reference: the loop over the parts at scs.py:139-155, each restricted as in :411-455
+    from spectralclustersupertree_amd import synthetic
+
+    rs = np.random.RandomState(seed)
+    arrays = synthetic.tree_arrays(seed, n, m, k, random_weights=True)
+    perm = rs.permutation(n)
+    cut = n // 3
+    _check_split(arrays, [np.sort(perm[:cut]), np.sort(perm[cut:])])  # a bipartition
+    lab = rs.randint(-1, 9, size=n)  # many parts, some taxa in none
+    _check_split(arrays, [np.flatnonzero(lab == c) for c in range(9) if np.any(lab == c)])
+    _check_split(arrays, [np.array([0, 1, 2]), np.array([5, 9]), np.array([7])])  # tiny parts
+    kid = arrays.split([np.sort(perm[: n // 2])])[0]  # a child (taxa renumbered) split again
+    sub = rs.permutation(kid.n_taxa)
+    _check_split(kid, [np.sort(sub[: kid.n_taxa // 2]), np.sort(sub[kid.n_taxa // 2:])])
+
+
+def test_split_polytomies_missing_lengths_unary_chains():
+    trees = [make_tree(s) for s in [
+        "((a:1,b:2,c:3)x:0.5,(d,(e:1,f)y:2)z,(g,h,i,j))", "(((a,b),c),((d,e),(f,(g,(h,(i,j))))))",
+        "((a:0.1,(b:0.2,(c:0.3,(d:0.4,e:0.5):0.6):0.7):0.8):0.9,f:1.0)", "(a,b)", "((a,j),(b,i))"]]
+    names = sorted({n for t in trees for n in t.get_tip_names()})
+    arr = TreeArrays.from_trees(trees, [1.0, 2.0, 0.5, 1.5, 3.0], names)
+    for parts in ([[0, 1, 2, 3], [4, 5, 6, 7, 8, 9]], [[0, 9], [1, 8], [2, 3, 4], [5, 6, 7]],
+                  [[0, 2, 4, 6, 8], [1, 3, 5, 7, 9]]):
+        _check_split(arr, [np.array(p) for p in parts])
