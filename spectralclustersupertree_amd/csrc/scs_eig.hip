@@ -1707,11 +1707,23 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 // ---------------------------------------------------------------------------
 // Deep levels of the recursion are thousands of nodes of a few to a few dozen taxa
 // (reference: scs.py:110-134 at depth; 47 spectral calls with V <= 100 in the reference's
-// supertriplets fixture).  One workgroup takes one such node from its flattened tables to the
-// V x 2 embedding without leaving LDS: the proper-cluster-graph weights (same addends, same
-// tree order as scs_pcg_build: bit-identical W), the contraction max-reduce over consecutive
-// id ranges, scipy's degree scaling, the full Jacobi eigen-decomposition and scikit-learn's
-// embedding conventions.  K nodes = K workgroups = one launch, one upload, one download.
+// supertriplets fixture), each with up to thousands of trees, and at any moment the recursion
+// knows only a handful of them (the children of the node it has just split).  A launch per
+// node with one workgroup walking the node's trees one after the other left the other 255
+// CUs idle for milliseconds (round 2: 3.2 us per tree, 16 ms for a 60-taxon node of 5 000
+// trees).  Round 3 spreads ONE node over the chip without giving up the tree-ordered sums:
+//   k_small_addends  the trees of a node are dealt to workgroups in runs; a workgroup stages
+//                    four trees at a time (one per wave: sparse table over the gaps' depths by
+//                    wave shuffles) and every thread writes, for its cells (x, y) and each
+//                    tree, the ADDEND value(LCA) * weight -- rounded on its own, 0 when the
+//                    tree does not join the two taxa -- to addends[tree][cell];
+//   k_small_sum      one thread per cell adds its addends in tree order: the reference's sum
+//                    (scs.py:644-658; x + 0.0 == x, so the zeros change nothing), bit-identical
+//                    to scs_pcg_build's W; the dependent chain is one fp64 add per tree;
+//   k_small_finish   one workgroup per node, in LDS: contraction max-reduce over consecutive id
+//                    ranges, scipy's degree scaling, the full Jacobi eigen-decomposition and
+//                    scikit-learn's embedding conventions.
+// K nodes = three launches, one upload, one download.
 struct small_batch {
     const int32_t *n_taxa;      // [K] taxa of the node (<= MAXS)
     const int32_t *n_trees;     // [K]
@@ -1729,155 +1741,137 @@ struct small_batch {
     double *lambda;              // [K][3]
     double *w_out;               // per node n_groups^2 doubles at w_ptr[k], or null
     const int64_t *w_ptr;
+    // work items of k_small_addends: (node, first tree, end tree); of k_small_sum: (node, first cell)
+    const int32_t *item_node, *item_t0, *item_t1;
+    const int32_t *sum_node, *sum_e0;
+    const int64_t *add_ptr;  // [K] first addend of node k: addends[add_ptr[k] + tree * v0^2 + x * v0 + y]
+    double *addends;
+    const int64_t *w0_ptr;   // [K] the node's v0 x v0 uncontracted weights in w0
+    double *w0;
 };
 
-__global__ __launch_bounds__(256) void k_small_nodes(small_batch p) {
+constexpr int SMALL_Q = MAXS * MAXS / 256;  // cells of a thread at the largest node
+
+__global__ __launch_bounds__(256) void k_small_addends(small_batch p) {
+    // per wave one staged tree: sparse table over the gaps' (depth << 6 | gap) keys, the gaps'
+    // values, the position of every taxon (-1: absent)
+    __shared__ unsigned s_sp[4][6][MAXS];
+    __shared__ double s_val[4][MAXS];
+    __shared__ int s_pos[4][MAXS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = p.item_node[blockIdx.x];
+    const int t0 = p.item_t0[blockIdx.x], t1 = p.item_t1[blockIdx.x];
+    const int v0 = p.n_taxa[k];
+    const int ncell = v0 * v0;
+    const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
+    const int64_t lbase = p.leaf_ptr[k];
+    double *out = p.addends + p.add_ptr[k];
+    const int nq = (ncell + 255) / 256;
+    int cx[SMALL_Q], cy[SMALL_Q];
+#pragma unroll
+    for (int q = 0; q < SMALL_Q; ++q) {
+        const int e = tid + 256 * q;
+        cx[q] = e / v0;
+        cy[q] = e - cx[q] * v0;
+        if (e >= ncell || cx[q] >= cy[q]) cx[q] = -1;  // not a cell of the upper triangle
+    }
+    for (int g = t0; g < t1; g += 4) {
+        __syncthreads();  // the cells of the previous four trees are done with the buffers
+        const int ts = g + wave;
+        if (ts < t1) {
+            const int off = toff[ts], n = toff[ts + 1] - off;
+            int f_tax = 0, f_dep = 0;
+            double f_val = 0.0;
+            if (lane < n) {
+                f_tax = p.leaf_taxon[lbase + off + lane];
+                f_dep = p.adj_depth[lbase + off + lane];
+                f_val = p.adj_val[lbase + off + lane];
+            }
+            // gap i = the LCA of leaves i and i + 1 (adj_* of leaf i), i < n - 1
+            unsigned key = lane + 1 < n ? ((unsigned)f_dep << 6) | (unsigned)lane : 0xFFFFFFFFu;
+            s_sp[wave][0][lane] = key;
+#pragma unroll
+            for (int j = 1; j < 6; ++j) {
+                if ((1 << j) >= n) break;  // (uniform) no pair of this tree is 2^j gaps apart
+                const unsigned other = __shfl_down(key, 1 << (j - 1), 64);
+                if (lane + (1 << (j - 1)) < 64) key = other < key ? other : key;
+                s_sp[wave][j][lane] = key;
+            }
+            s_val[wave][lane] = f_val;
+            s_pos[wave][lane] = -1;
+            if (lane < n) s_pos[wave][f_tax] = lane;  // (same wave: after the clearing store)
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = g + j;
+            if (t >= t1) break;
+            const double wt = p.tree_w[p.tree_ptr[k] + t];
+            double *row = out + (int64_t)t * ncell;
+#pragma unroll
+            for (int q = 0; q < SMALL_Q; ++q) {
+                if (q >= nq) break;  // (uniform) most nodes are tiny
+                if (cx[q] < 0) continue;
+                const int px = s_pos[j][cx[q]], py = s_pos[j][cy[q]];
+                const bool live = px >= 0 && py >= 0;
+                const int lo = live ? (px < py ? px : py) : 0, hi = live ? (px < py ? py : px) : 1;
+                const int lv = 31 - __clz(hi - lo);
+                const unsigned ka = s_sp[j][lv][lo], kb = s_sp[j][lv][hi - (1 << lv)];
+                // (leftmost on ties, as a left-to-right sweep finds it)
+                const unsigned key = kb < ka ? kb : ka;
+                const double mv = s_val[j][key & 63u];
+                double add = 0.0;
+                // the root (depth 0) separates the two: nothing to add
+                if (live && (key >> 6) != 0) {
+#pragma clang fp contract(off)
+                    add = mv * wt;  // rounded on its own, never fused into the sum
+                }
+                row[tid + 256 * q] = add;
+            }
+        }
+    }
+}
+
+// thread = one cell (x < y) of one node: its addends in tree order (reference: scs.py:655-657)
+__global__ __launch_bounds__(256) void k_small_sum(small_batch p) {
+    const int k = p.sum_node[blockIdx.x];
+    const int e = p.sum_e0[blockIdx.x] + threadIdx.x;
+    const int v0 = p.n_taxa[k], m = p.n_trees[k];
+    const int ncell = v0 * v0;
+    if (e >= ncell) return;
+    const int x = e / v0, y = e - x * v0;
+    double *w0 = p.w0 + p.w0_ptr[k];
+    if (x == y) w0[e] = 0.0;
+    if (x >= y) return;
+    const double *in = p.addends + p.add_ptr[k] + e;
+    double acc = 0.0;
+    int t = 0;
+    for (; t + 8 <= m; t += 8) {
+        double a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = in[(int64_t)(t + j) * ncell];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = acc + a[j];
+    }
+    for (; t < m; ++t) acc = acc + in[(int64_t)t * ncell];
+    w0[e] = acc;
+    w0[y * v0 + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
     __shared__ jacobi_lds s;
     __shared__ double s_dd[MAXS];
     __shared__ int s_gs[MAXS + 1];
-    // per tree, double-buffered: sparse table over the gaps' (depth << 6 | gap) keys, the gaps'
-    // values, the position of every taxon (-1: absent)
-    __shared__ unsigned s_sp[2][6][MAXS];
-    __shared__ double s_val[2][MAXS];
-    __shared__ int s_pos[2][MAXS];
     const int tid = threadIdx.x;
     const int k = blockIdx.x;
-    const int m = p.n_trees[k], v = p.n_groups[k], v0 = p.n_taxa[k];
-    const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
-    const int64_t lbase = p.leaf_ptr[k];
+    const int v = p.n_groups[k], v0 = p.n_taxa[k];
     double(*w0)[SLD] = s.e;  // the uncontracted weights live where Jacobi later keeps its vectors
-
-    for (int e = tid; e < MAXS * SLD; e += 256) (&s.e[0][0])[e] = 0.0;
     if (tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
-    // ---- W0, output-stationary like the tile kernels: a thread owns the cells (x, y), x < y,
-    // among e = tid + 256 q of the 64 x 64 square and keeps their sums in registers; per tree
-    // it looks the two taxa's positions up, takes the shallowest gap between them from a sparse
-    // table (leftmost on ties, as a left-to-right sweep finds it) and adds value * weight --
-    // every cell sees its addends in tree order (reference: scs.py:644-658; one rounded
-    // multiply, one rounded add: FMA contraction is switched off for that statement; an LCA at
-    // the root adds nothing).  Wave 0 stages a tree (lane = leaf); the next tree's leaves are
-    // fetched while the current one is used.
-    // (Nodes of a dozen taxa or fewer -- most nodes of a deep recursion -- take the plain sweep
-    // instead: leaf a walks the leaves to its right with the running shallowest LCA and adds
-    // into LDS.  Its dependent chain is as long as the tree has leaves, but it has none of the
-    // per-tree staging: 5 taxa x 400 trees 0.38 ms per node against 0.67 ms, 32 taxa 1.98
-    // against 1.42 ms, 64 taxa x 1000 trees 8.7 against 3.2 ms.  Same addends, same order.)
-    constexpr int SWEEP_MAX = 12;
-    if (v0 > SWEEP_MAX) {
-        constexpr int CELLS = MAXS * MAXS / 256;
-        double acc[CELLS];
-    #pragma unroll
-        for (int q = 0; q < CELLS; ++q) acc[q] = 0.0;
-        int f_tax = 0, f_dep = 0, f_n = 0;
-        double f_val = 0.0;
-        auto fetch = [&](int t) {
-            const int off = toff[t];
-            f_n = toff[t + 1] - off;
-            if (tid < f_n) {
-                f_tax = p.leaf_taxon[lbase + off + tid];
-                f_dep = p.adj_depth[lbase + off + tid];
-                f_val = p.adj_val[lbase + off + tid];
-            }
-        };
-        if (m > 0) fetch(0);
-        for (int t = 0; t < m; ++t) {
-            const int buf = t & 1;
-            const int n = f_n;
-            if (tid < 64) {
-                // gap i = the LCA of leaves i and i + 1 (adj_* of leaf i), i < n - 1
-                unsigned key = tid + 1 < n ? ((unsigned)f_dep << 6) | (unsigned)tid : 0xFFFFFFFFu;
-                s_sp[buf][0][tid] = key;
-    #pragma unroll
-                for (int j = 1; j < 6; ++j) {
-                    if ((1 << j) >= n) break;  // (uniform) no pair of this tree is 2^j gaps apart
-                    const unsigned other = __shfl_down(key, 1 << (j - 1), 64);
-                    if (tid + (1 << (j - 1)) < 64) key = other < key ? other : key;
-                    s_sp[buf][j][tid] = key;
-                }
-                s_val[buf][tid] = f_val;
-                s_pos[buf][tid] = -1;
-                if (tid < n) s_pos[buf][f_tax] = tid;  // (same wave: after the clearing store)
-            }
-            __syncthreads();  // tree t is staged; the other buffer is free again
-            if (t + 1 < m) fetch(t + 1);
-            const double wt = p.tree_w[p.tree_ptr[k] + t];
-            // (branch-free, stage by stage, so that the LDS reads of the sixteen cells overlap:
-            // positions, then the two table entries, then the value; y = tid & 63 for every cell)
-            const int y = tid & 63, x0 = tid >> 6;
-            const int py = s_pos[buf][y];
-            unsigned ka[CELLS], kb[CELLS];
-            bool live[CELLS];
-    #pragma unroll
-            for (int q = 0; q < CELLS; ++q) {
-                ka[q] = kb[q] = 0xFFFFFFFFu;
-                live[q] = false;
-                if (4 * q >= v0) continue;  // (uniform) rows beyond the node's taxa: most nodes are tiny
-                const int x = x0 + 4 * q;
-                const int px = s_pos[buf][x];
-                live[q] = x < y && px >= 0 && py >= 0;
-                const int lo = live[q] ? (px < py ? px : py) : 0, hi = live[q] ? (px < py ? py : px) : 1;
-                const int lv = 31 - __clz(hi - lo);
-                ka[q] = s_sp[buf][lv][lo];
-                kb[q] = s_sp[buf][lv][hi - (1 << lv)];
-            }
-    #pragma unroll
-            for (int q = 0; q < CELLS; ++q) {
-                if (4 * q >= v0) continue;
-                const unsigned key = kb[q] < ka[q] ? kb[q] : ka[q];
-                const double mv = s_val[buf][key & 63u];
-                // the root (depth 0) separates the two: nothing to add
-                if (live[q] && (key >> 6) != 0) {
-    #pragma clang fp contract(off)
-                    const double add = mv * wt;  // rounded on its own, never fused into the add
-                    acc[q] = acc[q] + add;
-                }
-            }
-        }
-    #pragma unroll
-        for (int q = 0; q < CELLS; ++q) {
-            const int e = tid + 256 * q, x = e >> 6, y = e & 63;
-            if (x < y) {
-                w0[x][y] = acc[q];
-                w0[y][x] = acc[q];
-            }
-        }
-        __syncthreads();
-    } else {
-        int *s_tax = s_pos[0], *s_dep = s_pos[1];  // (the staging arrays of the other path)
-        double *s_v = s_val[0];
-        for (int t = 0; t < m; ++t) {
-            const int off = toff[t], n = toff[t + 1] - off;
-            if (tid < n) {
-                s_tax[tid] = p.leaf_taxon[lbase + off + tid];
-                s_dep[tid] = p.adj_depth[lbase + off + tid];
-                s_v[tid] = p.adj_val[lbase + off + tid];
-            }
-            __syncthreads();
-            const double wt = p.tree_w[p.tree_ptr[k] + t];
-            if (tid + 1 < n) {
-                const int a = tid, ta = s_tax[a];
-                int md = s_dep[a];
-                double mv = s_v[a];
-                for (int b = a + 1; b < n; ++b) {
-                    if (b > a + 1 && s_dep[b - 1] < md) {
-                        md = s_dep[b - 1];
-                        mv = s_v[b - 1];
-                    }
-                    if (md == 0) break;  // the root separates a from every later leaf
-                    const int tb = s_tax[b];
-                    double sum;
-                    {
-#pragma clang fp contract(off)
-                        const double add = mv * wt;  // rounded on its own, never fused into the add
-                        sum = w0[ta][tb] + add;
-                    }
-                    w0[ta][tb] = sum;
-                    w0[tb][ta] = sum;
-                }
-            }
-            __syncthreads();
-        }
+    {
+        const double *src = p.w0 + p.w0_ptr[k];
+        for (int e = tid; e < v0 * v0; e += 256) w0[e / v0][e % v0] = src[e];
     }
+    __syncthreads();
     // ---- contraction: vertex g = taxa [gs[g], gs[g+1]); weight = max over member pairs
     // (reference: scs.py:336-387), diagonal 0
     for (int e = tid; e < v * v; e += 256) {
@@ -1977,6 +1971,30 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
         toff_at += n_trees[k] + 1;
     }
     const int64_t n_toff = toff_at, n_gs = vertex_ptr[K] + K, n_leaf = leaf_ptr[K], n_tree = tree_ptr[K];
+    // ---- work items: runs of trees for k_small_addends (enough runs to fill the chip, at
+    // least 16 trees each, whole groups of four), 256-cell pieces for k_small_sum
+    int per_item = (int)std::max<int64_t>(16, (n_tree + 1023) / 1024);
+    per_item = (per_item + 3) / 4 * 4;
+    std::vector<int32_t> item_node, item_t0, item_t1, sum_node, sum_e0;
+    std::vector<int64_t> add_ptr(K + 1, 0), w0_ptr(K + 1, 0);
+    for (int k = 0; k < K; ++k) {
+        const int64_t ncell = (int64_t)n_taxa[k] * n_taxa[k];
+        add_ptr[k + 1] = add_ptr[k] + ncell * n_trees[k];
+        w0_ptr[k + 1] = w0_ptr[k] + ncell;
+        for (int t = 0; t < n_trees[k]; t += per_item) {
+            item_node.push_back(k);
+            item_t0.push_back(t);
+            item_t1.push_back(std::min(n_trees[k], t + per_item));
+        }
+        for (int e = 0; e < ncell; e += 256) {
+            sum_node.push_back(k);
+            sum_e0.push_back(e);
+        }
+    }
+    const size_t n_items = item_node.size(), n_sums = sum_node.size();
+    SCS_REQUIRE((uint64_t)add_ptr[K] * 8 <= ((uint64_t)48 << 30),
+                "scs_small_solve: batch too large (%lld addends): pass fewer nodes per call",
+                (long long)add_ptr[K]);
     auto up8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
     size_t at = 0;
     const size_t o_nt = at; at += up8((size_t)K * 4);
@@ -1986,6 +2004,13 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
     const size_t o_vp = at; at += up8((size_t)(K + 1) * 4);
     const size_t o_lp = at; at += (size_t)(K + 1) * 8;
     const size_t o_wp = at; at += (size_t)(K + 1) * 8;
+    const size_t o_ap = at; at += (size_t)(K + 1) * 8;
+    const size_t o_w0p = at; at += (size_t)(K + 1) * 8;
+    const size_t o_in = at; at += up8(n_items * 4);
+    const size_t o_i0 = at; at += up8(n_items * 4);
+    const size_t o_i1 = at; at += up8(n_items * 4);
+    const size_t o_sn = at; at += up8(n_sums * 4);
+    const size_t o_s0 = at; at += up8(n_sums * 4);
     const size_t o_to = at; at += up8((size_t)n_toff * 4);
     const size_t o_gs = at; at += up8((size_t)n_gs * 4);
     const size_t o_lt = at; at += up8((size_t)n_leaf * 4);
@@ -2008,6 +2033,11 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
         SCS_HIP_CHECK(hipHostMalloc((void **)&ctx->small_host, cap, hipHostMallocDefault));
         ctx->small_cap = cap;
     }
+    // device scratch: the addends (trees x cells per node) and the uncontracted weights
+    t_ctx = ctx;
+    dbuf d_add, d_w0;
+    SCS_TRY(d_add.alloc((size_t)std::max<int64_t>(add_ptr[K], 1) * 8));
+    SCS_TRY(d_w0.alloc((size_t)std::max<int64_t>(w0_ptr[K], 1) * 8));
     unsigned char *h = ctx->small_host, *d = ctx->small_dev;
     memcpy(h + o_nt, n_taxa, (size_t)K * 4);
     memcpy(h + o_nm, n_trees, (size_t)K * 4);
@@ -2016,6 +2046,13 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
     memcpy(h + o_vp, vertex_ptr.data(), (size_t)(K + 1) * 4);
     memcpy(h + o_lp, leaf_ptr.data(), (size_t)(K + 1) * 8);
     memcpy(h + o_wp, w_ptr.data(), (size_t)(K + 1) * 8);
+    memcpy(h + o_ap, add_ptr.data(), (size_t)(K + 1) * 8);
+    memcpy(h + o_w0p, w0_ptr.data(), (size_t)(K + 1) * 8);
+    memcpy(h + o_in, item_node.data(), n_items * 4);
+    memcpy(h + o_i0, item_t0.data(), n_items * 4);
+    memcpy(h + o_i1, item_t1.data(), n_items * 4);
+    memcpy(h + o_sn, sum_node.data(), n_sums * 4);
+    memcpy(h + o_s0, sum_e0.data(), n_sums * 4);
     memcpy(h + o_to, tree_off, (size_t)n_toff * 4);
     memcpy(h + o_gs, group_start, (size_t)n_gs * 4);
     memcpy(h + o_lt, leaf_taxon, (size_t)n_leaf * 4);
@@ -2031,6 +2068,13 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
     sb.vertex_ptr = (const int32_t *)(d + o_vp);
     sb.leaf_ptr = (const int64_t *)(d + o_lp);
     sb.w_ptr = (const int64_t *)(d + o_wp);
+    sb.add_ptr = (const int64_t *)(d + o_ap);
+    sb.w0_ptr = (const int64_t *)(d + o_w0p);
+    sb.item_node = (const int32_t *)(d + o_in);
+    sb.item_t0 = (const int32_t *)(d + o_i0);
+    sb.item_t1 = (const int32_t *)(d + o_i1);
+    sb.sum_node = (const int32_t *)(d + o_sn);
+    sb.sum_e0 = (const int32_t *)(d + o_s0);
     sb.tree_off = (const int32_t *)(d + o_to);
     sb.group_start = (const int32_t *)(d + o_gs);
     sb.leaf_taxon = (const int32_t *)(d + o_lt);
@@ -2040,7 +2084,11 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
     sb.maps = (double *)(d + o_maps);
     sb.lambda = (double *)(d + o_lam);
     sb.w_out = w_out ? (double *)(d + o_w) : nullptr;
-    k_small_nodes<<<K, 256, 0, s>>>(sb);
+    sb.addends = d_add.d();
+    sb.w0 = d_w0.d();
+    k_small_addends<<<(unsigned)n_items, 256, 0, s>>>(sb);
+    k_small_sum<<<(unsigned)n_sums, 256, 0, s>>>(sb);
+    k_small_finish<<<K, 256, 0, s>>>(sb);
     SCS_HIP_CHECK(hipGetLastError());
     SCS_HIP_CHECK(hipMemcpyAsync(h + o_maps, d + o_maps, total - o_maps, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));

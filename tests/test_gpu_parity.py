@@ -695,3 +695,18 @@ def test_small_solve_equals_the_per_node_path(dev):
         if np.all(deg > 0) and len(ev) > 2 and ev[1] - ev[2] > 1e-6 and ev[0] - ev[1] > 1e-6:
             assert np.max(np.abs(maps - ref)) <= FIEDLER_TOL, tables.n_taxa
         assert abs(lam[1] - stats["lambda"][1]) <= 1e-12
+
+
+@pytest.mark.parametrize("n,m,k,strategy", [(5, 1500, 4, "branch"), (12, 700, 9, "bootstrap"), (40, 333, 25, "branch"),
+                                            (64, 150, 64, "depth"), (33, 37, 20, "one")])
+def test_small_solve_many_trees_bit_exact(dev, n, m, k, strategy):
+    # one node spread over many workgroups (runs of trees -> addends -> tree-ordered sums):
+    # W bit for bit the oracle's, in a batch with a second node of another shape
+    tables = synthetic.make_tables(900 + n, n, m, strategy, leaves_per_tree=k, random_weights=True)
+    other = synthetic.make_tables(77, 9, 21, "branch", leaves_per_tree=7)
+    out = dev.small_solve([(tables, None), (other, None), (tables, None)], want_w=True)
+    for tb, (maps, lam, w) in zip((tables, other, tables), out):
+        w_ref, _ = to.pcg_dense(tb)
+        assert np.array_equal(w, w_ref)
+        assert np.array_equal(w, w.T)
+    assert np.array_equal(out[0][0], out[2][0])  # the same node twice: the same bits
