@@ -256,6 +256,12 @@ int scs_debug_gram(scs_ctx *ctx, const double *a, const double *b, int32_t n, in
  * SYMM kernel with the graph's degree scaling. */
 int scs_debug_apply(scs_ctx *ctx, scs_graph *graph, const double *x, int32_t b, double *y);
 
+/* One grouped round of ncclSend + ncclRecv from this rank to itself through the wrapper the
+ * shared build's tile exchange uses (ncclGroupStart ... ncclGroupEnd, ncclFloat64, the
+ * context's stream): host_out receives host_in (count doubles).  Needs a context created
+ * with an RCCL communicator (scs_ctx_create with world >= 1 and a unique id). */
+int scs_debug_comm_selftest(scs_ctx *ctx, int32_t count, const double *host_in, double *host_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,16 @@ class Device:
         return out
 
     # -- building blocks exposed for the parity tests -----------------------
+    def comm_selftest(self, x: np.ndarray) -> np.ndarray:
+        """One grouped ncclSend/ncclRecv round to this rank itself plus an ncclAllGather,
+        through the library's RCCL wrappers (``scs_debug_comm_selftest``); returns what came
+        back.  The context must own an RCCL communicator (created with a unique id)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+        out = np.empty_like(x)
+        nv.check(self._lib.scs_debug_comm_selftest(self._ctx, len(x), nv.dptr(x), nv.dptr(out)))
+        return out
+
+
     def debug_jacobi(self, a: np.ndarray):
         a = np.ascontiguousarray(a, dtype=np.float64)
         n = a.shape[0]

@@ -37,7 +37,11 @@ def scs(in_file: str, out_file: str, pcg_weighting: str, *, disable_contraction:
         pcg_weighting=pcg_weighting.lower(),
         contract_edges=not disable_contraction,
     )
-    supertree.write(out_file)
+    from spectralclustersupertree_amd.scs import default_team
+
+    team = default_team()
+    if team is None or team.rank == 0:  # a launched job: every rank holds the tree, one writes it
+        supertree.write(out_file)
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 
@@ -145,6 +146,7 @@ struct scs_local_group {
     uint64_t generation = 0;
     std::vector<const double *> send;
     std::vector<const int64_t *> send_off;  // all-to-all-v: every rank's offsets into its send buffer
+    std::atomic<int> failed{0};  // a rank hit an error inside a collective: everybody returns SCS_ECOMM
     void barrier() {
         std::unique_lock<std::mutex> lock(m);
         uint64_t gen = generation;
@@ -191,16 +193,27 @@ int scs_comm_allgather_f64(scs_comm *comm, const double *sendbuf, double *recvbu
         }
         return SCS_OK;
     }
-    // local group: publish, meet, copy every slice, meet again
+    // local group: publish, meet, copy every slice, meet again.  A HIP failure on one rank
+    // must not leave its peers at the second meeting point: the error is kept, the barrier is
+    // reached, and the failure is published so that EVERY rank returns SCS_ECOMM.
     scs_local_group *g = comm->group;
-    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    hipError_t err = hipStreamSynchronize(stream);
     g->send[comm->rank] = sendbuf;
     g->barrier();
-    for (int r = 0; r < g->world; ++r)
-        SCS_HIP_CHECK(hipMemcpyAsync(recvbuf + (size_t)r * count, g->send[r],
-                                     count * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int r = 0; r < g->world && err == hipSuccess; ++r)
+        err = hipMemcpyAsync(recvbuf + (size_t)r * count, g->send[r], count * sizeof(double),
+                             hipMemcpyDeviceToDevice, stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);
+    if (err != hipSuccess) g->failed.store(1);
     g->barrier();
+    if (err != hipSuccess) {
+        scs_set_error("local all-gather failed: %s", hipGetErrorString(err));
+        return SCS_EHIP;
+    }
+    if (g->failed.load()) {
+        scs_set_error("local all-gather: a peer rank failed");
+        return SCS_ECOMM;
+    }
     return SCS_OK;
 }
 
@@ -246,14 +259,15 @@ int scs_comm_alltoallv_f64(scs_comm *comm, const double *sendbuf, const int64_t 
         }
         return SCS_OK;
     }
-    // local group: publish, meet, pull every peer's share, meet again
+    // local group: publish, meet, pull every peer's share, meet again (errors: as in the
+    // all-gather above -- always reach the second meeting point)
     scs_local_group *g = comm->group;
-    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    hipError_t err = hipStreamSynchronize(stream);
     g->send[rank] = sendbuf;
     g->send_off[rank] = send_off;
     g->barrier();
     int bad = 0;
-    for (int p = 0; p < world; ++p) {
+    for (int p = 0; p < world && err == hipSuccess; ++p) {
         const int64_t *po = g->send_off[p];
         const int64_t cnt = po[rank + 1] - po[rank];
         if (cnt != recv_off[p + 1] - recv_off[p]) {
@@ -261,14 +275,77 @@ int scs_comm_alltoallv_f64(scs_comm *comm, const double *sendbuf, const int64_t 
             continue;
         }
         if (cnt > 0)
-            SCS_HIP_CHECK(hipMemcpyAsync(recvbuf + recv_off[p], g->send[p] + po[rank], (size_t)cnt * 8,
-                                         hipMemcpyDeviceToDevice, stream));
+            err = hipMemcpyAsync(recvbuf + recv_off[p], g->send[p] + po[rank], (size_t)cnt * 8,
+                                 hipMemcpyDeviceToDevice, stream);
     }
-    SCS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);
+    if (err != hipSuccess || bad) g->failed.store(1);
     g->barrier();
+    if (err != hipSuccess) {
+        scs_set_error("local all-to-all-v failed: %s", hipGetErrorString(err));
+        return SCS_EHIP;
+    }
     if (bad) {
         scs_set_error("all-to-all-v: a peer sends a different count than this rank expects");
         return SCS_ECOMM;
+    }
+    if (g->failed.load()) {
+        scs_set_error("local all-to-all-v: a peer rank failed");
+        return SCS_ECOMM;
+    }
+    return SCS_OK;
+}
+
+// One grouped round of ncclSend / ncclRecv to THIS rank itself through the wrapper the tile
+// exchange uses (argument order, ncclFloat64 = 8, stream), plus an all-gather: lets a single
+// device exercise the RCCL bindings before the first multi-GPU run.  count doubles at
+// sendbuf -> recvbuf (device pointers).
+extern "C" int scs_debug_comm_selftest(scs_ctx *ctx, int32_t count, const double *host_in,
+                                       double *host_out) {
+    SCS_REQUIRE(ctx && host_in && host_out && count >= 1, "scs_debug_comm_selftest: bad argument");
+    SCS_REQUIRE(ctx->comm.kind == 1, "scs_debug_comm_selftest: the context has no RCCL communicator");
+    if (!g_rccl.send || !g_rccl.recv || !g_rccl.group_start || !g_rccl.group_end) {
+        scs_set_error("librccl lacks ncclSend / ncclRecv / ncclGroupStart / ncclGroupEnd");
+        return SCS_ECOMM;
+    }
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    SCS_TRY(scs_block_alloc(ctx, (size_t)count * 8, (void **)&d_in));
+    int rc_all = scs_block_alloc(ctx, (size_t)count * 8, (void **)&d_out);
+    if (rc_all != SCS_OK) {
+        scs_block_release(ctx, d_in);
+        return rc_all;
+    }
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d_in, host_in, (size_t)count * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, (size_t)count * 8, s);
+    int rc = e == hipSuccess ? 0 : -1;
+    if (rc == 0) {
+        rc = g_rccl.group_start();
+        if (rc == 0) rc = g_rccl.send(d_in, (size_t)count, /*ncclFloat64*/ 8, ctx->comm.rank, ctx->comm.rccl_comm, s);
+        if (rc == 0) rc = g_rccl.recv(d_out, (size_t)count, /*ncclFloat64*/ 8, ctx->comm.rank, ctx->comm.rccl_comm, s);
+        const int rc_end = g_rccl.group_end();
+        if (rc == 0) rc = rc_end;
+        // ... and ncclAllGather itself (the solver's per-iteration collective short-cuts a
+        // world of one to a device copy): rank 0's slice of the result is d_out again
+        if (rc == 0 && ctx->comm.world == 1)
+            rc = g_rccl.allgather(d_out, d_in, (size_t)count, /*ncclFloat64*/ 8, ctx->comm.rccl_comm, s);
+        if (rc == 0 && ctx->comm.world == 1)
+            rc = g_rccl.allgather(d_in, d_out, (size_t)count, /*ncclFloat64*/ 8, ctx->comm.rccl_comm, s);
+    }
+    if (rc == 0) {
+        e = hipMemcpyAsync(host_out, d_out, (size_t)count * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    scs_block_release(ctx, d_in);
+    scs_block_release(ctx, d_out);
+    if (rc != 0) {
+        scs_set_error("RCCL send/recv self-test failed: %s", rc > 0 ? rccl_err(rc) : "HIP copy failed");
+        return SCS_ECOMM;
+    }
+    if (e != hipSuccess) {
+        scs_set_error("RCCL send/recv self-test: %s", hipGetErrorString(e));
+        return SCS_EHIP;
     }
     return SCS_OK;
 }

@@ -84,9 +84,16 @@ def default_team():
     RANK / WORLD_SIZE / LOCAL_RANK): created on first use, None in a plain run."""
     global _default_team, _default_team_checked
     if not _default_team_checked:
-        from spectralclustersupertree_amd.partition import team_from_env
+        import os
 
-        _default_team = team_from_env()
+        # SCS_TEAM=0 (or off / none): never join the launcher's job -- for a process that
+        # merely lives inside someone else's torch.distributed.run and wants one GPU to itself
+        if os.environ.get("SCS_TEAM", "env").lower() in ("0", "off", "none", "no"):
+            _default_team = None
+        else:
+            from spectralclustersupertree_amd.partition import team_from_env
+
+            _default_team = team_from_env()
         _default_team_checked = True
     return _default_team
 
@@ -130,6 +137,7 @@ def relabel_for_contraction(tables: fl.TreeTables, groups: np.ndarray):
 # split moves only when entries move by far more); above it the node is refused, as the
 # reference's ARPACK call would raise ArpackNoConvergence rather than return a guess.
 ACCEPT_RESIDUAL = 1e-8
+ACCEPT_RESIDUAL_OVER_GAP = 1e-4  # and residual / (lambda2 - lambda3) at most this
 
 
 def _fiedler_checked(graph, v0, tol, max_iter, block):
@@ -145,18 +153,24 @@ def _fiedler_checked(graph, v0, tol, max_iter, block):
         return graph.fiedler(v0, tol=tol, max_iter=max_iter, block=block)
     except ConvergenceError as first:
         try:
+            # (the library clamps the width to what V supports: 3 b + 1 <= V)
             return graph.fiedler(v0, tol=tol, max_iter=4 * max_iter, block=16)
         except ConvergenceError as second:
             best = min((first, second), key=lambda e: max(e.stats["resid"]))
             resid = max(best.stats["resid"])
-            if not resid <= ACCEPT_RESIDUAL:
+            # eigenvector error ~ residual / gap: the residual is accepted against the gap to
+            # the next eigenvalue, not in absolute terms (lambda2 ~ lambda3 can turn a 1e-8
+            # residual into a mix of the two eigenvectors)
+            gap = abs(best.stats["lambda"][1] - best.stats["lambda_next"])
+            if not (resid <= ACCEPT_RESIDUAL and resid <= ACCEPT_RESIDUAL_OVER_GAP * gap):
                 msg = (f"Fiedler solve did not converge: residual {resid:.3e} "
                        f"(V = {best.stats['n_vertices']}, lambda2 {best.stats['lambda'][1]:.12g}, "
                        f"next {best.stats['lambda_next']:.12g})")
                 raise RuntimeError(msg) from second
             warnings.warn(
-                f"Fiedler solve stopped at residual {resid:.3e} (target {tol:.1e}); "
+                f"Fiedler solve stopped at residual {resid:.3e} (target {tol:.1e}, gap {gap:.3e}); "
                 "clustering the block it reached", RuntimeWarning, stacklevel=3)
+            best.stats["accepted_residual"] = resid
             return best.maps, best.stats
 
 
@@ -311,10 +325,17 @@ def construct_supertree(
     RandomState in the same state).  Left at None a job launched by ``torch.distributed.run``
     finds its team from the environment, a plain run uses GPU ``SCS_DEVICE`` (default 0).
     """
-    if random_state is None:
-        random_state = np.random.RandomState()
     if team is None:
         team = default_team()
+    if random_state is None:
+        if team is not None and team.world > 1:
+            # several ranks walk one recursion with ONE stream: rank 0 draws the seed for all
+            # (an OS-seeded generator per rank would send the ranks down different recursions
+            # and the next collective would meet mismatched shapes)
+            mine = int(np.random.RandomState().randint(0, 2**31 - 1)) if team.rank == 0 else None
+            random_state = np.random.RandomState(team.allgather(mine)[0])
+        else:
+            random_state = np.random.RandomState()
 
     if isinstance(trees, TreeArrays):
         # extension: a forest that was parsed straight into arrays (load.load_tree_arrays)
@@ -504,11 +525,24 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         from spectralclustersupertree_amd.partition import Team
 
         alone = Team(rank=0, world=1, device=team.solo, solo=team.solo)
-        mine = {slot: _construct(sub, pcg_weighting, contract_edges, rng, given, alone)
-                for slot, owner, sub, rng in dealt if owner == team.rank}
-        for part in team.allgather(mine):
-            for slot, tree in part.items():
-                child_trees[slot] = tree
+        # every rank solves its share, then the subtrees are exchanged in FLAT form (lists:
+        # pickling linked nodes recurses once per tree level); a failure on one rank travels
+        # with the exchange, so that all ranks raise instead of waiting for one another
+        mine, failure = {}, None
+        try:
+            for slot, owner, sub, rng in dealt:
+                if owner == team.rank:
+                    mine[slot] = _construct(sub, pcg_weighting, contract_edges, rng, given, alone).to_flat()
+        except Exception as exc:  # noqa: BLE001 - re-raised on every rank below
+            failure = f"rank {team.rank}: {type(exc).__name__}: {exc}"
+        gathered = team.allgather((mine, failure))
+        errors = [f for _, f in gathered if f is not None]
+        if errors:
+            msg = "a dealt sub-problem failed -- " + "; ".join(errors)
+            raise RuntimeError(msg)
+        for part, _ in gathered:
+            for slot, flat in part.items():
+                child_trees[slot] = TreeNode.from_flat(flat)
     return connect_trees(child_trees)
 
 

@@ -71,6 +71,40 @@ class TreeNode:
             for c in children:
                 self.append(c)
 
+    # -- flat form (what travels between ranks: pickling a linked tree recurses per level) --
+    def to_flat(self) -> tuple[list[int], list, list, list]:
+        """Preorder ``(parent index, name, length, support)`` lists; iterative, exact."""
+        parents: list[int] = []
+        names: list = []
+        lengths: list = []
+        supports: list = []
+        stack: list[tuple[TreeNode, int]] = [(self, -1)]
+        while stack:
+            node, par = stack.pop()
+            me = len(parents)
+            parents.append(par)
+            names.append(node.name)
+            lengths.append(node.length)
+            supports.append(node.support)
+            for child in reversed(node.children):
+                stack.append((child, me))
+        return parents, names, lengths, supports
+
+    @classmethod
+    def from_flat(cls, flat) -> "TreeNode":
+        parents, names, lengths, supports = flat
+        nodes: list[TreeNode] = []
+        for par, name, length, support in zip(parents, names, lengths, supports):
+            node = cls(name, None, length, support)
+            nodes.append(node)
+            if par >= 0:
+                nodes[par].append(node)
+        return nodes[0]
+
+    def __reduce__(self):
+        # (pickle and copy.deepcopy go through the flat form: no recursion per tree level)
+        return (TreeNode.from_flat, (self.to_flat(),))
+
     # -- structure ---------------------------------------------------------
     def append(self, child: "TreeNode") -> None:
         child.parent = self

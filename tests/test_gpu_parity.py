@@ -563,9 +563,14 @@ def test_rccl_world_of_one(dev):
         maps, stats = g.fiedler(None)
         g.free()
         dtab.free()
+        # the point-to-point wrappers of the shared build's tile exchange (ncclGroupStart,
+        # ncclSend, ncclRecv, ncclGroupEnd) and ncclAllGather itself, on this one rank
+        x = np.random.RandomState(3).standard_normal(100_003)
+        back = d.comm_selftest(x)
     finally:
         d.close()
     assert stats["converged"] == 1
+    assert np.array_equal(back, x)
 
 
 # ---------------------------------------------------------------------------

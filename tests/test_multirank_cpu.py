@@ -88,6 +88,35 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     assert got.sorted().same_shape(load_tree(DATA_DIR / exp).sorted())
     newicks = allgather(got.sorted().get_newick())
     assert newicks[0] == newicks[1]
+    # 5. no seed given: rank 0 draws it for every rank (one stream, not one per rank)
+    seen = {}
+
+    def capture(arr, weighting_, contract, rs, *a, **kw):
+        seen["state"] = rs.get_state()[1].tobytes()
+        return scs.tip_names_to_tree(["a", "b"])
+
+    real_construct = scs._construct
+    scs._construct = capture
+    try:
+        scs.construct_supertree(arrays, pcg_weighting=weighting, team=team)
+    finally:
+        scs._construct = real_construct
+    states = allgather(seen["state"])
+    assert states[0] == states[1]
+    # 6. a sub-problem that fails on ONE rank makes EVERY rank raise (nobody is left waiting in
+    # the exchange)
+    calls = {"n": 0}
+
+    def failing(tables, random_state, *, contract_edges):
+        calls["n"] += 1
+        if rank == 1 and calls["n"] == 2:  # the first node of rank 1's own dealt sub-problem
+            raise ArithmeticError("planted failure")
+        return cpu_bipartition(tables, random_state, contract_edges=contract_edges)
+
+    forest = synthetic.tree_arrays(3, 120, 8, 90)  # a top-level split with work for both ranks
+    with pytest.raises(RuntimeError, match="planted failure"):
+        scs._construct(forest, "branch", True, np.random.RandomState(0), failing, team)
+    assert calls["n"] >= 2
     dist.barrier()
     dist.destroy_process_group()
     Path(out_dir, f"ok{rank}").write_text("ok")
@@ -247,3 +276,25 @@ def test_bench_two_rank_control_flow(tmp_path):
     port = _free_port()
     mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "bench_ok0").exists() and (tmp_path / "bench_ok1").exists()
+
+
+def test_subtrees_travel_in_flat_form_at_the_default_recursion_limit():
+    # "forked" teams exchange subtrees; a linked tree pickles by recursion (one level per tree
+    # level), the flat form does not: a 5 000-level caterpillar at a recursion limit of 1 000
+    import pickle
+
+    from spectralclustersupertree_amd.tree import TreeNode
+
+    node = TreeNode("t0", None, 0.5)
+    for i in range(1, 5000):
+        node = TreeNode(None, [node, TreeNode(f"t{i}", None, 0.25 * i, None)], 1.0 / i, float(i))
+    old = sys.getrecursionlimit()
+    sys.setrecursionlimit(1000)
+    try:
+        back = pickle.loads(pickle.dumps(node))
+        again = TreeNode.from_flat(node.to_flat())
+    finally:
+        sys.setrecursionlimit(old)
+    for other in (back, again):
+        assert other.to_flat() == node.to_flat()
+        assert other.get_newick(with_distances=True) == node.get_newick(with_distances=True)
