@@ -256,3 +256,30 @@ def test_config3_fiedler_against_the_reference_solve():
 def test_config4_single_device_properties(dev):
     """configs[4] on ONE device: 100 000 taxa / 5 000 weighted trees / branch (W = 80 GB)."""
     _large_config_properties(dev, 100000, 5000, True, 24, [(0, 99000)])
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(not os.environ.get("SCS_SLOW_TESTS"),
+                    reason="about 7 minutes on the box (10^9 tree nodes, 61 000 recursion nodes): set "
+                           "SCS_SLOW_TESTS=1; committed runs: profiles/r03_config4_full_recursion_run*.json")
+def test_config4_full_recursion_properties():
+    """configs[4]'s "full recursion" leg at its real shape -- 100 000 taxa / 5 000 weighted trees
+    -- through ``construct_supertree``'s recursion (reference: scs.py:96-174): every taxon once,
+    the root's subtrees = the top-level labels, every call partitions its taxa, and the same
+    supertree and RandomState position as the committed run."""
+    import json
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    import full_recursion_check
+
+    res = full_recursion_check.run(100000, 5000, True)
+    print("CFG4 full recursion:", res)
+    assert res["every_taxon_exactly_once"]
+    assert res["top_level_parts_equal_top_level_labels"]
+    assert res["every_call_partitions_its_taxa"]
+    committed = Path(__file__).resolve().parents[1] / "profiles" / "r03_config4_full_recursion_run1.json"
+    if committed.exists():
+        want = json.loads(committed.read_text())
+        assert res["newick_sha256"] == want["newick_sha256"]
+        assert res["random_state_next_draw"] == want["random_state_next_draw"]
+        assert res["spectral_calls"] == want["spectral_calls"]
