@@ -176,14 +176,6 @@ struct mono_params {
     int mirror;                  // 1: last batch of a symmetric build: write the mirror image too
     double *tile_out;            // shared multi-rank build: packed 64 x 256 tiles (else null)
     unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
-    // Chunked launch: the batch's trees are cut into n_chunks runs of chunk_trees and the grid is
-    // n_chunks x n_tiles workgroups, chunk-major.  Workgroup (c, T) continues the sums of
-    // (c - 1, T): it waits until done[T] >= c.  With a few thousand uniform tiles on 768 slots a
-    // launch ends in a round that fills a quarter of the chip; shorter items hand the slots over
-    // as they finish (configs[2]: 3 277 tiles, 4.27 rounds -> the fifth round cost 15 %).
-    int n_tiles, n_chunks, chunk_trees;
-    int *done;                   // [n_tiles], zeroed before the launch
-    int *error;                  // set to 1 when a dependency wait ran out (never in a sound launch)
 };
 
 // ---- end of a tile (shared by the monotone and the general tile kernel): write the sums once,
@@ -191,7 +183,6 @@ struct mono_params {
 // of a symmetric build.  s_dv: the workgroup's table space (free once the last tree is done).
 template <bool SYM, typename P>
 __device__ __forceinline__ void tile_store(const P &p, double (&acc)[SCS_TR], const int2 tile,
-                                           const int tile_idx, const bool last_chunk,
                                            const int row0, const int col, const int self,
                                            const int tid, const int lane, const int wave,
                                            double *s_dv) {
@@ -201,7 +192,7 @@ __device__ __forceinline__ void tile_store(const P &p, double (&acc)[SCS_TR], co
             if (i == self) acc[i] = 0.0;
     }
     if (p.tile_out) {
-        double *tp = p.tile_out + (int64_t)tile_idx * SCS_TR * MONO_TCW + tid;
+        double *tp = p.tile_out + (int64_t)blockIdx.x * SCS_TR * MONO_TCW + tid;
 #pragma unroll
         for (int i = 0; i < SCS_TR; ++i) tp[i * MONO_TCW] = acc[i];
         return;
@@ -213,7 +204,7 @@ __device__ __forceinline__ void tile_store(const P &p, double (&acc)[SCS_TR], co
             if (r < p.row_end) p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
         }
     }
-    if (SYM && p.mirror && last_chunk) {
+    if (SYM && p.mirror) {
         // The mirror image W[c][r] of the tile (cells no tile of the schedule owns; only the last
         // batch writes it -- earlier batches are re-read through the direct cells).  Stored
         // straight from the accumulators every lane would write 8 bytes into a different row;
@@ -266,39 +257,11 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
     // (the wave index and everything read from the record are wave-uniform: saying so keeps
     // them in scalar registers)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // item = (chunk, tile), chunk-major: workgroups are dispatched in index order, so the
-    // workgroup this one waits for (same tile, previous chunk) was dispatched before it
-    const int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / (unsigned)p.n_tiles));
-    const int tile_idx = __builtin_amdgcn_readfirstlane((int)(blockIdx.x - (unsigned)chunk * (unsigned)p.n_tiles));
-    const int2 tile = p.tiles[tile_idx];
+    const int2 tile = p.tiles[blockIdx.x];
     const int blk = tile.x;
     const int row0 = p.row_begin + blk * SCS_TR;
     const int col = tile.y * MONO_TCW + tid;
     const int nt = p.n_batch;
-    const int t_lo = chunk * p.chunk_trees;
-    const int t_hi = min(nt, t_lo + p.chunk_trees);
-    const bool load_w = p.load_w || chunk > 0;
-    if (chunk > 0) {
-        // wait for the previous chunk of this tile (relaxed polls, one acquire at the end; the
-        // producer released its stores before it raised the counter).  Bounded: a launch whose
-        // dispatch order broke the assumption above ends with *error = 1, not with a hang.
-        __shared__ int s_ok;
-        if (tid == 0) {
-            int ok = 0;
-            for (unsigned spin = 0; spin < (1u << 22); ++spin) {
-                if (__hip_atomic_load(&p.done[tile_idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= chunk) {
-                    ok = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(32);
-            }
-            if (!ok) __hip_atomic_store(p.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            s_ok = ok;
-        }
-        __syncthreads();
-        if (!s_ok) return;
-    }
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     // a column that is one of the tile's own rows (tiles on the diagonal): its cells are the
     // row-row table itself, no search or range-minimum needed; W[c][c] stays 0
@@ -308,9 +271,9 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
 #pragma unroll
     for (int i = 0; i < SCS_TR; ++i) {
         double v = 0.0;
-        if (load_w && p.tile_out)
-            v = p.tile_out[((int64_t)tile_idx * SCS_TR + i) * MONO_TCW + tid];
-        else if (load_w && col < p.n && row0 + i < p.row_end)
+        if (p.load_w && p.tile_out)
+            v = p.tile_out[((int64_t)blockIdx.x * SCS_TR + i) * MONO_TCW + tid];
+        else if (p.load_w && col < p.n && row0 + i < p.row_end)
             v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
         acc[i] = v;
     }
@@ -385,7 +348,7 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         qx = *(const double *)(st + (unsigned)o[0] * 8u);
         qy = *(const double *)(st + (unsigned)o[1] * 8u);
         cpos_next = __builtin_amdgcn_raw_buffer_load_b32(
-            r_pos, col4, min(tl + 1, t_hi - 1) * (int)p.npad * 4, 0);
+            r_pos, col4, min(tl + 1, nt - 1) * (int)p.npad * 4, 0);
     };
 
     // expand tree tl's row-row value table into s_dv.  In rank space entry (a, b), a < b, is
@@ -426,12 +389,12 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
     };
 
     // ---- prologue: records 0 and 1, the column's position in tree 0; then tree 0's column step
-    issue_record(t_lo, t_lo & 1);
-    issue_record(min(t_lo + 1, t_hi - 1), (t_lo + 1) & 1);
-    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, t_lo * (int)p.npad * 4, 0);
+    issue_record(0, 0);
+    issue_record(min(1, nt - 1), 1);
+    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    column_issue(t_lo, cpos_next);  // 3 operations in flight: 2 table loads + the next position
+    column_issue(0, cpos_next);  // 3 operations in flight: 2 table loads + the next position
     if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 
     // Order inside a step (tree tl).  The compiler cannot tell an LDS-DMA in flight from the
@@ -439,7 +402,7 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
     // follows one, so the step's only DMA -- the record of tree tl + 2 -- is issued after the
     // last LDS access the compiler sees (the cell loop is opaque to it); the table loads of
     // the column step have the whole cell loop to come back.
-    for (int tl = t_lo; tl < t_hi; ++tl) {
+    for (int tl = 0; tl < nt; ++tl) {
         // the column's loads for tree tl, its position in tree tl + 1, this wave's piece of
         // the record of tree tl + 1 (all issued a cell loop ago)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,13 +426,13 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         stamp(2);
         // (the last step searches its own tree again, result unused: keeps the step free of
         // branches the compiler would have to merge wait states over)
-        column_issue(min(tl + 1, t_hi - 1), cpos_next);  // 3 operations
+        column_issue(min(tl + 1, nt - 1), cpos_next);  // 3 operations
         stamp(3);
         expand(tl);
         stamp(4);
         SCS_BARE_BARRIER();  // B: the table is complete; the record of tree tl is free
         stamp(5);
-        issue_record(min(tl + 2, t_hi - 1), tl & 1);
+        issue_record(min(tl + 2, nt - 1), tl & 1);
         {
             double tmp[SCS_CELLS_DEPTH];
             const unsigned addr =
@@ -484,15 +447,5 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
         atomicAdd(&p.stamps[7], 1ull);
     }
-    tile_store<SYM>(p, acc, tile, tile_idx, chunk == p.n_chunks - 1, row0, col, self, tid, lane, wave, s_dv);
-    if (p.n_chunks > 1 && chunk + 1 < p.n_chunks) {
-        // publish: every wave's stores are out, then ONE agent-scope release, then the counter
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&p.done[tile_idx], chunk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    tile_store<SYM>(p, acc, tile, row0, col, self, tid, lane, wave, s_dv);
 }
