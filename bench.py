@@ -75,9 +75,10 @@ def parse_args():
     ap.add_argument("--tol", type=float, default=1e-13)
     ap.add_argument("--max-iter", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-shared", action="store_true",
-                    help="multi-rank runs: every rank evaluates all cells of its own rows "
-                         "instead of sharing the upper-triangle tiles")
+    ap.add_argument("--multi-rank-mode", default="upper", choices=["upper", "shared", "rows"],
+                    help="N > 1: 'upper' = the job keeps only the upper triangle of W (no exchange, the "
+                         "solve adds the ranks' partial products); 'shared' = row-partitioned W, upper tiles "
+                         "computed once and exchanged; 'rows' = every rank evaluates all cells of its rows")
     ap.add_argument("--no-parity", action="store_true",
                     help="profiling runs: skip the oracle gates (never for a reported number)")
     ap.add_argument("--no-extra", action="store_true",
@@ -87,11 +88,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def even_splits(n: int, world: int) -> list[int]:
-    """Contiguous row blocks, boundaries on multiples of 64 (the build's tile height)."""
-    from spectralclustersupertree_amd.partition import row_splits
+def even_splits(n: int, world: int, upper: bool = False) -> list[int]:
+    """Contiguous row blocks: boundaries on multiples of 64 (the build's tile height), or --
+    upper-triangle jobs -- on multiples of 256 with equal trapezoid areas."""
+    from spectralclustersupertree_amd.partition import row_splits, row_splits_upper
 
-    return row_splits(n, world)
+    return row_splits_upper(n, world) if upper else row_splits(n, world)
 
 
 def make_input(name, args, seed, planted):
@@ -191,7 +193,8 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     """Time `steps` passes of build + solve on one named workload; returns the report."""
     seed = args.seed if seed is None else seed
     tables, (n, m, strategy, rw, cfg_idx), t_gen = make_input(name, args, seed, planted)
-    splits = even_splits(n, world)
+    mode = args.multi_rank_mode if world > 1 else "single"
+    splits = even_splits(n, world, upper=(mode == "upper"))
     rb, re_ = splits[rank], splits[rank + 1]
 
     t_up0 = time.perf_counter()
@@ -207,7 +210,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
 
     def one_step(keep=False, tab=None):
         """build + solve on resident tables (`tab`, default the set uploaded above)"""
-        graph = (tab or dtab).build(rb, re_, shared=(world > 1 and not args.no_shared))
+        graph = (tab or dtab).build(rb, re_, shared=(mode == "shared"), upper=(mode == "upper"))
         maps, stats = graph.fiedler(v0, tol=args.tol, max_iter=args.max_iter, block=args.block)
         bstats = graph.build_stats
         if keep:
@@ -268,7 +271,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     # B_C = n_apply (W bytes of one apply + 16 V b) + n_iter 72 V b with the W
     # bytes the SELECTED kernel must stream -- 4 V^2 (upper tiles) when the symmetric SYMM ran,
     # 8 rows V otherwise: stats["apply_bytes"] is exactly that; B_A = bytes_w + tables
-    symm_tri = stats["apply_bytes"] < 6.0 * (re_ - rb) * n
+    symm_tri = mode == "upper" or stats["apply_bytes"] < 6.0 * (re_ - rb) * n
     b_c = n_apply_step * stats["apply_bytes"] + (acc["iters"] / steps) * 72.0 * n * stats["block"]
     path_gbs = (build_bytes + b_c) / sec_per_step / 1e9
 
@@ -339,10 +342,13 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
             "pcg_weighting": strategy,
             "seed": seed,
             "parallelism": "single device, symmetric tile schedule" if world == 1
-            else f"W row-partitioned over {world} ranks ("
-                 + ("upper-triangle tiles split round-robin, packed tiles exchanged once"
-                    if bstats["symmetric"] == 2 else "every rank evaluates all cells of its rows")
-                 + "), RCCL all-gather of the Krylov block per iteration",
+            else (f"the upper triangle of W over {world} ranks by rows (equal trapezoids, no exchange); per "
+                  "iteration every rank applies its tiles directly and transposed and one RCCL all-gather "
+                  "collects the V x b partial products, added in rank order" if mode == "upper" else
+                  f"W row-partitioned over {world} ranks ("
+                  + ("upper-triangle tiles split round-robin, packed tiles exchanged once"
+                     if bstats["symmetric"] == 2 else "every rank evaluates all cells of its rows")
+                  + "), RCCL all-gather of the Krylov block per iteration"),
             "lobpcg_block": stats["block"],
             "tol": args.tol,
         },
@@ -468,7 +474,9 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
             want = to.pcg_rows(tables, rows)
             mismatch = 0
             for i, r in enumerate(rows):
-                mismatch += int(np.count_nonzero(kept.download_rows(int(r), 1)[0] != want[i]))
+                # (an upper-triangle job stores a row from its 256-column diagonal tile on)
+                c0 = (int(r) // 256 * 256) if mode == "upper" else 0
+                mismatch += int(np.count_nonzero(kept.download_rows(int(r), 1)[0][c0:] != want[i][c0:]))
             report["parity"] = {
                 "w_rows_checked": int(len(rows)),
                 "w_cells_mismatched": mismatch,

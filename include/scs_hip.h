@@ -161,6 +161,18 @@ int scs_tables_free(scs_ctx *ctx, scs_tables *tables);
  * NULL. */
 #define SCS_BUILD_MONOTONE 1
 #define SCS_BUILD_SHARED 2
+/* SCS_BUILD_UPPER (world > 1, every rank passes it or none does; not together with
+ * SCS_BUILD_SHARED): W is symmetric, so the job keeps only its upper triangle.  Rank r builds the
+ * tiles on and right of the diagonal of ITS rows and nothing else -- every cell is evaluated
+ * once across the job, there is NO exchange, and the rank stores (row_end - row_begin) x
+ * (V - row_begin) doubles instead of (row_end - row_begin) x V.  row_begin must be a multiple
+ * of 256 (the tile width); splits that balance the trapezoids' areas come from the host
+ * (partition.row_splits_upper).  scs_fiedler applies the operator from these tiles twice
+ * (directly and transposed), all-gathers the ranks' V x b partial products and adds them in
+ * rank order -- half the streamed bytes of the row-partitioned solve at every world size, the
+ * same bits on every rank.  Such a graph cannot be contracted (scs_graph_contract needs whole
+ * rows: SCS_EUNSUP); scs_graph_download_rows returns zeros left of the rank's first column. */
+#define SCS_BUILD_UPPER 4
 int scs_pcg_build(scs_ctx *ctx, const scs_tables *tables, int32_t row_begin, int32_t row_end,
                   int32_t flags, scs_graph **out, scs_build_stats *stats);
 

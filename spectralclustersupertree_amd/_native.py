@@ -18,6 +18,7 @@ LIB_PATH = _PKG / "libscs_hip.so"
 UNIQUE_ID_BYTES = 128
 BUILD_MONOTONE = 1  # SCS_BUILD_MONOTONE
 BUILD_SHARED = 2  # SCS_BUILD_SHARED
+BUILD_UPPER = 4  # SCS_BUILD_UPPER
 
 
 class ScsError(RuntimeError):

@@ -178,18 +178,26 @@ class DeviceTables:
             pass
 
     def build(self, row_begin: int = 0, row_end: int | None = None,
-              shared: bool | None = None) -> "DeviceGraph":
+              shared: bool | None = None, upper: bool = False) -> "DeviceGraph":
         """Rows [row_begin, row_end) of W (reference: scs.py:495-663).
 
         ``shared`` (default: on whenever the device belongs to a multi-rank job) makes the
         call collective: the ranks split the upper-triangle tiles, exchange them and keep
         their own rows, so no cell is evaluated twice across the job.
+
+        ``upper`` (multi-rank jobs, instead of ``shared``): every rank keeps only the tiles on
+        and right of the diagonal of its own rows -- no exchange, half the memory, and the
+        solve streams half the bytes (``SCS_BUILD_UPPER``; ``row_begin`` a multiple of 256, see
+        ``partition.row_splits_upper``).  Not for nodes that contract.
         """
         if row_end is None:
             row_end = self.n_taxa
         handle = C.c_void_p()
         stats = nv.BuildStats()
         flags = nv.BUILD_MONOTONE if self.monotone else 0
+        if upper:
+            flags |= nv.BUILD_UPPER
+            shared = False
         if shared is None:
             shared = self.dev.world > 1
         if shared:

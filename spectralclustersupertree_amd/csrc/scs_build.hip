@@ -226,6 +226,46 @@ __global__ __launch_bounds__(256) void k_degrees(const double *__restrict__ w, i
     if (lane == 0) deg_full[row_begin + r] = s;
 }
 
+// SCS_BUILD_UPPER graphs (a rank stores the tiles on and right of the diagonal of its rows):
+// the degree of v is the sum of what the symmetric SYMM applies -- row v from the first column
+// of its 256-column diagonal tile on (the tile is stored whole: pairs inside it are met from
+// both rows), plus, transposed, column v over the rows of earlier 256-row blocks.  One wave per
+// row, then one thread per column walking this rank's rows in order: fixed orders, no atomics.
+__global__ __launch_bounds__(256) void k_degrees_upper_rows(const double *__restrict__ w, int64_t ld, int n,
+                                                             int rows, int row_begin, int col0,
+                                                             double *__restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int rl = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rl >= rows) return;
+    const int r = row_begin + rl;
+    const int c0 = r / 256 * 256;
+    const double *row = w + (int64_t)rl * ld + (c0 - col0);
+    const int cnt = n - c0;
+    double s0 = 0.0, s1 = 0.0;
+    const int n2 = cnt & ~1;
+    for (int j = lane * 2; j < n2; j += 128) {
+        const double2 v = *(const double2 *)(row + j);
+        s0 += v.x;
+        s1 += v.y;
+    }
+    if ((cnt & 1) && lane == 0) s0 += row[cnt - 1];
+    double s = s0 + s1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) part[r] = s;
+}
+
+__global__ __launch_bounds__(256) void k_degrees_upper_cols(const double *__restrict__ w, int64_t ld, int n,
+                                                             int row_begin, int row_end, int col0,
+                                                             double *__restrict__ part) {
+    const int c = col0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const int r_end = min(row_end, c / 256 * 256);  // rows of earlier 256-row blocks only
+    double s = 0.0;
+    for (int r = row_begin; r < r_end; ++r) s += w[(int64_t)(r - row_begin) * ld + (c - col0)];
+    if (r_end > row_begin) part[c] += s;  // (c in this rank's rows: after its row sum; same thread order every run)
+}
+
 // row-partitioned graphs: the gathered per-rank degree vectors (zero outside a rank's rows)
 __global__ void k_combine_degrees(const double *__restrict__ gathered, int world, int n,
                                   double *__restrict__ deg) {
@@ -328,13 +368,15 @@ int levels_for(int64_t m) {
 }  // namespace
 
 static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_end,
-                       hipStream_t stream, scs_graph **out) {
+                       hipStream_t stream, scs_graph **out, int32_t col0 = 0) {
     auto *g = new scs_graph();
     g->n = n;
     g->row_begin = row_begin;
     g->row_end = row_end;
+    g->col0 = col0;
+    g->upper = col0 > 0 || false;
     // k_symm's layout contract: ld a multiple of 512 doubles, padding columns zero
-    g->ld = scs_round_up(n, SCS_LD_ALIGN);
+    g->ld = scs_round_up(n - col0, SCS_LD_ALIGN);
     const size_t rows = (size_t)(row_end - row_begin);
     size_t bytes = rows * (size_t)g->ld * sizeof(double);
     if (bytes < 16) bytes = 16;
@@ -360,8 +402,9 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
         }
         g->w_bytes = bytes;
     }
-    if (g->ld > n) {
-        hipError_t e = hipMemset2DAsync(g->d_w + n, (size_t)g->ld * 8, 0, (size_t)(g->ld - n) * 8, rows, stream);
+    if (g->ld > n - col0) {
+        hipError_t e = hipMemset2DAsync(g->d_w + (n - col0), (size_t)g->ld * 8, 0,
+                                        (size_t)(g->ld - (n - col0)) * 8, rows, stream);
         if (e != hipSuccess) {
             hipFree(g->d_w);
             delete g;
@@ -434,8 +477,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                              int32_t row_end, int32_t flags, scs_graph **out,
                              scs_build_stats *stats) {
     SCS_REQUIRE(ctx && tb && out, "scs_pcg_build: null argument");
-    SCS_REQUIRE((flags & ~(SCS_BUILD_MONOTONE | SCS_BUILD_SHARED)) == 0,
+    SCS_REQUIRE((flags & ~(SCS_BUILD_MONOTONE | SCS_BUILD_SHARED | SCS_BUILD_UPPER)) == 0,
                 "scs_pcg_build: unknown flag bits 0x%x", flags);
+    SCS_REQUIRE((flags & (SCS_BUILD_SHARED | SCS_BUILD_UPPER)) != (SCS_BUILD_SHARED | SCS_BUILD_UPPER),
+                "scs_pcg_build: SCS_BUILD_SHARED and SCS_BUILD_UPPER exclude each other");
     const bool monotone = (flags & SCS_BUILD_MONOTONE) != 0 &&
                           !(getenv("SCS_NO_MONOTONE") && atoi(getenv("SCS_NO_MONOTONE")));
     const int n = tb->n_taxa;
@@ -465,12 +510,24 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // rows the accumulate kernels see: the whole matrix when shared
     const int b_row_begin = shared ? 0 : row_begin, b_row_end = shared ? n : row_end;
     const bool sym = !shared && (row_begin == 0 && row_end == n && world == 1);
-    const bool upper = sym || shared;
+    // SCS_BUILD_UPPER: only the tiles on and right of the diagonal of this rank's rows, stored
+    // from column row_begin on; no mirror image, no exchange
+    const bool trapezoid = (flags & SCS_BUILD_UPPER) != 0;
+    if (trapezoid)
+        SCS_REQUIRE(row_begin % cols_per_tile == 0,
+                    "scs_pcg_build: SCS_BUILD_UPPER needs row_begin (%d) to be a multiple of %d", row_begin,
+                    cols_per_tile);
+    const bool upper = sym || shared || trapezoid;
+    const int gb0 = b_row_begin / SCS_TR;  // global index of the first row block (upper test)
     const int rows = row_end - row_begin;
     const int n_blocks = (b_row_end - b_row_begin + SCS_TR - 1) / SCS_TR;
 
     scs_graph *g = nullptr;
-    SCS_TRY(graph_alloc(ctx, n, row_begin, row_end, s, &g));
+    SCS_TRY(graph_alloc(ctx, n, row_begin, row_end, s, &g, trapezoid ? row_begin : 0));
+    g->upper = trapezoid;
+    // (the kernels index W by global column: a base shifted left by col0 makes
+    // w[(r - row_begin) * ld + c] land on the stored cell for every c >= col0)
+    double *w_base = g->d_w - g->col0;
     struct guard {
         scs_ctx *c;
         scs_graph *g;
@@ -484,7 +541,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     tiles.reserve((size_t)n_blocks * n_cgroups);
     for (int b = 0; b < n_blocks; ++b)
         for (int c = 0; c < n_cgroups; ++c) {
-            if (upper && (int64_t)(c + 1) * cols_per_tile <= (int64_t)b * SCS_TR) continue;
+            if (upper && (int64_t)(c + 1) * cols_per_tile <= (int64_t)(gb0 + b) * SCS_TR) continue;
             tiles.push_back(make_int2(b, c));
         }
     // XCD-aware order: workgroups go to the eight XCDs round-robin by index and all tiles
@@ -672,7 +729,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.npad = npad;
             mp.stv = (const double *)d_st.p;
             mp.n_batch = nb;
-            mp.w = g->d_w;
+            mp.w = w_base;
             mp.ld = g->ld;
             mp.n = n;
             mp.row_begin = b_row_begin;
@@ -711,7 +768,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             gp.npad = npad;
             gp.ste = (const gap_entry *)d_st.p;
             gp.n_batch = nb;
-            gp.w = g->d_w;
+            gp.w = w_base;
             gp.ld = g->ld;
             gp.n = n;
             gp.row_begin = b_row_begin;
@@ -841,6 +898,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
 extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *group_start,
                                   int32_t n_groups, scs_graph **out) {
     SCS_REQUIRE(ctx && g && group_start && out, "scs_graph_contract: null argument");
+    if (g->upper) {
+        scs_set_error("scs_graph_contract: an SCS_BUILD_UPPER graph holds no whole rows; build it "
+                      "row-partitioned (SCS_BUILD_SHARED) when the node contracts");
+        return SCS_EUNSUP;
+    }
     SCS_REQUIRE(n_groups >= 1 && n_groups <= g->n, "scs_graph_contract: bad group count %d",
                 n_groups);
     SCS_REQUIRE(group_start[0] == 0 && group_start[n_groups] == g->n,
@@ -882,11 +944,15 @@ extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *gro
     return SCS_OK;
 }
 
+extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t first, int32_t count,
+                                       double *out);
+
 extern "C" int scs_graph_download(scs_ctx *ctx, const scs_graph *g, double *out) {
     SCS_REQUIRE(ctx && g && out, "scs_graph_download: null argument");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const size_t rows = (size_t)(g->row_end - g->row_begin);
+    if (g->upper) return scs_graph_download_rows(ctx, g, g->row_begin, (int32_t)rows, out);
     SCS_HIP_CHECK(hipMemcpy2D(out, (size_t)g->n * 8, g->d_w, (size_t)g->ld * 8, (size_t)g->n * 8,
                               rows, hipMemcpyDeviceToHost));
     return SCS_OK;
@@ -900,6 +966,20 @@ extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t
                 first + count, g->row_begin, g->row_end);
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (g->upper) {
+        // stored: columns [col0, n); defined: from the row's 256-column diagonal tile on.  The
+        // rest comes back as zeros.
+        const size_t wcols = (size_t)(g->n - g->col0);
+        for (int32_t i = 0; i < count; ++i) memset(out + (size_t)i * g->n, 0, (size_t)g->n * 8);
+        SCS_HIP_CHECK(hipMemcpy2D(out + g->col0, (size_t)g->n * 8,
+                                  g->d_w + (int64_t)(first - g->row_begin) * g->ld, (size_t)g->ld * 8,
+                                  wcols * 8, (size_t)count, hipMemcpyDeviceToHost));
+        for (int32_t i = 0; i < count; ++i) {
+            const int32_t c0 = (first + i) / 256 * 256;
+            if (c0 > g->col0) memset(out + (size_t)i * g->n + g->col0, 0, (size_t)(c0 - g->col0) * 8);
+        }
+        return SCS_OK;
+    }
     SCS_HIP_CHECK(hipMemcpy2D(out, (size_t)g->n * 8, g->d_w + (int64_t)(first - g->row_begin) * g->ld,
                               (size_t)g->ld * 8, (size_t)g->n * 8, (size_t)count,
                               hipMemcpyDeviceToHost));
@@ -917,7 +997,7 @@ int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
     if (!g->d_deg) SCS_HIP_CHECK(hipMalloc((void **)&g->d_deg, (size_t)n * 8));
     if (!g->d_dinv) SCS_HIP_CHECK(hipMalloc((void **)&g->d_dinv, (size_t)n * 8));
     const int world = ctx->comm.world;
-    if (world == 1) {
+    if (world == 1 && !g->upper) {
         k_degrees<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg);
     } else {
         // every rank contributes a V-long vector that is zero outside its rows
@@ -925,6 +1005,12 @@ int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
         SCS_TRY(send.alloc((size_t)n * 8));
         SCS_TRY(recv.alloc((size_t)n * 8 * world));
         SCS_HIP_CHECK(hipMemsetAsync(send.p, 0, (size_t)n * 8, s));
+        if (g->upper) {
+            k_degrees_upper_rows<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin,
+                                                                g->col0, (double *)send.p);
+            k_degrees_upper_cols<<<(n - g->col0 + 255) / 256, 256, 0, s>>>(
+                g->d_w, g->ld, n, g->row_begin, g->row_end, g->col0, (double *)send.p);
+        } else
         k_degrees<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin,
                                                  (double *)send.p);
         SCS_TRY(scs_comm_allgather_f64(&ctx->comm, (const double *)send.p, (double *)recv.p,

@@ -297,6 +297,17 @@ __global__ void k_trivial(const double *__restrict__ deg, double inv_norm, int n
     if (i < n) u[i] = sqrt(deg[i]) * inv_norm;
 }
 
+// SCS_BUILD_UPPER jobs: y = dinv (.) (sum over ranks, in rank order, of the gathered partial
+// products); parts is world x (n * b)
+__global__ void k_sum_parts(const double *__restrict__ parts, int world, int n, int b,
+                            const double *__restrict__ dinv, double *__restrict__ y) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * b) return;
+    double s = 0.0;
+    for (int r = 0; r < world; ++r) s += parts[(int64_t)r * n * b + idx];
+    y[idx] = dinv[idx / b] * s;
+}
+
 // ---------------------------------------------------------------------------
 // one-workgroup parallel Jacobi eigensolver (n <= 64), LDS resident
 // ---------------------------------------------------------------------------
@@ -1058,18 +1069,27 @@ struct solver {
 
     int last_nseg = 1;  // column segments of the most recent k_symm launch
 
-    // symmetric schedule (k_symm_tri): the whole matrix on this device, streamed by upper tiles
-    bool tri = false;
+    // symmetric schedule (k_symm_tri): the whole matrix on this device, streamed by upper tiles;
+    // or (SCS_BUILD_UPPER graphs, `part`) this rank's tiles of the job's upper triangle: its
+    // product is then PARTIAL -- all V rows, to be added to the other ranks' in rank order
+    bool tri = false, part_mode = false;
     int tri_ct = 2, tri_nct = 0, tri_ntiles = 0;
-    dbuf tri_tiles, tri_pdir, tri_ptr;
+    int tri_rb_lo = 0, tri_rb_hi = 0x7FFFFFFF;  // this rank's row blocks (of TRI_TH rows)
+    dbuf tri_tiles, tri_pdir, tri_ptr, ysend;
+    int64_t ldz = 0;                 // leading dimension of the k-major operand z
     double w_bytes_per_apply = 0.0;  // bytes of W one application streams
 
     int launch_symm_tri(const double *zin, double *yout) {
         const int tw = tri_ct * 128;
+        // global indices address the stored block: an SCS_BUILD_UPPER rank keeps rows from
+        // row_begin and columns from col0 on; its transposed partials only need the slabs of
+        // its own row blocks
+        const double *w_eff = g->d_w - (int64_t)g->row_begin * g->ld - g->col0;
+        double *ptr_eff = tri_ptr.d() - (int64_t)tri_rb_lo * n * b;
 #define TRI(B_, CT_, RPW_, D_)                                                                       \
-    k_symm_tri<B_, CT_, RPW_, D_><<<tri_ntiles, 256, 0, s>>>(g->d_w, g->ld, n, zin,                  \
+    k_symm_tri<B_, CT_, RPW_, D_><<<tri_ntiles, 256, 0, s>>>(w_eff, g->ld, n, zin, ldz,              \
                                                              (const int2 *)tri_tiles.p, tri_pdir.d(), \
-                                                             tri_ptr.d())
+                                                             ptr_eff)
         if (b == 4) {
             if (tri_ct == 4) TRI(4, 4, 2, 3);
             else if (tri_ct == 1) TRI(4, 1, 4, 4);
@@ -1080,6 +1100,19 @@ struct solver {
         }
 #undef TRI
         SCS_HIP_CHECK(hipGetLastError());
+        if (part_mode) {
+            // this rank's partial product, unscaled, all V rows: gathered and added by the caller
+            k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), ptr_eff, n, b, tw, tri_nct,
+                                                                  nullptr, ysend.d(), tri_rb_lo, tri_rb_hi);
+            SCS_HIP_CHECK(hipGetLastError());
+            SCS_TRY(scs_comm_allgather_f64(&ctx->comm, ysend.d(), recv.d(), (size_t)n * b, s));
+            if (yout) {
+                k_sum_parts<<<(n * b + 255) / 256, 256, 0, s>>>(recv.d(), world, n, b, g->d_dinv, yout);
+                SCS_HIP_CHECK(hipGetLastError());
+            }
+            last_nseg = world;
+            return SCS_OK;
+        }
         // one segment: scaled into yout, or unscaled into ypart for k_gram_qaq to fold in
         k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), tri_ptr.d(), n, b, tw, tri_nct,
                                                               yout ? g->d_dinv : nullptr,
@@ -1137,9 +1170,39 @@ struct solver {
     int alloc_symm_buffers() {
         ypart_cap = (size_t)4 * rows * b;
         SCS_TRY(ypart.alloc(ypart_cap * 8));
-        SCS_TRY(z.alloc((size_t)b * g->ld * 8));
-        SCS_HIP_CHECK(hipMemsetAsync(z.p, 0, (size_t)b * g->ld * 8, s));
+        ldz = g->upper ? scs_round_up(n, SCS_LD_ALIGN) : g->ld;
+        SCS_TRY(z.alloc((size_t)b * ldz * 8));
+        SCS_HIP_CHECK(hipMemsetAsync(z.p, 0, (size_t)b * ldz * 8, s));
         w_bytes_per_apply = 8.0 * rows * (double)n;
+        if (g->upper) {
+            // the job's upper triangle, this rank's row blocks: TW = 256 (the diagonal tile of a
+            // row block then starts where the build's stored cells of those rows start)
+            if (b != 4 && b != 8) {
+                scs_set_error("an SCS_BUILD_UPPER graph is solved with block width 4 or 8 (asked: %d)", b);
+                return SCS_EUNSUP;
+            }
+            tri = true;
+            part_mode = true;
+            tri_ct = 2;
+            const int tw = 256;
+            tri_nct = (n + tw - 1) / tw;
+            tri_rb_lo = g->row_begin / TRI_TH;
+            tri_rb_hi = (g->row_end + TRI_TH - 1) / TRI_TH;
+            std::vector<int2> tiles;
+            for (int i = tri_rb_lo; i < tri_rb_hi; ++i)
+                for (int j = i * TRI_TH / tw; j < tri_nct; ++j) tiles.push_back(make_int2(i, j));
+            tri_ntiles = (int)tiles.size();
+            SCS_TRY(tri_tiles.alloc(std::max<size_t>(tiles.size(), 1) * sizeof(int2)));
+            SCS_HIP_CHECK(hipMemcpyAsync(tri_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
+                                         hipMemcpyHostToDevice, s));
+            SCS_HIP_CHECK(hipStreamSynchronize(s));  // `tiles` goes out of scope
+            SCS_TRY(tri_pdir.alloc((size_t)tri_nct * n * b * 8));
+            SCS_TRY(tri_ptr.alloc((size_t)(tri_rb_hi - tri_rb_lo) * n * b * 8));
+            SCS_TRY(ysend.alloc((size_t)n * b * 8));
+            if (!recv.p) SCS_TRY(recv.alloc((size_t)n * b * world * 8));
+            w_bytes_per_apply = 8.0 * (double)tri_ntiles * TRI_TH * tw;
+            return SCS_OK;
+        }
         // W is symmetric: with all of it on this device only the tiles on and above the
         // diagonal need streaming (small matrices keep k_symm, whose column segments fill the
         // chip better).  SCS_NO_TRI=1 keeps the full stream.
@@ -1169,7 +1232,7 @@ struct solver {
     int apply(const double *src, int c0s, double *dst, int c0d) {
         const int nb = n * b;
         k_scale_rows<<<(nb + 255) / 256, 256, 0, s>>>(src, 3 * b, c0s, b, n, g->d_dinv, z.d(),
-                                                      g->ld);
+                                                      ldz);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         SCS_TRY(new_event(&e0));
         SCS_TRY(new_event(&e1));
@@ -1180,7 +1243,10 @@ struct solver {
         SCS_HIP_CHECK(hipEventRecord(e1, s));
         ++n_apply;
         const double *yf = yloc.d();
-        if (world > 1) {
+        if (part_mode) {
+            // (launch_symm_tri gathered the ranks' partial products and yloc holds their scaled
+            // sum for all V rows)
+        } else if (world > 1) {
             SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
             k_unpack<<<(nb + 255) / 256, 256, 0, s>>>(recv.d(), chunk, b,
                                                       (const int32_t *)splits_d.p, world, n,
@@ -1238,7 +1304,7 @@ struct solver {
                                                       nullptr, 0);
         k_small_orth<<<1, 256, 0, s>>>(part.d(), nb, B, 0.0, coef, mask_r, theta, nullptr, 0.0);
         k_panel_tf<B, false, true><<<nb, 256, 0, s>>>(q.d(), uvec, coef, n, nullptr, g->d_dinv,
-                                                      z.d(), g->ld);
+                                                      z.d(), ldz);
         SCS_HIP_CHECK(hipGetLastError());
         return SCS_OK;
     }
@@ -1259,7 +1325,15 @@ struct solver {
         }
         const int nb = panel_blocks4();
         *nparts = nb;
-        if (world == 1) {
+        if (part_mode) {
+            // the gathered partial products (world x V x b, unscaled) are added in rank order and
+            // scaled inside the Gram kernel
+            if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
+            SCS_TRY(launch_symm(z.d(), nullptr));
+            if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
+            ++n_apply;
+            k_gram_qaq<B, 3><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, part.d());
+        } else if (world == 1) {
             if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
             SCS_TRY(launch_symm(z.d(), nullptr));
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
@@ -1350,6 +1424,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                            int32_t max_iter, int32_t block, double *maps_out, scs_stats *stats) {
     SCS_REQUIRE(ctx && g && maps_out, "scs_fiedler: null argument");
     SCS_REQUIRE(g->n >= 2, "scs_fiedler: need at least 2 vertices (have %d)", g->n);
+    SCS_REQUIRE(!g->upper || g->n > MAXS, "scs_fiedler: an SCS_BUILD_UPPER graph needs more than %d vertices", MAXS);
     SCS_REQUIRE(block >= 0 && block <= MAXB, "scs_fiedler: block must be in [0, %d]", MAXB);
     SCS_REQUIRE(tol > 0.0 && max_iter >= 1, "scs_fiedler: tol must be > 0 and max_iter >= 1");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1385,6 +1460,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // default width: 4 while the panel kernels and the 3b x 3b Rayleigh-Ritz solve weigh
     // against the SYMM stream, 8 once streaming W dominates (measured crossover ~ 16k)
     int b = block ? block : (n >= 16384 ? 8 : 4);
+    if (g->upper && b > 8) b = 8;  // the symmetric SYMM kernel comes in widths 4 and 8
     {
         const int allowed[] = {16, 12, 8, 4};
         const int cap = (n - 2) / 3;  // 3b basis vectors + the constraint must fit in V
@@ -1412,7 +1488,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     int max_rows = 0;
     for (int r = 0; r < sv.world; ++r)
         max_rows = std::max(max_rows, sv.splits[r + 1] - sv.splits[r]);
-    sv.chunk = (int64_t)max_rows * b;
+    sv.chunk = g->upper ? (int64_t)n * b : (int64_t)max_rows * b;  // (upper: whole partial products travel)
 
     SCS_TRY(sv.q.alloc((size_t)n * q3 * 8));
     SCS_TRY(sv.aq.alloc((size_t)n * q3 * 8));
@@ -1421,7 +1497,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_TRY(sv.u.alloc((size_t)n * 8));
     SCS_TRY(sv.part.alloc((size_t)1024 * q3 * q3 * 8));
     SCS_TRY(sv.small.alloc((size_t)SM_TOTAL * 8));
-    if (sv.world > 1) {
+    if (sv.world > 1 && !sv.part_mode) {
         SCS_TRY(sv.yfull.alloc((size_t)n * b * 8));
         SCS_TRY(sv.recv.alloc((size_t)sv.chunk * sv.world * 8));
         SCS_TRY(sv.splits_d.alloc((size_t)(sv.world + 1) * 4));
@@ -2155,17 +2231,20 @@ extern "C" int scs_debug_apply(scs_ctx *ctx, scs_graph *g, const double *x, int3
     sv.n = g->n;
     sv.b = b;
     sv.rows = g->row_end - g->row_begin;
+    sv.world = ctx->comm.world;
     const int n = g->n;
     dbuf dx;
     SCS_TRY(dx.alloc((size_t)n * b * 8));
     SCS_TRY(sv.alloc_symm_buffers());
-    SCS_TRY(sv.yloc.alloc((size_t)sv.rows * b * 8));
+    // (an SCS_BUILD_UPPER graph: collective, the product comes back for all V rows and this
+    // rank's slice of it is returned)
+    SCS_TRY(sv.yloc.alloc((size_t)(g->upper ? n : sv.rows) * b * 8));
     SCS_HIP_CHECK(hipMemcpyAsync(dx.p, x, (size_t)n * b * 8, hipMemcpyHostToDevice, ctx->stream));
     k_scale_rows<<<(n * b + 255) / 256, 256, 0, ctx->stream>>>(dx.d(), b, 0, b, n, g->d_dinv,
-                                                               sv.z.d(), g->ld);
+                                                               sv.z.d(), sv.ldz);
     SCS_TRY(sv.launch_symm(sv.z.d(), sv.yloc.d()));
-    SCS_HIP_CHECK(hipMemcpyAsync(y, sv.yloc.p, (size_t)sv.rows * b * 8, hipMemcpyDeviceToHost,
-                                 ctx->stream));
+    SCS_HIP_CHECK(hipMemcpyAsync(y, sv.yloc.d() + (g->upper ? (size_t)g->row_begin * b : 0),
+                                 (size_t)sv.rows * b * 8, hipMemcpyDeviceToHost, ctx->stream));
     SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SCS_OK;
 }

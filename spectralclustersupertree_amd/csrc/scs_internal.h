@@ -138,6 +138,11 @@ struct scs_graph {
     int32_t row_end = 0;
     int64_t ld = 0;         // leading dimension (doubles) of d_w
     double *d_w = nullptr;  // (row_end-row_begin) x ld, row-major
+    // SCS_BUILD_UPPER graphs: a row holds only the columns [col0, n) -- column c of row r sits at
+    // d_w[(r - row_begin) * ld + (c - col0)] -- and of those only the cells of the upper-triangle
+    // tiles are defined (everything the symmetric SYMM reads).  col0 = 0, upper = false otherwise.
+    int32_t col0 = 0;
+    bool upper = false;
     size_t w_bytes = 0;     // size of the d_w allocation (may exceed the need: reused buffer)
     // degree data for all V vertices (filled lazily by scs_graph_prepare_degrees)
     bool have_deg = false;

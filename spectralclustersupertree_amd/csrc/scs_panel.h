@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256) void k_panel_tf(double *q, const double *__res
 //   1  single-rank runs: combine k_symm's column segments, AR = dinv (.) sum_seg ypart[seg];
 //   2  multi-rank runs: the all-gathered row slices (ypart = the receive buffer: `nseg` ranks x
 //      `chunk` doubles, rank r's rows [splits[r], splits[r+1]), already scaled);
+//   3  SCS_BUILD_UPPER jobs: ypart = the gathered PARTIAL products of the `nseg` ranks (each
+//      n x B, unscaled): AR = dinv (.) their sum in rank order;
 //   0  AR is in place.
 template <int B, int FINISH>
 __global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, double *aq, int n,
@@ -232,6 +234,11 @@ __global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, 
                         int r = 0;
                         while (r + 1 < nseg && row >= splits[r + 1]) ++r;
                         v = ypart[(int64_t)r * chunk + (int64_t)(row - splits[r]) * B + (col - 2 * B)];
+                    } else if (FINISH == 3 && col >= 2 * B) {
+                        const int64_t idx = (int64_t)row * B + (col - 2 * B);
+                        double sum = 0.0;
+                        for (int g = 0; g < nseg; ++g) sum += ypart[(int64_t)g * n * B + idx];
+                        v = dinv[row] * sum;
                     } else if (FINISH == 1 && col >= 2 * B) {
                         const int64_t idx = (int64_t)row * B + (col - 2 * B);
                         // k_symm uses at most four column segments; the loads are independent

@@ -17,7 +17,10 @@
 // distance 32, 16, ...: 4 B + ... shuffles instead of 6 x 4 B); the transposed product
 // accumulates down the columns in registers and is combined across the four waves once per
 // tile.  Layout contract as k_symm: ld a multiple of 512 doubles, padding columns of W and of
-// zt zero (rows beyond n are clamped to a real row and meet z = 0).
+// zt zero (rows beyond n are clamped to a real row and meet z = 0).  zt has its own leading
+// dimension ldz: in a multi-rank SCS_BUILD_UPPER graph a rank's W holds only the columns from its
+// first row on (w then points col0 columns and row_begin rows in front of the stored block, so
+// that global indices address it), and `tiles` lists the tiles of the rank's own row blocks.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -52,7 +55,7 @@ __device__ __forceinline__ void tri_halving_reduce(double (&v)[NV], int lane) {
 
 template <int B, int CT, int RPW, int D>
 __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ w, int64_t ld, int n,
-                                                     const double *__restrict__ zt,
+                                                     const double *__restrict__ zt, int64_t ldz,
                                                      const int2 *__restrict__ tiles,
                                                      double *__restrict__ pdir,
                                                      double *__restrict__ ptr_) {
@@ -74,11 +77,11 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ 
     // ---- operands into LDS (16-byte pieces)
     for (int e = tid * 2; e < B * TW; e += 512) {
         const int k = e / TW, c = e - k * TW;
-        *(double2 *)&zc[k][c] = *(const double2 *)(zt + (int64_t)k * ld + cb + c);
+        *(double2 *)&zc[k][c] = *(const double2 *)(zt + (int64_t)k * ldz + cb + c);
     }
     for (int e = tid * 2; e < B * TRI_TH; e += 512) {
         const int k = e / TRI_TH, r = e - k * TRI_TH;
-        *(double2 *)&zr[k][r] = *(const double2 *)(zt + (int64_t)k * ld + rb + r);
+        *(double2 *)&zr[k][r] = *(const double2 *)(zt + (int64_t)k * ldz + rb + r);
     }
 
     const int r_wave = rb + wave * (RPW * NG);
@@ -183,11 +186,16 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ 
 // y[r][:] = scale(r) * ( sum_J pdir[J][r][:] + sum_I ptr[I][r][:] ), J from the diagonal tile
 // of r's row block upwards, I over the row blocks left of r's column tile; fixed order.
 // dinv == nullptr: no scaling (the fused LOBPCG loop applies it when it folds the result in).
+// rb_lo, rb_hi: the row blocks (of TRI_TH rows) whose tiles this rank streamed -- all of them on
+// a single device; a rank of an SCS_BUILD_UPPER job adds the direct partials only for its own
+// rows and the transposed ones only from its own row blocks: its y is then a PARTIAL product
+// (the ranks' vectors are added in rank order after the all-gather).
 __global__ __launch_bounds__(256) void k_symm_tri_finish(const double *__restrict__ pdir,
                                                            const double *__restrict__ ptr_, int n, int b,
                                                            int tw, int n_ct,
                                                            const double *__restrict__ dinv,
-                                                           double *__restrict__ y) {
+                                                           double *__restrict__ y, int rb_lo = 0,
+                                                           int rb_hi = 0x7FFFFFFF) {
     // Four lanes share an output: lane q of the quad sums the partials q, q + 4, ... (eight
     // independent loads in flight at a time), the quad is combined in a fixed order.
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -195,8 +203,10 @@ __global__ __launch_bounds__(256) void k_symm_tri_finish(const double *__restric
     const bool live = idx < n * b;
     const int r = live ? idx / b : 0;
     const int j0 = (r / TRI_TH) * TRI_TH / tw;  // the diagonal tile of r's row block
-    const int i1 = (r / tw) * tw / TRI_TH;      // row blocks strictly left of r's column tile
-    const int n_dir = n_ct - j0, n_all = n_dir + i1;
+    const int i1 = min((r / tw) * tw / TRI_TH, rb_hi);  // row blocks strictly left of r's column tile
+    const int i0 = min(rb_lo, i1);
+    const bool mine = r / TRI_TH >= rb_lo && r / TRI_TH < rb_hi;
+    const int n_dir = mine ? n_ct - j0 : 0, n_all = n_dir + (i1 - i0);
     const int64_t stride = (int64_t)n * b;
     double s = 0.0;
     if (live) {
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(256) void k_symm_tri_finish(const double *__restric
                 const int t = t0 + 4 * u;
                 v[u] = 0.0;
                 if (t < n_dir) v[u] = pdir[(int64_t)(j0 + t) * stride + idx];
-                else if (t < n_all) v[u] = ptr_[(int64_t)(t - n_dir) * stride + idx];
+                else if (t < n_all) v[u] = ptr_[(int64_t)(i0 + t - n_dir) * stride + idx];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];

@@ -82,6 +82,31 @@ def row_splits(n: int, world: int, group_start=None) -> list[int]:
     return out
 
 
+UPPER_ALIGN = 256  # SCS_BUILD_UPPER: a rank's first row is a multiple of the build's tile width
+
+
+def row_splits_upper(n: int, world: int) -> list[int]:
+    """Row splits for ``SCS_BUILD_UPPER`` jobs: rank r keeps the part of the upper triangle that
+    lies in its rows, a trapezoid of (V - row) cells per row, so equal ROWS would give rank 0
+    almost twice the average work and the last rank next to none.  The splits equalise the
+    trapezoids' areas -- row s_r = V (1 - sqrt(1 - r / world)) -- rounded to multiples of 256,
+    every rank at least one 256-row block.  Raises ``ValueError`` when V has fewer such blocks
+    than ranks."""
+    blocks = (n + UPPER_ALIGN - 1) // UPPER_ALIGN
+    if world < 1 or blocks < world:
+        msg = f"{n} rows are {blocks} blocks of {UPPER_ALIGN}: fewer than {world} ranks"
+        raise ValueError(msg)
+    out = [0]
+    for r in range(1, world):
+        ideal = n * (1.0 - (1.0 - r / world) ** 0.5)
+        s = int(round(ideal / UPPER_ALIGN)) * UPPER_ALIGN
+        s = max(s, out[-1] + UPPER_ALIGN)  # at least one block for the previous rank
+        s = min(s, (blocks - (world - r)) * UPPER_ALIGN)  # and for every later one
+        out.append(s)
+    out.append(n)
+    return out
+
+
 def group_splits(splits: list[int], group_start) -> list[int]:
     """The same partition in group indices: rank r owns groups
     ``[gsplits[r], gsplits[r+1])`` of the contracted graph."""

@@ -216,13 +216,20 @@ def spectral_bipartition_device(
 
     sharded = team is not None and team.world > 1 and n_groups >= team.shard_min
     splits = None
+    upper = False
     if sharded:
-        from spectralclustersupertree_amd.partition import row_splits
+        from spectralclustersupertree_amd.partition import row_splits, row_splits_upper
 
         try:
-            splits = row_splits(n, team.world, group_start)
+            if group_start is None:
+                # nothing contracts: the job keeps only the upper triangle of the symmetric
+                # matrix -- no tile exchange, half the bytes per operator application
+                splits = row_splits_upper(n, team.world)
+                upper = True
+            else:
+                splits = row_splits(n, team.world, group_start)
         except ValueError:
-            sharded = False  # fewer groups than ranks: every rank solves it alone
+            sharded = False  # fewer groups (or 256-row blocks) than ranks: every rank solves it alone
     if sharded:
         dev = team.device
     elif team is not None:
@@ -244,7 +251,9 @@ def spectral_bipartition_device(
 
     dtab = dev.upload(work)
     try:
-        if sharded:
+        if sharded and upper:
+            graph = dtab.build(splits[team.rank], splits[team.rank + 1], upper=True)
+        elif sharded:
             graph = dtab.build(splits[team.rank], splits[team.rank + 1], shared=True)
         else:
             graph = dtab.build()
@@ -260,6 +269,7 @@ def spectral_bipartition_device(
             report.update(stats)
             report["build"] = graph.build_stats
             report["sharded"] = bool(sharded)
+            report["upper"] = bool(sharded and upper)
             report["splits"] = splits
     finally:
         graph.free()

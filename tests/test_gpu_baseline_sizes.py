@@ -232,6 +232,56 @@ def test_config3_two_ranks_match_single(dev):
     _ = _run_local_group  # (shared helper kept importable)
 
 
+def test_config3_two_ranks_upper_triangle_job(dev):
+    """configs[3] as an SCS_BUILD_UPPER job of two in-process ranks: no tile exchange, each rank
+    stores and streams its trapezoid of the upper triangle, the partial products are added in
+    rank order -- rows bit-exact, the same embedding on both ranks, within 1e-10 of the
+    single-device solve."""
+    from spectralclustersupertree_amd.partition import LocalTeams, row_splits_upper
+
+    n, m = 50000, 2000
+    tables = synthetic.make_tables(0, n, m, "branch")
+    v0 = np.random.RandomState(0).uniform(-1, 1, n)
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    maps_single, stats_single = g.fiedler(v0)
+    g.free()
+    dtab.free()
+    splits = row_splits_upper(n, 2)
+    teams = LocalTeams(2)
+
+    def rank_work(team):
+        dtab = team.device.upload(tables)
+        g = dtab.build(splits[team.rank], splits[team.rank + 1], upper=True)
+        lo = splits[team.rank]
+        rows = (lo + _sample_rows(splits[team.rank + 1] - lo, 10, 7 + team.rank)).astype(np.int32)
+        got = np.vstack([g.download_rows(int(r), 1) for r in rows])
+        maps, stats = g.fiedler(v0)
+        bstats = g.build_stats
+        g.free()
+        dtab.free()
+        return rows, got, maps, stats, bstats
+
+    try:
+        out = teams.run(rank_work)
+    finally:
+        teams.close()
+    for rows, got, maps, stats, bstats in out:
+        want = to.pcg_rows(tables, rows)
+        for i, r in enumerate(rows):
+            c0 = int(r) // 256 * 256
+            assert np.array_equal(got[i, c0:], want[i, c0:])
+        assert stats["converged"] == 1 and bstats["exchange_bytes"] == 0
+        assert np.array_equal(maps, out[0][2])
+        assert np.max(np.abs(maps - maps_single)) <= FIEDLER_TOL
+    # half the streamed bytes of the row-partitioned solve: 4 V^2 over the job per application
+    job_bytes = sum(o[3]["apply_bytes"] for o in out)
+    assert job_bytes <= 1.1 * 4.0 * n * n + 1e9
+    print("CFG3 upper job: build ms", [round(o[4]["total_ms"], 1) for o in out], "solve ms",
+          [round(o[3]["solve_ms"], 1) for o in out], "iterations", out[0][3]["iterations"],
+          "single-device solve ms", round(stats_single["solve_ms"], 1))
+
+
 @pytest.mark.slow
 @pytest.mark.skipif(not os.environ.get("SCS_SLOW_TESTS"),
                     reason="about 6 minutes of LAPACK on the box's host cores: set SCS_SLOW_TESTS=1; "

@@ -145,3 +145,87 @@ def test_construct_supertree_with_a_team_children_one_per_device():
     for got in out:
         assert got.sorted().same_shape(expected.sorted())
     assert len({g.sorted().get_newick() for g in out}) == 1
+
+
+# ---------------------------------------------------------------------------
+# SCS_BUILD_UPPER: the job keeps only the upper triangle -- no exchange, half the bytes
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("world,strategy,n", [(2, "branch", 1300), (3, "bootstrap", 1700), (4, "branch", 2100)])
+def test_upper_triangle_job_build_apply_fiedler(world, strategy, n):
+    from spectralclustersupertree_amd.partition import row_splits_upper
+
+    tables = synthetic.make_tables(31 + world, n, 18, strategy, leaves_per_tree=n - 57, random_weights=True)
+    w_ref, _ = to.pcg_dense(tables)
+    s_ref, _ = to.normalized_operator(w_ref)
+    splits = row_splits_upper(n, world)
+    assert all(s % 256 == 0 for s in splits[:-1]) and splits[-1] == n
+    x = np.random.RandomState(1).standard_normal((n, 4))
+    v0 = np.random.RandomState(0).uniform(-1, 1, n)
+    with Device(0) as dev:
+        dtab = dev.upload(tables)
+        g = dtab.build()
+        maps_single, _ = g.fiedler(v0)
+        g.free()
+        dtab.free()
+
+    teams = LocalTeams(world)
+
+    def rank_work(team):
+        dtab = team.device.upload(tables)
+        g = dtab.build(splits[team.rank], splits[team.rank + 1], upper=True)
+        w = g.download()
+        deg = g.degrees()
+        y = g.apply(x)
+        maps, stats = g.fiedler(v0)
+        bstats = g.build_stats
+        with pytest.raises(Exception, match="UPPER"):
+            g.contract(np.arange(n + 1, dtype=np.int32))
+        g.free()
+        dtab.free()
+        return w, deg, y, maps, stats, bstats
+
+    try:
+        out = teams.run(rank_work)
+    finally:
+        teams.close()
+    cells = 0
+    for r, (w, deg, y, maps, stats, bstats) in enumerate(out):
+        lo, hi = splits[r], splits[r + 1]
+        for i in range(lo, hi):
+            c0 = i // 256 * 256  # a row's stored cells start with its 256-column diagonal tile
+            assert np.array_equal(w[i - lo, c0:], w_ref[i, c0:]), (r, i)
+            assert not np.any(w[i - lo, :c0])
+        cells += bstats["cell_trees"]
+        assert np.allclose(deg, w_ref.sum(axis=1)[lo:hi], rtol=1e-13, atol=0)
+        assert np.max(np.abs(y - (s_ref @ x)[lo:hi])) <= 1e-13
+        assert stats["converged"] == 1
+        assert np.array_equal(maps, out[0][3])  # the same bits on every rank
+        assert np.max(np.abs(maps - maps_single)) <= 1e-10
+    # every cell of the upper triangle evaluated about once across the job (whole tiles)
+    assert cells <= 0.5 * n * n * tables.n_trees * 1.6
+
+
+def test_bipartition_through_a_team_takes_the_upper_triangle_when_nothing_contracts():
+    # (60 full trees: no two taxa share a root side in every one of them, nothing contracts)
+    tables = synthetic.make_tables(5, 1100, 60, "depth")
+    assert int(fl.contraction_groups(tables).max()) + 1 == tables.n_taxa
+    with Device(0) as dev:
+        want_members, want_labels = spectral_bipartition_device(
+            tables, np.random.RandomState(5), contract_edges=True, device=dev)
+    teams = LocalTeams(2, shard_min=100)
+
+    def rank_work(team):
+        report = {}
+        rs = np.random.RandomState(5)
+        members, labels = spectral_bipartition_device(tables, rs, contract_edges=True, team=team, report=report)
+        return members, labels, report, rs.randint(1 << 30)
+
+    try:
+        out = teams.run(rank_work)
+    finally:
+        teams.close()
+    for members, labels, report, draw in out:
+        assert report["sharded"] and report["upper"] and report["build"]["exchange_bytes"] == 0
+        assert [m.tolist() for m in members] == [m.tolist() for m in want_members]
+        assert np.array_equal(labels, want_labels)
+        assert draw == out[0][3]

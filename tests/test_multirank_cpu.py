@@ -219,8 +219,10 @@ def _bench_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         def __init__(self, dev, tables):
             self.dev, self.tables = dev, tables
 
-        def build(self, rb=0, re_=None, shared=None):
+        def build(self, rb=0, re_=None, shared=None, upper=False):
             re_ = self.tables.n_taxa if re_ is None else re_
+            assert not (shared and upper)
+            assert not upper or rb % 256 == 0
             return FakeGraph(self.dev, self.tables, rb, re_, bool(shared))
 
         def free(self):
@@ -249,8 +251,20 @@ def _bench_worker(rank: int, world: int, port: int, out_dir: str) -> None:
     backend.Device = FakeDevice
     import bench
 
+    # the default multi-rank mode (the job keeps the upper triangle only) ...
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--workload", "custom",
+                "--taxa", "600", "--trees", "4", "--strategy", "depth", "--no-extra"]
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.main()
+    assert rc == 0
+    if rank == 0:
+        line = json.loads(buf.getvalue().strip().splitlines()[-1])
+        assert "upper triangle" in line["config"]["parallelism"] and line["parity"]["w_cells_mismatched"] == 0
+        assert line["stages"]["build_exchange_ms"] == 0
+    # ... and the row-partitioned one with the tile exchange
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "custom",
-                "--taxa", "200", "--trees", "5", "--strategy", "depth"]
+                "--taxa", "200", "--trees", "5", "--strategy", "depth", "--multi-rank-mode", "shared"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         rc = bench.main()
@@ -298,3 +312,17 @@ def test_subtrees_travel_in_flat_form_at_the_default_recursion_limit():
     for other in (back, again):
         assert other.to_flat() == node.to_flat()
         assert other.get_newick(with_distances=True) == node.get_newick(with_distances=True)
+
+
+def test_upper_triangle_splits_balance_the_trapezoids():
+    from spectralclustersupertree_amd.partition import row_splits_upper
+
+    for n, world in ((50000, 2), (50000, 4), (50000, 8), (100000, 8), (1300, 2), (2100, 4), (1024, 4)):
+        sp = row_splits_upper(n, world)
+        assert sp[0] == 0 and sp[-1] == n and len(sp) == world + 1
+        assert all(a < b for a, b in zip(sp, sp[1:])) and all(x % 256 == 0 for x in sp[:-1])
+        area = [(b - a) * (n - (a + b) / 2) for a, b in zip(sp, sp[1:])]
+        if n >= 50000:  # fine-grained enough to balance: every rank within 5 % of the mean
+            assert max(area) <= 1.05 * sum(area) / world
+    with pytest.raises(ValueError):
+        row_splits_upper(700, 4)
