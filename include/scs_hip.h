@@ -173,6 +173,12 @@ int scs_tables_free(scs_ctx *ctx, scs_tables *tables);
  * same bits on every rank.  Such a graph cannot be contracted (scs_graph_contract needs whole
  * rows: SCS_EUNSUP); scs_graph_download_rows returns zeros left of the rank's first column. */
 #define SCS_BUILD_UPPER 4
+/* SCS_BUILD_SCATTER (with SCS_BUILD_MONOTONE, one rank, the whole matrix): the input-stationary
+ * COMPARISON variant -- one workgroup per 64 x 64 block of leaf pairs of a tree, fp64 atomicAdd
+ * into W (both triangles).  Same sums up to the order of the additions (<= 1e-12 relative, not
+ * bit-exact), two orders of magnitude slower than the ordered tile kernel on random 8-byte
+ * read-modify-writes; kept so that the choice is a measured one (profiles/). */
+#define SCS_BUILD_SCATTER 8
 int scs_pcg_build(scs_ctx *ctx, const scs_tables *tables, int32_t row_begin, int32_t row_end,
                   int32_t flags, scs_graph **out, scs_build_stats *stats);
 

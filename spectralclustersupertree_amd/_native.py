@@ -19,6 +19,7 @@ UNIQUE_ID_BYTES = 128
 BUILD_MONOTONE = 1  # SCS_BUILD_MONOTONE
 BUILD_SHARED = 2  # SCS_BUILD_SHARED
 BUILD_UPPER = 4  # SCS_BUILD_UPPER
+BUILD_SCATTER = 8  # SCS_BUILD_SCATTER (comparison variant)
 
 
 class ScsError(RuntimeError):

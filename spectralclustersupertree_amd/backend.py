@@ -178,7 +178,7 @@ class DeviceTables:
             pass
 
     def build(self, row_begin: int = 0, row_end: int | None = None,
-              shared: bool | None = None, upper: bool = False) -> "DeviceGraph":
+              shared: bool | None = None, upper: bool = False, scatter: bool = False) -> "DeviceGraph":
         """Rows [row_begin, row_end) of W (reference: scs.py:495-663).
 
         ``shared`` (default: on whenever the device belongs to a multi-rank job) makes the
@@ -197,6 +197,9 @@ class DeviceTables:
         flags = nv.BUILD_MONOTONE if self.monotone else 0
         if upper:
             flags |= nv.BUILD_UPPER
+            shared = False
+        if scatter:  # the atomic-scatter comparison variant (measurements only)
+            flags |= nv.BUILD_SCATTER
             shared = False
         if shared is None:
             shared = self.dev.world > 1

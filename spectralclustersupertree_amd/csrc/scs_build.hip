@@ -111,6 +111,58 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 #include "scs_gen.h"   // general path on the same tile structure: k_block_records_gen, k_accumulate_gen
 
 // ---------------------------------------------------------------------------
+// comparison variant: input-stationary scatter with global fp64 atomics (SCS_BUILD_SCATTER)
+// ---------------------------------------------------------------------------
+// The formulation the north star's wording describes (reference loop
+// structure: scs.py:644-658): walk the TREES, and for every pair of leaves of a tree that share
+// a root side add value(LCA) * weight into W[a][b] and W[b][a] with atomicAdd.  A workgroup
+// takes a 64 x 64 block of leaf-position pairs of one tree (coalesced loads of the two leaf
+// ranges, the LCA value from the tree's sparse table), 16 pairs per thread.  The order of the
+// adds is whatever the hardware makes it: results agree with the ordered build to rounding
+// (<= 1e-12 relative), not bit for bit, and every pair update is a read-modify-write of 8 bytes
+// at a random address of the 8 V^2-byte matrix (twice, for the mirror image).  Kept as the
+// measured comparison only -- the product path is the output-stationary tile kernel.
+__global__ __launch_bounds__(256) void k_scatter_atomic(const int64_t *__restrict__ tree_off,
+                                                         const int32_t *__restrict__ leaf_taxon, int t0,
+                                                         const int64_t *__restrict__ st_off,
+                                                         const double *__restrict__ stv,
+                                                         double *__restrict__ w, int64_t ld) {
+    const int tl = blockIdx.y;
+    const int64_t off = tree_off[t0 + tl];
+    const int nl = (int)(tree_off[t0 + tl + 1] - off);
+    const int m = nl - 1;
+    const int nbk = (nl + 63) / 64;
+    // blockIdx.x enumerates the pairs (I <= J) of 64-position blocks row by row
+    int I = 0, rest = blockIdx.x;
+    while (I < nbk && rest >= nbk - I) {
+        rest -= nbk - I;
+        ++I;
+    }
+    if (I >= nbk) return;
+    const int J = I + rest;
+    __shared__ int s_ta[64], s_tb[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) s_ta[tid] = I * 64 + tid < nl ? leaf_taxon[off + I * 64 + tid] : -1;
+    else if (tid < 128) s_tb[tid - 64] = J * 64 + tid - 64 < nl ? leaf_taxon[off + J * 64 + tid - 64] : -1;
+    __syncthreads();
+    const double *st = stv + st_off[tl];
+    const int bj = tid & 63;
+    const int pb = J * 64 + bj;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int ai = (tid >> 6) + 4 * q;
+        const int pa = I * 64 + ai;
+        if (pa >= pb || pb >= nl) continue;
+        const double v = rmq_min<double>(st, m, pa, pb);  // 0 when the root separates the two
+        if (v != 0.0) {
+            const int ta = s_ta[ai], tb2 = s_tb[bj];
+            atomicAdd(&w[(int64_t)ta * ld + tb2], v);
+            atomicAdd(&w[(int64_t)tb2 * ld + ta], v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // shared multi-rank build: gathered upper-triangle tiles -> this rank's rows of W
 // ---------------------------------------------------------------------------
 // Tile t of the global upper-triangle list was computed by rank t % world into slot
@@ -477,8 +529,17 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                              int32_t row_end, int32_t flags, scs_graph **out,
                              scs_build_stats *stats) {
     SCS_REQUIRE(ctx && tb && out, "scs_pcg_build: null argument");
-    SCS_REQUIRE((flags & ~(SCS_BUILD_MONOTONE | SCS_BUILD_SHARED | SCS_BUILD_UPPER)) == 0,
+    SCS_REQUIRE((flags & ~(SCS_BUILD_MONOTONE | SCS_BUILD_SHARED | SCS_BUILD_UPPER | SCS_BUILD_SCATTER)) == 0,
                 "scs_pcg_build: unknown flag bits 0x%x", flags);
+    const bool scatter = (flags & SCS_BUILD_SCATTER) != 0;
+    if (scatter) {
+        if (!(flags & SCS_BUILD_MONOTONE) || (flags & (SCS_BUILD_SHARED | SCS_BUILD_UPPER)) ||
+            row_begin != 0 || row_end != tb->n_taxa || ctx->comm.world != 1) {
+            scs_set_error("scs_pcg_build: SCS_BUILD_SCATTER (the atomic comparison variant) takes monotone "
+                          "tables, the whole matrix, one rank");
+            return SCS_EUNSUP;
+        }
+    }
     SCS_REQUIRE((flags & (SCS_BUILD_SHARED | SCS_BUILD_UPPER)) != (SCS_BUILD_SHARED | SCS_BUILD_UPPER),
                 "scs_pcg_build: SCS_BUILD_SHARED and SCS_BUILD_UPPER exclude each other");
     const bool monotone = (flags & SCS_BUILD_MONOTONE) != 0 &&
@@ -525,6 +586,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     scs_graph *g = nullptr;
     SCS_TRY(graph_alloc(ctx, n, row_begin, row_end, s, &g, trapezoid ? row_begin : 0));
     g->upper = trapezoid;
+    if (scatter) SCS_HIP_CHECK(hipMemsetAsync(g->d_w, 0, (size_t)rows * (size_t)g->ld * 8, s));
     // (the kernels index W by global column: a base shifted left by col0 makes
     // w[(r - row_begin) * ld + c] land on the stored cell for every c >= col0)
     double *w_base = g->d_w - g->col0;
@@ -701,6 +763,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 k_sparse_level<double><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
                                                               (const int64_t *)d_stoff.p,
                                                               (double *)d_st.p);
+            if (!scatter)
             k_block_records_mono<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
                 tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
                 (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
@@ -721,7 +784,12 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
 
         SCS_HIP_CHECK(hipEventRecord(ev_acc.a, s));
         const unsigned nt = (unsigned)tiles.size();
-        if (monotone) {
+        if (scatter) {
+            const int64_t nbk = (max_n + 63) / 64;
+            k_scatter_atomic<<<dim3((unsigned)(nbk * (nbk + 1) / 2), (unsigned)nb), 256, 0, s>>>(
+                tb->d_tree_off, tb->d_leaf_taxon, t0, (const int64_t *)d_stoff.p, (const double *)d_st.p,
+                g->d_w, g->ld);
+        } else if (monotone) {
             mono_params mp;
             mp.tiles = (const int2 *)d_tiles.p;
             mp.rec = (const unsigned char *)d_rec.p;
