@@ -12,9 +12,10 @@ host.  The same pass on tables already resident in HBM is reported beside it as
 configs[2] (10 000 taxa / 500 trees / branch), the largest configuration
 BASELINE.json assigns to a single MI355X; N > 1 runs configs[3] (50 000 taxa /
 2 000 trees, row-partitioned W, RCCL all-gather of the Krylov block), one
-process per GPU as launched by ``torch.distributed.run``.  torch is used only
-for the host-side rendezvous (gloo: unique-id broadcast, barrier, max over
-ranks); every number is produced by libscs_hip.so through its C-ABI.
+process per GPU as launched by ``torch.distributed.run`` -- a launcher only: the
+host-side rendezvous (unique-id broadcast, barrier, max over ranks) is the
+package's own TCP star (hoststore.py), no torch import anywhere; every number
+is produced by libscs_hip.so through its C-ABI.
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline            the kernel with the most device time per step (HIP-event-timed on the
@@ -250,11 +251,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        import torch
-
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = dist.max(elapsed)
 
     maps, stats, bstats = last
     steps = max(steps, 1)
@@ -594,7 +591,7 @@ def main() -> int:
             result["same_workload_on_one_gpu"] = {"error": str(exc)}
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
     if rank == 0:
         print(json.dumps(result))
     return 0

@@ -5,7 +5,7 @@ process per GPU, RCCL all-gather of the Krylov block -- but only at the top
 recursion levels, where V justifies it; deeper sub-problems run on single
 devices.  This module holds the host side of that: the split computation
 (aligned to the build's 64-row tiles and, under contraction, to the groups --
-SURVEY.md section 8f-1), the rendezvous, and the ``Team`` a recursion walks with.
+SURVEY.md section 8f-1), the rendezvous (``hoststore``: a small TCP star, no torch), and the ``Team`` a recursion walks with.
 
 The reference has no counterpart (single process, ``n_jobs=1``,
 src/sc_supertree/scs.py:239).
@@ -150,36 +150,32 @@ class Team:
 
 
 def rendezvous_host(rank: int, world: int, make_unique_id):
-    """torch.distributed (gloo) rendezvous of the HOST side: returns ``(dist, unique_id)``
-    with rank 0's 128-byte RCCL id broadcast to everybody.  ``make_unique_id`` is called on
-    rank 0 only.  No GPU call is made here (tests/test_multirank_cpu.py drives exactly this
-    with world size 2)."""
+    """Rendezvous of the HOST side: returns ``(group, unique_id)`` -- a ``hoststore.HostGroup``
+    (allgather / broadcast / barrier / max over a small TCP star; no torch: the launcher only
+    provides RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT) and rank 0's 128-byte RCCL id on every
+    rank.  ``make_unique_id`` is called on rank 0 only.  No GPU call is made here
+    (tests/test_multirank_cpu.py drives exactly this with world size 2)."""
     if world <= 1:
         return None, None
-    import torch
-    import torch.distributed as dist
+    from spectralclustersupertree_amd.hoststore import HostGroup
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    if not dist.is_initialized():
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    buf = torch.zeros(128, dtype=torch.uint8)
+    group = HostGroup(rank, world)
+    uid = None
     if rank == 0:
-        uid = make_unique_id()
+        uid = bytes(make_unique_id())
         if len(uid) != 128:
             msg = "unique id must be 128 bytes"
             raise ValueError(msg)
-        buf = torch.frombuffer(bytearray(uid), dtype=torch.uint8).clone()
-    dist.broadcast(buf, 0)
-    return dist, bytes(buf.numpy().tobytes())
+    return group, group.broadcast(uid)
 
 
 def rendezvous(rank: int, world: int, dev_index: int):
-    """``(dist, Device)``: the job-wide context of this rank (RCCL communicator when
-    world > 1)."""
+    """``(group, Device)``: the host-side group (None for a single rank) and the job-wide
+    context of this rank (RCCL communicator when world > 1)."""
     from spectralclustersupertree_amd.backend import Device
 
-    dist, uid = rendezvous_host(rank, world, Device.unique_id)
-    return dist, Device(dev_index, rank, world, uid)
+    group, uid = rendezvous_host(rank, world, Device.unique_id)
+    return group, Device(dev_index, rank, world, uid)
 
 
 def team_from_env() -> Team | None:
@@ -193,14 +189,8 @@ def team_from_env() -> Team | None:
         return None
     rank = int(os.environ.get("RANK", "0"))
     dev_index = int(os.environ.get("SCS_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    dist, dev = rendezvous(rank, world, dev_index)
-
-    def allgather(obj):
-        out = [None] * world
-        dist.all_gather_object(out, obj)
-        return out
-
-    return Team(rank=rank, world=world, device=dev, solo=Device(dev_index), allgather=allgather,
+    group, dev = rendezvous(rank, world, dev_index)
+    return Team(rank=rank, world=world, device=dev, solo=Device(dev_index), allgather=group.allgather,
                 child_rng=os.environ.get("SCS_CHILD_RNG", "shared"))
 
 

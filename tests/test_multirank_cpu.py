@@ -1,7 +1,8 @@
-"""World-size-2 gloo tests (CPU) of the N > 1 host logic: the row-partition plan
-(tile- and group-aligned), the product's own rendezvous (partition.rendezvous_host, as
-bench.py and construct_supertree use it) up to the GPU call, the recursion walked by two
-ranks with sibling sub-problems dealt one per rank, and the slice-gather
+"""World-size-2 tests (CPU, two processes) of the N > 1 host logic: the row-partition plan
+(tile- and group-aligned), the product's own rendezvous (partition.rendezvous_host over
+hoststore.HostGroup, as bench.py and construct_supertree use it) up to the GPU call, the
+recursion walked by two ranks with sibling sub-problems dealt one per rank, and -- over a
+gloo process group, the CPU stand-in for the RCCL all-gather -- the slice-gather
 order the device path relies on (rank r contributes rows [split_r, split_{r+1})
 of S @ X; concatenating the gathered slices in rank order must equal the full
 product).  The arithmetic here is the oracle's numpy restatement -- the device
@@ -43,8 +44,17 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
         made.append(rank)
         return bytes(range(128))
 
-    dist, uid = partition.rendezvous_host(rank, world, make_id)
+    group, uid = partition.rendezvous_host(rank, world, make_id)
     assert uid == bytes(range(128)) and made == ([0] if rank == 0 else [])
+    # the host group's own collectives (what bench.py and the teams use)
+    assert group.allgather({"rank": rank, "x": np.arange(3) + rank})[1 - rank]["rank"] == 1 - rank
+    assert group.max(1.0 + rank) == float(world)
+    assert group.broadcast("from zero" if rank == 0 else None) == "from zero"
+    group.barrier()
+    # the gather-order arithmetic below runs over gloo (what RCCL does on the device)
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     # 2. row-partitioned operator apply, slices gathered in rank order
     n, b = 333, 8
     tables = synthetic.make_tables(3, n, 12, "branch", leaves_per_tree=300)
@@ -75,11 +85,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     from spectralclustersupertree_amd.load import load_tree_arrays
     from spectralclustersupertree_amd.tree import load_tree
 
-    def allgather(obj):
-        out = [None] * world
-        dist.all_gather_object(out, obj)
-        return out
-
+    allgather = group.allgather
     team = partition.Team(rank=rank, world=world, device=None, solo=None, allgather=allgather,
                           shard_min=10**9, child_rng="forked")
     name, src, exp, weighting = next(c for c in FILE_CASES if "supertriplets" in c[0])
@@ -119,6 +125,7 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
     assert calls["n"] >= 2
     dist.barrier()
     dist.destroy_process_group()
+    group.close()
     Path(out_dir, f"ok{rank}").write_text("ok")
 
 
@@ -326,3 +333,43 @@ def test_upper_triangle_splits_balance_the_trapezoids():
             assert max(area) <= 1.05 * sum(area) / world
     with pytest.raises(ValueError):
         row_splits_upper(700, 4)
+
+
+def test_host_group_three_ranks_skips_a_stranger_on_the_first_port():
+    # hoststore.HostGroup: rank 0 binds the first free port of the probe list, the others find
+    # it by handshake -- a foreign listener on the first port is passed over
+    import threading
+
+    from spectralclustersupertree_amd.hoststore import HostGroup
+
+    port = _free_port()
+    stranger = socket.socket()
+    stranger.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        stranger.bind(("127.0.0.1", port))
+        stranger.listen(4)
+    except OSError:
+        pytest.skip("port taken meanwhile")
+    out, err = [None] * 3, [None] * 3
+
+    def worker(r):
+        try:
+            g = HostGroup(r, 3, addr="127.0.0.1", port=port, timeout=30.0, tag="t")
+            got = g.allgather(("rank", r))
+            top = g.max(10.0 * r)
+            word = g.broadcast("hello" if r == 0 else None)
+            g.barrier()
+            g.close()
+            out[r] = (got, top, word)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    stranger.close()
+    assert err == [None, None, None], err
+    for got, top, word in out:
+        assert got == [("rank", 0), ("rank", 1), ("rank", 2)] and top == 20.0 and word == "hello"
