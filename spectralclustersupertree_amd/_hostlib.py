@@ -24,7 +24,7 @@ def load() -> C.CDLL:
         lib.scs_host_restrict_fill.restype = C.c_int
         lib.scs_host_restrict_fill.argtypes = [C.c_int32, lp, ip, ip, dp, dp, bp, bp, lp, ip, ip, dp, dp]
         lib.scs_host_split_begin.restype = C.c_int
-        lib.scs_host_split_begin.argtypes = [C.c_int32, lp, ip, ip, dp, dp, ip, ip, C.c_int32,
+        lib.scs_host_split_begin.argtypes = [C.c_int32, lp, ip, ip, dp, dp, lp, ip, ip, C.c_int32,
                                              C.POINTER(C.c_void_p), lp, lp]
         lib.scs_host_split_fill.restype = C.c_int
         lib.scs_host_split_fill.argtypes = [C.c_void_p, C.c_int32, lp, ip, lp, ip, ip, dp, dp, bp]

@@ -729,7 +729,11 @@ int scs_host_contraction_groups(int32_t n_taxa, int32_t n_trees, const int64_t *
     int32_t *cls = (int32_t *)calloc((size_t)n_taxa, sizeof(int32_t));
     int32_t *side = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_taxa);
     uint64_t cap = 16;
-    while (cap < (uint64_t)n_taxa * 2 + 1) cap <<= 1;
+    int cap_bits = 4;
+    while (cap < (uint64_t)n_taxa * 2 + 1) {
+        cap <<= 1;
+        ++cap_bits;
+    }
     uint64_t *hkey = (uint64_t *)malloc(sizeof(uint64_t) * cap);
     int32_t *hval = (int32_t *)malloc(sizeof(int32_t) * cap);
     int32_t *first = (int32_t *)malloc(sizeof(int32_t) * (size_t)n_taxa);
@@ -753,7 +757,10 @@ int scs_host_contraction_groups(int32_t n_taxa, int32_t n_trees, const int64_t *
         int32_t next = 0;
         for (int32_t x = 0; x < n_taxa; ++x) {
             const uint64_t key = ((uint64_t)(uint32_t)cls[x] << 32) | (uint32_t)side[x];
-            uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> 17 & (cap - 1);
+            /* the TOP bits of the product: the class sits in the key's upper half and only
+             * reaches the upper half of the product (bits 17.. of it ignored the class and made
+             * every probe sequence collide: quadratic) */
+            uint64_t h = (key * 0x9E3779B97F4A7C15ull) >> (64 - cap_bits);
             while (hkey[h] != UINT64_MAX && hkey[h] != key) h = (h + 1) & (cap - 1);
             if (hkey[h] == UINT64_MAX) {
                 hkey[h] = key;
@@ -850,21 +857,61 @@ int scs_host_components(int32_t n_taxa, int32_t n_trees, const int64_t *tree_off
  * part out in tree order.
  * ------------------------------------------------------------------------- */
 typedef struct {
-    int32_t tree, part, n_nodes, n_leaves, arena;
-    int64_t off;
+    int32_t tree, part, n_nodes, n_leaves;
+    int64_t off; /* into the plan's node region */
 } split_entry;
 
 typedef struct {
-    int32_t *parent, *taxon;
-    double *length, *support;
-    int64_t used, cap;
     split_entry *entries;
     int64_t n_entries, cap_entries;
 } split_arena;
 
+/* The restricted trees of ALL parts are written into one region, tree t owning the slice
+ * [slice_off[t], slice_off[t + 1]) of 2 * leaves(t) nodes (the parts of a tree hold its leaves
+ * once and at most leaves - 1 LCAs between them): no growing buffers, so the threads never
+ * meet in the allocator (a realloc that moves a mapping takes the address space's write lock
+ * and stalls every other thread's page faults -- the first version did not scale past one
+ * thread).  The region is kept per host thread and reused by the next split (fresh mappings
+ * cost a page fault per 4 KiB: seconds at 10^9 nodes). */
+typedef struct {
+    int32_t *parent, *taxon;
+    double *length, *support;
+    int64_t cap;
+} split_region;
+
+static __thread split_region t_region = {0, 0, 0, 0, 0};
+
+static int region_reserve(int64_t nodes) {
+    split_region *r = &t_region;
+    if (nodes <= r->cap) return SCS_HOST_OK;
+    free(r->parent);
+    free(r->taxon);
+    free(r->length);
+    free(r->support);
+    r->cap = 0;
+    const int64_t cap = nodes + nodes / 8 + 1024;
+    r->parent = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+    r->taxon = (int32_t *)malloc(sizeof(int32_t) * (size_t)cap);
+    r->length = (double *)malloc(sizeof(double) * (size_t)cap);
+    r->support = (double *)malloc(sizeof(double) * (size_t)cap);
+    if (!r->parent || !r->taxon || !r->length || !r->support) {
+        free(r->parent);
+        free(r->taxon);
+        free(r->length);
+        free(r->support);
+        r->parent = r->taxon = 0;
+        r->length = r->support = 0;
+        return SCS_HOST_ENOMEM;
+    }
+    r->cap = cap;
+    return SCS_HOST_OK;
+}
+
 typedef struct scs_split_plan {
     int32_t n_trees, n_parts, n_arenas, arenas_used;
     split_arena *arenas;
+    split_region region; /* (borrowed from the calling thread's t_region) */
+    int64_t *slice_off;  /* [n_trees + 1] */
     split_entry *sorted;
     int64_t n_sorted;
     int64_t *part_first; /* [n_parts + 1] */
@@ -879,24 +926,7 @@ typedef struct {
     scs_split_plan *plan;
 } split_ctx;
 
-static int arena_reserve(split_arena *a, int64_t extra_nodes) {
-    if (a->used + extra_nodes > a->cap) {
-        int64_t cap = a->cap ? a->cap : 4096;
-        while (cap < a->used + extra_nodes) cap *= 2;
-        int32_t *p = (int32_t *)realloc(a->parent, sizeof(int32_t) * (size_t)cap);
-        if (!p) return SCS_HOST_ENOMEM;
-        a->parent = p;
-        int32_t *x = (int32_t *)realloc(a->taxon, sizeof(int32_t) * (size_t)cap);
-        if (!x) return SCS_HOST_ENOMEM;
-        a->taxon = x;
-        double *l = (double *)realloc(a->length, sizeof(double) * (size_t)cap);
-        if (!l) return SCS_HOST_ENOMEM;
-        a->length = l;
-        double *s = (double *)realloc(a->support, sizeof(double) * (size_t)cap);
-        if (!s) return SCS_HOST_ENOMEM;
-        a->support = s;
-        a->cap = cap;
-    }
+static int arena_reserve(split_arena *a) {
     if (a->n_entries + 1 > a->cap_entries) {
         int64_t cap = a->cap_entries ? a->cap_entries * 2 : 256;
         split_entry *e = (split_entry *)realloc(a->entries, sizeof(split_entry) * (size_t)cap);
@@ -920,6 +950,7 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
     if (hdr[0] == 0) hdr[0] = 1 + __atomic_fetch_add(&plan->arenas_used, 1, __ATOMIC_RELAXED);
     if (hdr[0] > plan->n_arenas) return SCS_HOST_EINVAL;
     split_arena *ar = &plan->arenas[hdr[0] - 1];
+    const split_region *rg = &plan->region;
     const int32_t mk = c->max_k, np = c->n_parts;
     int32_t *sub_end = hdr + 4;
     int32_t *stack = sub_end + mk;
@@ -985,6 +1016,8 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
     }
     int rc = SCS_HOST_OK;
     int32_t at = 0;
+    int64_t cursor = plan->slice_off[t];
+    const int64_t slice_end = plan->slice_off[t + 1];
     for (int32_t q = 0; q < n_touched && rc == SCS_HOST_OK; ++q) {
         const int32_t pc = touched[q];
         const int32_t leaves = cnt[pc];
@@ -993,26 +1026,31 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
         const int32_t ne = 2 * leaves - 1;
         int32_t *nodes = sorted_node + at;
         at += ne;
+        /* the leaves come in order already; the LCAs (every second event) do not */
         qsort(nodes, (size_t)ne, sizeof(int32_t), cmp_i32);
         int32_t nv = 0;
         for (int32_t j = 0; j < ne; ++j)
             if (nv == 0 || nodes[j] != nodes[nv - 1]) nodes[nv++] = nodes[j];
-        rc = arena_reserve(ar, nv);
+        rc = arena_reserve(ar);
         if (rc != SCS_HOST_OK) break;
-        const int64_t base = ar->used;
+        if (cursor + nv > slice_end) {
+            rc = SCS_HOST_EINVAL; /* (cannot happen: a tree's parts hold <= 2 * leaves nodes) */
+            break;
+        }
+        const int64_t base = cursor;
         int32_t vs = 0;
         for (int32_t j = 0; j < nv; ++j) {
             const int32_t v = nodes[j];
             while (vs > 0 && v > sub_end[nodes[vstack[vs - 1]]]) --vs;
             const int32_t upj = vs > 0 ? vstack[vs - 1] : -1;
             const int32_t up = upj < 0 ? -1 : nodes[upj];
-            ar->parent[base + j] = upj;
-            ar->taxon[base + j] = tax[v] >= 0 ? c->new_id[tax[v]] : -1;
-            ar->support[base + j] = sup[v];
+            rg->parent[base + j] = upj;
+            rg->taxon[base + j] = tax[v] >= 0 ? c->new_id[tax[v]] : -1;
+            rg->support[base + j] = sup[v];
             double acc = len[v];
             for (int32_t u = v == 0 ? -1 : par[v]; u >= 0 && u != up; u = par[u])
                 if (!isnan(len[u]) && !isnan(acc)) acc = len[u] + acc;
-            ar->length[base + j] = acc;
+            rg->length[base + j] = acc;
             if (tax[v] < 0) vstack[vs++] = j;
         }
         split_entry *en = &ar->entries[ar->n_entries++];
@@ -1020,9 +1058,8 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
         en->part = pc;
         en->n_nodes = nv;
         en->n_leaves = leaves;
-        en->arena = hdr[0] - 1;
         en->off = base;
-        ar->used += nv;
+        cursor += nv;
     }
     /* (on an error the remaining touched parts still have to be cleaned) */
     for (int32_t q = 0; q < n_touched; ++q) last[touched[q]] = 0;
@@ -1037,14 +1074,9 @@ static int cmp_entry(const void *a, const void *b) {
 
 void scs_host_split_end(scs_split_plan *plan) {
     if (!plan) return;
-    for (int32_t i = 0; i < plan->n_arenas; ++i) {
-        free(plan->arenas[i].parent);
-        free(plan->arenas[i].taxon);
-        free(plan->arenas[i].length);
-        free(plan->arenas[i].support);
-        free(plan->arenas[i].entries);
-    }
+    for (int32_t i = 0; i < plan->n_arenas; ++i) free(plan->arenas[i].entries);
     free(plan->arenas);
+    free(plan->slice_off);
     free(plan->sorted);
     free(plan->part_first);
     free(plan);
@@ -1057,8 +1089,9 @@ void scs_host_split_end(scs_split_plan *plan) {
  */
 int scs_host_split_begin(int32_t n_trees, const int64_t *node_off, const int32_t *parent,
                          const int32_t *taxon, const double *length, const double *support,
-                         const int32_t *part_of, const int32_t *new_id, int32_t n_parts,
-                         scs_split_plan **out_plan, int64_t *part_trees, int64_t *part_nodes) {
+                         const int64_t *leaf_counts, const int32_t *part_of, const int32_t *new_id,
+                         int32_t n_parts, scs_split_plan **out_plan, int64_t *part_trees,
+                         int64_t *part_nodes) {
     if (n_parts < 1 || !out_plan) return SCS_HOST_EINVAL;
     int32_t max_k = 1;
     for (int32_t t = 0; t < n_trees; ++t) {
@@ -1073,10 +1106,17 @@ int scs_host_split_begin(int32_t n_trees, const int64_t *node_off, const int32_t
     plan->n_arenas = 64; /* for_each_tree runs at most 64 threads */
     plan->arenas = (split_arena *)calloc((size_t)plan->n_arenas, sizeof(split_arena));
     plan->part_first = (int64_t *)calloc((size_t)n_parts + 1, sizeof(int64_t));
-    if (!plan->arenas || !plan->part_first) {
+    plan->slice_off = (int64_t *)calloc((size_t)n_trees + 1, sizeof(int64_t));
+    if (!plan->arenas || !plan->part_first || !plan->slice_off) {
         scs_host_split_end(plan);
         return SCS_HOST_ENOMEM;
     }
+    for (int32_t t = 0; t < n_trees; ++t) plan->slice_off[t + 1] = plan->slice_off[t] + 2 * leaf_counts[t];
+    if (region_reserve(plan->slice_off[n_trees]) != SCS_HOST_OK) {
+        scs_host_split_end(plan);
+        return SCS_HOST_ENOMEM;
+    }
+    plan->region = t_region;
     split_ctx c = {node_off, parent, taxon, length, support, part_of, new_id, n_parts, max_k, plan};
     /* scratch: header + 10 max_k + 3 n_parts ints, zeroed by the worker (header: no arena
      * yet; last[]: no leaf seen) */
@@ -1117,7 +1157,35 @@ int scs_host_split_begin(int32_t n_trees, const int64_t *node_off, const int32_t
 
 /* Part `part` in tree order: node_off_out [trees + 1], tree_index_out [trees] (index of the
  * tree in the parent forest), leaf_count_out [trees], the node arrays, and present_out[id] = 1
- * for every (new) taxon id that occurs (zeroed by the caller). */
+ * for every (new) taxon id that occurs (zeroed by the caller).  Call from the thread that
+ * called scs_host_split_begin, before its next split (the node region belongs to it). */
+typedef struct {
+    const scs_split_plan *plan;
+    int64_t first;
+    const int64_t *node_off_out;
+    int32_t *parent_out, *taxon_out;
+    double *length_out, *support_out;
+    uint8_t *present_out;
+} fill2_ctx;
+
+static int split_fill_entry(int32_t j, void *scratch, void *vctx) {
+    (void)scratch;
+    const fill2_ctx *c = (const fill2_ctx *)vctx;
+    const split_entry *e = &c->plan->sorted[c->first + j];
+    const split_region *a = &c->plan->region;
+    const int64_t at = c->node_off_out[j];
+    memcpy(c->parent_out + at, a->parent + e->off, sizeof(int32_t) * (size_t)e->n_nodes);
+    memcpy(c->taxon_out + at, a->taxon + e->off, sizeof(int32_t) * (size_t)e->n_nodes);
+    memcpy(c->length_out + at, a->length + e->off, sizeof(double) * (size_t)e->n_nodes);
+    memcpy(c->support_out + at, a->support + e->off, sizeof(double) * (size_t)e->n_nodes);
+    if (c->present_out)
+        for (int32_t q = 0; q < e->n_nodes; ++q) {
+            const int32_t x = a->taxon[e->off + q];
+            if (x >= 0 && !c->present_out[x]) c->present_out[x] = 1;
+        }
+    return SCS_HOST_OK;
+}
+
 int scs_host_split_fill(const scs_split_plan *plan, int32_t part, int64_t *node_off_out,
                         int32_t *tree_index_out, int64_t *leaf_count_out, int32_t *parent_out,
                         int32_t *taxon_out, double *length_out, double *support_out,
@@ -1127,20 +1195,13 @@ int scs_host_split_fill(const scs_split_plan *plan, int32_t part, int64_t *node_
     node_off_out[0] = 0;
     for (int64_t i = plan->part_first[part]; i < plan->part_first[part + 1]; ++i, ++j) {
         const split_entry *e = &plan->sorted[i];
-        const split_arena *a = &plan->arenas[e->arena];
-        memcpy(parent_out + at, a->parent + e->off, sizeof(int32_t) * (size_t)e->n_nodes);
-        memcpy(taxon_out + at, a->taxon + e->off, sizeof(int32_t) * (size_t)e->n_nodes);
-        memcpy(length_out + at, a->length + e->off, sizeof(double) * (size_t)e->n_nodes);
-        memcpy(support_out + at, a->support + e->off, sizeof(double) * (size_t)e->n_nodes);
-        if (present_out)
-            for (int32_t q = 0; q < e->n_nodes; ++q) {
-                const int32_t x = a->taxon[e->off + q];
-                if (x >= 0) present_out[x] = 1;
-            }
         tree_index_out[j] = e->tree;
         leaf_count_out[j] = e->n_leaves;
         at += e->n_nodes;
         node_off_out[j + 1] = at;
     }
-    return SCS_HOST_OK;
+    if (j > INT32_MAX) return SCS_HOST_EINVAL;
+    fill2_ctx c = {plan, plan->part_first[part], node_off_out, parent_out, taxon_out, length_out,
+                   support_out, present_out};
+    return for_each_tree((int32_t)j, at, 0, split_fill_entry, &c);
 }

@@ -224,9 +224,13 @@ class TreeArrays:
         plan = C.c_void_p()
         part_trees = np.zeros(n_parts, dtype=np.int64)
         part_nodes = np.zeros(n_parts, dtype=np.int64)
+        leaf_counts = np.ascontiguousarray(self.leaf_counts(), dtype=np.int64)
+        if len(leaf_counts) == 0:
+            leaf_counts = np.zeros(1, dtype=np.int64)
         rc = lib.scs_host_split_begin(self.n_trees, _p(self.node_off, C.c_int64), _p(self.parent, C.c_int32),
                                       _p(self.taxon, C.c_int32), _p(self.length, C.c_double),
-                                      _p(self.support, C.c_double), _p(part_of, C.c_int32),
+                                      _p(self.support, C.c_double), _p(leaf_counts, C.c_int64),
+                                      _p(part_of, C.c_int32),
                                       _p(new_id, C.c_int32), n_parts, C.byref(plan),
                                       _p(part_trees, C.c_int64), _p(part_nodes, C.c_int64))
         if rc:
