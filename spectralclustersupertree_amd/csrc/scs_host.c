@@ -38,11 +38,11 @@
 /*
  * The trees of a forest are independent in everything below, and a node of the recursion
  * walks the whole forest of its parent (a child of three taxa split off a parent of 30 000
- * still visits every node of every tree): forests above SCS_HOST_PAR_NODES nodes are cut over
- * threads, trees handed out one at a time from a shared counter.  SCS_HOST_THREADS sets the
- * team size (default: the online cores, at most 32; 1 = serial).
+ * still visits every node of every tree): forests of more than a few tens of thousands of
+ * nodes are cut over a persistent team of threads, trees handed out one at a time from a shared
+ * counter.  SCS_HOST_THREADS sets the team size (default: the online cores, at most 32; 1 =
+ * serial).
  */
-#define SCS_HOST_PAR_NODES 200000
 
 typedef int (*tree_fn)(int32_t t, void *scratch, void *ctx);
 typedef struct {
@@ -84,25 +84,88 @@ static int host_threads(void) {
     return cached;
 }
 
+/*
+ * A persistent team.  Creating and joining threads per call (round 2) only paid for forests of
+ * hundreds of thousands of nodes; the recursion makes tens of thousands of calls on forests of
+ * 10^4..10^5 nodes (a node of a dozen taxa still carries every source tree), each a
+ * millisecond of serial work.  The workers are created once, sleep on a condition variable
+ * between jobs and are handed a job by generation number; the caller works along and waits
+ * for the last worker.  One job at a time: a caller that finds the team busy (another host
+ * thread of the process is in here) simply runs its job alone.
+ */
+typedef struct {
+    pthread_mutex_t m;
+    pthread_cond_t cv_work, cv_done;
+    pthread_mutex_t busy;
+    tree_team *job;
+    unsigned long generation;
+    int want;    /* workers asked to join the current job */
+    int joined;  /* ... that have picked it up */
+    int active;  /* ... still working */
+    int started; /* threads created */
+    pthread_t th[64];
+} team_pool;
+
+static team_pool g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER,
+                           PTHREAD_MUTEX_INITIALIZER, 0, 0, 0, 0, 0, 0, {0}};
+
+static void *pool_worker(void *arg) {
+    (void)arg;
+    unsigned long seen = 0;
+    pthread_mutex_lock(&g_pool.m);
+    for (;;) {
+        while (g_pool.generation == seen || g_pool.joined >= g_pool.want) {
+            if (g_pool.generation != seen) seen = g_pool.generation; /* job is fully staffed: skip it */
+            pthread_cond_wait(&g_pool.cv_work, &g_pool.m);
+        }
+        seen = g_pool.generation;
+        g_pool.joined += 1;
+        tree_team *job = g_pool.job;
+        pthread_mutex_unlock(&g_pool.m);
+        tree_team_worker(job);
+        pthread_mutex_lock(&g_pool.m);
+        if (--g_pool.active == 0) pthread_cond_signal(&g_pool.cv_done);
+    }
+    return 0;
+}
+
 /* fn(t, scratch, ctx) for every tree t; scratch is a per-thread block of scratch_bytes */
 static int for_each_tree(int32_t n_trees, int64_t total_nodes, size_t scratch_bytes, tree_fn fn,
                          void *ctx) {
     tree_team tm = {n_trees, 0, fn, ctx, scratch_bytes, SCS_HOST_OK};
     int n_thr = host_threads();
-    if (total_nodes < SCS_HOST_PAR_NODES || n_trees < 2) n_thr = 1;
+    /* about 20 000 nodes of work per thread before another one is worth waking */
+    if (total_nodes / 20000 + 1 < n_thr) n_thr = (int)(total_nodes / 20000 + 1);
     if (n_thr > n_trees) n_thr = n_trees;
-    if (n_thr <= 1) {
+    if (n_thr <= 1 || pthread_mutex_trylock(&g_pool.busy) != 0) {
         tree_team_worker(&tm);
         return tm.rc;
     }
-    pthread_t th[64];
-    int started = 0;
-    for (int i = 0; i < n_thr - 1; ++i) {
-        if (pthread_create(&th[started], 0, tree_team_worker, &tm) != 0) break;
-        ++started;
+    pthread_mutex_lock(&g_pool.m);
+    while (g_pool.started < n_thr - 1 && g_pool.started < 63) {
+        pthread_attr_t at;
+        pthread_attr_init(&at);
+        pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+        const int rc = pthread_create(&g_pool.th[g_pool.started], &at, pool_worker, 0);
+        pthread_attr_destroy(&at);
+        if (rc != 0) break;
+        g_pool.started += 1;
     }
+    const int helpers = n_thr - 1 < g_pool.started ? n_thr - 1 : g_pool.started;
+    g_pool.job = &tm;
+    g_pool.want = helpers;
+    g_pool.joined = 0;
+    g_pool.active = helpers;
+    g_pool.generation += 1;
+    if (helpers > 0) pthread_cond_broadcast(&g_pool.cv_work);
+    pthread_mutex_unlock(&g_pool.m);
     tree_team_worker(&tm); /* the caller is a member of the team */
-    for (int i = 0; i < started; ++i) pthread_join(th[i], 0);
+    pthread_mutex_lock(&g_pool.m);
+    while (g_pool.active > 0) pthread_cond_wait(&g_pool.cv_done, &g_pool.m);
+    g_pool.job = 0;
+    g_pool.want = 0;
+    pthread_mutex_unlock(&g_pool.m);
+    pthread_mutex_unlock(&g_pool.busy);
     return tm.rc;
 }
 
@@ -1026,8 +1089,22 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
         const int32_t ne = 2 * leaves - 1;
         int32_t *nodes = sorted_node + at;
         at += ne;
-        /* the leaves come in order already; the LCAs (every second event) do not */
-        qsort(nodes, (size_t)ne, sizeof(int32_t), cmp_i32);
+        /* the leaves come in order already; the LCAs (every second event) do not.  Deep levels
+         * of the recursion are thousands of trees of a handful of leaves: a call into qsort per
+         * (tree, part) cost more than everything else there */
+        if (ne <= 48) {
+            for (int32_t j = 1; j < ne; ++j) {
+                const int32_t x = nodes[j];
+                int32_t i = j - 1;
+                while (i >= 0 && nodes[i] > x) {
+                    nodes[i + 1] = nodes[i];
+                    --i;
+                }
+                nodes[i + 1] = x;
+            }
+        } else {
+            qsort(nodes, (size_t)ne, sizeof(int32_t), cmp_i32);
+        }
         int32_t nv = 0;
         for (int32_t j = 0; j < ne; ++j)
             if (nv == 0 || nodes[j] != nodes[nv - 1]) nodes[nv++] = nodes[j];
@@ -1134,23 +1211,44 @@ int scs_host_split_begin(int32_t n_trees, const int64_t *node_off, const int32_t
         scs_host_split_end(plan);
         return SCS_HOST_ENOMEM;
     }
-    int64_t w = 0;
-    for (int32_t i = 0; i < plan->n_arenas; ++i) {
-        memcpy(plan->sorted + w, plan->arenas[i].entries, sizeof(split_entry) * (size_t)plan->arenas[i].n_entries);
-        w += plan->arenas[i].n_entries;
-    }
-    plan->n_sorted = n;
-    qsort(plan->sorted, (size_t)n, sizeof(split_entry), cmp_entry);
+    /* entries by (part, tree): count per part, place arena by arena (an arena's trees
+     * increase: with one thread the placement IS the order; with several, a part's run is
+     * sorted afterwards only if it has an inversion) */
     for (int32_t p = 0; p < n_parts; ++p) {
         part_trees[p] = 0;
         part_nodes[p] = 0;
     }
-    for (int64_t i = 0; i < n; ++i) {
-        part_trees[plan->sorted[i].part] += 1;
-        part_nodes[plan->sorted[i].part] += plan->sorted[i].n_nodes;
-    }
+    for (int32_t i = 0; i < plan->n_arenas; ++i)
+        for (int64_t e = 0; e < plan->arenas[i].n_entries; ++e) {
+            part_trees[plan->arenas[i].entries[e].part] += 1;
+            part_nodes[plan->arenas[i].entries[e].part] += plan->arenas[i].entries[e].n_nodes;
+        }
     plan->part_first[0] = 0;
     for (int32_t p = 0; p < n_parts; ++p) plan->part_first[p + 1] = plan->part_first[p] + part_trees[p];
+    plan->n_sorted = n;
+    {
+        int64_t *cursor = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_parts);
+        if (!cursor) {
+            scs_host_split_end(plan);
+            return SCS_HOST_ENOMEM;
+        }
+        for (int32_t p = 0; p < n_parts; ++p) cursor[p] = plan->part_first[p];
+        for (int32_t i = 0; i < plan->n_arenas; ++i)
+            for (int64_t e = 0; e < plan->arenas[i].n_entries; ++e) {
+                const split_entry *en = &plan->arenas[i].entries[e];
+                plan->sorted[cursor[en->part]++] = *en;
+            }
+        free(cursor);
+        if (plan->arenas_used > 1)
+            for (int32_t p = 0; p < n_parts; ++p) {
+                split_entry *run = plan->sorted + plan->part_first[p];
+                const int64_t len = plan->part_first[p + 1] - plan->part_first[p];
+                int sorted_already = 1;
+                for (int64_t e = 1; e < len && sorted_already; ++e)
+                    if (run[e - 1].tree > run[e].tree) sorted_already = 0;
+                if (!sorted_already) qsort(run, (size_t)len, sizeof(split_entry), cmp_entry);
+            }
+    }
     *out_plan = plan;
     return SCS_HOST_OK;
 }
