@@ -73,13 +73,14 @@ def _seed_two_centres(x, x_sq, weight, weight_col, cdf, random_state):
 def _fast(maps, random_state):
     from sklearn.cluster import _k_means_common as kc
     from sklearn.cluster import _k_means_lloyd as kl
-    from sklearn.utils._openmp_helpers import _openmp_effective_n_threads
-
     x = np.array(maps, dtype=np.float64, order="C", copy=True)
     n = x.shape[0]
-    # up to 256 samples are one chunk of the Lloyd kernel, worked on by one thread whatever the
-    # team size: ask for one and skip the fork/join
-    n_threads = 1 if n <= 256 else _openmp_effective_n_threads()
+    # One thread: up to 256 samples are one chunk of the Lloyd kernel anyway, and above that (the
+    # fast path ends at 4 096 points x 2 coordinates) an OpenMP team costs far more than it
+    # computes -- 6-12 ms per call on a 256-thread host against < 1 ms, for hundreds of
+    # recursion nodes.  The chunks are then reduced in index order: deterministic, which the
+    # team's order of arrival is not.
+    n_threads = 1
     tol = np.mean(np.var(x, axis=0)) * 1e-4
     weight = np.ones(n, dtype=np.float64)
     weight_col = weight.reshape(-1, 1)

@@ -61,3 +61,25 @@ def test_inputs_outside_the_fast_range_use_the_public_function():
     # a seed instead of a generator is the public function's business
     lab = kmeans2.labels(x[:30], 11)
     assert set(np.unique(lab)) <= {0, 1}
+
+
+def test_single_thread_lloyd_equals_the_public_call_above_one_chunk():
+    # the fast path runs sklearn's Lloyd kernel on ONE thread also above 256 samples (several
+    # chunks): same labels and the same generator state as the public, team-parallel call
+    import warnings
+
+    from spectralclustersupertree_amd import kmeans2
+
+    if not kmeans2.fast_path_active():
+        pytest.skip("fast path not active with this scikit-learn")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for seed in range(24):
+            rs = np.random.RandomState(seed)
+            n = int(rs.choice([257, 300, 511, 512, 513, 1000, 2049, 4096]))
+            x = rs.standard_normal((n, 2)) * [1.0, 10.0 ** rs.randint(-4, 1)]
+            if seed % 3 == 0:
+                x[:, 1] = np.where(rs.rand(n) < 0.4, -1, 1) * 0.1 + x[:, 1] * 1e-3
+            ra, rb = np.random.RandomState(7 + seed), np.random.RandomState(7 + seed)
+            assert np.array_equal(kmeans2._fast(x, ra), kmeans2._public(x, rb)), (seed, n)
+            assert np.array_equal(ra.get_state()[1], rb.get_state()[1]) and ra.get_state()[2:] == rb.get_state()[2:]
