@@ -47,7 +47,9 @@
 typedef int (*tree_fn)(int32_t t, void *scratch, void *ctx);
 typedef struct {
     int32_t n_trees;
-    int32_t next; /* shared counter (atomic) */
+    int32_t next;  /* shared counter (atomic) */
+    int32_t chunk; /* trees handed out per visit to the counter (tiny trees: the counter's cache
+                      line would otherwise bounce between the threads once per microsecond) */
     tree_fn fn;
     void *ctx;
     size_t scratch_bytes;
@@ -61,11 +63,18 @@ static void *tree_team_worker(void *arg) {
         __atomic_store_n(&tm->rc, SCS_HOST_ENOMEM, __ATOMIC_RELAXED);
         return 0;
     }
+    const int32_t chunk = tm->chunk > 0 ? tm->chunk : 1;
     for (;;) {
-        const int32_t t = __atomic_fetch_add(&tm->next, 1, __ATOMIC_RELAXED);
-        if (t >= tm->n_trees || __atomic_load_n(&tm->rc, __ATOMIC_RELAXED) != SCS_HOST_OK) break;
-        const int rc = tm->fn(t, scratch, tm->ctx);
-        if (rc != SCS_HOST_OK) __atomic_store_n(&tm->rc, rc, __ATOMIC_RELAXED);
+        const int32_t t0 = __atomic_fetch_add(&tm->next, chunk, __ATOMIC_RELAXED);
+        if (t0 >= tm->n_trees || __atomic_load_n(&tm->rc, __ATOMIC_RELAXED) != SCS_HOST_OK) break;
+        const int32_t t1 = t0 + chunk < tm->n_trees ? t0 + chunk : tm->n_trees;
+        for (int32_t t = t0; t < t1; ++t) {
+            const int rc = tm->fn(t, scratch, tm->ctx);
+            if (rc != SCS_HOST_OK) {
+                __atomic_store_n(&tm->rc, rc, __ATOMIC_RELAXED);
+                break;
+            }
+        }
     }
     free(scratch);
     return 0;
@@ -132,15 +141,22 @@ static void *pool_worker(void *arg) {
 /* fn(t, scratch, ctx) for every tree t; scratch is a per-thread block of scratch_bytes */
 static int for_each_tree(int32_t n_trees, int64_t total_nodes, size_t scratch_bytes, tree_fn fn,
                          void *ctx) {
-    tree_team tm = {n_trees, 0, fn, ctx, scratch_bytes, SCS_HOST_OK};
+    tree_team tm = {n_trees, 0, 1, fn, ctx, scratch_bytes, SCS_HOST_OK};
     int n_thr = host_threads();
-    /* about 20 000 nodes of work per thread before another one is worth waking */
-    if (total_nodes / 20000 + 1 < n_thr) n_thr = (int)(total_nodes / 20000 + 1);
+    /* a few thousand nodes of work per thread before another one is worth waking (a deep node
+     * of configs[4] is 5 000 trees of a dozen nodes: 5 ms alone, a fraction of that shared) */
+    if (total_nodes < 16384) n_thr = 1; /* (waking the team costs more than such a job) */
+    if (total_nodes / 4096 + 1 < n_thr) n_thr = (int)(total_nodes / 4096 + 1);
     if (n_thr > n_trees) n_thr = n_trees;
     if (n_thr <= 1 || pthread_mutex_trylock(&g_pool.busy) != 0) {
+        tm.chunk = n_trees > 0 ? n_trees : 1;
         tree_team_worker(&tm);
         return tm.rc;
     }
+    /* about eight visits to the counter per thread, at most 64 trees each */
+    tm.chunk = n_trees / (n_thr * 8);
+    if (tm.chunk < 1) tm.chunk = 1;
+    if (tm.chunk > 64) tm.chunk = 64;
     pthread_mutex_lock(&g_pool.m);
     while (g_pool.started < n_thr - 1 && g_pool.started < 63) {
         pthread_attr_t at;
@@ -1143,12 +1159,6 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
     return rc;
 }
 
-static int cmp_entry(const void *a, const void *b) {
-    const split_entry *x = (const split_entry *)a, *y = (const split_entry *)b;
-    if (x->part != y->part) return (x->part > y->part) - (x->part < y->part);
-    return (x->tree > y->tree) - (x->tree < y->tree);
-}
-
 void scs_host_split_end(scs_split_plan *plan) {
     if (!plan) return;
     for (int32_t i = 0; i < plan->n_arenas; ++i) free(plan->arenas[i].entries);
@@ -1211,43 +1221,49 @@ int scs_host_split_begin(int32_t n_trees, const int64_t *node_off, const int32_t
         scs_host_split_end(plan);
         return SCS_HOST_ENOMEM;
     }
-    /* entries by (part, tree): count per part, place arena by arena (an arena's trees
-     * increase: with one thread the placement IS the order; with several, a part's run is
-     * sorted afterwards only if it has an inversion) */
+    /* entries by (part, tree): two stable counting passes (least significant key first: the
+     * tree, then the part) -- linear, whatever order the threads produced them in */
     for (int32_t p = 0; p < n_parts; ++p) {
         part_trees[p] = 0;
         part_nodes[p] = 0;
     }
-    for (int32_t i = 0; i < plan->n_arenas; ++i)
-        for (int64_t e = 0; e < plan->arenas[i].n_entries; ++e) {
-            part_trees[plan->arenas[i].entries[e].part] += 1;
-            part_nodes[plan->arenas[i].entries[e].part] += plan->arenas[i].entries[e].n_nodes;
-        }
-    plan->part_first[0] = 0;
-    for (int32_t p = 0; p < n_parts; ++p) plan->part_first[p + 1] = plan->part_first[p] + part_trees[p];
     plan->n_sorted = n;
     {
+        split_entry *tmp = (split_entry *)malloc(sizeof(split_entry) * (size_t)(n ? n : 1));
+        int64_t *cnt_tree = (int64_t *)calloc((size_t)n_trees + 1, sizeof(int64_t));
+        if (!tmp || !cnt_tree) {
+            free(tmp);
+            free(cnt_tree);
+            scs_host_split_end(plan);
+            return SCS_HOST_ENOMEM;
+        }
+        for (int32_t i = 0; i < plan->n_arenas; ++i)
+            for (int64_t e = 0; e < plan->arenas[i].n_entries; ++e) {
+                const split_entry *en = &plan->arenas[i].entries[e];
+                cnt_tree[en->tree + 1] += 1;
+                part_trees[en->part] += 1;
+                part_nodes[en->part] += en->n_nodes;
+            }
+        for (int32_t t = 0; t < n_trees; ++t) cnt_tree[t + 1] += cnt_tree[t];
+        for (int32_t i = 0; i < plan->n_arenas; ++i)
+            for (int64_t e = 0; e < plan->arenas[i].n_entries; ++e) {
+                const split_entry *en = &plan->arenas[i].entries[e];
+                tmp[cnt_tree[en->tree]++] = *en;
+            }
+        plan->part_first[0] = 0;
+        for (int32_t p = 0; p < n_parts; ++p) plan->part_first[p + 1] = plan->part_first[p] + part_trees[p];
         int64_t *cursor = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_parts);
         if (!cursor) {
+            free(tmp);
+            free(cnt_tree);
             scs_host_split_end(plan);
             return SCS_HOST_ENOMEM;
         }
         for (int32_t p = 0; p < n_parts; ++p) cursor[p] = plan->part_first[p];
-        for (int32_t i = 0; i < plan->n_arenas; ++i)
-            for (int64_t e = 0; e < plan->arenas[i].n_entries; ++e) {
-                const split_entry *en = &plan->arenas[i].entries[e];
-                plan->sorted[cursor[en->part]++] = *en;
-            }
+        for (int64_t e = 0; e < n; ++e) plan->sorted[cursor[tmp[e].part]++] = tmp[e];
         free(cursor);
-        if (plan->arenas_used > 1)
-            for (int32_t p = 0; p < n_parts; ++p) {
-                split_entry *run = plan->sorted + plan->part_first[p];
-                const int64_t len = plan->part_first[p + 1] - plan->part_first[p];
-                int sorted_already = 1;
-                for (int64_t e = 1; e < len && sorted_already; ++e)
-                    if (run[e - 1].tree > run[e].tree) sorted_already = 0;
-                if (!sorted_already) qsort(run, (size_t)len, sizeof(split_entry), cmp_entry);
-            }
+        free(cnt_tree);
+        free(tmp);
     }
     *out_plan = plan;
     return SCS_HOST_OK;

@@ -272,7 +272,7 @@ def test_fiedler_block_widths(dev, block):
     _fiedler_case(dev, tables, block=block)
 
 
-@pytest.mark.parametrize("n", [3, 4, 8, 33, 64])
+@pytest.mark.parametrize("n", [3, 4, 8, 33, 64, 65, 97, 127, 128])
 def test_fiedler_small_dense_path(dev, n):
     # generic (random tree weights, branch lengths) so that no eigenvalue is repeated
     tables = synthetic.make_tables(n, n, 9, "branch", random_weights=True)
@@ -289,7 +289,7 @@ def test_fiedler_small_dense_path(dev, n):
     assert np.max(np.abs(maps - ref)) <= FIEDLER_TOL, (maps, ref)
 
 
-@pytest.mark.parametrize("n", [40, 150])
+@pytest.mark.parametrize("n", [40, 90, 150])
 def test_fiedler_with_isolated_vertices(dev, n):
     # taxa that never share a root side with anything have degree 0: scipy scales their rows by 1
     # (reference: scipy/sparse/csgraph/_laplacian.py:550-557), the trivial eigenvector is no
