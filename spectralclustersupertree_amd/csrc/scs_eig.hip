@@ -771,8 +771,9 @@ __global__ __launch_bounds__(256) void k_dense_onesided(const double *__restrict
                 be += __shfl_xor(be, 2, 64);
                 ga += __shfl_xor(ga, 2, 64);
                 // (the four threads of a pair hold the same sums: the same decision); columns
-                // whose cosine is at the rounding floor of a 128-term dot product are orthogonal
-                if (ga * ga > 1e-29 * al * be) {
+                // whose cosine is at the rounding floor of a 128-term dot product (~ n eps = 3e-14)
+                // are orthogonal: rotating them again would never end
+                if (ga * ga > 1e-27 * al * be) {
                     const double zeta = (be - al) / (2.0 * ga);
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
                     const double c = 1.0 / sqrt(fma(t, t, 1.0)), sn = c * t;
@@ -1591,10 +1592,13 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));
 
-    // 65 .. 128 vertices on one rank: the one-sided dense solve (SCS_DENSE128=0 keeps LOBPCG);
-    // asked-for block widths and tolerances other than the defaults keep the iterative path too
-    static const bool dense128 = !(getenv("SCS_DENSE128") && atoi(getenv("SCS_DENSE128")) == 0);
-    if (n > MAXS && n <= DENSE2_MAX && dense128 && block == 0 && ctx->comm.world == 1 && !g->upper) {
+    // 65 .. 96 vertices on one rank: the one-sided dense solve.  Its time grows with n^2 (n - 1
+    // steps per sweep, each rewriting two columns per pair): measured 1.9 ms at 80 vertices
+    // against 3.0 ms for LOBPCG, 4.5 against 3.5 ms at 120 -- the crossover is near 100.
+    // SCS_DENSE_MAX=n moves the limit (<= 128; 64 switches the path off); an asked-for block
+    // width keeps the iterative path too.
+    static const int dense_max = getenv("SCS_DENSE_MAX") ? std::min(atoi(getenv("SCS_DENSE_MAX")), DENSE2_MAX) : 96;
+    if (n > MAXS && n <= dense_max && block == 0 && ctx->comm.world == 1 && !g->upper) {
         SCS_TRY(fiedler_dense_onesided(ctx, g, maps_out, st));
         SCS_HIP_CHECK(hipEventRecord(ev_b, s));
         SCS_HIP_CHECK(hipEventSynchronize(ev_b));
