@@ -63,7 +63,7 @@ def key_of(acc, needle):
 k_symm = key_of(fetch, "k_symm")
 k_acc = key_of(fetch, "k_accumulate_mono")
 roofs = {r["kernel"].split(" ")[0].split("<")[0]: r for r in (bench["roofline"], bench["roofline_other"])}
-symm_alg = roofs["k_symm"]["bytes_per_launch"]
+symm_alg = next(v for k, v in roofs.items() if k.startswith("k_symm"))["bytes_per_launch"]
 acc_alg = roofs["k_accumulate_mono"]["bytes_per_launch"]
 alg = {k_symm: (symm_alg, "bytes of W tiles streamed + block in/out"),
        "k_degrees": (8.0 * n * n, "8 V^2"),
@@ -86,8 +86,14 @@ for r in rows[:16]:
                  f"{float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.2f} |")
 lines += ["", "Live measurement inside bench.py in the same run (HIP events on the library's stream):"]
 for name, r in roofs.items():
-    lines.append(f"* `{name}`: {r['avg_launch_ms']*1e3:.1f} us per launch x {r['launches_per_step']:.0f} launches per step, "
-                 f"{r['achieved']:.1f} GB/s of algorithmic bytes (frac {r['frac']}).")
+    if r.get("bound") == "lds":
+        lines.append(f"* `{name}`: {r['avg_launch_ms']*1e3:.1f} us per launch x {r['launches_per_step']:.0f} launches per step; "
+                     f"bound = LDS: {r['achieved']:.0f} GB/s of ds_read_b64 bytes (8 per cell-tree) of ~150 000 = frac {r['frac']}; "
+                     f"algorithmic HBM bytes {r['hbm']['achieved']:.1f} GB/s (frac {r['hbm']['frac']}); "
+                     f"{r['cell_trees_per_s']:.3e} cell-trees/s, fp64 VALU frac {r['frac_f64_valu']}.")
+    else:
+        lines.append(f"* `{name}`: {r['avg_launch_ms']*1e3:.1f} us per launch x {r['launches_per_step']:.0f} launches per step, "
+                     f"{r['achieved']:.1f} GB/s of algorithmic bytes (frac {r['frac']}).")
 lines += ["", "## HBM-side traffic per launch (PMC; FETCH_SIZE / WRITE_SIZE count KB: x 1024)", "",
           "gfx950 note (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports exactly half of the bytes of a wide coalesced "
           "streaming read, so the SYMM kernel and k_degrees are doubled before comparing with the algorithmic byte count; the "
@@ -135,12 +141,15 @@ except (FileNotFoundError, KeyError, ZeroDivisionError) as e:
 
 st = default["stages"]
 lines += ["## Default bench line (un-profiled)", "",
-          f"configs[2]: {default['value']*1e3:.1f} ms per step (build {st['build_ms']:.1f} ms of which accumulate "
+          f"configs[2]: {default['value']*1e3:.1f} ms per step by the SURVEY 8d protocol (tables upload {st.get('tables_upload_ms', 0):.1f} ms, "
+          f"build {st['build_ms']:.1f} ms of which accumulate "
           f"{st['build_accumulate_ms']:.1f}, solve {st['fiedler_ms']:.1f} ms of which SYMM {st['fiedler_symm_ms']:.1f}, "
-          f"{st['lobpcg_iterations']:.0f} LOBPCG iterations); including the tables' upload {default['value_incl_h2d_d2h']*1e3:.1f} ms; "
+          f"{st['lobpcg_iterations']:.0f} LOBPCG iterations); on HBM-resident tables {default.get('value_tables_resident', 0)*1e3:.1f} ms; "
           f"dominant kernel {default['roofline']['kernel'].split(' ')[0]} (frac {default['roofline']['frac']}); path figure "
           f"{default['roofline_path']['achieved']:.0f} GB/s = {default['roofline_path']['frac']} of spec; cpu_baseline "
-          f"{default['cpu_baseline']['value']:.1f} s ({default['cpu_baseline']['sample'][:60]}...).", "",
+          f"{default['cpu_baseline']['value']:.1f} s ({default['cpu_baseline']['sample'][:60]}...); reference-style dict build sample: "
+          f"{json.dumps(default['cpu_baseline'].get('reference_style_build', {}))}; kmeans2 fast path active: "
+          f"{default.get('kmeans2_fast_path_active')}.", "",
           f"Parity gates at full size: {json.dumps(default['parity'])}", "",
           f"Seeds: {json.dumps(default.get('seeds', {}))}", "",
           f"Planted input: {default['planted'].get('value')} s, lambda2 {default['planted']['stages']['lambda2']:.4f}, "
