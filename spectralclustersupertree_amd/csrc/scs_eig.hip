@@ -18,6 +18,8 @@
 #include "scs_internal.h"
 #include "scs_symm.h"
 #include "scs_symm_tri.h"
+
+#include <sched.h>
 #include "scs_panel.h"
 
 constexpr int MAXB = 16;      // widest LOBPCG block
@@ -295,6 +297,25 @@ __global__ void k_trivial(const double *__restrict__ deg, double inv_norm, int n
                           double *__restrict__ u) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) u[i] = sqrt(deg[i]) * inv_norm;
+}
+
+// The two columns the caller gets, taken from the panel on the device: the trivial eigenvector
+// (constant 1 / ||sqrt d|| when it was deflated analytically, else X's first column / sqrt d) and
+// the Fiedler column / sqrt d (sklearn/manifold/_spectral_embedding.py:463).  16 V bytes travel
+// instead of the 8 V 3b of the whole panel.
+__global__ void k_extract_maps(const double *__restrict__ q, int ldq, int n,
+                               const double *__restrict__ dinv, double inv_norm, int constrained,
+                               double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double di = dinv[i];
+    if (constrained) {
+        out[2 * i] = inv_norm;  // (sqrt(d_i) / ||sqrt d||) / sqrt(d_i)
+        out[2 * i + 1] = q[(int64_t)i * ldq] * di;
+    } else {
+        out[2 * i] = q[(int64_t)i * ldq] * di;
+        out[2 * i + 1] = q[(int64_t)i * ldq + 1] * di;
+    }
 }
 
 // SCS_BUILD_UPPER jobs: y = dinv (.) (sum over ranks, in rank order, of the gathered partial
@@ -1779,6 +1800,10 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 const auto t_wait = std::chrono::steady_clock::now();
                 unsigned spins = 0;
                 while (hr[40] != seq) {
+                    __builtin_ia32_pause();
+                    // (a report normally arrives within a few microseconds; a host thread that has
+                    // waited much longer lets others run -- eight ranks may share the cores)
+                    if (spins > (1u << 18) && (spins & 0x3FF) == 0) sched_yield();
                     if ((++spins & 0xFFFF) == 0) {
                         const hipError_t qe = hipStreamQuery(s);
                         if (qe != hipSuccess && qe != hipErrorNotReady) {
@@ -1874,30 +1899,28 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         SCS_HIP_CHECK(hipGetLastError());
     }
 
-    // ---- results
-    std::vector<double> xcol((size_t)n * q3), dinv(n);
-    SCS_HIP_CHECK(hipMemcpyAsync(xcol.data(), Q, (size_t)n * q3 * 8, hipMemcpyDeviceToHost, s));
-    SCS_HIP_CHECK(hipMemcpyAsync(dinv.data(), g->d_dinv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    // ---- results: the two wanted columns, scaled, from the device (not the whole panel)
+    dbuf maps_d;
+    SCS_TRY(maps_d.alloc((size_t)n * 2 * 8));
+    k_extract_maps<<<(n + 255) / 256, 256, 0, s>>>(Q, q3, n, g->d_dinv, 1.0 / g->dd_norm, constrained ? 1 : 0,
+                                                  maps_d.d());
+    std::vector<double> cols((size_t)n * 2);
+    SCS_HIP_CHECK(hipMemcpyAsync(cols.data(), maps_d.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost, s));
     // (fused loop: TH already holds the next iteration's Ritz values; h_th has X's)
     if (!fused)
         SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipEventRecord(ev_b, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));
     std::vector<double> c0(n), c1(n);
+    for (int i = 0; i < n; ++i) {
+        c0[i] = cols[(size_t)i * 2];
+        c1[i] = cols[(size_t)i * 2 + 1];
+    }
     if (constrained) {
-        const double inv = 1.0 / g->dd_norm;
-        for (int i = 0; i < n; ++i) {
-            c0[i] = inv;  // (sqrt(d_i)/||sqrt d||) / sqrt(d_i)
-            c1[i] = xcol[(size_t)i * q3 + 0] * dinv[i];
-        }
         st->lambda[0] = 1.0;
         st->lambda[1] = h_th[0];
         st->lambda_next = b > 1 ? h_th[1] : 0.0;
     } else {
-        for (int i = 0; i < n; ++i) {
-            c0[i] = xcol[(size_t)i * q3 + 0] * dinv[i];
-            c1[i] = xcol[(size_t)i * q3 + 1] * dinv[i];
-        }
         st->lambda[0] = h_th[0];
         st->lambda[1] = h_th[1];
         st->lambda_next = b > 2 ? h_th[2] : 0.0;
