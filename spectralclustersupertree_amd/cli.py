@@ -12,23 +12,23 @@ from spectralclustersupertree_amd import __version__
 
 @click.command(no_args_is_help=True)
 @click.version_option(__version__)
-@click.option("-i", "--in-file", required=True, help="File containing source trees.")
-@click.option("-o", "--out-file", required=True, help="Output file.")
+@click.option("-i", "--in-file", required=True, help="Line-separated Newick file with the source trees (parsed straight into flat arrays).")
+@click.option("-o", "--out-file", required=True, help="Where the supertree is written (Newick).")
 @click.option(
     "-p",
     "--pcg-weighting",
-    help="Proper cluster graph weighting strategy.",
+    help="How an edge of the proper cluster graph is weighted by the LCA of its two taxa.",
     default="branch",
     type=click.Choice(["one", "depth", "branch", "bootstrap"], case_sensitive=False),
 )
 @click.option(
     "--disable-contraction",
-    help="Disable edge contraction (not recommended).",
+    help="Keep always-together taxa as separate vertices (slower, same result up to ties).",
     default=False,
     is_flag=True,
 )
 def scs(in_file: str, out_file: str, pcg_weighting: str, *, disable_contraction: bool) -> None:
-    """Run spectral cluster supertree over the given set of source trees."""
+    """Spectral Cluster Supertree of the source trees in IN_FILE, on the MI355X core."""
     from spectralclustersupertree_amd import construct_supertree
     from spectralclustersupertree_amd.load import load_tree_arrays
 
