@@ -21,7 +21,7 @@ warnings.simplefilter("ignore")
 rng = np.random.RandomState(args.seed)
 dev = Device(0)
 t_end = time.time() + args.seconds
-n_cases = n_fiedler = n_multi = n_small = 0
+n_cases = n_fiedler = n_multi = n_small = n_upper = 0
 worst = 0.0
 fails = []
 while time.time() < t_end:
@@ -84,8 +84,15 @@ while time.time() < t_end:
         import threading
         from spectralclustersupertree_amd import _native as nv
         world = int(rng.randint(2, 5))
-        cuts = sorted(set(int(x) for x in rng.choice(np.arange(1, n), world - 1, replace=False)))
-        splits = [0] + cuts + [n]
+        # alternately: row-partitioned with shared tiles (arbitrary splits), or an upper-triangle
+        # job (SCS_BUILD_UPPER: splits on multiples of 256, equal trapezoids)
+        upper_job = (n_cases // 4) % 2 == 1 and n >= 256 * world
+        if upper_job:
+            from spectralclustersupertree_amd.partition import row_splits_upper
+            splits = row_splits_upper(n, world)
+        else:
+            cuts = sorted(set(int(x) for x in rng.choice(np.arange(1, n), world - 1, replace=False)))
+            splits = [0] + cuts + [n]
         world = len(splits) - 1
         lib = nv.load_library()
         group = nv.C.c_void_p()
@@ -96,7 +103,7 @@ while time.time() < t_end:
             try:
                 d = Device(0, r, world, _local_group=group)
                 dt = d.upload(tables)
-                gg = dt.build(splits[r], splits[r + 1], shared=True)
+                gg = dt.build(splits[r], splits[r + 1], shared=not upper_job, upper=upper_job)
                 ww = gg.download()
                 mm, _ = gg.fiedler(v0m)
                 outs[r] = (ww, mm)
@@ -112,13 +119,19 @@ while time.time() < t_end:
             fails.append(f"multi-rank error: {tag} splits={splits}: {errs}")
         else:
             for r in range(world):
-                if not np.array_equal(outs[r][0], w_ref[splits[r]:splits[r + 1]]):
-                    fails.append(f"multi-rank W mismatch: {tag} splits={splits} rank {r}")
+                want_rows = w_ref[splits[r]:splits[r + 1]].copy()
+                if upper_job:  # a row is stored from its 256-column diagonal tile on
+                    for i in range(splits[r], splits[r + 1]):
+                        want_rows[i - splits[r], : i // 256 * 256] = 0.0
+                    n_upper += 1
+                if not np.array_equal(outs[r][0], want_rows):
+                    fails.append(f"multi-rank W mismatch: {tag} splits={splits} upper={upper_job} rank {r}")
                 if not np.array_equal(outs[r][1], outs[0][1]):
                     fails.append(f"multi-rank maps differ between ranks: {tag} splits={splits} rank {r}")
 dev.close()
 print(f"fuzz: {n_cases} builds bit-exact checked, {n_fiedler} Fiedler comparisons, worst |diff| {worst:.2e}, "
-      f"{n_multi} multi-rank shared builds + solves, {n_small} fused small-node solves, {len(fails)} failures")
+      f"{n_multi} multi-rank builds + solves ({n_upper} rank-blocks of upper-triangle jobs), {n_small} fused small-node "
+      f"solves, {len(fails)} failures")
 for f in fails[:20]:
     print("  ", f)
 sys.exit(1 if fails else 0)
