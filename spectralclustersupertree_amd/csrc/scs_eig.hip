@@ -1203,6 +1203,12 @@ struct solver {
     bool tri = false, part_mode = false;
     int tri_ct = 2, tri_nct = 0, tri_ntiles = 0;
     int tri_rb_lo = 0, tri_rb_hi = 0x7FFFFFFF;  // this rank's row blocks (of TRI_TH rows)
+    // The tile list is stored twice, forwards and backwards, and consecutive applications
+    // alternate: the tiles an application streamed last are the ones the next one starts with,
+    // so whatever part of W the 256 MiB Infinity Cache still holds is read there and not from
+    // HBM (a cyclic sweep of more than the cache's size would find nothing).  Every tile writes
+    // its own slabs of the partial sums: the order of the tiles does not touch the result.
+    bool tri_backwards = false;
     dbuf tri_tiles, tri_pdir, tri_ptr, ysend;
     int64_t ldz = 0;                 // leading dimension of the k-major operand z
     double w_bytes_per_apply = 0.0;  // bytes of W one application streams
@@ -1216,8 +1222,10 @@ struct solver {
         double *ptr_eff = tri_ptr.d() - (int64_t)tri_rb_lo * n * b;
 #define TRI(B_, CT_, RPW_, D_)                                                                       \
     k_symm_tri<B_, CT_, RPW_, D_><<<tri_ntiles, 256, 0, s>>>(w_eff, g->ld, n, zin, ldz,              \
-                                                             (const int2 *)tri_tiles.p, tri_pdir.d(), \
-                                                             ptr_eff)
+                                                             tile_list, tri_pdir.d(), ptr_eff)
+        const int2 *tile_list = (const int2 *)tri_tiles.p + (tri_backwards ? tri_ntiles : 0);
+        static const bool no_flip = getenv("SCS_TRI_NO_FLIP") && atoi(getenv("SCS_TRI_NO_FLIP"));
+        tri_backwards = !no_flip && !tri_backwards;
         if (b == 4) {
             if (tri_ct == 4) TRI(4, 4, 2, 3);
             else if (tri_ct == 1) TRI(4, 1, 4, 4);
@@ -1320,6 +1328,7 @@ struct solver {
             for (int i = tri_rb_lo; i < tri_rb_hi; ++i)
                 for (int j = i * TRI_TH / tw; j < tri_nct; ++j) tiles.push_back(make_int2(i, j));
             tri_ntiles = (int)tiles.size();
+            tiles.insert(tiles.end(), tiles.rbegin(), tiles.rend());  // and backwards
             SCS_TRY(tri_tiles.alloc(std::max<size_t>(tiles.size(), 1) * sizeof(int2)));
             SCS_HIP_CHECK(hipMemcpyAsync(tri_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                          hipMemcpyHostToDevice, s));
@@ -1345,6 +1354,7 @@ struct solver {
             for (int i = 0; i < n_rb; ++i)
                 for (int j = i * TRI_TH / tw; j < tri_nct; ++j) tiles.push_back(make_int2(i, j));
             tri_ntiles = (int)tiles.size();
+            tiles.insert(tiles.end(), tiles.rbegin(), tiles.rend());  // and backwards
             SCS_TRY(tri_tiles.alloc(tiles.size() * sizeof(int2)));
             SCS_HIP_CHECK(hipMemcpyAsync(tri_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                          hipMemcpyHostToDevice, s));
