@@ -47,6 +47,9 @@ def load() -> C.CDLL:
         lib.scs_host_contraction_groups.argtypes = [C.c_int32, C.c_int32, lp, ip, ip, ip]
         lib.scs_host_components.restype = C.c_int
         lib.scs_host_components.argtypes = [C.c_int32, C.c_int32, lp, ip, ip, ip]
+        lib.scs_host_lloyd2.restype = C.c_int
+        lib.scs_host_lloyd2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 

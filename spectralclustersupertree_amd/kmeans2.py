@@ -12,6 +12,14 @@ among the initialisations (``KMeans.fit``, ``_kmeans_plusplus``, ``_kmeans_singl
 sklearn/cluster/_kmeans.py) -- with the same numpy operations in the same order and the same
 draws from the ``RandomState``: same labels, same stream position afterwards.
 
+Round 3: the Lloyd iteration itself -- three quarters of a call for the tiny embeddings of the
+deep recursion, all of it call overhead of the Cython entry point -- runs in ``libscs_host.so``
+(``csrc/scs_kmeans.c``: the iteration of ``_k_means_lloyd.pyx`` restated for two clusters of
+two-coordinate points, its one BLAS call made through the very ``dgemm`` pointer scikit-learn's
+Cython code uses).  The self-test holds it against the Cython kernel bit for bit (labels, inertia,
+iteration count); without the library, the pointer or a clean self-test the Cython kernel is
+driven from Python as before.  ``SCS_KMEANS=cython`` forces that.
+
 Because this leans on private modules of scikit-learn, it is used only when
   * the installed version is one the restatement was written against (``_KNOWN``), and
   * a self-test at first use reproduces the public ``k_means`` bit for bit (labels and the
@@ -28,7 +36,7 @@ import numpy as np
 
 _KNOWN = ("1.7.2",)
 _MAX_SAMPLES = 4096  # larger inputs: the call overhead does not matter
-_state = {"checked": False, "ok": False}
+_state = {"checked": False, "ok": False, "native": None}
 
 
 def _public(maps, random_state):
@@ -70,17 +78,110 @@ def _seed_two_centres(x, x_sq, weight, weight_col, cdf, random_state):
     return centres, (int(first), int(second))
 
 
-def _fast(maps, random_state):
+def _dgemm_pointer():
+    """Address of the ``dgemm`` scikit-learn's Cython code calls (``sklearn/utils/_cython_blas.pyx``
+    cimports it from ``scipy.linalg.cython_blas``, which exports it in ``__pyx_capi__``)."""
+    import ctypes as C
+
+    import scipy.linalg.cython_blas as cb
+
+    cap = cb.__pyx_capi__["dgemm"]
+    api = C.pythonapi
+    api.PyCapsule_GetName.restype = C.c_char_p
+    api.PyCapsule_GetName.argtypes = [C.py_object]
+    api.PyCapsule_GetPointer.restype = C.c_void_p
+    api.PyCapsule_GetPointer.argtypes = [C.py_object, C.c_char_p]
+    name = api.PyCapsule_GetName(cap)
+    if b"(char *, char *, int *, int *, int *," not in name:  # not the signature this file calls it with
+        return None
+    return api.PyCapsule_GetPointer(cap, name)
+
+
+def _lloyd_cython(x, weight, tol, kl, kc):
+    """``_kmeans_single_lloyd`` on scikit-learn's compiled iteration: centres -> (labels, inertia)."""
+    n = x.shape[0]
+    n_threads = 1
+
+    def run(centres, want_iterations=False):
+        centres_new = np.zeros_like(centres)
+        lab = np.full(n, -1, dtype=np.int32)
+        lab_old = lab.copy()
+        in_clusters = np.zeros(2, dtype=np.float64)
+        shift = np.zeros(2, dtype=np.float64)
+        strict = False
+        done = 300
+        for it in range(300):
+            kl.lloyd_iter_chunked_dense(x, weight, centres, centres_new, in_clusters, lab, shift, n_threads)
+            centres, centres_new = centres_new, centres
+            if np.array_equal(lab, lab_old):
+                strict = True
+                done = it + 1
+                break
+            if (shift**2).sum() <= tol:
+                done = it + 1
+                break
+            lab_old[:] = lab
+        if not strict:
+            kl.lloyd_iter_chunked_dense(x, weight, centres, centres, in_clusters, lab, shift, n_threads,
+                                        update_centers=False)
+        inertia = kc._inertia_dense(x, weight, centres, lab, n_threads)
+        return (lab, inertia, done) if want_iterations else (lab, inertia)
+
+    return run
+
+
+def _native():
+    """(library, dgemm address) of the C iteration, or None."""
+    if _state["native"] is None:
+        _state["native"] = False
+        if os.environ.get("SCS_KMEANS", "") != "cython":
+            try:
+                from spectralclustersupertree_amd import _hostlib
+
+                lib, ptr = _hostlib.load(), _dgemm_pointer()
+                if ptr:
+                    _state["native"] = (lib, ptr)
+            except Exception:  # noqa: BLE001 -- no library / no scipy capsule: the Cython kernel it is
+                pass
+    return _state["native"] or None
+
+
+def _lloyd_native(x, tol, fallback, lib, ptr):
+    """The same on ``scs_host_lloyd2``; a start that empties a cluster goes to `fallback`."""
+    import ctypes as C
+
+    n = x.shape[0]
+    x_ptr = x.ctypes.data
+    c_buf = np.empty((2, 2), dtype=np.float64)
+    c_ptr = c_buf.ctypes.data
+    inertia = C.c_double()
+    iters = C.c_int32()
+    inertia_ref, iters_ref = C.byref(inertia), C.byref(iters)
+    fn = lib.scs_host_lloyd2
+
+    def run(centres, want_iterations=False):
+        c_buf[...] = centres
+        lab = np.empty(n, dtype=np.int32)
+        rc = fn(ptr, n, x_ptr, c_ptr, tol, 300, lab.ctypes.data, inertia_ref, iters_ref)
+        if rc != 0:
+            if rc < 0:
+                msg = "scs_host_lloyd2 failed"
+                raise RuntimeError(msg)
+            return fallback(centres, want_iterations)
+        return (lab, inertia.value, iters.value) if want_iterations else (lab, inertia.value)
+
+    return run
+
+
+def _fast(maps, random_state, use_native=True):
     from sklearn.cluster import _k_means_common as kc
     from sklearn.cluster import _k_means_lloyd as kl
     x = np.array(maps, dtype=np.float64, order="C", copy=True)
     n = x.shape[0]
-    # One thread: up to 256 samples are one chunk of the Lloyd kernel anyway, and above that (the
-    # fast path ends at 4 096 points x 2 coordinates) an OpenMP team costs far more than it
-    # computes -- 6-12 ms per call on a 256-thread host against < 1 ms, for hundreds of
-    # recursion nodes.  The chunks are then reduced in index order: deterministic, which the
-    # team's order of arrival is not.
-    n_threads = 1
+    # (one thread in the Lloyd kernel: up to 256 samples are one chunk anyway, and above that -- the
+    # fast path ends at 4 096 points x 2 coordinates -- an OpenMP team costs far more than it
+    # computes: 6-12 ms per call on a 256-thread host against < 1 ms; the chunks are then reduced
+    # in index order, which the team's order of arrival is not)
     tol = np.mean(np.var(x, axis=0)) * 1e-4
     weight = np.ones(n, dtype=np.float64)
     weight_col = weight.reshape(-1, 1)
@@ -88,6 +189,10 @@ def _fast(maps, random_state):
     cdf /= cdf[-1]
     x -= x.mean(axis=0)
     x_sq = np.einsum("ij,ij->i", x, x)
+    lloyd = _lloyd_cython(x, weight, tol, kl, kc)
+    native = _native() if use_native else None
+    if native is not None:
+        lloyd = _lloyd_native(x, float(tol), lloyd, *native)
     best_inertia, best_labels = None, None
     seen = {}  # (first, second) seed points -> (labels, inertia): the same start, the same run
     for _ in range(10):
@@ -97,26 +202,7 @@ def _fast(maps, random_state):
             if best_inertia is None or (inertia < best_inertia and not kc._is_same_clustering(lab, best_labels, 2)):
                 best_labels, best_inertia = lab, inertia
             continue
-        # ---- _kmeans_single_lloyd
-        centres_new = np.zeros_like(centres)
-        lab = np.full(n, -1, dtype=np.int32)
-        lab_old = lab.copy()
-        in_clusters = np.zeros(2, dtype=np.float64)
-        shift = np.zeros(2, dtype=np.float64)
-        strict = False
-        for _it in range(300):
-            kl.lloyd_iter_chunked_dense(x, weight, centres, centres_new, in_clusters, lab, shift, n_threads)
-            centres, centres_new = centres_new, centres
-            if np.array_equal(lab, lab_old):
-                strict = True
-                break
-            if (shift**2).sum() <= tol:
-                break
-            lab_old[:] = lab
-        if not strict:
-            kl.lloyd_iter_chunked_dense(x, weight, centres, centres, in_clusters, lab, shift, n_threads,
-                                        update_centers=False)
-        inertia = kc._inertia_dense(x, weight, centres, lab, n_threads)
+        lab, inertia = lloyd(centres)
         seen[seeds] = (lab, inertia)
         if best_inertia is None or (inertia < best_inertia and not kc._is_same_clustering(lab, best_labels, 2)):
             best_labels, best_inertia = lab, inertia
@@ -130,6 +216,46 @@ def _fast(maps, random_state):
     return best_labels
 
 
+def _native_agrees() -> bool:
+    """The C iteration against scikit-learn's Cython kernel, start by start: labels, inertia and
+    iteration count bit for bit -- on tiny, ragged, multi-chunk and duplicate-ridden inputs, and
+    from good and bad starting centres.  Also the one formula of the C file that restates a numpy
+    call (the centres' squared norms, ``row_norms`` = einsum) on its own."""
+    from sklearn.cluster import _k_means_common as kc
+    from sklearn.cluster import _k_means_lloyd as kl
+    from sklearn.utils.extmath import row_norms
+
+    native = _native()
+    if native is None:
+        return False
+    probe = np.random.RandomState(2718)
+    for _ in range(64):
+        c = probe.standard_normal((2, 2)) * 10.0 ** probe.randint(-6, 3)
+        if not np.array_equal(row_norms(c, squared=True), c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1]):
+            return False
+    sizes = [2, 3, 4, 5, 8, 13, 31, 64, 65, 200, 256, 257, 600, 1025]
+    for n in sizes:
+        for rep in range(3):
+            x = probe.standard_normal((n, 2)) * [1.0, 10.0 ** probe.randint(-4, 1)]
+            if rep == 2:
+                x[n // 2:] = x[: n - n // 2]  # duplicates
+            x = np.ascontiguousarray(x - x.mean(axis=0))
+            weight = np.ones(n)
+            tol = float(np.mean(np.var(x, axis=0)) * 1e-4)
+            ref = _lloyd_cython(x, weight, tol, kl, kc)
+            nat = _lloyd_native(x, tol, lambda c, w=False: None, *native)
+            for start in range(4):
+                centres = x[probe.choice(n, 2, replace=False)].copy() if start < 3 else \
+                    probe.standard_normal((2, 2)) * 3.0
+                got = nat(centres.copy(), True)
+                want = ref(centres.copy(), True)
+                if got is None:  # an empty cluster: the C side hands the start back, nothing to compare
+                    continue
+                if not (np.array_equal(got[0], want[0]) and got[1] == want[1] and got[2] == want[2]):
+                    return False
+    return True
+
+
 def _self_test() -> bool:
     """The fast path against the public function: labels and generator state, bit for bit."""
     try:
@@ -139,6 +265,8 @@ def _self_test() -> bool:
 
         if sklearn.__version__ not in _KNOWN:
             return False
+        if _native() is not None and not _native_agrees():
+            _state["native"] = False
         probe = np.random.RandomState(12345)
         cases = [probe.standard_normal((n, 2)) * [1.0, 10.0 ** probe.randint(-3, 1)] for n in (3, 4, 5, 7, 12, 33, 100, 300)]
         cases.append(np.array([[0.0, 1.0], [0.0, 1.0], [0.0, -1.0], [0.0, -1.0]]))  # duplicates
@@ -156,6 +284,11 @@ def _self_test() -> bool:
         return True
     except Exception:  # noqa: BLE001 -- anything unexpected in private modules: use the public function
         return False
+
+
+def native_lloyd_active() -> bool:
+    """True when the Lloyd iteration runs in libscs_host.so (after the self-test)."""
+    return fast_path_active() and bool(_state["native"])
 
 
 def fast_path_active() -> bool:

@@ -83,3 +83,75 @@ def test_single_thread_lloyd_equals_the_public_call_above_one_chunk():
             ra, rb = np.random.RandomState(7 + seed), np.random.RandomState(7 + seed)
             assert np.array_equal(kmeans2._fast(x, ra), kmeans2._public(x, rb)), (seed, n)
             assert np.array_equal(ra.get_state()[1], rb.get_state()[1]) and ra.get_state()[2:] == rb.get_state()[2:]
+
+
+def _starts(x, tol, native):
+    from sklearn.cluster import _k_means_common as kc
+    from sklearn.cluster import _k_means_lloyd as kl
+
+    ref = kmeans2._lloyd_cython(x, np.ones(len(x)), tol, kl, kc)
+    return ref, kmeans2._lloyd_native(x, tol, ref, *native)
+
+
+def test_native_lloyd_iteration_equals_the_cython_kernel_start_by_start():
+    # csrc/scs_kmeans.c against lloyd_iter_chunked_dense / _inertia_dense: labels, inertia bits and
+    # the number of iterations, from seeded and from arbitrary centres
+    if not kmeans2.native_lloyd_active():
+        pytest.skip("the C iteration is not active here")
+    native = kmeans2._native()
+    rs = np.random.RandomState(99)
+    checked = 0
+    for case in range(300):
+        n = int(rs.choice([2, 3, 4, 5, 7, 16, 33, 64, 100, 255, 256, 257, 511, 513, 1500, 4096]))
+        x = rs.standard_normal((n, 2)) * [1.0, 10.0 ** rs.randint(-8, 2)]
+        if case % 4 == 1:
+            x = np.round(x, 1)
+        if case % 4 == 2:
+            x[:, 0] = rs.rand()
+        x = np.ascontiguousarray(x - x.mean(axis=0))
+        tol = float(np.mean(np.var(x, axis=0)) * 1e-4)
+        ref, nat = _starts(x, tol, native)
+        for start in range(3):
+            c = x[rs.choice(n, 2, replace=False)].copy() if start < 2 else rs.standard_normal((2, 2))
+            got, want = nat(c.copy(), True), ref(c.copy(), True)
+            assert np.array_equal(got[0], want[0]), (case, n, start)
+            assert got[1] == want[1] and got[2] == want[2], (case, n, start, got[1:], want[1:])
+            checked += 1
+    assert checked == 900
+
+
+def test_native_lloyd_hands_an_empty_cluster_back():
+    # every point nearer to the first centre: scikit-learn relocates the empty cluster's centre with
+    # numpy operations -- the C side returns 1 and the start runs on the Cython kernel
+    if not kmeans2.native_lloyd_active():
+        pytest.skip("the C iteration is not active here")
+    import ctypes as C
+
+    lib, ptr = kmeans2._native()
+    rs = np.random.RandomState(5)
+    x = np.ascontiguousarray(rs.standard_normal((40, 2)))
+    x -= x.mean(axis=0)
+    far = np.array([[0.0, 0.0], [50.0, 50.0]])
+    lab = np.empty(40, dtype=np.int32)
+    inertia, iters = C.c_double(), C.c_int32()
+    rc = lib.scs_host_lloyd2(ptr, 40, x.ctypes.data, far.ctypes.data, 1e-4, 300, lab.ctypes.data,
+                             C.byref(inertia), C.byref(iters))
+    assert rc == 1
+    ref, nat = _starts(x, 1e-4, (lib, ptr))
+    got, want = nat(far.copy(), True), ref(far.copy(), True)
+    assert np.array_equal(got[0], want[0]) and got[1:] == want[1:]
+    assert lib.scs_host_lloyd2(None, 40, x.ctypes.data, far.ctypes.data, 1e-4, 300, lab.ctypes.data,
+                               C.byref(inertia), C.byref(iters)) == -1
+
+
+def test_forced_cython_kernel(monkeypatch):
+    monkeypatch.setenv("SCS_KMEANS", "cython")
+    saved = dict(kmeans2._state)
+    try:
+        kmeans2._state.update(checked=False, ok=False, native=None)
+        assert kmeans2._native() is None
+        if kmeans2.fast_path_active():
+            assert not kmeans2.native_lloyd_active()
+        assert _same(np.random.RandomState(1).standard_normal((21, 2)), 8)
+    finally:
+        kmeans2._state.update(saved)
