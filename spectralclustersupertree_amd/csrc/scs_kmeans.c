@@ -152,3 +152,161 @@ int scs_host_lloyd2(void *dgemm, int32_t n, const double *x, const double *centr
     if (lab_old != lab_old_small) free(lab_old);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * The whole label assignment of one node: ten k-means++ seedings (sklearn/cluster/_kmeans.py,
+ * _kmeans_plusplus with two clusters: 2 + int(log 2) = 2 local trials), the Lloyd run of every
+ * distinct start and the choice among them (KMeans.fit) -- kmeans2.py's `_Seeder` and the loop
+ * of `_fast`, which remain the definition (and the fallback); this is their restatement for
+ * embeddings of at most a few hundred points, where ten seedings cost ~300 numpy calls.
+ *
+ * The four matrix products of a seeding are numpy `@` calls in scikit-learn.  They are made here
+ * through the CBLAS entry points of the OpenBLAS that numpy itself is linked to (kmeans2.py finds
+ * them in the library numpy loaded: cblas_dgemv / cblas_ddot / cblas_dgemm, 64-bit integer
+ * interface), in the forms that reproduce numpy's results bit for bit:
+ *     points (1 x 2) @ x.T          cblas_dgemv(RowMajor, NoTrans, n, 2, 1, x, 2, point, 1, 0, y, 1)
+ *     closest (1 x n) @ weight      cblas_ddot(n, closest, 1, ones, 1)
+ *     points (2 x 2) @ x.T          cblas_dgemm(RowMajor, NoTrans, Trans, 2, n, 2, 1, pts, 2, x, 2, 0, out, n)
+ *     to_cand (2 x n) @ weight_col  cblas_dgemv(RowMajor, NoTrans, 2, n, 1, to_cand, n, ones, 1, 0, y, 1)
+ * kmeans2.py's self-test compares the seeds AND the potentials (`dbg`) with the numpy path bitwise
+ * on hundreds of inputs before this is used; everything else is scalar arithmetic in numpy's
+ * order (elementwise passes, a sequential running sum, binary searches).
+ * The thirty uniform draws come from the caller (one RandomState.random_sample call).
+ */
+typedef void (*cblas_dgemv_fn)(int, int, int64_t, int64_t, double, const double *, int64_t, const double *,
+                               int64_t, double, double *, int64_t);
+typedef double (*cblas_ddot_fn)(int64_t, const double *, int64_t, const double *, int64_t);
+typedef void (*cblas_dgemm_fn)(int, int, int, int64_t, int64_t, int64_t, double, const double *, int64_t,
+                               const double *, int64_t, double, double *, int64_t);
+
+typedef struct {
+    void *dgemm_f;      /* scipy.linalg.cython_blas dgemm (Fortran interface): the Lloyd iteration's */
+    void *cblas_dgemv;  /* numpy's OpenBLAS, ILP64 */
+    void *cblas_ddot;
+    void *cblas_dgemm;
+} scs_km_blas;
+
+enum { KM_ROW_MAJOR = 101, KM_NO_TRANS = 111, KM_TRANS = 112 };
+
+/* d[i] = max(((-2 r[i]) + pp) + x_sq[i], 0): _euclidean_distances(..., squared=True) after the product */
+static void km_finish_distances(int n, double *d, double pp, const double *x_sq) {
+    for (int i = 0; i < n; ++i) {
+        double v = -2.0 * d[i];
+        v += pp;
+        v += x_sq[i];
+        d[i] = v >= 0.0 ? v : 0.0;
+    }
+}
+
+static int km_same_clustering(const int32_t *a, const int32_t *b, int n) {
+    int32_t map[2] = {-1, -1};
+    for (int i = 0; i < n; ++i) {
+        if (map[a[i]] == -1) map[a[i]] = b[i];
+        else if (map[a[i]] != b[i]) return 0;
+    }
+    return 1;
+}
+
+/* Returns 0 (labels_out filled), 1 (a start emptied a cluster: run the call on the Python path
+ * with the same draws) or -1.  seeds_out: 2 x starts sample indices; dbg (nullable): per start
+ * pot, cand_pot[0], cand_pot[1]. */
+int scs_host_kmeans2(const scs_km_blas *blas, int32_t n, const double *x, const double *x_sq,
+                     const double *cdf, const double *draws, int32_t starts, double tol, int32_t max_iter,
+                     int32_t *labels_out, int32_t *seeds_out, double *dbg) {
+    if (!blas || !blas->dgemm_f || !blas->cblas_dgemv || !blas->cblas_ddot || !blas->cblas_dgemm || n < 2 ||
+        starts < 1 || starts > 64 || !x || !x_sq || !cdf || !draws || !labels_out)
+        return -1;
+    const cblas_dgemv_fn gemv = (cblas_dgemv_fn)blas->cblas_dgemv;
+    const cblas_ddot_fn dot = (cblas_ddot_fn)blas->cblas_ddot;
+    const cblas_dgemm_fn gemm = (cblas_dgemm_fn)blas->cblas_dgemm;
+    /* one block: ones[n], closest[n], running[n], to_cand[2n], labels of up to `starts` runs */
+    const size_t nd = (size_t)n;
+    double *buf = (double *)malloc(sizeof(double) * 5 * nd + sizeof(int32_t) * nd * (size_t)starts);
+    if (!buf) return -1;
+    double *ones = buf, *closest = buf + nd, *running = buf + 2 * nd, *to_cand = buf + 3 * nd;
+    int32_t *run_labels = (int32_t *)(buf + 5 * nd);
+    for (int i = 0; i < n; ++i) ones[i] = 1.0;
+    int32_t run_first[64], run_second[64];
+    double run_inertia[64];
+    int n_runs = 0, best = -1, rc = 0, cached_first = -1;
+    double pot = 0.0;
+    for (int s = 0; s < starts && rc == 0; ++s) {
+        const double u0 = draws[3 * s], u1 = draws[3 * s + 1], u2 = draws[3 * s + 2];
+        /* first = cdf.searchsorted(u0, side="right"): the number of entries <= u0 */
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cdf[mid] <= u0) lo = mid + 1;
+            else hi = mid;
+        }
+        const int first = lo < n ? lo : n - 1;
+        if (first != cached_first) {  /* the distances of a first centre seen in the previous start are kept */
+            const double *c = x + 2 * (size_t)first;
+            gemv(KM_ROW_MAJOR, KM_NO_TRANS, n, 2, 1.0, x, 2, c, 1, 0.0, closest, 1);
+            km_finish_distances(n, closest, c[0] * c[0] + c[1] * c[1], x_sq);
+            pot = dot(n, closest, 1, ones, 1);
+            double acc = closest[0] * 1.0;
+            running[0] = acc;
+            for (int i = 1; i < n; ++i) {
+                acc += closest[i] * 1.0;
+                running[i] = acc;
+            }
+            cached_first = first;
+        }
+        int cand[2];
+        const double vals[2] = {u1 * pot, u2 * pot};
+        for (int k = 0; k < 2; ++k) {  /* searchsorted(running, v), side="left": entries < v */
+            int a = 0, b = n;
+            while (a < b) {
+                const int mid = (a + b) >> 1;
+                if (running[mid] < vals[k]) a = mid + 1;
+                else b = mid;
+            }
+            cand[k] = a < n - 1 ? a : n - 1;
+        }
+        double pts[4] = {x[2 * (size_t)cand[0]], x[2 * (size_t)cand[0] + 1], x[2 * (size_t)cand[1]],
+                         x[2 * (size_t)cand[1] + 1]};
+        gemm(KM_ROW_MAJOR, KM_NO_TRANS, KM_TRANS, 2, n, 2, 1.0, pts, 2, x, 2, 0.0, to_cand, n);
+        for (int k = 0; k < 2; ++k) {
+            double *row = to_cand + (size_t)k * nd;
+            km_finish_distances(n, row, pts[2 * k] * pts[2 * k] + pts[2 * k + 1] * pts[2 * k + 1], x_sq);
+            for (int i = 0; i < n; ++i) row[i] = closest[i] <= row[i] ? closest[i] : row[i];  /* np.minimum */
+        }
+        double cand_pot[2] = {0.0, 0.0};
+        gemv(KM_ROW_MAJOR, KM_NO_TRANS, 2, n, 1.0, to_cand, n, ones, 1, 0.0, cand_pot, 1);
+        const int second = cand[cand_pot[1] < cand_pot[0] ? 1 : 0];  /* argmin: the first of equals */
+        if (seeds_out) {
+            seeds_out[2 * s] = first;
+            seeds_out[2 * s + 1] = second;
+        }
+        if (dbg) {
+            dbg[3 * s] = pot;
+            dbg[3 * s + 1] = cand_pot[0];
+            dbg[3 * s + 2] = cand_pot[1];
+        }
+        /* the same two seed points: the same run */
+        int run = -1;
+        for (int r = 0; r < n_runs; ++r)
+            if (run_first[r] == first && run_second[r] == second) run = r;
+        if (run < 0) {
+            const double centres[4] = {x[2 * (size_t)first], x[2 * (size_t)first + 1], x[2 * (size_t)second],
+                                       x[2 * (size_t)second + 1]};
+            run = n_runs;
+            const int lrc = scs_host_lloyd2(blas->dgemm_f, n, x, centres, tol, max_iter,
+                                            run_labels + (size_t)run * nd, &run_inertia[run], NULL);
+            if (lrc != 0) {
+                rc = lrc;
+                break;
+            }
+            run_first[run] = first;
+            run_second[run] = second;
+            ++n_runs;
+        }
+        if (best < 0 || (run_inertia[run] < run_inertia[best] &&
+                         !km_same_clustering(run_labels + (size_t)run * nd, run_labels + (size_t)best * nd, n)))
+            best = run;
+    }
+    if (rc == 0) memcpy(labels_out, run_labels + (size_t)best * nd, sizeof(int32_t) * nd);
+    free(buf);
+    return rc;
+}

@@ -36,7 +36,9 @@ import numpy as np
 
 _KNOWN = ("1.7.2",)
 _MAX_SAMPLES = 4096  # larger inputs: the call overhead does not matter
-_state = {"checked": False, "ok": False, "native": None}
+_NATIVE_WHOLE_MAX = 256  # the C restatement of the seeding is held against numpy up to this size
+_state = {"checked": False, "ok": False, "native": None, "whole": None}
+_per_size = {}  # n -> (weight, weight_col, cdf): functions of n alone
 
 
 def _public(maps, random_state):
@@ -56,26 +58,55 @@ def _sq_dist_to(points, x, x_sq):
     return d
 
 
-def _seed_two_centres(x, x_sq, weight, weight_col, cdf, random_state):
-    """``_kmeans_plusplus`` for two clusters (2 + int(log 2) = 2 local trials).  The first centre
-    is ``random_state.choice(n, p=weight / weight.sum())``, spelled out (numpy's legacy
-    ``RandomState.choice`` with probabilities: one uniform draw looked up in the normalised
-    cumulative sum, ``cdf``, which is the same for all ten initialisations)."""
-    centres = np.empty((2, x.shape[1]), dtype=x.dtype)
-    first = cdf.searchsorted(random_state.random_sample(), side="right")
-    centres[0] = x[first]
-    closest = _sq_dist_to(centres[0, np.newaxis], x, x_sq)
-    pot = closest @ weight
-    rand_vals = random_state.uniform(size=2) * pot
-    cand = np.searchsorted(np.cumsum(weight * closest, dtype=np.float64), rand_vals)
-    np.clip(cand, None, closest.size - 1, out=cand)
-    to_cand = _sq_dist_to(x[cand], x, x_sq)
-    np.minimum(closest, to_cand, out=to_cand)
-    cand_pot = to_cand @ weight_col
-    best = np.argmin(cand_pot)
-    second = cand[best]
-    centres[1] = x[second]
-    return centres, (int(first), int(second))
+class _Seeder:
+    """``_kmeans_plusplus`` for two clusters (2 + int(log 2) = 2 local trials), ten times over.
+    The first centre is ``random_state.choice(n, p=weight / weight.sum())``, spelled out (numpy's
+    legacy ``RandomState.choice`` with probabilities: one uniform draw looked up in the normalised
+    cumulative sum, ``cdf``, which is the same for all ten initialisations).
+
+    An embedding of a handful of points sees the same first centre -- and the same pair of
+    candidates for the second -- again and again among the ten starts: everything that depends
+    only on the first centre (its distances, their sum and running sum) and only on (first
+    centre, candidates) (which candidate wins) is computed once per distinct key, with the very
+    numpy calls of the public function.  The thirty uniform draws are taken in one call by the
+    caller: ``uniform(size=2)`` is ``0.0 + 1.0 * random_sample(2)``, the same doubles from the same
+    stream positions."""
+
+    def __init__(self, x, x_sq, weight, weight_col, cdf, draws):
+        self.x, self.x_sq, self.weight, self.weight_col, self.cdf = x, x_sq, weight, weight_col, cdf
+        self.draws = draws  # random_state.random_sample(3 * starts)
+        self.by_first = {}
+        self.by_candidates = {}
+        self.at = 0
+        self.trace = None  # a list: (first, second, pot, potential of either candidate) per start
+
+    def next(self):
+        """(first, second) sample indices of the next start's two centres."""
+        x, x_sq = self.x, self.x_sq
+        u = self.draws[self.at: self.at + 3]
+        self.at += 3
+        first = int(self.cdf.searchsorted(u[0], side="right"))
+        ent = self.by_first.get(first)
+        if ent is None:
+            centre = np.empty((2, x.shape[1]), dtype=x.dtype)
+            centre[0] = x[first]
+            closest = _sq_dist_to(centre[0, np.newaxis], x, x_sq)
+            pot = closest @ self.weight
+            ent = self.by_first[first] = (closest, pot, np.cumsum(self.weight * closest, dtype=np.float64))
+        closest, pot, running = ent
+        cand = np.searchsorted(running, u[1:] * pot)
+        np.clip(cand, None, closest.size - 1, out=cand)
+        key = (first, int(cand[0]), int(cand[1]))
+        hit = self.by_candidates.get(key)
+        if hit is None:
+            to_cand = _sq_dist_to(x[cand], x, x_sq)
+            np.minimum(closest, to_cand, out=to_cand)
+            cand_pot = to_cand @ self.weight_col
+            hit = self.by_candidates[key] = (int(cand[np.argmin(cand_pot)]), float(cand_pot[0, 0]),
+                                             float(cand_pot[1, 0]))
+        if self.trace is not None:
+            self.trace.append((first, hit[0], float(pot[0]), hit[1], hit[2]))
+        return first, hit[0]
 
 
 def _dgemm_pointer():
@@ -173,6 +204,69 @@ def _lloyd_native(x, tol, fallback, lib, ptr):
     return run
 
 
+def _numpy_cblas():
+    """Addresses of cblas_dgemv / cblas_ddot / cblas_dgemm (64-bit integer interface) in the
+    OpenBLAS numpy itself is linked to -- the routines behind the ``@`` calls of the seeding."""
+    import ctypes as C
+
+    from threadpoolctl import threadpool_info
+
+    for info in threadpool_info():
+        path = info.get("filepath") or ""
+        if info.get("internal_api") != "openblas" or os.path.basename(os.path.dirname(path)) != "numpy.libs":
+            continue
+        lib = C.CDLL(path)
+        found = []
+        for name in ("dgemv", "ddot", "dgemm"):
+            for sym in (f"scipy_cblas_{name}64_", f"cblas_{name}64_"):
+                try:
+                    found.append(C.cast(getattr(lib, sym), C.c_void_p).value)
+                    break
+                except AttributeError:
+                    continue
+        if len(found) == 3:
+            return found
+    return None
+
+
+def _whole():
+    """(library, pointer to the struct of BLAS entry points) for ``scs_host_kmeans2``, or None."""
+    if _state["whole"] is None:
+        _state["whole"] = False
+        native = _native()
+        if native is not None and os.environ.get("SCS_KMEANS", "") != "seed-numpy":
+            try:
+                import ctypes as C
+
+                cblas = _numpy_cblas()
+                if cblas:
+                    table = (C.c_void_p * 4)(native[1], *cblas)
+                    _state["whole"] = (native[0], table)
+            except Exception:  # noqa: BLE001 -- numpy linked otherwise: the seeding stays numpy's
+                pass
+    return _state["whole"] or None
+
+
+def _whole_call(whole, x, x_sq, cdf, draws, tol, want_debug=False):
+    """``scs_host_kmeans2``: labels of the best of the ten starts, or None when a start emptied a
+    cluster (the caller then runs the numpy / Cython path on the same draws)."""
+    lib, table = whole
+    n = x.shape[0]
+    lab = np.empty(n, dtype=np.int32)
+    seeds = dbg = None
+    if want_debug:
+        seeds, dbg = np.zeros(20, dtype=np.int32), np.zeros(30, dtype=np.float64)
+    rc = lib.scs_host_kmeans2(table, n, x.ctypes.data, x_sq.ctypes.data, cdf.ctypes.data, draws.ctypes.data,
+                              10, tol, 300, lab.ctypes.data,
+                              seeds.ctypes.data if want_debug else None, dbg.ctypes.data if want_debug else None)
+    if rc < 0:
+        msg = "scs_host_kmeans2 failed"
+        raise RuntimeError(msg)
+    if want_debug:
+        return (lab if rc == 0 else None), seeds, dbg
+    return lab if rc == 0 else None
+
+
 def _fast(maps, random_state, use_native=True):
     from sklearn.cluster import _k_means_common as kc
     from sklearn.cluster import _k_means_lloyd as kl
@@ -183,29 +277,41 @@ def _fast(maps, random_state, use_native=True):
     # computes: 6-12 ms per call on a 256-thread host against < 1 ms; the chunks are then reduced
     # in index order, which the team's order of arrival is not)
     tol = np.mean(np.var(x, axis=0)) * 1e-4
-    weight = np.ones(n, dtype=np.float64)
-    weight_col = weight.reshape(-1, 1)
-    cdf = (weight / weight.sum()).cumsum()
-    cdf /= cdf[-1]
+    per_size = _per_size.get(n)
+    if per_size is None:
+        weight = np.ones(n, dtype=np.float64)
+        cdf = (weight / weight.sum()).cumsum()
+        cdf /= cdf[-1]
+        per_size = (weight, weight.reshape(-1, 1), cdf)
+        if n <= 4096:
+            _per_size[n] = per_size
+    weight, weight_col, cdf = per_size
     x -= x.mean(axis=0)
     x_sq = np.einsum("ij,ij->i", x, x)
-    lloyd = _lloyd_cython(x, weight, tol, kl, kc)
-    native = _native() if use_native else None
-    if native is not None:
-        lloyd = _lloyd_native(x, float(tol), lloyd, *native)
-    best_inertia, best_labels = None, None
-    seen = {}  # (first, second) seed points -> (labels, inertia): the same start, the same run
-    for _ in range(10):
-        centres, seeds = _seed_two_centres(x, x_sq, weight, weight_col, cdf, random_state)
-        if seeds in seen:
-            lab, inertia = seen[seeds]
+    draws = random_state.random_sample(30)
+    best_labels = None
+    whole = _whole() if use_native and n <= _NATIVE_WHOLE_MAX else None
+    if whole is not None:
+        best_labels = _whole_call(whole, x, x_sq, cdf, draws, float(tol))
+    if best_labels is None:
+        lloyd = _lloyd_cython(x, weight, tol, kl, kc)
+        native = _native() if use_native else None
+        if native is not None:
+            lloyd = _lloyd_native(x, float(tol), lloyd, *native)
+        best_inertia = None
+        seen = {}  # (first, second) seed points -> (labels, inertia): the same start, the same run
+        seeder = _Seeder(x, x_sq, weight, weight_col, cdf, draws)
+        for _ in range(10):
+            seeds = seeder.next()
+            run = seen.get(seeds)
+            if run is None:
+                centres = np.empty((2, 2), dtype=np.float64)
+                centres[0] = x[seeds[0]]
+                centres[1] = x[seeds[1]]
+                run = seen[seeds] = lloyd(centres)
+            lab, inertia = run
             if best_inertia is None or (inertia < best_inertia and not kc._is_same_clustering(lab, best_labels, 2)):
                 best_labels, best_inertia = lab, inertia
-            continue
-        lab, inertia = lloyd(centres)
-        seen[seeds] = (lab, inertia)
-        if best_inertia is None or (inertia < best_inertia and not kc._is_same_clustering(lab, best_labels, 2)):
-            best_labels, best_inertia = lab, inertia
     if len(set(best_labels)) < 2:
         import warnings
 
@@ -256,6 +362,62 @@ def _native_agrees() -> bool:
     return True
 
 
+def _whole_agrees() -> bool:
+    """``scs_host_kmeans2`` against the numpy seeding + Cython iteration on the same draws: the
+    seed points of all ten starts, the three potentials of every seeding (the results of the BLAS
+    calls) and the chosen labels, bit for bit, over the sizes the C path is used for."""
+    from sklearn.cluster import _k_means_common as kc
+    from sklearn.cluster import _k_means_lloyd as kl
+
+    whole = _whole()
+    if whole is None:
+        return False
+    probe = np.random.RandomState(31415)
+    sizes = list(range(2, 40)) + [47, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256]
+    for n in sizes:
+        for rep in range(4):
+            x = probe.standard_normal((n, 2)) * [1.0, 10.0 ** probe.randint(-6, 2)]
+            if rep == 1:
+                x[:, 0] = probe.rand()  # the constant column of an embedding
+            if rep == 2:
+                x = np.round(x, 1)  # duplicates, ties
+            if rep == 3 and n >= 4:
+                x[n // 2:] = -x[: n - n // 2]  # mirror symmetry: equal potentials
+            x = np.ascontiguousarray(x - x.mean(axis=0))
+            tol = float(np.mean(np.var(x, axis=0)) * 1e-4)
+            weight = np.ones(n)
+            cdf = (weight / weight.sum()).cumsum()
+            cdf /= cdf[-1]
+            x_sq = np.einsum("ij,ij->i", x, x)
+            draws = probe.random_sample(30)
+            lab, seeds, dbg = _whole_call(whole, x, x_sq, cdf, draws, tol, want_debug=True)
+            seeder = _Seeder(x, x_sq, weight, weight.reshape(-1, 1), cdf, draws)
+            seeder.trace = []
+            lloyd = _lloyd_cython(x, weight, tol, kl, kc)
+            best, best_inertia, seen = None, None, {}
+            for _ in range(10):
+                sd = seeder.next()
+                if lab is None and len(seeder.trace) * 2 > np.count_nonzero(seeds) + 2:
+                    break
+                if sd not in seen:
+                    c = np.empty((2, 2))
+                    c[0], c[1] = x[sd[0]], x[sd[1]]
+                    seen[sd] = lloyd(c)
+                run = seen[sd]
+                if best is None or (run[1] < best_inertia and not kc._is_same_clustering(run[0], best, 2)):
+                    best, best_inertia = run
+            if lab is None:  # a start emptied a cluster: the C side stopped there, nothing chosen
+                continue
+            for k, (first, second, pot, p0, p1) in enumerate(seeder.trace):
+                if (seeds[2 * k], seeds[2 * k + 1]) != (first, second):
+                    return False
+                if not (dbg[3 * k] == pot and dbg[3 * k + 1] == p0 and dbg[3 * k + 2] == p1):
+                    return False
+            if not np.array_equal(lab, best):
+                return False
+    return True
+
+
 def _self_test() -> bool:
     """The fast path against the public function: labels and generator state, bit for bit."""
     try:
@@ -267,6 +429,9 @@ def _self_test() -> bool:
             return False
         if _native() is not None and not _native_agrees():
             _state["native"] = False
+            _state["whole"] = False
+        if _whole() is not None and not _whole_agrees():
+            _state["whole"] = False
         probe = np.random.RandomState(12345)
         cases = [probe.standard_normal((n, 2)) * [1.0, 10.0 ** probe.randint(-3, 1)] for n in (3, 4, 5, 7, 12, 33, 100, 300)]
         cases.append(np.array([[0.0, 1.0], [0.0, 1.0], [0.0, -1.0], [0.0, -1.0]]))  # duplicates
@@ -289,6 +454,12 @@ def _self_test() -> bool:
 def native_lloyd_active() -> bool:
     """True when the Lloyd iteration runs in libscs_host.so (after the self-test)."""
     return fast_path_active() and bool(_state["native"])
+
+
+def native_seeding_active() -> bool:
+    """True when embeddings of up to ``_NATIVE_WHOLE_MAX`` points are labelled by one call into
+    libscs_host.so (seedings included)."""
+    return fast_path_active() and bool(_state["whole"])
 
 
 def fast_path_active() -> bool:

@@ -155,3 +155,37 @@ def test_forced_cython_kernel(monkeypatch):
         assert _same(np.random.RandomState(1).standard_normal((21, 2)), 8)
     finally:
         kmeans2._state.update(saved)
+
+
+def test_native_seeding_equals_the_numpy_seeding_bit_for_bit():
+    # scs_host_kmeans2 (seedings through numpy's own OpenBLAS entry points + the C iteration) against
+    # the numpy / Cython path on the same draws: seeds, potentials, labels (kmeans2._whole_agrees)
+    if not kmeans2.native_seeding_active():
+        pytest.skip("the C seeding is not active here")
+    assert kmeans2._whole_agrees()
+    rs = np.random.RandomState(17)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for case in range(300):
+            n = int(rs.randint(2, 257))
+            x = rs.standard_normal((n, 2)) * [1.0, 10.0 ** rs.randint(-7, 2)]
+            if case % 5 == 0:
+                x = np.round(x, 1)
+            ra, rb = np.random.RandomState(case), np.random.RandomState(case)
+            la, lb = kmeans2._fast(x, ra), kmeans2._fast(x, rb, use_native=False)
+            assert np.array_equal(la, lb), (case, n)
+            assert np.array_equal(ra.get_state()[1], rb.get_state()[1]) and ra.get_state()[2:] == rb.get_state()[2:]
+
+
+def test_native_seeding_hands_an_emptied_cluster_back():
+    # one distinct point: both centres coincide, the second cluster stays empty, the C call returns 1
+    # and the numpy / Cython path finishes the call on the same draws
+    if not kmeans2.native_seeding_active():
+        pytest.skip("the C seeding is not active here")
+    x = np.zeros((6, 2))
+    x_sq = np.zeros(6)
+    cdf = np.arange(1, 7) / 6.0
+    draws = np.random.RandomState(0).random_sample(30)
+    assert kmeans2._whole_call(kmeans2._whole(), x, x_sq, cdf, draws, 0.0) is None
+    assert _same(x, 9)
+    assert _same(np.array([[1.0, 2.0]] * 3 + [[1.0, 2.0 + 1e-300]]), 10)
