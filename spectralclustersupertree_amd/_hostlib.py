@@ -17,8 +17,8 @@ def load() -> C.CDLL:
             msg = f"{_LIB_PATH} not found: run __graft_entry__.build()"
             raise ImportError(msg)
         lib = C.CDLL(str(_LIB_PATH))
-        ip, dp, lp, bp = (C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int64),
-                          C.POINTER(C.c_uint8))
+        # int32 / double / int64 / uint8 arrays, passed as plain addresses (see _native.py)
+        ip = dp = lp = bp = C.c_void_p
         lib.scs_host_restrict_sizes.restype = C.c_int
         lib.scs_host_restrict_sizes.argtypes = [C.c_int32, lp, ip, ip, bp, bp, ip]
         lib.scs_host_restrict_fill.restype = C.c_int

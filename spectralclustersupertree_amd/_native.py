@@ -96,9 +96,10 @@ class BuildStats(C.Structure):
 _P = C.c_void_p
 _PP = C.POINTER(C.c_void_p)
 _I32 = C.c_int32
-_DP = C.POINTER(C.c_double)
-_IP = C.POINTER(C.c_int32)
-_LP = C.POINTER(C.c_int64)
+# array arguments travel as plain addresses (``ndarray.ctypes.data``): building a typed ctypes pointer
+# per argument (``data_as``) costs more than the call itself for the tiny nodes of a deep recursion;
+# dptr / iptr / lptr below check the dtype instead
+_DP = _IP = _LP = C.c_void_p
 SIGNATURES = {
     "scs_version": (C.c_int, []),
     "scs_last_error": (C.c_char_p, []),
@@ -188,12 +189,15 @@ def pinned_empty(shape, dtype) -> np.ndarray:
 
 
 def dptr(a: np.ndarray):
-    return a.ctypes.data_as(_DP)
+    assert a.dtype == np.float64
+    return a.ctypes.data
 
 
 def iptr(a: np.ndarray):
-    return a.ctypes.data_as(_IP)
+    assert a.dtype == np.int32
+    return a.ctypes.data
 
 
 def lptr(a: np.ndarray):
-    return a.ctypes.data_as(_LP)
+    assert a.dtype == np.int64
+    return a.ctypes.data

@@ -29,8 +29,13 @@ _STRATEGY_CODE = {"one": 0, "depth": 1, "branch": 2, "bootstrap": 3}  # csrc/scs
 _ERRORS = {-1: "out of memory", -2: "malformed tree arrays", -3: "missing support"}
 
 
+_NP_OF = {C.c_int32: np.int32, C.c_int64: np.int64, C.c_double: np.float64, C.c_uint8: np.uint8}
+
+
 def _p(a: np.ndarray, ct):
-    return a.ctypes.data_as(C.POINTER(ct))
+    """Address of a contiguous array of the C type `ct` (the bindings take plain addresses)."""
+    assert a.dtype == _NP_OF[ct] and a.flags.c_contiguous
+    return a.ctypes.data
 
 
 @dataclass
