@@ -26,6 +26,7 @@ class Device:
         self._lib = nv.load_library()
         self._ctx = C.c_void_p()
         self.rank, self.world = rank, world
+        self.index = device  # the GPU this context lives on
         if _local_group is not None:
             nv.check(self._lib.scs_ctx_create_local(device, rank, _local_group, C.byref(self._ctx)))
         else:

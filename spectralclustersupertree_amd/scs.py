@@ -48,6 +48,7 @@ _default_team_checked = False
 # per spectral call of the recursion, in call order (``trace_nodes`` sets and clears it); the
 # whole-recursion parity tests compare it with the oracle's trace node by node.
 _node_trace: list | None = None
+_last_ahead_stats: dict | None = None  # jobs of the latest recursion's ahead.Ahead (diagnostics, tests)
 
 
 class trace_nodes:
@@ -201,15 +202,22 @@ def spectral_bipartition_device(
 
     A node of at most 64 taxa goes through ``scs_small_solve`` (one fused launch);
     ``presolved`` carries the embedding of a node whose device work was already done in a
-    batch with its siblings (``_construct``).
+    batch with its siblings, or queued ahead of the walk (``_construct``, ``ahead.Ahead``).
+
+    The embedding depends on the node's forest only: the reference's ARPACK start vector is
+    drawn from ``random_state`` (the stream stays where the reference has it) and not used.
     """
     n = tables.n_taxa
     if presolved is not None:
         work, perm, group_start, n_groups, maps = presolved
         # the reference's ARPACK start vector is still the first draw from the stream
         random_state.uniform(-1, 1, n_groups)
+        stats = None
+        if isinstance(maps, _Pending):
+            maps, stats = maps.fetch(device or (team.solo if team is not None else default_device()))
         if report is not None:
-            report.update({"n_vertices": n_groups, "block": 0, "presolved": True})
+            report.update(stats or {"n_vertices": n_groups, "block": 0})
+            report["presolved"] = True
         return _labels_and_members(maps, random_state, n, perm, group_start, n_groups)
 
     work, perm, group_start, n_groups = prepare_node(tables, contract_edges)
@@ -240,8 +248,7 @@ def spectral_bipartition_device(
     if not sharded and n <= dev.SMALL_MAX_TAXA and tol == DEFAULT_TOL and block == 0 and _small_path():
         # a small node: tables -> W -> contraction -> Jacobi -> embedding in ONE launch
         # (scs_small_solve)
-        v0 = random_state.uniform(-1, 1, n_groups)  # the stream position of the reference
-        del v0
+        random_state.uniform(-1, 1, n_groups)  # the stream position of the reference
         maps, lam = dev.small_solve([(work, group_start)])[0]
         if report is not None:
             report.update({"n_vertices": n_groups, "block": 0, "iterations": 0, "converged": 1,
@@ -249,12 +256,28 @@ def spectral_bipartition_device(
                            "sharded": False, "splits": None, "small_path": True})
         return _labels_and_members(maps, random_state, n, perm, group_start, n_groups)
 
+    # the reference's ARPACK start vector is the first draw from the stream
+    random_state.uniform(-1, 1, n_groups)
+    span = (splits[team.rank], splits[team.rank + 1]) if sharded else None
+    maps, stats = _solve_node(dev, work, group_start, tol, max_iter, block, span, upper)
+    if report is not None:
+        report.update(stats)
+        report["sharded"] = bool(sharded)
+        report["upper"] = bool(sharded and upper)
+        report["splits"] = splits
+    return _labels_and_members(maps, random_state, n, perm, group_start, n_groups)
+
+
+def _solve_node(dev, work, group_start, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_ITER, block=0, span=None,
+                upper=False):
+    """Tables -> W -> contraction -> embedding of one node on ``dev``: ``(maps, stats)``.
+    ``span``: this rank's rows of a sharded job (``upper``: the upper-triangle job)."""
     dtab = dev.upload(work)
     try:
-        if sharded and upper:
-            graph = dtab.build(splits[team.rank], splits[team.rank + 1], upper=True)
-        elif sharded:
-            graph = dtab.build(splits[team.rank], splits[team.rank + 1], shared=True)
+        if span is not None and upper:
+            graph = dtab.build(span[0], span[1], upper=True)
+        elif span is not None:
+            graph = dtab.build(span[0], span[1], shared=True)
         else:
             graph = dtab.build()
     finally:
@@ -262,18 +285,25 @@ def spectral_bipartition_device(
     try:
         if group_start is not None:
             graph = graph.contract(group_start)
-        # the reference's ARPACK start vector is the first draw from the stream
-        v0 = random_state.uniform(-1, 1, n_groups)
-        maps, stats = _fiedler_checked(graph, v0, tol, max_iter, block)
-        if report is not None:
-            report.update(stats)
-            report["build"] = graph.build_stats
-            report["sharded"] = bool(sharded)
-            report["upper"] = bool(sharded and upper)
-            report["splits"] = splits
+        maps, stats = _fiedler_checked(graph, None, tol, max_iter, block)
+        stats = dict(stats)
+        stats["build"] = graph.build_stats
     finally:
         graph.free()
-    return _labels_and_members(maps, random_state, n, perm, group_start, n_groups)
+    return maps, stats
+
+
+class _Pending:
+    """The embedding of a node whose device work is queued on an ``ahead.Ahead``:
+    ``fetch(own_device)`` -> ``(maps, stats)`` (a job nobody started yet runs on ``own_device``)."""
+
+    __slots__ = ("queue", "job")
+
+    def __init__(self, queue, job) -> None:
+        self.queue, self.job = queue, job
+
+    def fetch(self, own_device):
+        return self.queue.result(self.job, own_device)
 
 
 def _small_path() -> bool:
@@ -428,8 +458,44 @@ def _induce(names: set[str], trees, weights):
     return out_trees, out_weights
 
 
+def _ahead_enabled() -> bool:
+    """SCS_AHEAD=0 (diagnostic) keeps all device work on the walk's own thread, node by node."""
+    import os
+
+    return bool(int(os.environ.get("SCS_AHEAD", "1") or 0))
+
+
 def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
                bipartition=None, team=None, pre=None) -> TreeNode:
+    """The recursion on flat tree arrays from its root node: ``_construct_node`` with, for a
+    single-process run on the device path, a queue that lets the device work on nodes ahead of
+    the walk (``ahead.Ahead``)."""
+    single = team is None or team.world == 1
+    if bipartition is None and single and _small_path() and _ahead_enabled():
+        import sys
+
+        from spectralclustersupertree_amd.ahead import Ahead
+
+        # the worker comes back from a library call every few hundred microseconds and needs the
+        # interpreter for a few lines each time: do not let it wait 5 ms (the default) for it
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(interval, 2e-4))
+        try:
+            index = (team.solo if team is not None else default_device()).index
+            with Ahead(lambda: Device(index)) as queue:
+                global _last_ahead_stats
+                try:
+                    return _construct_node(arrays, pcg_weighting, contract_edges, random_state, None, team, pre,
+                                           queue)
+                finally:
+                    _last_ahead_stats = dict(queue.stats)
+        finally:
+            sys.setswitchinterval(interval)
+    return _construct_node(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre, None)
+
+
+def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
+                    bipartition=None, team=None, pre=None, ahead=None) -> TreeNode:
     """One node of the recursion on flat tree arrays (reference: scs.py:96-174).
 
     Same decisions in the same order as the reference -- and therefore the same draws from
@@ -441,7 +507,9 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     device work of every small single-component child (tables -> W -> contraction -> Jacobi ->
     embedding, ``scs_small_solve``) runs as ONE batched launch; it depends on no random
     draw, so each child later consumes the stream exactly where the reference does and only
-    finds its embedding ready (``pre``).
+    finds its embedding ready (``pre``).  With ``ahead`` the larger single-component children that
+    are not next in the walk are queued for a second context on the same GPU: they are built
+    and solved while the walk is busy with their left siblings' subtrees.
 
     ``team`` (several ranks walking together): nodes of at least ``team.shard_min`` vertices
     are solved collectively.  Below it, ``team.child_rng == "shared"`` has every rank solve
@@ -511,7 +579,7 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             msg = "There must be at least one tree to make a supertree."
             raise ValueError(msg)
     if given is None and not forked and _small_path():
-        _presolve_small_children(children, pcg_weighting, contract_edges, team)
+        _presolve_small_children(children, pcg_weighting, contract_edges, team, ahead)
 
     child_trees: list = []
     dealt: list[tuple[int, int, TreeArrays, np.random.RandomState]] = []  # (slot, owner, sub, rng)
@@ -526,8 +594,8 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
             dealt.append((len(child_trees), len(dealt) % team.world, sub, rng))
             child_trees.append(None)
         else:
-            child_trees.append(_construct(sub, pcg_weighting, contract_edges, random_state, given, team,
-                                          child_pre))
+            child_trees.append(_construct_node(sub, pcg_weighting, contract_edges, random_state, given, team,
+                                               child_pre, ahead))
         if len(sub.present_taxa()) < len(component):  # taxa no surviving tree holds (scs.py:166-170)
             covered = set(int(i) for i in sub.present_taxa())  # (ids of the child: positions in component)
             child_trees.extend(TreeNode(name(x)) for j, x in enumerate(component) if j not in covered)
@@ -542,7 +610,7 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         try:
             for slot, owner, sub, rng in dealt:
                 if owner == team.rank:
-                    mine[slot] = _construct(sub, pcg_weighting, contract_edges, rng, given, alone).to_flat()
+                    mine[slot] = _construct_node(sub, pcg_weighting, contract_edges, rng, given, alone).to_flat()
         except Exception as exc:  # noqa: BLE001 - re-raised on every rank below
             failure = f"rank {team.rank}: {type(exc).__name__}: {exc}"
         gathered = team.allgather((mine, failure))
@@ -556,14 +624,18 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     return connect_trees(child_trees)
 
 
-def _presolve_small_children(children, pcg_weighting, contract_edges, team) -> None:
+def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahead=None) -> None:
     """Flatten every child problem, and run the device work of those that are one component of
     at most 64 taxa as ONE ``scs_small_solve`` launch; fills the ``pre`` slot of each child
-    (present taxa, tables, components, embedding-or-None)."""
-    batch, where = [], []
+    (present taxa, tables, components, embedding-or-None).  With ``ahead`` every larger
+    single-component child but the one the walk enters next becomes a job of that queue (the
+    ``pre`` slot then holds a ``_Pending``)."""
+    batch, where, larger = [], [], []
+    first_sub = True
     for child in children:
         if child[0] != "sub":
             continue
+        first, first_sub = first_sub, False
         sub = child[2]
         if sub.n_trees == 1:
             continue  # grafted as it is (reference: scs.py:96-98)
@@ -574,10 +646,19 @@ def _presolve_small_children(children, pcg_weighting, contract_edges, team) -> N
         tables = sub.flatten(pcg_weighting, local_ids=present)
         comp = fl.pcg_components(tables)
         child[3] = [present, tables, comp, None]
-        if int(comp.max()) == 0 and tables.n_taxa <= Device.SMALL_MAX_TAXA:
+        if int(comp.max()) != 0:
+            continue
+        if tables.n_taxa <= Device.SMALL_MAX_TAXA:
             work, perm, group_start, n_groups = prepare_node(tables, contract_edges)
             batch.append((work, group_start))
             where.append((child, work, perm, group_start, n_groups))
+        elif ahead is not None and not first:
+            # (the child the walk enters next is on the walk's own chain: solved there, at the visit)
+            larger.append(child)
+    for child in larger:  # (first: the worker starts on them while the batch below runs here)
+        work, perm, group_start, n_groups = prepare_node(child[3][1], contract_edges)
+        job = ahead.submit(lambda dev, work=work, group_start=group_start: _solve_node(dev, work, group_start))
+        child[3][3] = (work, perm, group_start, n_groups, _Pending(ahead, job))
     if batch:  # (a recursion that never reaches the spectral step never touches the device)
         dev = team.solo if team is not None else default_device()
         for (child, work, perm, group_start, n_groups), (maps, _) in zip(where, dev.small_solve(batch)):

@@ -1,0 +1,91 @@
+"""ahead.Ahead: the queue that lets the device work on recursion nodes before the walk visits
+them (pure host logic; the jobs here are plain Python callables)."""
+
+import threading
+import time
+
+import pytest
+
+from spectralclustersupertree_amd.ahead import Ahead
+
+
+class FakeDevice:
+    made = 0
+    closed = 0
+
+    def __init__(self):
+        FakeDevice.made += 1
+        self.owner = threading.current_thread().name
+
+    def close(self):
+        FakeDevice.closed += 1
+
+
+def test_results_do_not_depend_on_who_ran_the_job():
+    mine = FakeDevice()
+    with Ahead(FakeDevice) as q:
+        jobs = [q.submit(lambda dev, i=i: i * i) for i in range(200)]
+        assert [q.result(j, mine) for j in jobs] == [i * i for i in range(200)]
+        assert q.stats["submitted"] == 200
+        assert q.stats["by_worker"] + q.stats["by_walk"] == 200
+
+
+def test_the_worker_has_a_device_of_its_own_and_a_needed_job_runs_on_the_callers():
+    gate = threading.Event()
+    made, closed = FakeDevice.made, FakeDevice.closed
+    mine = FakeDevice()
+
+    def work(dev, tag, wait=False):
+        if wait:
+            gate.wait(5)
+        return tag, dev.owner
+
+    with Ahead(FakeDevice) as q:
+        first = q.submit(lambda dev: work(dev, "first", wait=True))  # the worker picks it up and blocks
+        time.sleep(0.05)
+        later = [q.submit(lambda dev, i=i: work(dev, i)) for i in range(5)]
+        # a queued job: the asker runs it itself, at once, on its own device
+        assert q.result(later[3], mine) == (3, mine.owner)
+        gate.set()
+        assert q.result(first, mine) == ("first", "scs-ahead")
+        assert [q.result(j, mine)[0] for j in later] == list(range(5))
+        assert q.stats["by_walk"] >= 1
+    assert FakeDevice.made == made + 2  # mine + the worker's, made on the worker thread
+    assert FakeDevice.closed == closed + 1  # the worker closes its own
+
+
+def test_a_failure_travels_with_the_result_and_close_drops_what_is_queued():
+    def boom(dev):
+        msg = "no good"
+        raise ValueError(msg)
+
+    mine = FakeDevice()
+    q = Ahead(FakeDevice)
+    job = q.submit(boom)
+    with pytest.raises(ValueError, match="no good"):
+        q.result(job, mine)
+    block = threading.Event()
+    q.submit(lambda dev: block.wait(5))
+    time.sleep(0.02)
+    never = [q.submit(lambda dev: 1 / 0) for _ in range(3)]
+    block.set()
+    q.close()
+    for j in never:  # dropped, not run
+        if j.state == 0:
+            with pytest.raises(RuntimeError, match="closed"):
+                q.result(j, mine)
+    with pytest.raises(RuntimeError):
+        q.submit(lambda dev: 1)
+    q.close()  # idempotent
+
+
+def test_a_worker_that_cannot_make_its_device_fails_the_job_not_the_process():
+    def no_device():
+        msg = "no GPU"
+        raise OSError(msg)
+
+    with Ahead(no_device) as q:
+        job = q.submit(lambda dev: 1)
+        time.sleep(0.05)
+        with pytest.raises(OSError, match="no GPU"):
+            q.result(job, None)

@@ -152,3 +152,28 @@ def test_whole_recursion_without_contraction():
     trace, ties = compare_with_oracle(trees, weights, "branch", seed=7, contract_edges=False)
     assert not ties
     assert all(len(v) == 1 for e in trace for v in e["vertices"])
+
+
+def test_device_work_queued_ahead_changes_nothing(monkeypatch):
+    # ahead.Ahead: the larger right siblings are built and solved on a worker thread with a second
+    # context while the walk is in the left subtree -- the supertree, every label vector and the
+    # stream are those of the node-by-node run (SCS_AHEAD=0)
+    from spectralclustersupertree_amd import scs
+
+    trees, weights = recursion_input(13, 1200, 30, 800, 60, weighted=True)
+    taxa = sorted({n for t in trees for n in t.get_tip_names()})
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    runs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SCS_AHEAD", mode)
+        scs._last_ahead_stats = None
+        rs = np.random.RandomState(21)
+        with trace_nodes() as trace:
+            tree = construct_supertree(arrays, pcg_weighting="branch", random_state=rs)
+        runs[mode] = (canonical(tree), [e["labels"].tolist() for e in trace], rs.randint(1 << 30),
+                      scs._last_ahead_stats)
+    assert runs["1"][:3] == runs["0"][:3]
+    assert runs["0"][3] is None
+    stats = runs["1"][3]
+    assert stats["submitted"] >= 3 and stats["by_worker"] + stats["by_walk"] == stats["submitted"]
+    assert stats["by_worker"] >= 1  # some node was solved before the walk asked for it
