@@ -36,7 +36,7 @@ import numpy as np
 
 _KNOWN = ("1.7.2",)
 _MAX_SAMPLES = 4096  # larger inputs: the call overhead does not matter
-_NATIVE_WHOLE_MAX = 256  # the C restatement of the seeding is held against numpy up to this size
+_NATIVE_WHOLE_MAX = 4096  # the C restatement of the seeding is held against numpy up to this size
 _state = {"checked": False, "ok": False, "native": None, "whole": None}
 _per_size = {}  # n -> (weight, weight_col, cdf): functions of n alone
 
@@ -373,7 +373,9 @@ def _whole_agrees() -> bool:
     if whole is None:
         return False
     probe = np.random.RandomState(31415)
-    sizes = list(range(2, 40)) + [47, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256]
+    # (every size up to 24: the BLAS kernels' tails; then around their blockings and the Lloyd chunk)
+    sizes = list(range(2, 25)) + [31, 32, 33, 47, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, 511, 513, 1000,
+                                  2048, 4096]
     for n in sizes:
         for rep in range(4):
             x = probe.standard_normal((n, 2)) * [1.0, 10.0 ** probe.randint(-6, 2)]
@@ -457,7 +459,7 @@ def native_lloyd_active() -> bool:
 
 
 def native_seeding_active() -> bool:
-    """True when embeddings of up to ``_NATIVE_WHOLE_MAX`` points are labelled by one call into
+    """True when the embeddings of the fast path's range are labelled by one call into
     libscs_host.so (seedings included)."""
     return fast_path_active() and bool(_state["whole"])
 

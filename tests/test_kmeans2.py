@@ -167,7 +167,7 @@ def test_native_seeding_equals_the_numpy_seeding_bit_for_bit():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for case in range(300):
-            n = int(rs.randint(2, 257))
+            n = int(rs.randint(2, 257)) if case % 6 else int(rs.choice([257, 600, 1000, 2048, 4096]))
             x = rs.standard_normal((n, 2)) * [1.0, 10.0 ** rs.randint(-7, 2)]
             if case % 5 == 0:
                 x = np.round(x, 1)
