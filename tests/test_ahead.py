@@ -9,6 +9,13 @@ import pytest
 from spectralclustersupertree_amd.ahead import Ahead
 
 
+def _until(cond, seconds=5.0):
+    end = time.monotonic() + seconds
+    while not cond() and time.monotonic() < end:
+        time.sleep(0.002)
+    assert cond()
+
+
 class FakeDevice:
     made = 0
     closed = 0
@@ -42,7 +49,7 @@ def test_the_worker_has_a_device_of_its_own_and_a_needed_job_runs_on_the_callers
 
     with Ahead(FakeDevice) as q:
         first = q.submit(lambda dev: work(dev, "first", wait=True))  # the worker picks it up and blocks
-        time.sleep(0.05)
+        _until(lambda: first.state == 1)
         later = [q.submit(lambda dev, i=i: work(dev, i)) for i in range(5)]
         # a queued job: the asker runs it itself, at once, on its own device
         assert q.result(later[3], mine) == (3, mine.owner)
@@ -65,8 +72,8 @@ def test_a_failure_travels_with_the_result_and_close_drops_what_is_queued():
     with pytest.raises(ValueError, match="no good"):
         q.result(job, mine)
     block = threading.Event()
-    q.submit(lambda dev: block.wait(5))
-    time.sleep(0.02)
+    blocker = q.submit(lambda dev: block.wait(5))
+    _until(lambda: blocker.state == 1)
     never = [q.submit(lambda dev: 1 / 0) for _ in range(3)]
     block.set()
     q.close()
@@ -86,6 +93,6 @@ def test_a_worker_that_cannot_make_its_device_fails_the_job_not_the_process():
 
     with Ahead(no_device) as q:
         job = q.submit(lambda dev: 1)
-        time.sleep(0.05)
+        _until(lambda: job.state != 0)
         with pytest.raises(OSError, match="no GPU"):
             q.result(job, None)
