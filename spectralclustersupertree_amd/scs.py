@@ -295,15 +295,21 @@ def _solve_node(dev, work, group_start, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_IT
 
 class _Pending:
     """The embedding of a node whose device work is queued on an ``ahead.Ahead``:
-    ``fetch(own_device)`` -> ``(maps, stats)`` (a job nobody started yet runs on ``own_device``)."""
+    ``fetch(own_device)`` -> ``(maps, stats)`` (a job nobody started yet runs on ``own_device``).
+    A job that failed on the worker's context is run once more on the walk's own: two nodes in
+    flight need more device memory than one, and what fails for that reason must not fail the
+    run (a failure of the node itself just repeats)."""
 
-    __slots__ = ("queue", "job")
+    __slots__ = ("queue", "job", "again")
 
-    def __init__(self, queue, job) -> None:
-        self.queue, self.job = queue, job
+    def __init__(self, queue, job, again) -> None:
+        self.queue, self.job, self.again = queue, job, again
 
     def fetch(self, own_device):
-        return self.queue.result(self.job, own_device)
+        try:
+            return self.queue.result(self.job, own_device)
+        except RuntimeError:
+            return self.again(own_device)
 
 
 def _small_path() -> bool:
@@ -657,8 +663,8 @@ def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahea
             larger.append(child)
     for child in larger:  # (first: the worker starts on them while the batch below runs here)
         work, perm, group_start, n_groups = prepare_node(child[3][1], contract_edges)
-        job = ahead.submit(lambda dev, work=work, group_start=group_start: _solve_node(dev, work, group_start))
-        child[3][3] = (work, perm, group_start, n_groups, _Pending(ahead, job))
+        solve = lambda dev, work=work, group_start=group_start: _solve_node(dev, work, group_start)  # noqa: E731
+        child[3][3] = (work, perm, group_start, n_groups, _Pending(ahead, ahead.submit(solve), solve))
     if batch:  # (a recursion that never reaches the spectral step never touches the device)
         dev = team.solo if team is not None else default_device()
         for (child, work, perm, group_start, n_groups), (maps, _) in zip(where, dev.small_solve(batch)):
