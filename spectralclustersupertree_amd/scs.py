@@ -49,11 +49,13 @@ _default_team_checked = False
 # whole-recursion parity tests compare it with the oracle's trace node by node.
 _node_trace: list | None = None
 _last_ahead_stats: dict | None = None  # jobs of the latest recursion's ahead.Ahead (diagnostics, tests)
+_traced_maps = None  # the embedding of the spectral call being traced (set by _labels_and_members)
 
 
 class trace_nodes:
     """``with trace_nodes() as trace: construct_supertree(...)`` -- every spectral call of the
-    recursion appends ``{"vertices": [tuple of taxon names, ...], "labels": int array}``."""
+    recursion appends ``{"vertices": [tuple of taxon names, ...], "labels": int array, "maps": the
+    V x 2 embedding the labels were assigned on}``."""
 
     def __enter__(self):
         global _node_trace
@@ -344,6 +346,9 @@ def _labels_and_members(maps, random_state, n, perm, group_start, n_groups):
     vertex."""
     from . import kmeans2
 
+    if _node_trace is not None:
+        global _traced_maps
+        _traced_maps = np.array(maps, dtype=np.float64, copy=True)
     labels = kmeans2.labels(maps, random_state)
     if group_start is None:
         members = [np.array([i], dtype=np.int32) for i in range(n)]
@@ -554,7 +559,7 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
         if _node_trace is not None:
             _node_trace.append({
                 "vertices": [tuple(name(present[int(i)]) for i in ids) for ids in members],
-                "labels": np.asarray(labels).copy()})
+                "labels": np.asarray(labels).copy(), "maps": _traced_maps if given is None else None})
     else:
         parts = [[] for _ in range(n_comp)]
         for i, c in enumerate(comp):

@@ -26,7 +26,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-from test_gpu_recursion import compare_with_oracle, recursion_input  # noqa: E402
+from test_gpu_recursion import TIE_PROOFS, compare_with_oracle, recursion_input  # noqa: E402
 
 
 def main():
@@ -78,7 +78,7 @@ def main():
             print(f"... {n_cases} cases, {n_calls} spectral calls, {n_ties} proven ties, {failures} failures",
                   flush=True)
     print(f"fuzz_recursion: {n_cases} recursions ({by_strategy}), {n_calls} spectral calls compared node by node, "
-          f"{n_ties} proven ties followed, {failures} failures")
+          f"{n_ties} proven ties followed ({dict(TIE_PROOFS)}), {failures} failures")
     return 1 if failures else 0
 
 
