@@ -492,8 +492,12 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         interval = sys.getswitchinterval()
         sys.setswitchinterval(min(interval, 2e-4))
         try:
-            index = (team.solo if team is not None else default_device()).index
-            with Ahead(lambda: Device(index)) as queue:
+            # (the worker's context is made when the first job arrives -- by then the walk has solved
+            # the root on its own; a recursion that never reaches the spectral step touches no device)
+            def second_context():
+                return Device((team.solo if team is not None else default_device()).index)
+
+            with Ahead(second_context) as queue:
                 global _last_ahead_stats
                 try:
                     return _construct_node(arrays, pcg_weighting, contract_edges, random_state, None, team, pre,
