@@ -88,11 +88,24 @@ def _within_fiedler_tolerance(points, km_state, mine, lam):
         close = sign_tie and bool(np.all(np.abs(maps - points * np.array([1.0, -1.0])) <= 1e-10 * size))
     if not close and not (len(lam) > 2 and lam[1] - lam[2] <= 1e-9):
         return False
-    rs = np.random.RandomState()
-    rs.set_state(km_state.get_state())
+    # The public function itself is not repeatable on such inputs: with equal inertia among the
+    # ten starts, ``inertia < best_inertia`` hangs on the last bit of an OpenMP reduction whose
+    # order of summation changes from run to run (seen: two different label vectors from the same
+    # embedding and stream position in two runs of this test).  On ONE OpenMP thread it is
+    # repeatable -- that is the run the product's restatement reproduces bit for bit -- so that
+    # run is asked first, the team's run second.
+    from threadpoolctl import threadpool_limits
+
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        return bool(np.array_equal(k_means(maps, 2, random_state=rs, n_init=10)[1], mine["labels"]))
+        for limit in (1, None):
+            rs = np.random.RandomState()
+            rs.set_state(km_state.get_state())
+            with threadpool_limits(limits=limit, user_api="openmp"):
+                got = k_means(maps, 2, random_state=rs, n_init=10)[1]
+            if np.array_equal(got, mine["labels"]):
+                return True
+    return False
 
 
 def _unstable_under_solver_noise(points, km_state, wanted, trials=48):
