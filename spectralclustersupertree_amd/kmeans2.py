@@ -438,7 +438,12 @@ def _self_test() -> bool:
         cases = [probe.standard_normal((n, 2)) * [1.0, 10.0 ** probe.randint(-3, 1)] for n in (3, 4, 5, 7, 12, 33, 100, 300)]
         cases.append(np.array([[0.0, 1.0], [0.0, 1.0], [0.0, -1.0], [0.0, -1.0]]))  # duplicates
         cases.append(np.column_stack([np.full(9, 0.3), np.r_[np.zeros(4), np.ones(5)]]))
-        with warnings.catch_warnings():
+        # (one OpenMP thread for the public function: with equal inertia among the starts its choice
+        # hangs on the summation order of a team-wide reduction and is not repeatable -- DESIGN.md
+        # section 1; the one-thread run is the one this module reproduces)
+        from threadpoolctl import threadpool_limits
+
+        with warnings.catch_warnings(), threadpool_limits(limits=1, user_api="openmp"):
             warnings.simplefilter("ignore")
             for c in cases:
                 ra, rb = np.random.RandomState(7), np.random.RandomState(7)
