@@ -283,3 +283,28 @@ def test_device_work_queued_ahead_changes_nothing(monkeypatch):
     stats = runs["1"][3]
     assert stats["submitted"] >= 3 and stats["by_worker"] + stats["by_walk"] == stats["submitted"]
     assert stats["by_worker"] >= 1  # some node was solved before the walk asked for it
+
+
+def test_a_look_ahead_job_that_fails_on_the_worker_is_solved_by_the_walk(monkeypatch):
+    # two nodes in flight need more device memory than one: a job that fails on the worker's context
+    # must not fail the run -- it is solved again on the walk's own context, with the same result
+    import threading
+
+    from spectralclustersupertree_amd import scs
+
+    trees, weights = recursion_input(21, 900, 24, 600, 30, weighted=False)
+    taxa = sorted({n for t in trees for n in t.get_tip_names()})
+    arrays = TreeArrays.from_trees(trees, weights or [1.0] * len(trees), taxa)
+    want = canonical(construct_supertree(arrays, pcg_weighting="branch", random_state=np.random.RandomState(4)))
+    real, failed = scs._solve_node, []
+
+    def flaky(dev, *args, **kwargs):
+        if threading.current_thread().name == "scs-ahead":
+            failed.append(1)
+            msg = "libscs_hip error -3: out of device memory (simulated)"
+            raise RuntimeError(msg)
+        return real(dev, *args, **kwargs)
+
+    monkeypatch.setattr(scs, "_solve_node", flaky)
+    got = canonical(construct_supertree(arrays, pcg_weighting="branch", random_state=np.random.RandomState(4)))
+    assert failed and got == want
