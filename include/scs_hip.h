@@ -130,7 +130,14 @@ int scs_host_free(void *p);
  *   tree_w     fp64  [n_trees]     tree weights
  * Shapes are checked on the host, the ranges of leaf_taxon / adj_depth by a kernel on the
  * uploaded copy (SCS_EINVAL, nothing is kept).  The arrays share ONE device block taken from
- * the context's block cache.                                                     */
+ * the context's block cache.
+ * Page-locked arrays (scs_host_alloc) of a forest that scs_pcg_build walks in several tree
+ * batches (more than 2 048 taxa): the call returns once the first batch's worth of trees has
+ * arrived and been checked; the rest travels on a copy stream in chunks, and scs_pcg_build makes
+ * its stream wait for the chunks each tree batch needs -- the copy overlaps the first batches.
+ * The three leaf arrays must then stay valid and unchanged until the first scs_pcg_build on
+ * these tables (or scs_tables_free) has returned, and a range error in a late chunk is reported
+ * by that call (SCS_EINVAL) instead of this one.  Pageable arrays: copied whole, as before.  */
 int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, const int64_t *tree_off,
                       const int32_t *leaf_taxon, const int32_t *adj_depth, const double *adj_val,
                       const double *tree_w, scs_tables **out);

@@ -79,7 +79,9 @@ class Device:
             msg = self._lib.scs_last_error()
             raise ValueError(msg.decode() if msg else "scs_tables_upload: invalid tables")
         nv.check(rc)
-        return DeviceTables(self, handle, tables.n_taxa, tables.n_trees, bool(tables.monotone))
+        out = DeviceTables(self, handle, tables.n_taxa, tables.n_trees, bool(tables.monotone))
+        out._source = tables  # (page-locked arrays may still be read until the first build returns)
+        return out
 
     # -- batched small nodes --------------------------------------------------
     SMALL_MAX_TAXA = 64  # MAXS of the device Jacobi kernel

@@ -751,6 +751,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         SCS_TRY(d_rec.alloc(need_rec));
 
         SCS_HIP_CHECK(hipEventRecord(ev_prep.a, s));
+        SCS_TRY(scs_tables_wait(ctx, tb, t1, s));  // (leaf arrays still on their way: scs_tables_upload)
         SCS_HIP_CHECK(hipMemcpyAsync(d_stoff.p, st_off.data(), need_stoff, hipMemcpyHostToDevice, s));
         SCS_HIP_CHECK(hipMemsetAsync(d_pos.p, 0xFF, need_pos, s));
         dim3 grid_l((unsigned)((max_n + 255) / 256), (unsigned)nb);
@@ -933,6 +934,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     }
     SCS_HIP_CHECK(hipEventRecord(ev_total.b, s));
     SCS_HIP_CHECK(hipEventSynchronize(ev_total.b));
+    SCS_TRY(scs_tables_finish(ctx, tb));  // the range check of the chunks that arrived meanwhile
     float total_ms = 0.f;
     SCS_HIP_CHECK(hipEventElapsedTime(&total_ms, ev_total.a, ev_total.b));
     if (n_batches == 1) {

@@ -14,6 +14,7 @@
 #include "scs_internal.h"
 
 #include <algorithm>
+#include <cmath>
 
 // ---------------------------------------------------------------------------
 // errors
@@ -501,6 +502,7 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
         hipStreamSynchronize(ctx->stream);
     }
     scs_comm_destroy(&ctx->comm);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->h_report) hipHostFree(ctx->h_report);
     for (auto &sl : ctx->scratch)
@@ -566,10 +568,51 @@ extern "C" int scs_host_free(void *p) {
     return SCS_OK;
 }
 
+int scs_tables_wait(scs_ctx *ctx, const scs_tables *t, int32_t t_end, hipStream_t stream) {
+    for (size_t c = 0; c < t->late_ev.size(); ++c)
+        if (t->late_start[c] < t_end) SCS_HIP_CHECK(hipStreamWaitEvent(stream, t->late_ev[c], 0));
+    return SCS_OK;
+}
+
+int scs_tables_finish(scs_ctx *ctx, const scs_tables *t) {
+    if (t->late_ev.empty()) return SCS_OK;
+    hipError_t e = hipSuccess;
+    for (hipEvent_t ev : t->late_ev) {
+        const hipError_t w = hipEventSynchronize(ev);
+        if (e == hipSuccess) e = w;
+        hipEventDestroy(ev);
+    }
+    t->late_ev.clear();
+    t->late_start.clear();
+    unsigned bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, t->d_flags, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        scs_set_error("table upload failed: %s", hipGetErrorString(e));
+        return SCS_EHIP;
+    }
+    if (bad) {
+        scs_set_error("scs_tables_upload: %s", (bad & 1u) ? "a leaf_taxon entry is out of range [0, n_taxa)"
+                                                          : "an adj_depth entry is negative");
+        return SCS_EINVAL;
+    }
+    return SCS_OK;
+}
+
+// the memory a pointer names is page-locked host memory (hipHostMalloc / hipHostRegister)
+static bool scs_is_pinned(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary pageable pointer: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
 extern "C" int scs_tables_free(scs_ctx *ctx, scs_tables *t) {
     if (!t) return SCS_OK;
     if (ctx) {
         hipSetDevice(ctx->device);
+        (void)scs_tables_finish(ctx, t);  // nothing may still be writing into the block
         scs_block_release(ctx, t->d_block);
     } else if (t->d_block) {
         hipFree(t->d_block);
@@ -623,20 +666,60 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
     t->d_adj_val = (double *)(base + o_val);
     t->d_tree_w = (double *)(base + o_w);
     unsigned *d_flags = (unsigned *)(base + o_flag);
+    t->d_flags = d_flags;
     hipStream_t s = ctx->stream;
+    // How much has to be there before the call returns.  Pageable arrays: everything (the runtime
+    // stages such a copy and blocks anyway).  Page-locked arrays of a forest that scs_pcg_build will
+    // walk in several tree batches: the first batch's worth -- the same rule of thumb as the build's
+    // (about 600 MB of range-minimum tables, 64 to 256 trees) -- and the rest in chunks of that many
+    // trees on the copy stream, overlapping the build's first batches.
+    int32_t first = n_trees;
+    if (n_taxa > 2048 && (size_t)L * 16 >= ((size_t)8 << 20) && scs_is_pinned(leaf_taxon) &&
+        scs_is_pinned(adj_depth) && scs_is_pinned(adj_val)) {
+        const double avg = std::max((double)L / n_trees - 1.0, 1.0);
+        const double table_bytes = (std::floor(std::log2(avg)) + 1.0) * avg * 8.0;
+        const int32_t per = (int32_t)std::min(256.0, std::max(64.0, 600e6 / table_bytes));
+        if (n_trees >= 2 * per || n_trees - per >= 32) first = per;
+    }
+    const int64_t L0 = tree_off[first];
     hipError_t e = hipMemsetAsync(d_flags, 0, 4, s);
     if (e == hipSuccess) e = hipMemcpyAsync(t->d_tree_off, tree_off, ((size_t)n_trees + 1) * 8, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_leaf_taxon, leaf_taxon, (size_t)L * 4, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_depth, adj_depth, (size_t)L * 4, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_val, adj_val, (size_t)L * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && L0) e = hipMemcpyAsync(t->d_leaf_taxon, leaf_taxon, (size_t)L0 * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && L0) e = hipMemcpyAsync(t->d_adj_depth, adj_depth, (size_t)L0 * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && L0) e = hipMemcpyAsync(t->d_adj_val, adj_val, (size_t)L0 * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(t->d_tree_w, tree_w, (size_t)n_trees * 8, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        const int grid = (int)std::min<int64_t>((L + 255) / 256 + 1, 4096);
-        k_validate_tables<<<grid, 256, 0, s>>>(t->d_leaf_taxon, t->d_adj_depth, L, n_taxa, d_flags);
+        const int grid = (int)std::min<int64_t>((L0 + 255) / 256 + 1, 4096);
+        k_validate_tables<<<grid, 256, 0, s>>>(t->d_leaf_taxon, t->d_adj_depth, L0, n_taxa, d_flags);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_flags, d_flags, 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && first < n_trees) {
+        if (!ctx->copy_stream) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+        hipStream_t cs = ctx->copy_stream;
+        for (int32_t a = first; a < n_trees && e == hipSuccess; a += first) {
+            const int32_t b = std::min(n_trees, a + first);
+            const int64_t p0 = tree_off[a], cnt = tree_off[b] - tree_off[a];
+            e = hipMemcpyAsync(t->d_leaf_taxon + p0, leaf_taxon + p0, (size_t)cnt * 4, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(t->d_adj_depth + p0, adj_depth + p0, (size_t)cnt * 4, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) e = hipMemcpyAsync(t->d_adj_val + p0, adj_val + p0, (size_t)cnt * 8, hipMemcpyHostToDevice, cs);
+            if (e == hipSuccess) {
+                const int grid = (int)std::min<int64_t>((cnt + 255) / 256 + 1, 4096);
+                k_validate_tables<<<grid, 256, 0, cs>>>(t->d_leaf_taxon + p0, t->d_adj_depth + p0, cnt, n_taxa, d_flags);
+                e = hipGetLastError();
+            }
+            hipEvent_t ev = nullptr;
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev, cs);
+            if (e == hipSuccess) {
+                t->late_start.push_back(a);
+                t->late_ev.push_back(ev);
+            } else if (ev) {
+                hipEventDestroy(ev);
+            }
+        }
+    }
     if (e != hipSuccess) {
         scs_tables_free(ctx, t);
         scs_set_error("table upload failed: %s", hipGetErrorString(e));

@@ -78,6 +78,7 @@ int scs_comm_destroy(scs_comm *comm);
 struct scs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // late chunks of a table upload (created on first use)
     scs_comm comm;
     int n_cu = 256;
     size_t ws_limit = 0;  // bytes of build scratch allowed per tree batch
@@ -130,7 +131,20 @@ struct scs_tables {
     int32_t *d_adj_depth = nullptr;    // [L]
     double *d_adj_val = nullptr;       // [L]
     double *d_tree_w = nullptr;        // [n_trees]
+    // Page-locked source arrays: scs_tables_upload returns once the leaf arrays of the first
+    // `late_start[0]` trees have arrived and been checked; the rest travels on the context's copy
+    // stream in chunks -- chunk c holds the trees [late_start[c], late_start[c + 1]) and is complete
+    // (copied and range-checked into d_flags) when late_ev[c] has fired.  scs_pcg_build makes its
+    // stream wait for the chunks a tree batch needs and collects the verdict at its end.
+    mutable std::vector<int32_t> late_start;  // empty: everything arrived with the upload
+    mutable std::vector<hipEvent_t> late_ev;
+    unsigned *d_flags = nullptr;
 };
+
+// scs_ctx.hip: make `stream` wait until the leaf arrays of the trees [0, t_end) are on the device
+int scs_tables_wait(scs_ctx *ctx, const scs_tables *t, int32_t t_end, hipStream_t stream);
+// wait (on the host) for everything still on its way; SCS_EINVAL when its range check failed
+int scs_tables_finish(scs_ctx *ctx, const scs_tables *t);
 
 struct scs_graph {
     int32_t n = 0;          // V: number of vertices (columns)

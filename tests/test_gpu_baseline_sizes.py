@@ -333,3 +333,48 @@ def test_config4_full_recursion_properties():
         assert res["newick_sha256"] == want["newick_sha256"]
         assert res["random_state_next_draw"] == want["random_state_next_draw"]
         assert res["spectral_calls"] == want["spectral_calls"]
+
+
+def test_page_locked_tables_arrive_behind_the_first_tree_batch(dev):
+    """scs_tables_upload with page-locked arrays returns after the first tree batch's worth of
+    trees; the rest travels on the copy stream while scs_pcg_build works on the first batches
+    (include/scs_hip.h).  Same W, bit for bit, as from pageable arrays (everything copied
+    first) -- both tile kernels, and a second build from the same tables."""
+    from spectralclustersupertree_amd import _native as nv
+
+    n, m = 10000, 500
+    for strategy in ("branch", "bootstrap"):
+        pinned = synthetic.make_tables(0, n, m, strategy, pinned=True)
+        plain = synthetic.make_tables(0, n, m, strategy)
+        assert np.array_equal(pinned.leaf_taxon, plain.leaf_taxon) and np.array_equal(pinned.adj_val, plain.adj_val)
+        rows = _sample_rows(n, 24, 7)
+        got = []
+        for tables in (pinned, plain):
+            dtab = dev.upload(tables)
+            graph = dtab.build()
+            try:
+                assert graph.build_stats["n_batches"] > 1
+                got.append(_check_rows_bit_exact(graph, tables, rows))
+                if tables is pinned:  # the tables are complete now: a second build reads them as they are
+                    again = dtab.build()
+                    try:
+                        assert np.array_equal(again.download_rows(4000, 64), graph.download_rows(4000, 64))
+                    finally:
+                        again.free()
+            finally:
+                graph.free()
+                dtab.free()
+        assert np.array_equal(got[0], got[1])
+    # a taxon id out of range in the LAST tree: the upload cannot see it any more, the build reports it
+    bad = synthetic.make_tables(0, n, m, "branch", pinned=True)
+    bad.leaf_taxon[-5] = n + 3
+    dtab = dev.upload(bad)
+    try:
+        with pytest.raises(nv.ScsError, match="out of range") as err:
+            dtab.build()
+        assert err.value.code == nv.EINVAL
+    finally:
+        dtab.free()
+    # freed without ever being built: the pending copies are drained first
+    dev.upload(synthetic.make_tables(1, n, m, "branch", pinned=True)).free()
+    dev.synchronize()
