@@ -45,7 +45,10 @@ constexpr int SCS_TCW = 256;  // threads per workgroup = columns per column grou
 constexpr int SCS_NPAD = 512; // position tables are padded to a multiple of this
 constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_symm.h
 
-constexpr size_t SCS_SCRATCH_KEEP = (size_t)64 << 20;
+// a scratch slot of the build above this size is released when the call ends (a batch's range-minimum
+// tables are 0.3 GB at 10 000 leaves and 0.6 GB from 50 000 on: kept -- a hipFree / hipMalloc pair of that
+// size cost 0.4 ms of every 21 ms step; the workspace of a memory-bound job, tens of GB, is not)
+constexpr size_t SCS_SCRATCH_KEEP = (size_t)1 << 30;
 constexpr size_t SCS_BLOCK_KEEP = (size_t)32 << 30;  // free cached blocks kept per context (of 288 GB)
 
 struct scs_ctx;
