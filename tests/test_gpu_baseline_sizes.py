@@ -240,7 +240,9 @@ def test_config3_two_ranks_upper_triangle_job(dev):
     from spectralclustersupertree_amd.partition import LocalTeams, row_splits_upper
 
     n, m = 50000, 2000
-    tables = synthetic.make_tables(0, n, m, "branch")
+    # (page-locked tables: each rank's upload returns after the first tree batch's worth of trees and
+    # the rest arrives on that rank's copy stream while its build is under way -- include/scs_hip.h)
+    tables = synthetic.make_tables(0, n, m, "branch", pinned=True)
     v0 = np.random.RandomState(0).uniform(-1, 1, n)
     dtab = dev.upload(tables)
     g = dtab.build()
