@@ -132,8 +132,8 @@ int scs_host_free(void *p);
  * uploaded copy (SCS_EINVAL, nothing is kept).  The arrays share ONE device block taken from
  * the context's block cache.
  * Page-locked arrays (scs_host_alloc) of a forest that scs_pcg_build walks in several tree
- * batches (more than 2 048 taxa): the call returns once the first batch's worth of trees has
- * arrived and been checked; the rest travels on a copy stream in chunks, and scs_pcg_build makes
+ * batches (more than 2 048 taxa): the call returns once the first 64 trees have arrived and been
+ * checked (scs_pcg_build makes them a first, short batch); the rest travels on a copy stream in chunks, and scs_pcg_build makes
  * its stream wait for the chunks each tree batch needs -- the copy overlaps the first batches.
  * The three leaf arrays must then stay valid and unchanged until the first scs_pcg_build on
  * these tables (or scs_tables_free) has returned, and a range error in a late chunk is reported

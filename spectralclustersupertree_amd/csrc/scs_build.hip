@@ -484,8 +484,15 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
     } else {
         hipFree(g->d_w);
     }
-    hipFree(g->d_deg);
-    hipFree(g->d_dinv);
+    // (the two V-vectors come from the context's block cache: a hipFree each cost every step of the
+    // benchmark and every node of a recursion a device-wide synchronisation)
+    if (ctx) {
+        if (g->d_deg) scs_block_release(ctx, g->d_deg);
+        if (g->d_dinv) scs_block_release(ctx, g->d_dinv);
+    } else {
+        hipFree(g->d_deg);
+        hipFree(g->d_dinv);
+    }
     delete g;
     return SCS_OK;
 }
@@ -697,13 +704,17 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // handful of tiles whose tables sit in L2: one batch, one set of launches)
         if (n <= 2048) max_batch_trees = 4096;
         if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
+        // tables whose later trees are still on their way (page-locked source, scs_tables_upload): the
+        // trees that have arrived make a first, short batch -- the copy of the rest runs beside it
+        const int arrived = tb->late_start.empty() ? M : tb->late_start[0];
         size_t used = 0;
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
             const int64_t m = nt - 1;
             const size_t need =
                 (size_t)table_entries(m) * entry_bytes + (size_t)npad * 4 + (size_t)n_blocks * rec_bytes;
-            if ((used + need > ctx->ws_limit || t - batch_start.back() >= max_batch_trees) &&
+            if ((used + need > ctx->ws_limit || t - batch_start.back() >= max_batch_trees ||
+                 (t == arrived && batch_start.size() == 1)) &&
                 t > batch_start.back()) {
                 batch_start.push_back(t);
                 used = 0;
@@ -1064,8 +1075,8 @@ int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
     hipStream_t s = ctx->stream;
     const int n = g->n;
     const int rows = g->row_end - g->row_begin;
-    if (!g->d_deg) SCS_HIP_CHECK(hipMalloc((void **)&g->d_deg, (size_t)n * 8));
-    if (!g->d_dinv) SCS_HIP_CHECK(hipMalloc((void **)&g->d_dinv, (size_t)n * 8));
+    if (!g->d_deg) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_deg));
+    if (!g->d_dinv) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_dinv));
     const int world = ctx->comm.world;
     if (world == 1 && !g->upper) {
         k_degrees<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg);

@@ -673,13 +673,18 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
     // walk in several tree batches: the first batch's worth -- the same rule of thumb as the build's
     // (about 600 MB of range-minimum tables, 64 to 256 trees) -- and the rest in chunks of that many
     // trees on the copy stream, overlapping the build's first batches.
-    int32_t first = n_trees;
+    int32_t first = n_trees, chunk = n_trees;
     if (n_taxa > 2048 && (size_t)L * 16 >= ((size_t)8 << 20) && scs_is_pinned(leaf_taxon) &&
         scs_is_pinned(adj_depth) && scs_is_pinned(adj_val)) {
         const double avg = std::max((double)L / n_trees - 1.0, 1.0);
         const double table_bytes = (std::floor(std::log2(avg)) + 1.0) * avg * 8.0;
         const int32_t per = (int32_t)std::min(256.0, std::max(64.0, 600e6 / table_bytes));
-        if (n_trees >= 2 * per || n_trees - per >= 32) first = per;
+        if (n_trees >= 2 * per || n_trees - per >= 32) {
+            // the call waits for 64 trees only (scs_pcg_build then makes them a first, short batch:
+            // an extra launch is cheaper than waiting for the other three quarters of a batch)
+            first = std::min(per, 64);
+            chunk = per;
+        }
     }
     const int64_t L0 = tree_off[first];
     hipError_t e = hipMemsetAsync(d_flags, 0, 4, s);
@@ -698,8 +703,8 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
     if (e == hipSuccess && first < n_trees) {
         if (!ctx->copy_stream) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
         hipStream_t cs = ctx->copy_stream;
-        for (int32_t a = first; a < n_trees && e == hipSuccess; a += first) {
-            const int32_t b = std::min(n_trees, a + first);
+        for (int32_t a = first; a < n_trees && e == hipSuccess; a += chunk) {
+            const int32_t b = std::min(n_trees, a + chunk);
             const int64_t p0 = tree_off[a], cnt = tree_off[b] - tree_off[a];
             e = hipMemcpyAsync(t->d_leaf_taxon + p0, leaf_taxon + p0, (size_t)cnt * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipMemcpyAsync(t->d_adj_depth + p0, adj_depth + p0, (size_t)cnt * 4, hipMemcpyHostToDevice, cs);
