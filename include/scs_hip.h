@@ -264,6 +264,23 @@ int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa, const 
                     const int32_t *group_start, double *maps_out, double *lambda_out,
                     double *w_out);
 
+/* The same in two halves.  _begin copies the inputs into a page-locked block of the context,
+ * enqueues the upload, the three launches and the download of the results and returns a ticket
+ * without waiting; _end waits for that ticket's results and copies them out (NULL outputs: the
+ * results are dropped).  Several tickets may be outstanding on a context; they complete in the
+ * order they were begun.  The recursion begins a child's solve as soon as its tables are
+ * flattened: the next child is flattened on the host meanwhile, and a right sibling's embedding is
+ * long there when the walk arrives (reference order of the walk: scs.py:139-171).
+ * want_w != 0: the contracted weight matrices are kept for _end's w_out.  The input arrays may be
+ * reused as soon as _begin returns. */
+int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
+                          const int32_t *n_trees, const int32_t *n_groups, const int32_t *tree_off,
+                          const int32_t *leaf_taxon, const int32_t *adj_depth, const double *adj_val,
+                          const double *tree_w, const int32_t *group_start, int32_t want_w,
+                          int32_t *ticket_out);
+int scs_small_solve_end(scs_ctx *ctx, int32_t ticket, double *maps_out, double *lambda_out,
+                        double *w_out);
+
 /* ---- diagnostics used by the parity tests ------------------------------ */
 
 /* Eigen-decomposition of a dense symmetric n x n matrix (n <= 64) by the

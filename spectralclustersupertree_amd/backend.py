@@ -91,9 +91,14 @@ class Device:
         at depth).  ``nodes``: list of ``(tables, group_start or None)`` with at most
         ``SMALL_MAX_TAXA`` taxa each, taxa numbered so that contraction groups are consecutive
         ranges.  Returns one ``(maps, lambdas)`` -- or ``(maps, lambdas, W)`` -- per node."""
-        k = len(nodes)
-        if k == 0:
+        if len(nodes) == 0:
             return []
+        return self.small_solve_begin(nodes, want_w).result()
+
+    def small_solve_begin(self, nodes, want_w: bool = False) -> "SmallTicket":
+        """The same, not waited for (``scs_small_solve_begin``): the returned ticket's
+        ``result()`` is the list ``small_solve`` returns.  At least one node."""
+        k = len(nodes)
         n_taxa = np.empty(k, dtype=np.int32)
         n_trees = np.empty(k, dtype=np.int32)
         n_groups = np.empty(k, dtype=np.int32)
@@ -109,31 +114,22 @@ class Device:
             ad.append(tables.adj_depth)
             av.append(tables.adj_val)
             tw.append(tables.tree_w)
-        cat = np.concatenate
+        if k == 1:
+            cat = lambda parts: parts[0]  # noqa: E731
+        else:
+            cat = np.concatenate
         toff_a = np.ascontiguousarray(cat(toff), dtype=np.int32)
         gs_a = np.ascontiguousarray(cat(gstart), dtype=np.int32)
         lt_a = np.ascontiguousarray(cat(lt), dtype=np.int32)
         ad_a = np.ascontiguousarray(cat(ad), dtype=np.int32)
         av_a = np.ascontiguousarray(cat(av), dtype=np.float64)
         tw_a = np.ascontiguousarray(cat(tw), dtype=np.float64)
-        total_v = int(n_groups.sum())
-        maps = np.empty((total_v, 2))
-        lam = np.empty((k, 3))
-        w = np.empty(int((n_groups.astype(np.int64) ** 2).sum())) if want_w else None
-        nv.check(self._lib.scs_small_solve(
+        ticket = C.c_int32(-1)
+        nv.check(self._lib.scs_small_solve_begin(
             self._ctx, k, nv.iptr(n_taxa), nv.iptr(n_trees), nv.iptr(n_groups), nv.iptr(toff_a),
-            nv.iptr(lt_a), nv.iptr(ad_a), nv.dptr(av_a), nv.dptr(tw_a), nv.iptr(gs_a), nv.dptr(maps),
-            nv.dptr(lam), nv.dptr(w) if want_w else None))
-        out, at, wat = [], 0, 0
-        for i in range(k):
-            v = int(n_groups[i])
-            item = (maps[at:at + v].copy(), lam[i].copy())
-            if want_w:
-                item += (w[wat:wat + v * v].reshape(v, v).copy(),)
-                wat += v * v
-            out.append(item)
-            at += v
-        return out
+            nv.iptr(lt_a), nv.iptr(ad_a), nv.dptr(av_a), nv.dptr(tw_a), nv.iptr(gs_a), int(want_w),
+            C.byref(ticket)))
+        return SmallTicket(self, ticket.value, n_groups, want_w)
 
     # -- building blocks exposed for the parity tests -----------------------
     def comm_selftest(self, x: np.ndarray) -> np.ndarray:
@@ -161,6 +157,44 @@ class Device:
         nv.check(self._lib.scs_debug_gram(self._ctx, nv.dptr(a), nv.dptr(b), a.shape[0], a.shape[1],
                                           b.shape[1], int(use_mfma), nv.dptr(out)))
         return out
+
+
+class SmallTicket:
+    """An ``scs_small_solve_begin`` that has not been ended: ``result()`` waits and returns one
+    ``(maps, lambdas[, W])`` per node (once; kept).  Dropped unasked-for, it releases its slot."""
+
+    def __init__(self, dev: Device, ticket: int, n_groups: np.ndarray, want_w: bool) -> None:
+        self.dev, self._ticket, self._n_groups, self._want_w = dev, ticket, n_groups, want_w
+        self._out = None
+
+    def result(self):
+        if self._out is None:
+            n_groups, want_w = self._n_groups, self._want_w
+            k = len(n_groups)
+            maps = np.empty((int(n_groups.sum()), 2))
+            lam = np.empty((k, 3))
+            w = np.empty(int((n_groups.astype(np.int64) ** 2).sum())) if want_w else None
+            ticket, self._ticket = self._ticket, -1
+            nv.check(self.dev._lib.scs_small_solve_end(self.dev._ctx, ticket, nv.dptr(maps), nv.dptr(lam),
+                                                       nv.dptr(w) if want_w else None))
+            out, at, wat = [], 0, 0
+            for i in range(k):
+                v = int(n_groups[i])
+                item = (maps[at:at + v], lam[i])
+                if want_w:
+                    item += (w[wat:wat + v * v].reshape(v, v),)
+                    wat += v * v
+                out.append(item)
+                at += v
+            self._out = out
+        return self._out
+
+    def __del__(self) -> None:
+        try:
+            if self._ticket >= 0 and self.dev._ctx:
+                self.dev._lib.scs_small_solve_end(self.dev._ctx, self._ticket, None, None, None)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 class DeviceTables:

@@ -514,8 +514,12 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     if (ctx->w_cache) hipFree(ctx->w_cache);
     for (auto &b : ctx->blocks) hipFree(b.p);
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    if (ctx->small_dev) hipFree(ctx->small_dev);
-    if (ctx->small_host) hipHostFree(ctx->small_host);
+    for (auto &sl : ctx->small_slots) {
+        if (sl.done) hipEventDestroy(sl.done);
+        if (sl.dev) hipFree(sl.dev);
+        if (sl.host) hipHostFree(sl.host);
+    }
+    ctx->small_slots.clear();
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     delete ctx;
     return SCS_OK;

@@ -2202,15 +2202,16 @@ __global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
     if (tid < 3) p.lambda[k * 3 + tid] = tid < v ? s.w[tid] : 0.0;
 }
 
-extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
-                               const int32_t *n_trees, const int32_t *n_groups,
-                               const int32_t *tree_off, const int32_t *leaf_taxon,
-                               const int32_t *adj_depth, const double *adj_val,
-                               const double *tree_w, const int32_t *group_start, double *maps_out,
-                               double *lambda_out, double *w_out) {
+extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
+                                     const int32_t *n_trees, const int32_t *n_groups,
+                                     const int32_t *tree_off, const int32_t *leaf_taxon,
+                                     const int32_t *adj_depth, const double *adj_val,
+                                     const double *tree_w, const int32_t *group_start, int32_t want_w,
+                                     int32_t *ticket_out) {
     SCS_REQUIRE(ctx && n_taxa && n_trees && n_groups && tree_off && leaf_taxon && adj_depth &&
-                    adj_val && tree_w && group_start && maps_out && lambda_out,
+                    adj_val && tree_w && group_start && ticket_out,
                 "scs_small_solve: null argument");
+    const bool w_out = want_w != 0;
     SCS_REQUIRE(n_nodes >= 1, "scs_small_solve: need at least one node");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -2293,23 +2294,43 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
     const size_t o_lam = at; at += (size_t)K * 24;
     const size_t o_w = at; if (w_out) at += (size_t)w_ptr[K] * 8;
     const size_t total = at;
-    if (ctx->small_cap < total) {
-        if (ctx->small_dev) hipFree(ctx->small_dev);
-        if (ctx->small_host) hipHostFree(ctx->small_host);
-        ctx->small_dev = nullptr;
-        ctx->small_host = nullptr;
-        ctx->small_cap = 0;
-        const size_t cap = std::max<size_t>(total * 2, (size_t)1 << 20);
-        SCS_HIP_CHECK(hipMalloc((void **)&ctx->small_dev, cap));
-        SCS_HIP_CHECK(hipHostMalloc((void **)&ctx->small_host, cap, hipHostMallocDefault));
-        ctx->small_cap = cap;
+    // a free slot that is large enough (the smallest such), else the largest free one (grown), else
+    // a new one
+    int pick = -1;
+    for (size_t i = 0; i < ctx->small_slots.size(); ++i) {
+        const auto &c = ctx->small_slots[i];
+        if (c.busy) continue;
+        if (pick < 0) {
+            pick = (int)i;
+            continue;
+        }
+        const auto &p = ctx->small_slots[pick];
+        const bool c_fits = c.cap >= total, p_fits = p.cap >= total;
+        if ((c_fits && (!p_fits || c.cap < p.cap)) || (!c_fits && !p_fits && c.cap > p.cap)) pick = (int)i;
     }
+    if (pick < 0) {
+        ctx->small_slots.emplace_back();
+        pick = (int)ctx->small_slots.size() - 1;
+    }
+    scs_ctx::small_slot &slot = ctx->small_slots[pick];
+    if (slot.cap < total) {
+        if (slot.dev) hipFree(slot.dev);
+        if (slot.host) hipHostFree(slot.host);
+        slot.dev = nullptr;
+        slot.host = nullptr;
+        slot.cap = 0;
+        const size_t cap = std::max<size_t>(total * 2, (size_t)1 << 20);
+        SCS_HIP_CHECK(hipMalloc((void **)&slot.dev, cap));
+        SCS_HIP_CHECK(hipHostMalloc((void **)&slot.host, cap, hipHostMallocDefault));
+        slot.cap = cap;
+    }
+    if (!slot.done) SCS_HIP_CHECK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     // device scratch: the addends (trees x cells per node) and the uncontracted weights
     t_ctx = ctx;
     dbuf d_add, d_w0;
     SCS_TRY(d_add.alloc((size_t)std::max<int64_t>(add_ptr[K], 1) * 8));
     SCS_TRY(d_w0.alloc((size_t)std::max<int64_t>(w0_ptr[K], 1) * 8));
-    unsigned char *h = ctx->small_host, *d = ctx->small_dev;
+    unsigned char *h = slot.host, *d = slot.dev;
     memcpy(h + o_nt, n_taxa, (size_t)K * 4);
     memcpy(h + o_nm, n_trees, (size_t)K * 4);
     memcpy(h + o_ng, n_groups, (size_t)K * 4);
@@ -2362,11 +2383,48 @@ extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_t
     k_small_finish<<<K, 256, 0, s>>>(sb);
     SCS_HIP_CHECK(hipGetLastError());
     SCS_HIP_CHECK(hipMemcpyAsync(h + o_maps, d + o_maps, total - o_maps, hipMemcpyDeviceToHost, s));
-    SCS_HIP_CHECK(hipStreamSynchronize(s));
-    memcpy(maps_out, h + o_maps, (size_t)vertex_ptr[K] * 16);
-    memcpy(lambda_out, h + o_lam, (size_t)K * 24);
-    if (w_out) memcpy(w_out, h + o_w, (size_t)w_ptr[K] * 8);
+    SCS_HIP_CHECK(hipEventRecord(slot.done, s));
+    slot.busy = true;
+    slot.o_maps = o_maps;
+    slot.maps_bytes = (size_t)vertex_ptr[K] * 16;
+    slot.o_lam = o_lam;
+    slot.lam_bytes = (size_t)K * 24;
+    slot.o_w = o_w;
+    slot.w_bytes = w_out ? (size_t)w_ptr[K] * 8 : 0;
+    *ticket_out = pick;
     return SCS_OK;
+}
+
+extern "C" int scs_small_solve_end(scs_ctx *ctx, int32_t ticket, double *maps_out, double *lambda_out,
+                                   double *w_out) {
+    SCS_REQUIRE(ctx != nullptr, "scs_small_solve_end: null context");
+    SCS_REQUIRE(ticket >= 0 && (size_t)ticket < ctx->small_slots.size() && ctx->small_slots[ticket].busy,
+                "scs_small_solve_end: no such ticket (%d)", ticket);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    scs_ctx::small_slot &slot = ctx->small_slots[ticket];
+    const hipError_t e = hipEventSynchronize(slot.done);
+    slot.busy = false;  // (whatever happened: the slot is the caller's no longer)
+    if (e != hipSuccess) {
+        scs_set_error("scs_small_solve: %s", hipGetErrorString(e));
+        return SCS_EHIP;
+    }
+    if (maps_out) memcpy(maps_out, slot.host + slot.o_maps, slot.maps_bytes);
+    if (lambda_out) memcpy(lambda_out, slot.host + slot.o_lam, slot.lam_bytes);
+    if (w_out && slot.w_bytes) memcpy(w_out, slot.host + slot.o_w, slot.w_bytes);
+    return SCS_OK;
+}
+
+extern "C" int scs_small_solve(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
+                               const int32_t *n_trees, const int32_t *n_groups,
+                               const int32_t *tree_off, const int32_t *leaf_taxon,
+                               const int32_t *adj_depth, const double *adj_val,
+                               const double *tree_w, const int32_t *group_start, double *maps_out,
+                               double *lambda_out, double *w_out) {
+    SCS_REQUIRE(maps_out && lambda_out, "scs_small_solve: null output");
+    int32_t ticket = -1;
+    SCS_TRY(scs_small_solve_begin(ctx, n_nodes, n_taxa, n_trees, n_groups, tree_off, leaf_taxon, adj_depth,
+                                  adj_val, tree_w, group_start, w_out != nullptr, &ticket));
+    return scs_small_solve_end(ctx, ticket, maps_out, lambda_out, w_out);
 }
 
 // ---------------------------------------------------------------------------

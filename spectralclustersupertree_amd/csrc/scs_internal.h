@@ -117,9 +117,18 @@ struct scs_ctx {
     std::vector<hipEvent_t> event_pool;  // events of the timed SYMM launches, reused
     // staging of scs_small_solve (one pinned host block, one device block), grown on demand
     unsigned *h_flags = nullptr;  // 64 pinned bytes: results of device-side argument checks
-    unsigned char *small_host = nullptr;
-    unsigned char *small_dev = nullptr;
-    size_t small_cap = 0;
+    // one slot per scs_small_solve_begin that has not been ended yet (and the free ones kept for
+    // the next): page-locked host block + device block of the same layout, the event that fires
+    // when the results have landed in the host block, where they sit in it
+    struct small_slot {
+        unsigned char *host = nullptr;
+        unsigned char *dev = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+        size_t o_maps = 0, maps_bytes = 0, o_lam = 0, lam_bytes = 0, o_w = 0, w_bytes = 0;
+    };
+    std::vector<small_slot> small_slots;
 };
 
 struct scs_tables {

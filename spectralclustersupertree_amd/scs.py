@@ -215,7 +215,7 @@ def spectral_bipartition_device(
         # the reference's ARPACK start vector is still the first draw from the stream
         random_state.uniform(-1, 1, n_groups)
         stats = None
-        if isinstance(maps, _Pending):
+        if isinstance(maps, (_Pending, _Begun)):
             maps, stats = maps.fetch(device or (team.solo if team is not None else default_device()))
         if report is not None:
             report.update(stats or {"n_vertices": n_groups, "block": 0})
@@ -293,6 +293,18 @@ def _solve_node(dev, work, group_start, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_IT
     finally:
         graph.free()
     return maps, stats
+
+
+class _Begun:
+    """The embedding of a small node whose ``scs_small_solve_begin`` is under way."""
+
+    __slots__ = ("ticket",)
+
+    def __init__(self, ticket) -> None:
+        self.ticket = ticket
+
+    def fetch(self, own_device):
+        return self.ticket.result()[0][0], None
 
 
 class _Pending:
@@ -642,10 +654,13 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
 def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahead=None) -> None:
     """Flatten every child problem, and run the device work of those that are one component of
     at most 64 taxa as ONE ``scs_small_solve`` launch; fills the ``pre`` slot of each child
-    (present taxa, tables, components, embedding-or-None).  With ``ahead`` every larger
-    single-component child but the one the walk enters next becomes a job of that queue (the
-    ``pre`` slot then holds a ``_Pending``)."""
+    (present taxa, tables, components, embedding-or-None).  With ``ahead`` every small child's
+    solve is BEGUN as soon as its tables are flattened (``scs_small_solve_begin``: the next child
+    is flattened meanwhile, the result is fetched at the visit), and every larger single-component
+    child but the one the walk enters next becomes a job of the queue (``_Begun`` / ``_Pending`` in
+    the ``pre`` slot)."""
     batch, where, larger = [], [], []
+    small_dev = None
     first_sub = True
     for child in children:
         if child[0] != "sub":
@@ -665,8 +680,16 @@ def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahea
             continue
         if tables.n_taxa <= Device.SMALL_MAX_TAXA:
             work, perm, group_start, n_groups = prepare_node(tables, contract_edges)
-            batch.append((work, group_start))
-            where.append((child, work, perm, group_start, n_groups))
+            if ahead is not None:
+                # begun at once, not waited for: the next child is flattened meanwhile, and a right
+                # sibling's embedding is long there when the walk arrives
+                if small_dev is None:
+                    small_dev = team.solo if team is not None else default_device()
+                ticket = small_dev.small_solve_begin([(work, group_start)])
+                child[3][3] = (work, perm, group_start, n_groups, _Begun(ticket))
+            else:
+                batch.append((work, group_start))
+                where.append((child, work, perm, group_start, n_groups))
         elif ahead is not None and not first:
             # (the child the walk enters next is on the walk's own chain: solved there, at the visit)
             larger.append(child)
