@@ -717,6 +717,41 @@ def test_small_solve_many_trees_bit_exact(dev, n, m, k, strategy):
     assert np.array_equal(out[0][0], out[2][0])  # the same node twice: the same bits
 
 
+def test_small_solve_begin_end_tickets(dev):
+    # scs_small_solve_begin / _end: several solves outstanding on one context, ended in any order,
+    # one dropped unasked-for -- the same bits as the waited-for call, slots reused
+    from spectralclustersupertree_amd import _native as nv
+
+    rs = np.random.RandomState(8)
+    nodes = []
+    for i in range(9):
+        n = int(rs.randint(3, 65))
+        nodes.append((synthetic.make_tables(700 + i, n, int(rs.randint(3, 400)), ["branch", "bootstrap", "one"][i % 3],
+                                            leaves_per_tree=max(2, n - int(rs.randint(0, 3))),
+                                            random_weights=bool(i % 2)), None))
+    want = dev.small_solve(nodes, want_w=True)
+    for round_ in range(3):
+        tickets = [dev.small_solve_begin([nd], want_w=True) for nd in nodes]
+        dropped = tickets.pop(4)
+        del dropped  # never asked for: its slot goes back
+        order = list(range(len(tickets)))
+        rs.shuffle(order)
+        for j in order:
+            i = j if j < 4 else j + 1
+            (maps, lam, w), = tickets[j].result()
+            assert np.array_equal(maps, want[i][0]) and np.array_equal(lam, want[i][1])
+            assert np.array_equal(w, want[i][2])
+            assert tickets[j].result()[0][0] is maps  # kept, not fetched twice
+    # a batch as one ticket next to single ones
+    a = dev.small_solve_begin(nodes[:3])
+    b = dev.small_solve_begin(nodes[3:4])
+    assert np.array_equal(b.result()[0][0], want[3][0])
+    for i, (maps, lam) in enumerate(a.result()):
+        assert np.array_equal(maps, want[i][0])
+    with pytest.raises(nv.ScsError, match="no such ticket"):
+        nv.check(dev._lib.scs_small_solve_end(dev._ctx, 12345, None, None, None))
+
+
 @pytest.mark.parametrize("n,m,k,strategy", [(1000, 100, 1000, "depth"), (700, 40, 600, "branch"), (130, 9, 100, "one")])
 def test_atomic_scatter_variant_agrees_with_the_ordered_build(dev, n, m, k, strategy):
     # SURVEY.md section 7 (ii) / the north star's literal wording: input-stationary scatter with
