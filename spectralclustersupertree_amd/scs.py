@@ -657,15 +657,12 @@ def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahea
     (present taxa, tables, components, embedding-or-None).  With ``ahead`` every small child's
     solve is BEGUN as soon as its tables are flattened (``scs_small_solve_begin``: the next child
     is flattened meanwhile, the result is fetched at the visit), and every larger single-component
-    child but the one the walk enters next becomes a job of the queue (``_Begun`` / ``_Pending`` in
-    the ``pre`` slot)."""
-    batch, where, larger = [], [], []
+    child becomes a job of the queue (``_Begun`` / ``_Pending`` in the ``pre`` slot)."""
+    batch, where = [], []
     small_dev = None
-    first_sub = True
     for child in children:
         if child[0] != "sub":
             continue
-        first, first_sub = first_sub, False
         sub = child[2]
         if sub.n_trees == 1:
             continue  # grafted as it is (reference: scs.py:96-98)
@@ -690,13 +687,12 @@ def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahea
             else:
                 batch.append((work, group_start))
                 where.append((child, work, perm, group_start, n_groups))
-        elif ahead is not None and not first:
-            # (the child the walk enters next is on the walk's own chain: solved there, at the visit)
-            larger.append(child)
-    for child in larger:  # (first: the worker starts on them while the batch below runs here)
-        work, perm, group_start, n_groups = prepare_node(child[3][1], contract_edges)
-        solve = lambda dev, work=work, group_start=group_start: _solve_node(dev, work, group_start)  # noqa: E731
-        child[3][3] = (work, perm, group_start, n_groups, _Pending(ahead, ahead.submit(solve), solve))
+        elif ahead is not None:
+            # queued at once, the child the walk enters next included: its solve starts while the
+            # remaining children are still being flattened
+            work, perm, group_start, n_groups = prepare_node(tables, contract_edges)
+            solve = lambda dev, work=work, group_start=group_start: _solve_node(dev, work, group_start)  # noqa: E731
+            child[3][3] = (work, perm, group_start, n_groups, _Pending(ahead, ahead.submit(solve), solve))
     if batch:  # (a recursion that never reaches the spectral step never touches the device)
         dev = team.solo if team is not None else default_device()
         for (child, work, perm, group_start, n_groups), (maps, _) in zip(where, dev.small_solve(batch)):
