@@ -159,7 +159,8 @@ class TreeArrays:
         if self.n_trees:
             _load().scs_host_present(self.n_trees, _p(self.node_off, C.c_int64), _p(self.taxon, C.c_int32),
                                      _p(mark, C.c_uint8))
-        return np.flatnonzero(mark[: self.n_taxa]).astype(np.int32)
+        self._present = np.flatnonzero(mark[: self.n_taxa]).astype(np.int32)
+        return self._present
 
     def leaf_counts(self) -> np.ndarray:
         if self._leaf_counts is not None:
@@ -168,6 +169,7 @@ class TreeArrays:
         if self.n_trees:
             _load().scs_host_leaf_counts(self.n_trees, _p(self.node_off, C.c_int64),
                                          _p(self.taxon, C.c_int32), _p(out, C.c_int64))
+        self._leaf_counts = out
         return out
 
     # ------------------------------------------------------------ restriction
