@@ -50,6 +50,8 @@ def load() -> C.CDLL:
         lib.scs_host_lloyd2.restype = C.c_int
         lib.scs_host_lloyd2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.scs_host_malloc_tune.restype = C.c_int
+        lib.scs_host_malloc_tune.argtypes = [C.c_int]
         lib.scs_host_kmeans2.restype = C.c_int
         lib.scs_host_kmeans2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]

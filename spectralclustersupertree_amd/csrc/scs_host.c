@@ -23,6 +23,7 @@
  *
  * Plain C, no GPU code; bound with ctypes in spectralclustersupertree_amd/treearrays.py.
  */
+#include <malloc.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdint.h>
@@ -1318,4 +1319,30 @@ int scs_host_split_fill(const scs_split_plan *plan, int32_t part, int64_t *node_
     fill2_ctx c = {plan, plan->part_first[part], node_off_out, parent_out, taxon_out, length_out,
                    support_out, present_out};
     return for_each_tree((int32_t)j, at, 0, split_fill_entry, &c);
+}
+
+
+/* ---------------------------------------------------------------------------
+ * The recursion allocates and drops numpy arrays of a few hundred kilobytes thousands of times a
+ * second (every split hands each child fresh node arrays).  glibc serves such sizes by mmap and gives
+ * them back by munmap: every array is born as untouched pages and costs a page fault per 4 KiB --
+ * 14 % of a whole recursion of 5 000-tree forests on the measured host.  While a recursion runs the
+ * threshold is raised so that these arrays come from the heap and are reused warm (on: 1), and put
+ * back to glibc's static defaults afterwards (on: 0; the dynamic adjustment of the threshold cannot be
+ * re-armed).  Process-wide, which is why scs.py does it only for the duration of a recursion and
+ * SCS_MALLOC_TUNE=0 leaves the allocator alone.
+ * ------------------------------------------------------------------------- */
+int scs_host_malloc_tune(int on) {
+    int ok = 1;
+    if (on) {
+        ok &= mallopt(M_MMAP_THRESHOLD, 32 << 20);
+        ok &= mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        ok &= mallopt(M_TOP_PAD, 64 << 20);
+    } else {
+        ok &= mallopt(M_MMAP_THRESHOLD, 128 * 1024);
+        ok &= mallopt(M_TRIM_THRESHOLD, 128 * 1024);
+        ok &= mallopt(M_TOP_PAD, 128 * 1024);
+        malloc_trim(0);
+    }
+    return ok ? SCS_HOST_OK : SCS_HOST_EINVAL;
 }

@@ -26,6 +26,7 @@ HIP device this function raises.
 
 from __future__ import annotations
 
+import threading
 from collections.abc import Sequence
 
 import numpy as np
@@ -493,6 +494,48 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     """The recursion on flat tree arrays from its root node: ``_construct_node`` with, for a
     single-process run on the device path, a queue that lets the device work on nodes ahead of
     the walk (``ahead.Ahead``)."""
+    with _warm_allocator():
+        return _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre)
+
+
+_allocator_users = 0
+_allocator_lock = threading.Lock()
+
+
+class _warm_allocator:
+    """glibc's mmap threshold raised for the duration of a recursion (``scs_host_malloc_tune``,
+    csrc/scs_host.c: the node arrays of every split then come from the warm heap instead of fresh
+    pages); counted, so that recursions on several threads (in-process teams) share it.
+    ``SCS_MALLOC_TUNE=0`` leaves the allocator alone."""
+
+    def __enter__(self):
+        import os
+
+        global _allocator_users
+        self.active = bool(int(os.environ.get("SCS_MALLOC_TUNE", "1") or 0))
+        if not self.active:
+            return self
+        from spectralclustersupertree_amd import _hostlib
+
+        with _allocator_lock:
+            if _allocator_users == 0:
+                _hostlib.load().scs_host_malloc_tune(1)
+            _allocator_users += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _allocator_users
+        if self.active:
+            from spectralclustersupertree_amd import _hostlib
+
+            with _allocator_lock:
+                _allocator_users -= 1
+                if _allocator_users == 0:
+                    _hostlib.load().scs_host_malloc_tune(0)
+        return False
+
+
+def _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre):
     single = team is None or team.world == 1
     if bipartition is None and single and _small_path() and _ahead_enabled():
         import sys
