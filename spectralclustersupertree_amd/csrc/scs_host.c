@@ -1054,6 +1054,13 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
         if (p < 0 || p >= i) return SCS_HOST_EINVAL; /* not preorder */
         if (sub_end[i] > sub_end[p]) sub_end[p] = sub_end[i];
     }
+    /* Up to eight parts (a spectral split has two): the nodes a part keeps -- its leaves and the LCAs
+     * of consecutive ones -- are MARKED, one bit per part, and read off in index order by one
+     * branch-free pass; no event lists, no sorting, no duplicates.  (The sorting path below spent
+     * most of its time in mispredicted compares of the insertion sort: thousands of trees of a few
+     * leaves each.)  The marks live in the event array's space and are cleared by the pass. */
+    const int by_marks = np <= 8;
+    uint8_t *mark = (uint8_t *)ev_part;
     int32_t sp = 0, n_ev = 0, n_touched = 0;
     for (int32_t i = 0; i < k; ++i) {
         while (sp > 0 && i > sub_end[stack[sp - 1]]) --sp;
@@ -1075,24 +1082,64 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
                 if (stack[mid] <= x) lo = mid;
                 else hi = mid - 1;
             }
-            ev_part[n_ev] = pc;
-            ev_node[n_ev++] = stack[lo];
+            if (by_marks) {
+                mark[stack[lo]] |= (uint8_t)(1u << pc);
+            } else {
+                ev_part[n_ev] = pc;
+                ev_node[n_ev++] = stack[lo];
+            }
         }
-        ev_part[n_ev] = pc;
-        ev_node[n_ev++] = i;
+        if (by_marks) {
+            mark[i] |= (uint8_t)(1u << pc);
+        } else {
+            ev_part[n_ev] = pc;
+            ev_node[n_ev++] = i;
+        }
         last[pc] = i + 1;
         cnt[pc] += 1;
     }
-    /* bucket the events by part (parts with >= 2 leaves only) */
+    /* the node lists of the parts, one after the other (parts with >= 2 leaves only) */
     int32_t total = 0;
     for (int32_t q = 0; q < n_touched; ++q) {
         const int32_t pc = touched[q];
         fill[pc] = total;
         if (cnt[pc] >= 2) total += 2 * cnt[pc] - 1;
     }
-    for (int32_t e = 0; e < n_ev; ++e) {
-        const int32_t pc = ev_part[e];
-        if (cnt[pc] >= 2) sorted_node[fill[pc]++] = ev_node[e];
+    int32_t list_start[8], list_end[8];
+    if (by_marks) {
+        /* one write cursor per bit.  A cursor stores every node and advances only on its own bit, so
+         * it keeps writing one slot past its list: the lists are laid out with a spare slot between
+         * them, and the bits of absent or dropped parts write to a dummy */
+        int32_t dummy = 0, *cur[8];
+        unsigned live = 0;
+        int32_t at2 = 0;
+        for (int b = 0; b < 8; ++b) cur[b] = &dummy;
+        for (int32_t q = 0; q < n_touched; ++q) {
+            const int32_t pc = touched[q];
+            if (cnt[pc] >= 2) {
+                list_start[pc] = at2;
+                cur[pc] = sorted_node + at2;
+                at2 += 2 * cnt[pc]; /* 2 cnt - 1 nodes at most, and the spare slot */
+                live |= 1u << pc;
+            }
+        }
+        for (int32_t i = 0; i < k; ++i) {
+            const unsigned m = mark[i] & live;
+            mark[i] = 0;
+            for (int b = 0; b < np; ++b) {
+                *cur[b] = i;
+                cur[b] += (m >> b) & 1u;
+            }
+        }
+        for (int32_t q = 0; q < n_touched; ++q) {
+            const int32_t pc = touched[q];
+            if (cnt[pc] >= 2) list_end[pc] = (int32_t)(cur[pc] - sorted_node);
+        }
+    } else {
+        for (int32_t e = 0; e < n_ev; ++e) {
+            const int32_t pc = ev_part[e];
+            if (cnt[pc] >= 2) sorted_node[fill[pc]++] = ev_node[e];
+        }
     }
     int rc = SCS_HOST_OK;
     int32_t at = 0;
@@ -1106,6 +1153,11 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
         const int32_t ne = 2 * leaves - 1;
         int32_t *nodes = sorted_node + at;
         at += ne;
+        int32_t nv = 0;
+        if (by_marks) {
+            nodes = sorted_node + list_start[pc]; /* sorted and distinct already */
+            nv = list_end[pc] - list_start[pc];
+        } else
         /* the leaves come in order already; the LCAs (every second event) do not.  Deep levels
          * of the recursion are thousands of trees of a handful of leaves: a call into qsort per
          * (tree, part) cost more than everything else there */
@@ -1122,9 +1174,9 @@ static int split_tree(int32_t t, void *scratch, void *vctx) {
         } else {
             qsort(nodes, (size_t)ne, sizeof(int32_t), cmp_i32);
         }
-        int32_t nv = 0;
-        for (int32_t j = 0; j < ne; ++j)
-            if (nv == 0 || nodes[j] != nodes[nv - 1]) nodes[nv++] = nodes[j];
+        if (!by_marks)
+            for (int32_t j = 0; j < ne; ++j)
+                if (nv == 0 || nodes[j] != nodes[nv - 1]) nodes[nv++] = nodes[j];
         rc = arena_reserve(ar);
         if (rc != SCS_HOST_OK) break;
         if (cursor + nv > slice_end) {

@@ -474,3 +474,32 @@ def test_split_polytomies_missing_lengths_unary_chains():
     for parts in ([[0, 1, 2, 3], [4, 5, 6, 7, 8, 9]], [[0, 9], [1, 8], [2, 3, 4], [5, 6, 7]],
                   [[0, 2, 4, 6, 8], [1, 3, 5, 7, 9]]):
         _check_split(arr, [np.array(p) for p in parts])
+
+
+def test_split_equals_restrict_on_random_forests_few_and_many_parts():
+    # scs_host_split_* reads a part's nodes off per-part bit marks for up to eight parts and sorts
+    # event lists above that: both against the per-part restriction, bit for bit, on ragged forests
+    from spectralclustersupertree_amd import synthetic
+
+    rs = np.random.RandomState(0)
+    checked = 0
+    for case in range(250):
+        n = int(rs.randint(4, 80))
+        m = int(rs.randint(1, 30))
+        arrays = synthetic.tree_arrays(case, n, m, int(rs.randint(2, n + 1)))
+        k = int(rs.randint(1, 12))
+        perm = rs.permutation(n)
+        cuts = np.sort(rs.choice(np.arange(1, n), size=min(k - 1, n - 1), replace=False)) if k > 1 else np.array([], int)
+        groups = np.split(perm, cuts)
+        if rs.rand() < 0.3 and len(groups) > 1:
+            groups = groups[:-1]  # some taxa belong to no part
+        parts = [np.sort(g).astype(np.int32) for g in groups if len(g)]
+        for ids, child in zip(parts, arrays.split(parts)):
+            ref = arrays.restrict(ids)
+            assert child.n_trees == ref.n_trees and np.array_equal(child.node_off, ref.node_off), (case, len(parts))
+            assert np.array_equal(child.parent, ref.parent)
+            assert np.array_equal(np.where(child.taxon >= 0, ids[np.clip(child.taxon, 0, None)], -1), ref.taxon)
+            assert np.array_equal(child.length, ref.length, equal_nan=True)
+            assert np.array_equal(child.support, ref.support, equal_nan=True)
+            checked += 1
+    assert checked > 1000
