@@ -12,7 +12,9 @@ host.  The same pass on tables already resident in HBM is reported beside it as
 configs[2] (10 000 taxa / 500 trees / branch), the largest configuration
 BASELINE.json assigns to a single MI355X; N > 1 runs configs[3] (50 000 taxa /
 2 000 trees, row-partitioned W, RCCL all-gather of the Krylov block), one
-process per GPU as launched by ``torch.distributed.run`` -- a launcher only: the
+process per GPU -- launched by ``torch.distributed.run`` or, when ``--gpus N`` is given
+to a plain ``python bench.py``, by this script itself (``launch_ranks``: N fresh child
+processes before anything touches the GPU) -- launchers only: the
 host-side rendezvous (unique-id broadcast, barrier, max over ranks) is the
 package's own TCP star (hoststore.py), no torch import anywhere; every number
 is produced by libscs_hip.so through its C-ABI.
@@ -488,6 +490,68 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     return report
 
 
+def launch_ranks(n: int, cmd: list[str] | None = None) -> int:
+    """Start `n` copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT as torch.distributed.run would set them), wait for all of them,
+    print what rank 0 printed, and return non-zero if any rank failed.  The parent never touches
+    the GPU; a rank that fails takes the others down with it (their exact PIDs).  `cmd` replaces
+    the command line of a rank (tests)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:  # a free port; the host store binds MASTER_PORT + 1 ... + 16
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    port = min(port, 65535 - 32)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen(cmd or [sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    timeout_s = float(os.environ.get("SCS_BENCH_LAUNCH_TIMEOUT", "3000"))
+    deadline = time.monotonic() + timeout_s
+    rc = 0
+    live = set(range(n))
+    out0 = ""
+    import threading
+
+    def drain():  # rank 0's stdout is read while it runs (a full pipe would block it)
+        nonlocal out0
+        out0 = procs[0].stdout.read()
+
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+        if live and (rc != 0 or time.monotonic() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"bench.py: ranks {sorted(live)} still running after {timeout_s:.0f} s", file=sys.stderr)
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        elif live:
+            time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
 def main() -> int:
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -495,10 +559,10 @@ def main() -> int:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    if args.gpus > 1 and world == 1:
-        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run "
-              f"--nproc-per-node {args.gpus}", file=sys.stderr)
-        return 2
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher (it has made no
+        # HIP call and makes none) -- one fresh child per GPU, rank 0's JSON line relayed
+        return launch_ranks(args.gpus)
 
     from spectralclustersupertree_amd.partition import rendezvous
 
@@ -508,6 +572,12 @@ def main() -> int:
     dist, dev = rendezvous(rank, world, dev_index)
 
     name = args.workload or ("cfg2" if world == 1 else "cfg3")
+    # the box's own copy rate beside the nominal 8 TB/s (SURVEY.md 8d "Peak to quote")
+    try:
+        copy_gbs = dev.copy_bandwidth() if rank == 0 else None
+    except Exception as exc:  # noqa: BLE001 - a report field, never fatal
+        copy_gbs = None
+        print(f"bench.py: copy bandwidth not measured: {exc}", file=sys.stderr)
     main_rep = run_workload(name, args, dev, dist, rank, world, args.steps, args.warmup, full=True,
                             planted=args.planted)
 
@@ -542,6 +612,16 @@ def main() -> int:
                 "parity", "cpu_baseline"):
         if key in main_rep:
             result[key] = main_rep[key]
+    if copy_gbs:
+        # every HBM roofline of the line also against what this box's copy engine-free DtoD copy reaches
+        result["hbm_copy_measured_gbs"] = round(copy_gbs, 1)
+        for key in ("roofline", "roofline_other", "roofline_path"):
+            roof = result.get(key)
+            for part in (roof, (roof or {}).get("hbm")):
+                if isinstance(part, dict) and part.get("bound", "hbm") == "hbm" and part.get("unit") == "GB/s":
+                    scale = world if key == "roofline_path" else 1
+                    part["peak_measured"] = round(copy_gbs * scale, 1)
+                    part["frac_of_measured"] = round(part["achieved"] / (copy_gbs * scale), 4)
 
     if world == 1 and args.workload is None and not args.no_extra:
         # seeds 0, 1, 2 (median) and one planted input, lambda2 / lambda3 printed

@@ -304,6 +304,12 @@ int scs_debug_apply(scs_ctx *ctx, scs_graph *graph, const double *x, int32_t b, 
  * with an RCCL communicator (scs_ctx_create with world >= 1 and a unique id). */
 int scs_debug_comm_selftest(scs_ctx *ctx, int32_t count, const double *host_in, double *host_out);
 
+/* The box's own copy rate, to quote beside the nominal 8 TB/s (SURVEY.md 8d "Peak to quote"):
+ * `reps` device-to-device copies of `bytes` bytes on the context's stream, timed with HIP
+ * events after one untimed copy; *gbs_out = 2 * bytes * reps / time in GB/s (a copy reads
+ * and writes every byte once). */
+int scs_debug_copy_bandwidth(scs_ctx *ctx, int64_t bytes, int32_t reps, double *gbs_out);
+
 #ifdef __cplusplus
 }
 #endif

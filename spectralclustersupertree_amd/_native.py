@@ -131,6 +131,7 @@ SIGNATURES = {
     "scs_debug_gram": (C.c_int, [_P, _DP, _DP, _I32, _I32, _I32, _I32, _DP]),
     "scs_debug_apply": (C.c_int, [_P, _P, _DP, _I32, _DP]),
     "scs_debug_comm_selftest": (C.c_int, [_P, _I32, _DP, _DP]),
+    "scs_debug_copy_bandwidth": (C.c_int, [_P, C.c_int64, _I32, _DP]),
 }
 
 _lib = None

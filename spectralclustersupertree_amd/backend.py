@@ -131,6 +131,13 @@ class Device:
             C.byref(ticket)))
         return SmallTicket(self, ticket.value, n_groups, want_w)
 
+    def copy_bandwidth(self, nbytes: int = 1 << 30, reps: int = 6) -> float:
+        """Measured device-to-device copy rate of this GPU in GB/s (read + write bytes over
+        time; ``scs_debug_copy_bandwidth``) -- the figure to hold beside the nominal HBM peak."""
+        out = C.c_double(0.0)
+        nv.check(self._lib.scs_debug_copy_bandwidth(self._ctx, int(nbytes), int(reps), C.byref(out)))
+        return float(out.value)
+
     # -- building blocks exposed for the parity tests -----------------------
     def comm_selftest(self, x: np.ndarray) -> np.ndarray:
         """One grouped ncclSend/ncclRecv round to this rank itself plus an ncclAllGather,
@@ -244,13 +251,16 @@ class DeviceTables:
             flags |= nv.BUILD_SHARED
         nv.check(self.dev._lib.scs_pcg_build(self.dev._ctx, self._h, row_begin, row_end, flags,
                                              C.byref(handle), C.byref(stats)))
-        return DeviceGraph(self.dev, handle, stats.as_dict())
+        graph = DeviceGraph(self.dev, handle, stats.as_dict())
+        graph.upper = bool(upper)
+        return graph
 
 
 class DeviceGraph:
     def __init__(self, dev: Device, handle, build_stats: dict | None = None) -> None:
         self.dev, self._h = dev, handle
         self.build_stats = build_stats or {}
+        self.upper = False  # an upper-triangle job (SCS_BUILD_UPPER): block widths 4 and 8 only
 
     def free(self) -> None:
         if self._h:

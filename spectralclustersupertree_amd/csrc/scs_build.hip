@@ -77,7 +77,11 @@ __global__ void k_positions_values(const int64_t *__restrict__ tree_off,
     const int n = (int)(tree_off[t + 1] - off);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    pos[(int64_t)tl * npad + leaf_taxon[off + p]] = p;
+    // (ids of table chunks that arrive behind the first tree batch are range-checked on the copy
+    // stream and the verdict is read at the end of the build: an id nobody has vouched for yet
+    // must not leave the tree's row of `pos` -- npad >= n_taxa)
+    const unsigned tx = (unsigned)leaf_taxon[off + p];
+    if (tx < (unsigned)npad) pos[(int64_t)tl * npad + tx] = p;
     if (p < n - 1)  // one rounded multiply, as the reference's `length * tree_weight`
         stv[st_off[tl] + p] = adj_depth[off + p] ? adj_val[off + p] * tree_w[t] : 0.0;
 }
@@ -539,6 +543,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_REQUIRE((flags & ~(SCS_BUILD_MONOTONE | SCS_BUILD_SHARED | SCS_BUILD_UPPER | SCS_BUILD_SCATTER)) == 0,
                 "scs_pcg_build: unknown flag bits 0x%x", flags);
     const bool scatter = (flags & SCS_BUILD_SCATTER) != 0;
+    // (the comparison variant indexes W by taxon ids straight from the tables: every chunk has to
+    // have arrived and passed its range check first)
+    if (scatter && tb) SCS_TRY(scs_tables_finish(ctx, tb));
     if (scatter) {
         if (!(flags & SCS_BUILD_MONOTONE) || (flags & (SCS_BUILD_SHARED | SCS_BUILD_UPPER)) ||
             row_begin != 0 || row_end != tb->n_taxa || ctx->comm.world != 1) {

@@ -351,6 +351,42 @@ extern "C" int scs_debug_comm_selftest(scs_ctx *ctx, int32_t count, const double
     return SCS_OK;
 }
 
+// the measured copy rate of this device (bench.py prints it beside the nominal HBM peak)
+extern "C" int scs_debug_copy_bandwidth(scs_ctx *ctx, int64_t bytes, int32_t reps, double *gbs_out) {
+    SCS_REQUIRE(ctx && gbs_out && bytes >= 4096 && reps >= 1, "scs_debug_copy_bandwidth: bad argument");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    void *a = nullptr, *b = nullptr;
+    SCS_TRY(scs_block_alloc(ctx, (size_t)bytes, &a));
+    const int rc_b = scs_block_alloc(ctx, (size_t)bytes, &b);
+    if (rc_b != SCS_OK) {
+        scs_block_release(ctx, a);
+        return rc_b;
+    }
+    hipStream_t s = ctx->stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipMemsetAsync(a, 0x5A, (size_t)bytes, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(b, a, (size_t)bytes, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipEventRecord(e0, s);
+    for (int32_t r = 0; r < reps && e == hipSuccess; ++r)
+        e = hipMemcpyAsync((r & 1) ? b : a, (r & 1) ? a : b, (size_t)bytes, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipEventRecord(e1, s);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    scs_block_release(ctx, a);
+    scs_block_release(ctx, b);
+    if (e != hipSuccess) {
+        scs_set_error("scs_debug_copy_bandwidth: %s", hipGetErrorString(e));
+        return SCS_EHIP;
+    }
+    *gbs_out = ms > 0.f ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+    return SCS_OK;
+}
+
 int scs_comm_destroy(scs_comm *comm) {
     if (comm->kind == 1 && comm->rccl_comm) {
         g_rccl.destroy(comm->rccl_comm);

@@ -78,7 +78,9 @@ __global__ void k_positions_pairs(const int64_t *__restrict__ tree_off,
     const int n = (int)(tree_off[t + 1] - off);
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    pos[(int64_t)tl * npad + leaf_taxon[off + p]] = p;
+    // (an id of a late table chunk may not have been range-checked yet: see k_positions_values)
+    const unsigned tx = (unsigned)leaf_taxon[off + p];
+    if (tx < (unsigned)npad) pos[(int64_t)tl * npad + tx] = p;
     if (p < n - 1) {
         gap_entry e;
         e.d = (u32)adj_depth[off + p];

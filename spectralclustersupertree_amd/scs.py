@@ -26,6 +26,7 @@ HIP device this function raises.
 
 from __future__ import annotations
 
+import os
 import threading
 from collections.abc import Sequence
 
@@ -157,8 +158,10 @@ def _fiedler_checked(graph, v0, tol, max_iter, block):
         return graph.fiedler(v0, tol=tol, max_iter=max_iter, block=block)
     except ConvergenceError as first:
         try:
-            # (the library clamps the width to what V supports: 3 b + 1 <= V)
-            return graph.fiedler(v0, tol=tol, max_iter=4 * max_iter, block=16)
+            # (the library clamps the width to what V supports: 3 b + 1 <= V; an upper-triangle
+            # job's symmetric SYMM comes in widths 4 and 8 -- ask for what the job has)
+            widest = 8 if getattr(graph, "upper", False) else 16
+            return graph.fiedler(v0, tol=tol, max_iter=4 * max_iter, block=widest)
         except ConvergenceError as second:
             best = min((first, second), key=lambda e: max(e.stats["resid"]))
             resid = max(best.stats["resid"])
@@ -232,9 +235,10 @@ def spectral_bipartition_device(
         from spectralclustersupertree_amd.partition import row_splits, row_splits_upper
 
         try:
-            if group_start is None:
+            if group_start is None and os.environ.get("SCS_MULTI_MODE", "upper") != "shared":
                 # nothing contracts: the job keeps only the upper triangle of the symmetric
                 # matrix -- no tile exchange, half the bytes per operator application
+                # (SCS_MULTI_MODE=shared keeps whole rows on every rank, as for nodes that contract)
                 splits = row_splits_upper(n, team.world)
                 upper = True
             else:

@@ -229,3 +229,61 @@ def test_bipartition_through_a_team_takes_the_upper_triangle_when_nothing_contra
         assert [m.tolist() for m in members] == [m.tolist() for m in want_members]
         assert np.array_equal(labels, want_labels)
         assert draw == out[0][3]
+
+
+def test_upper_triangle_job_equals_the_row_partitioned_job(monkeypatch):
+    """The two multi-rank layouts against each other (two in-process ranks, nothing contracts):
+    the stored cells of the upper-triangle job are the row-partitioned job's, bit for bit, the
+    embeddings agree within the Fiedler tolerance and both give the single-device labels;
+    SCS_MULTI_MODE=shared is the switch back to whole rows."""
+    from spectralclustersupertree_amd.partition import row_splits_upper
+
+    n = 1500
+    tables = synthetic.make_tables(77, n, 24, "branch", random_weights=True)
+    v0 = np.random.RandomState(0).uniform(-1, 1, n)
+    sp_rows, sp_upper = row_splits(n, 2), row_splits_upper(n, 2)
+    teams = LocalTeams(2, shard_min=100)
+
+    def rank_work(team):
+        dtab = team.device.upload(tables)
+        got = {}
+        for mode, splits in (("shared", sp_rows), ("upper", sp_upper)):
+            g = dtab.build(splits[team.rank], splits[team.rank + 1], shared=(mode == "shared"),
+                           upper=(mode == "upper"))
+            maps, stats = g.fiedler(v0)
+            got[mode] = (g.download(), maps, stats, splits[team.rank])
+            g.free()
+        dtab.free()
+        return got
+
+    def rank_bipartition(team):
+        rep = {}
+        _, labels = spectral_bipartition_device(tables, np.random.RandomState(5), contract_edges=True,
+                                                team=team, report=rep)
+        return labels, rep
+
+    try:
+        out_got = teams.run(rank_work)
+        by_mode = {}
+        for mode in ("upper", "shared"):
+            monkeypatch.setenv("SCS_MULTI_MODE", mode)
+            by_mode[mode] = teams.run(rank_bipartition)
+    finally:
+        teams.close()
+    out = [(out_got[r], {mode: by_mode[mode][r] for mode in by_mode}) for r in range(2)]
+    with Device(0) as dev:
+        _, want_labels = spectral_bipartition_device(tables, np.random.RandomState(5), contract_edges=True,
+                                                     device=dev)
+    for got, reports in out:
+        w_s, maps_s, stats_s, lo_s = got["shared"]
+        w_u, maps_u, stats_u, lo_u = got["upper"]
+        assert stats_s["converged"] == 1 and stats_u["converged"] == 1
+        # rows both layouts store on this rank
+        for i in range(max(lo_s, lo_u), min(lo_s + w_s.shape[0], lo_u + w_u.shape[0])):
+            c0 = i // 256 * 256
+            assert np.array_equal(w_u[i - lo_u, c0:], w_s[i - lo_s, c0:])
+        assert np.max(np.abs(maps_u - maps_s)) <= 1e-10
+        assert reports["upper"][1]["upper"] and not reports["shared"][1]["upper"]
+        for mode in ("upper", "shared"):
+            assert reports[mode][1]["sharded"]
+            assert np.array_equal(reports[mode][0], want_labels)

@@ -8,9 +8,11 @@ of S @ X; concatenating the gathered slices in rank order must equal the full
 product).  The arithmetic here is the oracle's numpy restatement -- the device
 kernels themselves are covered by the -m gpu tests."""
 
+import json
 import os
 import socket
 import sys
+import time
 from pathlib import Path
 
 import numpy as np
@@ -297,6 +299,40 @@ def test_bench_two_rank_control_flow(tmp_path):
     port = _free_port()
     mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "bench_ok0").exists() and (tmp_path / "bench_ok1").exists()
+
+
+def test_bench_launches_its_own_ranks(tmp_path, capsys, monkeypatch):
+    """`python bench.py --gpus N` without a launcher: bench.launch_ranks starts N fresh processes
+    with the launcher's environment, relays rank 0's line and fails if any rank fails (the
+    ranks here are a stand-in script: no GPU in this container; what a rank does with that
+    environment is test_bench_two_rank_control_flow)."""
+    import bench
+
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import json, os, sys, time\n"
+        "r, w = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == str(r) and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "assert 1024 < int(os.environ['MASTER_PORT']) < 65536 - 16\n"
+        "open(os.path.join(sys.argv[1], f'seen{r}'), 'w').write(os.environ['MASTER_PORT'])\n"
+        "if sys.argv[2] == 'fail' and r == 1: sys.exit(7)\n"
+        "if sys.argv[2] == 'fail': time.sleep(60)\n"
+        "print(json.dumps({'rank': r, 'n_gpus': w}))\n")
+    rc = bench.launch_ranks(3, [sys.executable, str(script), str(tmp_path), "ok"])
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and out == [json.dumps({"rank": 0, "n_gpus": 3})]
+    ports = {(tmp_path / f"seen{r}").read_text() for r in range(3)}
+    assert len(ports) == 1
+    # a failing rank: its code comes back, the ranks still waiting are stopped
+    t0 = time.perf_counter()
+    rc = bench.launch_ranks(2, [sys.executable, str(script), str(tmp_path), "fail"])
+    assert rc == 7 and time.perf_counter() - t0 < 30
+    # main() takes that road when no launcher set WORLD_SIZE
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    called = {}
+    monkeypatch.setattr(bench, "launch_ranks", lambda n, cmd=None: called.setdefault("n", n) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "1"])
+    assert bench.main() == 0 and called["n"] == 4
 
 
 def test_subtrees_travel_in_flat_form_at_the_default_recursion_limit():
