@@ -112,6 +112,7 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 }
 
 #include "scs_mono.h"  // monotone fast path: k_block_records_mono, k_accumulate_mono
+#include "scs_mono_wide.h"  // the same walk for three column tiles of a row block per workgroup
 #include "scs_gen.h"   // general path on the same tile structure: k_block_records_gen, k_accumulate_gen
 
 // ---------------------------------------------------------------------------
@@ -568,7 +569,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     const int cols_per_tile = MONO_TCW;
     static_assert(MONO_TCW == SCS_TCW, "one tile width for all kernels");
     const size_t entry_bytes = monotone ? 8 : sizeof(gap_entry);
-    const size_t rec_bytes = monotone ? R3_BYTES : G3_BYTES;
+    size_t rec_bytes = monotone ? R3_BYTES : G3_BYTES;
     const int n_cgroups = (n + cols_per_tile - 1) / cols_per_tile;
     // (the last column group may reach past n: its threads read "absent" positions)
     const int64_t npad = scs_round_up((int64_t)n_cgroups * cols_per_tile, SCS_NPAD);
@@ -680,6 +681,39 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                  hipMemcpyHostToDevice, s));
 
+    // ---- wide workgroups (scs_mono_wide.h): up to three tiles of ONE row block per workgroup,
+    // the row block's table expanded once for all of them.  Worth it once the groups fill the
+    // chip (one twelve-wave workgroup per CU); a handful of tiles -- a node of the deep recursion
+    // -- keeps one workgroup per tile.  SCS_WIDE=0 / 1 force either kernel (A/B runs).
+    constexpr int WIDE_NG = 3;
+    bool wide = monotone && !scatter && tiles.size() >= 3 * 256;
+    if (const char *e = getenv("SCS_WIDE")) wide = monotone && !scatter && atoi(e) != 0 && !tiles.empty();
+    std::vector<int4> groups;
+    dev_buf d_groups;
+    if (wide) {
+        rec_bytes = wide_layout<WIDE_NG>::BYTES;
+        // the tiles of a row block in list order, three at a time; XCD x is handed the groups of
+        // the row blocks b = x (mod 8), one row block after the other (as the tile order above)
+        std::vector<std::vector<int>> of_block((size_t)n_blocks);
+        for (size_t i = 0; i < tiles.size(); ++i) of_block[(size_t)tiles[i].x].push_back((int)i);
+        std::vector<int4> per[8];
+        for (int b = 0; b < n_blocks; ++b) {
+            const std::vector<int> &v = of_block[(size_t)b];
+            for (size_t k = 0; k < v.size(); k += WIDE_NG)
+                per[b & 7].push_back(make_int4(v[k], k + 1 < v.size() ? v[k + 1] : -1,
+                                               k + 2 < v.size() ? v[k + 2] : -1, 0));
+        }
+        size_t total = 0, at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (auto &v : per) total += v.size();
+        groups.reserve(total);
+        while (groups.size() < total)
+            for (int x = 0; x < 8; ++x)
+                if (at[x] < per[x].size()) groups.push_back(per[x][at[x]++]);
+        SCS_TRY(d_groups.alloc(groups.size() * sizeof(int4)));
+        SCS_HIP_CHECK(hipMemcpyAsync(d_groups.p, groups.data(), groups.size() * sizeof(int4),
+                                     hipMemcpyHostToDevice, s));
+    }
+
     auto table_entries = [](int64_t m) -> int64_t { return (int64_t)levels_for(m) * m; };
 
     // ---- batch plan: bound range-minimum tables + records + positions by the workspace
@@ -782,7 +816,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 k_sparse_level<double><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
                                                               (const int64_t *)d_stoff.p,
                                                               (double *)d_st.p);
-            if (!scatter)
+            if (wide)
+                k_block_records_wide<WIDE_NG><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
+                    tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
+                    (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
+            else if (!scatter)
             k_block_records_mono<<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
                 tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
                 (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
@@ -826,7 +864,40 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
             mp.stamps = nullptr;
             static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
-            if (nt && stamp) {
+            if (wide) {
+                using WL = wide_layout<WIDE_NG>;
+                wide_params wp;
+                wp.m = mp;
+                wp.groups = (const int4 *)d_groups.p;
+                const unsigned ng = (unsigned)groups.size();
+                const void *fn = stamp ? (sym ? (const void *)k_accumulate_wide<WIDE_NG, true, true>
+                                              : (const void *)k_accumulate_wide<WIDE_NG, false, true>)
+                                       : (sym ? (const void *)k_accumulate_wide<WIDE_NG, true, false>
+                                              : (const void *)k_accumulate_wide<WIDE_NG, false, false>);
+                // (more dynamic LDS than the default 64 KiB: per function and device, set every time)
+                SCS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)WL::LDS_BYTES));
+                dev_buf d_st8;
+                if (stamp) {
+                    SCS_TRY(d_st8.alloc(64));
+                    SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
+                    wp.m.stamps = (unsigned long long *)d_st8.p;
+                }
+                void *args[] = {&wp};
+                SCS_HIP_CHECK(hipLaunchKernel(fn, dim3(ng), dim3(WIDE_NG * MONO_TCW), args, WL::LDS_BYTES, s));
+                if (stamp) {
+                    unsigned long long h[8];
+                    SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
+                    SCS_HIP_CHECK(hipStreamSynchronize(s));
+                    const char *nm[7] = {"combine", "search + issue", "expand (next tree)", "record DMA issue",
+                                         "cells", "wait loads+record", "barrier"};
+                    double tot = 0;
+                    for (int i = 0; i < 7; ++i) tot += (double)h[i];
+                    for (int i = 0; i < 7; ++i)
+                        fprintf(stderr, "[stamp wide] %-24s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i],
+                                100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
+                }
+            } else if (nt && stamp) {
                 dev_buf d_st8;
                 SCS_TRY(d_st8.alloc(64));
                 SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));

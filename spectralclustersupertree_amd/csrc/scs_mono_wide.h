@@ -1,0 +1,374 @@
+// Wide variant of the monotone tile kernel (included by scs_build.hip after scs_mono.h).
+//
+// Round 4.  profiles/r03_accumulate_phase_stamps.txt and the LDS cycle count of DESIGN.md 3.1:
+// of the ~1 900 LDS cycles a (64 x 256 tile, tree) step costs, 768 are the stores that expand
+// the tile's 64 x 64 row-row table -- and every one of the 40 (10 000 taxa) to 196 (50 000)
+// column tiles of a row block expands the SAME table again.  Here ONE workgroup of 4 NG waves
+// walks the trees for NG column tiles of one row block at once (NG = 3: 64 rows x 768 columns,
+// twelve waves = the three waves per SIMD the 128 accumulator registers allow): the record is
+// staged once, the table expanded once -- 64 / (4 NG) steps per wave -- and used by NG x 256
+// columns.  Round 2's first attempt at wider tiles kept the two barriers and the single table
+// buffer of the 4-wave kernel and lost (+22 % at 768 columns: with one workgroup per CU nothing
+// runs while its waves wait); this kernel has TWO table buffers and ONE barrier per tree: the
+// table of tree t + 1 is expanded into the other buffer before the cells of tree t are read, so
+// a wave meets the others once per tree, after its cell loop.
+//
+// The cells, the column step (one range-minimum query per column, issued one tree ahead) and
+// the arithmetic are those of k_accumulate_mono (scs_mono.h): same addends, same order, same
+// bits (reference: src/sc_supertree/scs.py:644-658).  The external tile geometry (64 x 256,
+// tile lists, packed tiles of the shared multi-rank build, mirror image) is unchanged: a
+// workgroup is handed up to NG tiles of one row block (`groups`).
+#pragma once
+
+template <int NG>
+struct wide_layout {
+    static constexpr int NSEG = 4 * NG;  // expansion segments = waves
+    static constexpr int SPOS = 0;       // int32[64]  sorted DFS positions (INT_MAX beyond cnt)
+    static constexpr int G = 256;        // f64[64]    value of LCA(sorted k, sorted k+1); 0 beyond cnt-1
+    static constexpr int SEED = 768;     // f64[NSEG-1][64] seed[w-1][a] = min g[a .. seg(w)-1] for a < seg(w)
+    static constexpr int ARGPOS = SEED + (NSEG - 1) * 512;  // int32[64]
+    static constexpr int SORIG = ARGPOS + 256;              // u8[64]
+    static constexpr int RANK = SORIG + 64;                 // u8[64]
+    static constexpr int PIV = RANK + 64;                   // int32[8]
+    static constexpr int CNT = PIV + 32;                    // int32
+    static constexpr int M = CNT + 4;                       // int32
+    static constexpr int STOFF = M + 4;                     // int64
+    static constexpr int BYTES = (STOFF + 8 + 15) / 16 * 16;
+    static constexpr int PIECES = (BYTES + 1023) / 1024;    // 1 KiB LDS-DMA pieces, one per wave
+    __host__ __device__ static constexpr int seg(int w) { return 64 * w / NSEG; }
+    static constexpr int MAXSEG = (64 + NSEG - 1) / NSEG;
+    static constexpr size_t LDS_BYTES = 2 * (size_t)DT_DOUBLES * 8 + 2 * (size_t)BYTES;
+    static_assert(STOFF % 8 == 0 && PIECES <= NSEG, "record layout");
+    static_assert((size_t)NG * MONO_TCW * 9 * 8 <= LDS_BYTES, "mirror staging fits the table space");
+};
+
+// one wave per (local row block, tree): grid (n_blocks, trees in batch), 64 threads.  As
+// k_block_records_mono with the seeds of 4 NG expansion segments.
+template <int NG>
+__global__ __launch_bounds__(64) void k_block_records_wide(
+    const int64_t *__restrict__ tree_off, int t0, int n_batch, const int32_t *__restrict__ pos,
+    int64_t npad, const int64_t *__restrict__ st_off, const double *__restrict__ stv,
+    int row_begin, int row_end, unsigned char *__restrict__ rec_all) {
+    using L = wide_layout<NG>;
+    const int blk = blockIdx.x;
+    const int tl = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
+    const int row = row_begin + blk * SCS_TR + lane;
+    int p = -1;
+    if (row < row_end) p = pos[(int64_t)tl * npad + row];
+    const u32 pk = p < 0 ? 0x7FFFFFFFu : (u32)p;
+    u64 key = ((u64)pk << 32) | (u32)lane;
+    for (int k = 2; k <= 64; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const u64 other = __shfl_xor(key, j, 64);
+            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);
+            const u64 lo = key < other ? key : other;
+            const u64 hi = key < other ? other : key;
+            key = take_min ? lo : hi;
+        }
+    }
+    const int spos = (int)(key >> 32);
+    const int orig = (int)(key & 63);
+    const bool present = spos != 0x7FFFFFFF;
+    const int cnt = __popcll(__ballot(present));
+    const int next_pos = __shfl_down(spos, 1, 64);
+    const double *st = stv + st_off[tl];
+    double g = 0.0;
+    int argpos = 0;
+    if (lane < cnt - 1) {
+        g = rmq_min<double>(st, m, spos, next_pos);
+        int lo = spos, hi = next_pos;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rmq_min<double>(st, m, lo, mid) == g) hi = mid;
+            else lo = mid;
+        }
+        argpos = lo;
+    }
+    unsigned char *rec = rec_all + ((int64_t)blk * n_batch + tl) * L::BYTES;
+    ((int *)(rec + L::SPOS))[lane] = spos;
+    ((double *)(rec + L::G))[lane] = g;
+    ((int *)(rec + L::ARGPOS))[lane] = argpos;
+    if ((lane & 7) == 7) ((int *)(rec + L::PIV))[lane >> 3] = spos;
+    rec[L::SORIG + lane] = (unsigned char)orig;
+    rec[L::RANK + orig] = (unsigned char)lane;
+    if (lane == 0) {
+        *(int *)(rec + L::CNT) = cnt;
+        *(int *)(rec + L::M) = m;
+        *(int64_t *)(rec + L::STOFF) = st_off[tl];
+    }
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double *seed = (double *)(rec + L::SEED);
+#pragma unroll
+    for (int w = 1; w < L::NSEG; ++w) {
+        const int end = L::seg(w);
+        double mine = lane < end ? g : inf;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double other = __shfl_down(mine, off, 64);
+            if (lane + off < end) mine = min_f64(mine, other);
+        }
+        seed[(w - 1) * 64 + lane] = mine;
+    }
+}
+
+struct wide_params {
+    mono_params m;
+    const int4 *groups;  // x, y, z: indices into m.tiles of up to three tiles of ONE row block (-1: none)
+};
+
+template <bool SYM>
+__device__ __forceinline__ void tile_store_wide(const mono_params &p, double (&acc)[SCS_TR],
+                                                const int2 tile, const bool active, const int slot,
+                                                const int row0, const int col, const int self,
+                                                const int ltid, const int lane, const int wl,
+                                                double *t) {
+    if (self >= 0) {
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i)
+            if (i == self) acc[i] = 0.0;
+    }
+    if (p.tile_out) {
+        if (active) {
+            double *tp = p.tile_out + (int64_t)slot * SCS_TR * MONO_TCW + ltid;
+#pragma unroll
+            for (int i = 0; i < SCS_TR; ++i) tp[i * MONO_TCW] = acc[i];
+        }
+        return;
+    }
+    if (active && col < p.n) {
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) {
+            const int r = row0 + i;
+            if (r < p.row_end) p.w[(int64_t)(r - p.row_begin) * p.ld + col] = acc[i];
+        }
+    }
+    if (SYM && p.mirror) {
+        // mirror image through LDS, eight rows at a time (tile_store of scs_mono.h); every wave of
+        // the workgroup joins the barriers, a sub-tile works in its own staging region `t`
+        const bool wave_mirrors =
+            active && ((row0 / MONO_TCW) + 1) * MONO_TCW <= ((tile.y * MONO_TCW + wl * 64) / SCS_TR) * SCS_TR;
+#pragma unroll
+        for (int q = 0; q < SCS_TR / 8; ++q) {
+            SCS_BARE_BARRIER();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[ltid * 9 + j] = acc[q * 8 + j];
+            SCS_BARE_BARRIER();
+            if (wave_mirrors) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int cl = wl * 64 + it * 8 + (lane >> 3);
+                    const int c = tile.y * MONO_TCW + cl;
+                    const int r = row0 + q * 8 + (lane & 7);
+                    if (c < p.n && r < p.row_end) p.w[(int64_t)c * p.ld + r] = t[cl * 9 + (lane & 7)];
+                }
+            }
+        }
+    }
+}
+
+template <int NG, bool SYM, bool STAMPED>
+__global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_wide(wide_params wp) {
+    using L = wide_layout<NG>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    double *const s_t = (double *)s_mem;                                // [2][DT_DOUBLES]
+    unsigned char *const s_rec = s_mem + 2 * (size_t)DT_DOUBLES * 8;  // [2][L::BYTES]
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const mono_params &p = wp.m;
+
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if (STAMPED) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            ts[k] += tnow - tprev;
+            tprev = tnow;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ltid = tid & (MONO_TCW - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wave >> 2, wl = wave & 3;
+    const int4 grp = wp.groups[blockIdx.x];
+    const int ti = sub == 0 ? grp.x : (sub == 1 ? grp.y : grp.z);
+    const bool active = ti >= 0;
+    // (a missing sub-tile takes the first tile's geometry: its waves expand their share of the
+    // table and join the barriers, nothing else)
+    const int2 tile = p.tiles[active ? ti : grp.x];
+    const int blk = tile.x;
+    const int row0 = p.row_begin + blk * SCS_TR;
+    const int col = tile.y * MONO_TCW + ltid;
+    const int nt = p.n_batch;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
+
+    double acc[SCS_TR];
+#pragma unroll
+    for (int i = 0; i < SCS_TR; ++i) {
+        double v = 0.0;
+        if (active && p.load_w && p.tile_out)
+            v = p.tile_out[((int64_t)ti * SCS_TR + i) * MONO_TCW + ltid];
+        else if (active && p.load_w && col < p.n && row0 + i < p.row_end)
+            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
+        acc[i] = v;
+    }
+
+    const unsigned char *rec_base = p.rec + (int64_t)blk * nt * L::BYTES;
+    const __amdgpu_buffer_rsrc_t r_rec =
+        __builtin_amdgcn_make_buffer_rsrc((void *)rec_base, 0, nt * L::BYTES, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_pos =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.pos, 0, (int)(nt * p.npad * 4), 0x00020000);
+    const int lane16 = lane * 16;
+    const int col4 = col * 4;
+    // record of tree t lives in s_rec[t & 1]; wave w < PIECES copies its 1 KiB piece
+    auto issue_record = [&](int tl) {
+        if (wave < L::PIECES) {
+            const int left = (L::BYTES - wave * 1024) / 16;
+            if (lane < left)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    r_rec, (lds_ptr)(s_rec + (tl & 1) * L::BYTES + wave * 1024), 16, lane16,
+                    tl * L::BYTES + wave * 1024, 0, 0);
+        }
+    };
+
+    double qx = 0.0, qy = 0.0;
+    int cstate = 0;  // bits 0-7: row nb; bit 8: a neighbour exists; bit 9: self
+    int cpos_next = -1;
+
+    // the column step of scs_mono.h (k_accumulate_mono::column_issue), on the record of tree tl
+    auto column_issue = [&](int tl, int cpos) {
+        const unsigned char *rb = s_rec + (tl & 1) * L::BYTES;
+        const int *s_spos = (const int *)(rb + L::SPOS);
+        const int *s_arg = (const int *)(rb + L::ARGPOS);
+        const unsigned char *s_sorig = rb + L::SORIG;
+        const int *s_piv = (const int *)(rb + L::PIV);
+        const int cnt = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::CNT));
+        const bool present = cpos >= 0 && cnt > 0;
+        int lo;
+        {
+            const int4 pa = *(const int4 *)&s_piv[0];
+            const int4 pb = *(const int4 *)&s_piv[4];
+            lo = ((pa.x < cpos) + (pa.y < cpos) + (pa.z < cpos) + (pa.w < cpos) + (pb.x < cpos) +
+                  (pb.y < cpos) + (pb.z < cpos) + (pb.w < cpos)) * 8;
+            // (the octet's eight positions in two independent 16-byte reads: one LDS round trip
+            // where a binary descent makes three -- with one workgroup per CU the waves search at
+            // about the same time and nothing else hides the latency; its last position is the
+            // pivot itself, not below cpos unless lo == 64)
+            const int base = min(lo, 56);
+            const int4 qa = *(const int4 *)&s_spos[base];
+            const int4 qb = *(const int4 *)&s_spos[base + 4];
+            const int l2 = base + (qa.x < cpos) + (qa.y < cpos) + (qa.z < cpos) + (qa.w < cpos) +
+                           (qb.x < cpos) + (qb.y < cpos) + (qb.z < cpos);
+            lo = lo == 64 ? 64 : l2;
+        }
+        const bool hasl = present && self < 0 && lo > 0;
+        const bool hasr = present && self < 0 && lo < cnt;
+        const int il = max(lo - 1, 0), ir = min(lo, 63);
+        const bool left = hasl && (!hasr || s_arg[il] >= cpos);
+        const int q_anchor = s_spos[left ? il : ir];
+        const int nbrow = s_sorig[left ? il : ir];
+        cstate = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && self >= 0) ? 512 : 0);
+        const int m = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::M));
+        const unsigned so_lo = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF));
+        const unsigned so_hi = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF + 4));
+        const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
+        const bool any = hasl || hasr;
+        int o[2];
+        rmq_offsets(m, any ? (left ? q_anchor : cpos) : 0, any ? (left ? cpos : q_anchor) : 1, o);
+        qx = *(const double *)(st + (unsigned)o[0] * 8u);
+        qy = *(const double *)(st + (unsigned)o[1] * 8u);
+        cpos_next = __builtin_amdgcn_raw_buffer_load_b32(
+            r_pos, col4, min(tl + 1, nt - 1) * (int)p.npad * 4, 0);
+    };
+
+    // expansion of tree tl's row-row table into s_t[tl & 1] (k_accumulate_mono::expand); wave w
+    // walks the steps b in [seg(w), seg(w + 1))
+    auto expand = [&](int tl) {
+        const unsigned char *rb = s_rec + (tl & 1) * L::BYTES;
+        double *dv = s_t + (tl & 1) * DT_DOUBLES;
+        const int b0 = L::seg(wave), b1 = L::seg(wave + 1);
+        const double g_rank = ((const double *)(rb + L::G))[lane];
+        const int so_rank = rb[L::SORIG + lane];
+        const int rho = rb[L::RANK + lane];
+        double cur = inf;
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        double *row_a = &dv[lane * DV_LD];
+        double *col_a = &dv[lane];
+#pragma unroll
+        for (int j = 0; j < L::MAXSEG; ++j) {
+            const int b = b0 + j;
+            if (b >= b1) break;
+            const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_rank), b);
+            const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_rank), b);
+            const int so_b = __builtin_amdgcn_readlane(so_rank, b);
+            const double gb = __hiloint2double(hi32, lo32);
+            if (rho <= b) {
+                row_a[so_b] = cur;
+                col_a[so_b * DV_LD] = cur;
+                cur = min_f64(cur, gb);
+            }
+        }
+    };
+
+    // ---- prologue: records 0 and 1, the column's position in tree 0, tree 0's column step and table
+    issue_record(0);
+    if (nt > 1) issue_record(1);
+    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) column_issue(0, cpos_next);
+    expand(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SCS_BARE_BARRIER();
+    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+
+    // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
+    // s_t[tl & 1], the record of tree tl + 1 in s_rec[(tl + 1) & 1], this wave's range-minimum
+    // loads for tree tl have landed; s_rec[tl & 1] and s_t[(tl + 1) & 1] are free.
+    for (int tl = 0; tl < nt; ++tl) {
+        int nb = 0;
+        double vn = 0.0;
+        if (cstate & 256) {
+            vn = min_f64(qx, qy);
+            nb = cstate & 255;
+        } else if (cstate & 512) {
+            nb = self;
+            vn = inf;
+        }
+        stamp(0);
+        if (tl + 1 < nt) {
+            if (active) column_issue(tl + 1, cpos_next);  // loads stay in flight until the next step
+            stamp(1);
+            expand(tl + 1);
+            stamp(2);
+        }
+        // (the step's one LDS-DMA is issued after the last LDS access the compiler sees: it would
+        // drain vmcnt in front of every later one -- scs_mono.h)
+        if (tl + 2 < nt) issue_record(tl + 2);
+        stamp(3);
+        if (active) {
+            double tmp[SCS_CELLS_DEPTH];
+            const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_t[(
+                tl & 1) * DT_DOUBLES + nb * DV_LD];
+            SCS_CELLS_ASM(acc, tmp, addr, vn);
+        }
+        stamp(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);
+        SCS_BARE_BARRIER();
+        stamp(6);
+    }
+
+    if (STAMPED && lane == 0 && p.stamps) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
+        atomicAdd(&p.stamps[7], 1ull);
+    }
+    tile_store_wide<SYM>(p, acc, tile, active, ti, row0, col, self, ltid, lane, wl,
+                         (double *)s_mem + (size_t)sub * MONO_TCW * 9);
+}

@@ -552,6 +552,78 @@ def test_shared_build_multi_batch(dev, monkeypatch):
     assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
 
 
+# ---------------------------------------------------------------------------
+# the wide tile kernel (scs_mono_wide.h): three column tiles of a row block per workgroup.
+# It is chosen by itself once the groups fill the chip (the configs[2]-size tests and the
+# bench run it); SCS_WIDE=1 puts the small shapes through it.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("strategy", ["one", "depth", "branch"])
+@pytest.mark.parametrize(("n", "m", "k"), [(37, 6, 20), (300, 12, 300), (700, 7, 512), (1100, 9, 900),
+                                           (1537, 5, 1537), (330, 300, 200)])
+def test_wide_kernel_bit_exact(dev, monkeypatch, strategy, n, m, k):
+    # one, two, three (a full group), five and seven column tiles per row block: full and
+    # partial groups, ragged last tile, taxa missing from trees, a single tree batch of 300 trees
+    monkeypatch.setenv("SCS_WIDE", "1")
+    tables = synthetic.make_tables(200 + n, n, m, strategy, leaves_per_tree=k, random_weights=(n % 2 == 0))
+    assert tables.monotone
+    _build_and_compare(dev, tables)
+
+
+def test_wide_kernel_row_blocks_and_batches(dev, monkeypatch):
+    # the non-symmetric schedule of row-partitioned ranks (no mirror image, every column tile of
+    # a row block), and several tree batches through a tiny workspace (the sums travel through W)
+    monkeypatch.setenv("SCS_WIDE", "1")
+    tables = synthetic.make_tables(6, 1000, 10, "branch", leaves_per_tree=800, random_weights=True)
+    _build_and_compare(dev, tables, [(0, 100), (100, 1000), (64, 65), (7, 601)])
+    monkeypatch.setenv("SCS_WS_LIMIT_MB", "1")
+    small = Device(0)
+    try:
+        tables = synthetic.make_tables(9, 900, 40, "branch", leaves_per_tree=700)
+        dtab = small.upload(tables)
+        g = dtab.build()
+        assert g.build_stats["n_batches"] > 1
+        w = g.download()
+        g.free()
+        dtab.free()
+    finally:
+        small.close()
+    w_ref, _ = to.pcg_dense(tables)
+    assert np.array_equal(w, w_ref)
+
+
+def test_wide_kernel_shared_multi_rank_build(dev, monkeypatch):
+    # packed tiles of the shared multi-rank build (a rank's tiles of a row block are every
+    # world-th column tile), several batches, and the upper-triangle job
+    monkeypatch.setenv("SCS_WIDE", "1")
+    monkeypatch.setenv("SCS_WS_LIMIT_MB", "2")
+    tables = synthetic.make_tables(5, 1300, 30, "branch", leaves_per_tree=1200)
+    w_ref, _ = to.pcg_dense(tables)
+    out = _run_local_group(tables, [0, 500, 1300], True, None)
+    assert out[0][3]["n_batches"] > 1
+    assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
+    out = _run_local_group(tables, [0, 333, 800, 1300], False, None)
+    assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
+
+
+def test_wide_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
+    # 3 000 taxa / 300 trees: 12 column tiles per row block, two tree batches by the tree cap;
+    # the two kernels against each other, whole matrix, and sampled rows against the oracle
+    tables = synthetic.make_tables(3, 3000, 300, "branch", random_weights=True)
+    got = {}
+    for wide in ("0", "1"):
+        monkeypatch.setenv("SCS_WIDE", wide)
+        dtab = dev.upload(tables)
+        g = dtab.build()
+        got[wide] = g.download()
+        assert g.build_stats["n_batches"] > 1
+        g.free()
+        dtab.free()
+    assert np.array_equal(got["0"], got["1"])
+    rows = np.unique(np.random.RandomState(2).randint(0, 3000, size=12)).astype(np.int32)
+    assert np.array_equal(got["1"][rows], to.pcg_rows(tables, rows))
+    assert np.array_equal(got["1"], got["1"].T) and not np.any(np.diag(got["1"]))
+
+
 def test_rccl_world_of_one(dev):
     # exercises the RCCL binding (dlopen, unique id, comm init, all-gather) on one GPU
     uid = Device.unique_id()
