@@ -870,21 +870,27 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 wp.m = mp;
                 wp.groups = (const int4 *)d_groups.p;
                 const unsigned ng = (unsigned)groups.size();
-                const void *fn = stamp ? (sym ? (const void *)k_accumulate_wide<WIDE_NG, true, true>
-                                              : (const void *)k_accumulate_wide<WIDE_NG, false, true>)
-                                       : (sym ? (const void *)k_accumulate_wide<WIDE_NG, true, false>
-                                              : (const void *)k_accumulate_wide<WIDE_NG, false, false>);
-                // (more dynamic LDS than the default 64 KiB: per function and device, set every time)
-                SCS_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  (int)WL::LDS_BYTES));
                 dev_buf d_st8;
                 if (stamp) {
                     SCS_TRY(d_st8.alloc(64));
                     SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
                     wp.m.stamps = (unsigned long long *)d_st8.p;
                 }
-                void *args[] = {&wp};
-                SCS_HIP_CHECK(hipLaunchKernel(fn, dim3(ng), dim3(WIDE_NG * MONO_TCW), args, WL::LDS_BYTES, s));
+                // (more dynamic LDS than the default 64 KiB: per function and device, set every time)
+#define SCS_LAUNCH_WIDE(SYM_, STAMP_)                                                                   \
+    do {                                                                                                \
+        SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_wide<WIDE_NG, SYM_, STAMP_>,       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,                   \
+                                          (int)WL::LDS_BYTES));                                         \
+        k_accumulate_wide<WIDE_NG, SYM_, STAMP_><<<ng, WIDE_NG * MONO_TCW, WL::LDS_BYTES, s>>>(wp);     \
+    } while (0)
+                if (ng) {
+                    if (stamp && sym) SCS_LAUNCH_WIDE(true, true);
+                    else if (stamp) SCS_LAUNCH_WIDE(false, true);
+                    else if (sym) SCS_LAUNCH_WIDE(true, false);
+                    else SCS_LAUNCH_WIDE(false, false);
+                }
+#undef SCS_LAUNCH_WIDE
                 if (stamp) {
                     unsigned long long h[8];
                     SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));

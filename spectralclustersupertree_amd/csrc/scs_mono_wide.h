@@ -113,6 +113,17 @@ __global__ __launch_bounds__(64) void k_block_records_wide(
     }
 }
 
+// 16 bytes per lane, global -> LDS at `dst` + 16 * lane, no round trip through registers.  (A plain
+// function on purpose: inside the kernel template the call would have value-dependent
+// arguments, be checked again when the template is instantiated -- also by the HOST pass, which
+// does not know the builtin, drops the instantiation without a word and leaves the kernel's
+// launch stub undefined.)
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned char *dst,
+                                          const int voffset, const int soffset) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voffset, soffset, 0, 0);
+}
+
 struct wide_params {
     mono_params m;
     const int4 *groups;  // x, y, z: indices into m.tiles of up to three tiles of ONE row block (-1: none)
@@ -174,7 +185,6 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_wide(wide_params w
     extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
     double *const s_t = (double *)s_mem;                                // [2][DT_DOUBLES]
     unsigned char *const s_rec = s_mem + 2 * (size_t)DT_DOUBLES * 8;  // [2][L::BYTES]
-    typedef __attribute__((address_space(3))) void *lds_ptr;
     const mono_params &p = wp.m;
 
     unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -230,9 +240,8 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_wide(wide_params w
         if (wave < L::PIECES) {
             const int left = (L::BYTES - wave * 1024) / 16;
             if (lane < left)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    r_rec, (lds_ptr)(s_rec + (tl & 1) * L::BYTES + wave * 1024), 16, lane16,
-                    tl * L::BYTES + wave * 1024, 0, 0);
+                lds_dma16(r_rec, s_rec + (tl & 1) * L::BYTES + wave * 1024, lane16,
+                          tl * L::BYTES + wave * 1024);
         }
     };
 
