@@ -31,6 +31,7 @@ otherwise, and for inputs outside the fast path's range, the public function is 
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 
@@ -469,12 +470,22 @@ def native_seeding_active() -> bool:
     return fast_path_active() and bool(_state["whole"])
 
 
+_self_test_lock = threading.Lock()
+
+
 def fast_path_active() -> bool:
     if os.environ.get("SCS_KMEANS", "") == "sklearn":
         return False
     if not _state["checked"]:
-        _state["ok"] = _self_test()
-        _state["checked"] = True
+        # ONE thread runs the self-test, the others wait here (without the interpreter lock).  Two
+        # ranks of an in-process team reaching their first label assignment together deadlocked:
+        # one inside threadpoolctl's dl_iterate_phdr callback (loader lock held, waiting for the
+        # interpreter), the other importing a scikit-learn extension (interpreter held, dlopen
+        # waiting for the loader lock) -- profiles/r04_team_first_use_deadlock.txt.
+        with _self_test_lock:
+            if not _state["checked"]:
+                _state["ok"] = _self_test()
+                _state["checked"] = True
     return _state["ok"]
 
 

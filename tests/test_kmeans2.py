@@ -189,3 +189,32 @@ def test_native_seeding_hands_an_emptied_cluster_back():
     assert kmeans2._whole_call(kmeans2._whole(), x, x_sq, cdf, draws, 0.0) is None
     assert _same(x, 9)
     assert _same(np.array([[1.0, 2.0]] * 3 + [[1.0, 2.0 + 1e-300]]), 10)
+
+
+def test_first_use_from_two_threads_at_once():
+    """Two ranks of an in-process team (or the walk and its look-ahead worker) can reach their
+    first label assignment together: the self-test must run once, on one thread -- run
+    concurrently, threadpoolctl's library scan (loader lock) and a scikit-learn import
+    (interpreter lock) waited for each other (profiles/r04_team_first_use_deadlock.txt).  A
+    fresh interpreter, so that nothing is imported or self-tested yet."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    code = (
+        "import threading, numpy as np\n"
+        "from spectralclustersupertree_amd import kmeans2\n"
+        "x = np.random.RandomState(3).standard_normal((40, 2))\n"
+        "out = [None, None]\n"
+        "gate = threading.Barrier(2)\n"
+        "def work(i):\n"
+        "    gate.wait()\n"
+        "    out[i] = kmeans2.labels(x, np.random.RandomState(5))\n"
+        "ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]\n"
+        "[t.start() for t in ts]; [t.join() for t in ts]\n"
+        "assert np.array_equal(out[0], out[1])\n"
+        "print('ok', kmeans2.fast_path_active())\n")
+    root = Path(__file__).resolve().parent.parent
+    res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.stdout.split()[0] == "ok"
