@@ -685,13 +685,16 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // the row block's table expanded once for all of them.  Worth it once the groups fill the
     // chip (one twelve-wave workgroup per CU); a handful of tiles -- a node of the deep recursion
     // -- keeps one workgroup per tile.  SCS_WIDE=0 / 1 force either kernel (A/B runs).
-    constexpr int WIDE_NG = 3;
-    bool wide = monotone && !scatter && tiles.size() >= 3 * 256;
-    if (const char *e = getenv("SCS_WIDE")) wide = monotone && !scatter && atoi(e) != 0 && !tiles.empty();
+    constexpr int WIDE_NG = 3, PIPE_NG = 2;
+    // SCS_WIDE: 0 the 4-wave kernel, 1 the 12-wave kernel, 2 the pipelined 8-wave kernel
+    int wide_mode = (monotone && !scatter && tiles.size() >= 3 * 256) ? 1 : 0;
+    if (const char *e = getenv("SCS_WIDE")) wide_mode = (monotone && !scatter && !tiles.empty()) ? atoi(e) : 0;
+    const bool wide = wide_mode != 0, pipe = wide_mode == 2;
+    const int group_tiles = pipe ? PIPE_NG : WIDE_NG;
     std::vector<int4> groups;
     dev_buf d_groups;
     if (wide) {
-        rec_bytes = wide_layout<WIDE_NG>::BYTES;
+        rec_bytes = pipe ? wide_layout<PIPE_NG>::BYTES : wide_layout<WIDE_NG>::BYTES;
         // the tiles of a row block in list order, three at a time; XCD x is handed the groups of
         // the row blocks b = x (mod 8), one row block after the other (as the tile order above)
         std::vector<std::vector<int>> of_block((size_t)n_blocks);
@@ -699,9 +702,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         std::vector<int4> per[8];
         for (int b = 0; b < n_blocks; ++b) {
             const std::vector<int> &v = of_block[(size_t)b];
-            for (size_t k = 0; k < v.size(); k += WIDE_NG)
+            for (size_t k = 0; k < v.size(); k += group_tiles)
                 per[b & 7].push_back(make_int4(v[k], k + 1 < v.size() ? v[k + 1] : -1,
-                                               k + 2 < v.size() ? v[k + 2] : -1, 0));
+                                               (group_tiles > 2 && k + 2 < v.size()) ? v[k + 2] : -1, 0));
         }
         size_t total = 0, at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (auto &v : per) total += v.size();
@@ -816,7 +819,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 k_sparse_level<double><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
                                                               (const int64_t *)d_stoff.p,
                                                               (double *)d_st.p);
-            if (wide)
+            if (pipe)
+                k_block_records_wide<PIPE_NG><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
+                    tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
+                    (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
+            else if (wide)
                 k_block_records_wide<WIDE_NG><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
                     tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
                     (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
@@ -879,10 +886,19 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 // (more dynamic LDS than the default 64 KiB: per function and device, set every time)
 #define SCS_LAUNCH_WIDE(SYM_, STAMP_)                                                                   \
     do {                                                                                                \
-        SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_wide<WIDE_NG, SYM_, STAMP_>,       \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,                   \
-                                          (int)WL::LDS_BYTES));                                         \
-        k_accumulate_wide<WIDE_NG, SYM_, STAMP_><<<ng, WIDE_NG * MONO_TCW, WL::LDS_BYTES, s>>>(wp);     \
+        if (pipe) {                                                                                     \
+            using PL = wide_layout<PIPE_NG>;                                                            \
+            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_pipe<PIPE_NG, SYM_, STAMP_>,   \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                              (int)PL::LDS_BYTES_PIPE));                                \
+            k_accumulate_pipe<PIPE_NG, SYM_, STAMP_>                                                    \
+                <<<ng, PIPE_NG * MONO_TCW, PL::LDS_BYTES_PIPE, s>>>(wp);                                \
+        } else {                                                                                        \
+            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_wide<WIDE_NG, SYM_, STAMP_>,   \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                              (int)WL::LDS_BYTES));                                     \
+            k_accumulate_wide<WIDE_NG, SYM_, STAMP_><<<ng, WIDE_NG * MONO_TCW, WL::LDS_BYTES, s>>>(wp); \
+        }                                                                                               \
     } while (0)
                 if (ng) {
                     if (stamp && sym) SCS_LAUNCH_WIDE(true, true);
@@ -895,8 +911,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                     unsigned long long h[8];
                     SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
                     SCS_HIP_CHECK(hipStreamSynchronize(s));
-                    const char *nm[7] = {"combine", "search + issue", "expand (next tree)", "record DMA issue",
-                                         "cells", "wait loads+record", "barrier"};
+                    const char *nm_w[7] = {"combine", "search + issue", "expand (next tree)", "record DMA issue",
+                                           "cells", "wait loads+record", "barrier"};
+                    const char *nm_p[7] = {"combine", "search + issue (early)", "table state + DMA issue",
+                                           "cells + expansion", "search (late) / wait (early)", "barrier", "-"};
+                    const char **nm = pipe ? nm_p : nm_w;
                     double tot = 0;
                     for (int i = 0; i < 7; ++i) tot += (double)h[i];
                     for (int i = 0; i < 7; ++i)

@@ -20,6 +20,8 @@
 // workgroup is handed up to NG tiles of one row block (`groups`).
 #pragma once
 
+#include <type_traits>
+
 template <int NG>
 struct wide_layout {
     static constexpr int NSEG = 4 * NG;  // expansion segments = waves
@@ -38,6 +40,7 @@ struct wide_layout {
     __host__ __device__ static constexpr int seg(int w) { return 64 * w / NSEG; }
     static constexpr int MAXSEG = (64 + NSEG - 1) / NSEG;
     static constexpr size_t LDS_BYTES = 2 * (size_t)DT_DOUBLES * 8 + 2 * (size_t)BYTES;
+    static constexpr size_t LDS_BYTES_PIPE = 2 * (size_t)DT_DOUBLES * 8 + 3 * (size_t)BYTES;  // k_accumulate_pipe
     static_assert(STOFF % 8 == 0 && PIECES <= NSEG, "record layout");
     static_assert((size_t)NG * MONO_TCW * 9 * 8 <= LDS_BYTES, "mirror staging fits the table space");
 };
@@ -111,6 +114,20 @@ __global__ __launch_bounds__(64) void k_block_records_wide(
         }
         seed[(w - 1) * 64 + lane] = mine;
     }
+}
+
+// The same copy as inline asm: k_accumulate_pipe's waves of sub-tile 1 never issue one, yet in a
+// loop shared with the waves that do the compiler drains vmcnt in front of every LDS access that
+// may follow a pending LDS-DMA -- and with it the range-minimum loads those waves issued a moment
+// ago.  Hidden from the compiler, the copy is ordered by hand: s_waitcnt vmcnt(0) by the issuing
+// wave, then the workgroup barrier, before anyone reads the record.
+typedef int scs_int4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_dma16_asm(const scs_int4 rsrc, const unsigned lds_addr,
+                                              const int voffset, const int soffset) {
+    asm volatile("s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[voff], %[rsrc], %[soff] offen lds"
+                 :
+                 : [lds] "s"(lds_addr), [voff] "v"(voffset), [rsrc] "s"(rsrc), [soff] "s"(soffset)
+                 : "memory", "m0");
 }
 
 // 16 bytes per lane, global -> LDS at `dst` + 16 * lane, no round trip through registers.  (A plain
@@ -371,6 +388,264 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_wide(wide_params w
         stamp(5);
         SCS_BARE_BARRIER();
         stamp(6);
+    }
+
+    if (STAMPED && lane == 0 && p.stamps) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
+        atomicAdd(&p.stamps[7], 1ull);
+    }
+    tile_store_wide<SYM>(p, acc, tile, active, ti, row0, col, self, ltid, lane, wl,
+                         (double *)s_mem + (size_t)sub * MONO_TCW * 9);
+}
+
+// ---------------------------------------------------------------------------
+// k_accumulate_pipe: the wide kernel with the phases of a step overlapped
+// ---------------------------------------------------------------------------
+// profiles/r04_wide_phase_stamps.txt: merely widening the tile bought nothing -- a wave's step is
+// a chain of dependent phases (column search, table expansion, cells) and every phase waits on
+// LDS operations queued behind the other waves' traffic: 7 250 cycles per step for 768 columns
+// against 3 x 2 500 for three 4-wave workgroups, a quarter of it at the barrier.  Here
+//   * the wave's expansion steps of tree t + 1's table are WOVEN INTO the cell loop of tree t
+//     (one inline-asm statement, scs_cells_asm.h: SCS_CELLS_EXPAND_ASM) -- the stores and the
+//     v_readlane broadcasts ride in the shadow of the cells' reads;
+//   * the two sub-tiles run half a step apart: the waves of sub-tile 0 search (tree t + 1) BEFORE
+//     their cell loop, the waves of sub-tile 1 AFTER it (tree t + 2: their range-minimum loads
+//     then have a whole step to come back), so the latency-bound search of one half runs beside
+//     the LDS-bound cell loop of the other -- what independent workgroups did by accident;
+//   * NG = 2: eight waves, two per SIMD, 256 registers each.
+// Three record buffers (trees t + 1 for the expansion and the early search, t + 2 for the late
+// search, t + 3 landing), two table buffers, one barrier per tree.  Arithmetic as
+// k_accumulate_mono: same addends, same order, same bits.
+template <int NG, bool SYM, bool STAMPED>
+__global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_pipe(wide_params wp) {
+    using L = wide_layout<NG>;
+    static_assert(NG == 2 && L::NSEG == 8 && L::seg(1) == 8,
+                  "eight waves, eight expansion steps each, woven into the cell loop");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    double *const s_t = (double *)s_mem;                                // [2][DT_DOUBLES]
+    unsigned char *const s_rec = s_mem + 2 * (size_t)DT_DOUBLES * 8;  // [3][L::BYTES]
+    const mono_params &p = wp.m;
+
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if (STAMPED) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            ts[k] += tnow - tprev;
+            tprev = tnow;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int ltid = tid & (MONO_TCW - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sub = wave >> 2, wl = wave & 3;
+    const int4 grp = wp.groups[blockIdx.x];
+    const int ti = sub == 0 ? grp.x : grp.y;
+    const bool active = ti >= 0;
+    const int2 tile = p.tiles[active ? ti : grp.x];
+    const int blk = tile.x;
+    const int row0 = p.row_begin + blk * SCS_TR;
+    const int col = tile.y * MONO_TCW + ltid;
+    const int nt = p.n_batch;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
+
+    double acc[SCS_TR];
+#pragma unroll
+    for (int i = 0; i < SCS_TR; ++i) {
+        double v = 0.0;
+        if (active && p.load_w && p.tile_out)
+            v = p.tile_out[((int64_t)ti * SCS_TR + i) * MONO_TCW + ltid];
+        else if (active && p.load_w && col < p.n && row0 + i < p.row_end)
+            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
+        acc[i] = v;
+    }
+
+    const unsigned char *rec_base = p.rec + (int64_t)blk * nt * L::BYTES;
+    const scs_int4 rs_rec = {(int)(unsigned)(u64)rec_base, (int)(((u64)rec_base >> 32) & 0xffffu),
+                             nt * L::BYTES, 0x00020000};
+    const __amdgpu_buffer_rsrc_t r_pos =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.pos, 0, (int)(nt * p.npad * 4), 0x00020000);
+    const int lane16 = lane * 16;
+    const int col4 = col * 4;
+    // record of tree t lives in s_rec[t % 3]; the four waves of sub-tile 0 copy its 1 KiB pieces
+    // (they are the ones whose step has no LDS access the compiler sees after this point)
+    auto issue_record = [&](int t) {
+#pragma unroll
+        for (int pc = 0; pc < L::PIECES; pc += 4) {
+            const int piece = pc + wave;
+            if (piece < L::PIECES) {
+                const int left = (L::BYTES - piece * 1024) / 16;
+                if (lane < left)
+                    lds_dma16_asm(rs_rec,
+                                  (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
+                                      s_rec + (t % 3) * L::BYTES + piece * 1024),
+                                  lane16, t * L::BYTES + piece * 1024);
+            }
+        }
+    };
+
+    struct pending {
+        double qx, qy;  // raw table values of the column's one range-minimum query
+        int cstate;     // bits 0-7: row nb; bit 8: a neighbour exists; bit 9: self
+    };
+    int cpos_next = -1;
+
+    // the column step of k_accumulate_mono on the record of tree t (clamped to the batch)
+    auto column_issue = [&](int t_raw, int cpos, pending &q) {
+        const int t = min(t_raw, nt - 1);
+        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
+        const int *s_spos = (const int *)(rb + L::SPOS);
+        const int *s_arg = (const int *)(rb + L::ARGPOS);
+        const unsigned char *s_sorig = rb + L::SORIG;
+        const int *s_piv = (const int *)(rb + L::PIV);
+        const int cnt = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::CNT));
+        const bool present = cpos >= 0 && cnt > 0;
+        int lo;
+        {
+            const int4 pa = *(const int4 *)&s_piv[0];
+            const int4 pb = *(const int4 *)&s_piv[4];
+            lo = ((pa.x < cpos) + (pa.y < cpos) + (pa.z < cpos) + (pa.w < cpos) + (pb.x < cpos) +
+                  (pb.y < cpos) + (pb.z < cpos) + (pb.w < cpos)) * 8;
+            const int base = min(lo, 56);
+            const int4 qa = *(const int4 *)&s_spos[base];
+            const int4 qb = *(const int4 *)&s_spos[base + 4];
+            const int l2 = base + (qa.x < cpos) + (qa.y < cpos) + (qa.z < cpos) + (qa.w < cpos) +
+                           (qb.x < cpos) + (qb.y < cpos) + (qb.z < cpos);
+            lo = lo == 64 ? 64 : l2;
+        }
+        const bool hasl = present && self < 0 && lo > 0;
+        const bool hasr = present && self < 0 && lo < cnt;
+        const int il = max(lo - 1, 0), ir = min(lo, 63);
+        const bool left = hasl && (!hasr || s_arg[il] >= cpos);
+        const int q_anchor = s_spos[left ? il : ir];
+        const int nbrow = s_sorig[left ? il : ir];
+        q.cstate = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && self >= 0) ? 512 : 0);
+        const int m = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::M));
+        const unsigned so_lo = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF));
+        const unsigned so_hi = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF + 4));
+        const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
+        const bool any = hasl || hasr;
+        int o[2];
+        rmq_offsets(m, any ? (left ? q_anchor : cpos) : 0, any ? (left ? cpos : q_anchor) : 1, o);
+        q.qx = *(const double *)(st + (unsigned)o[0] * 8u);
+        q.qy = *(const double *)(st + (unsigned)o[1] * 8u);
+        cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, min(t + 1, nt - 1) * (int)p.npad * 4, 0);
+    };
+
+    // whole expansion of tree 0's table (prologue only; the steady state weaves it into the cells)
+    auto expand_whole = [&](int t) {
+        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
+        double *dv = s_t + (t & 1) * DT_DOUBLES;
+        const int b0 = L::seg(wave);
+        const double g_rank = ((const double *)(rb + L::G))[lane];
+        const int so_rank = rb[L::SORIG + lane];
+        const int rho = rb[L::RANK + lane];
+        double cur = inf;
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        double *row_a = &dv[lane * DV_LD];
+        double *col_a = &dv[lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = b0 + j;
+            const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_rank), b);
+            const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_rank), b);
+            const int so_b = __builtin_amdgcn_readlane(so_rank, b);
+            const double gb = __hiloint2double(hi32, lo32);
+            if (rho <= b) {
+                row_a[so_b] = cur;
+                col_a[so_b * DV_LD] = cur;
+                cur = min_f64(cur, gb);
+            }
+        }
+    };
+
+    // ---- prologue: records 0, 1, 2; tree 0's table; the first column steps
+    if (sub == 0) {
+        issue_record(0);
+        if (nt > 1) issue_record(1);
+        if (nt > 2) issue_record(2);
+    }
+    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    pending pa = {0.0, 0.0, 0};
+    const bool late = sub == 1;
+    // a column's query -> the tile row next to it and its own LCA value with that row
+    auto combine = [&](const pending &q, int &nb, double &vn) {
+        nb = 0;
+        vn = 0.0;
+        if (q.cstate & 256) {
+            vn = min_f64(q.qx, q.qy);
+            nb = q.cstate & 255;
+        } else if (q.cstate & 512) {
+            nb = self;
+            vn = inf;
+        }
+    };
+    int nb = 0;
+    double vn = 0.0;
+    if (active) column_issue(0, cpos_next, pa);
+    if (late) {
+        // a late wave combines a tree's query at the END of the step before (its loads were issued a
+        // whole step earlier) and only then issues the next one: nothing to wait for at the top
+        combine(pa, nb, vn);
+        if (active) column_issue(1, cpos_next, pa);
+    }
+    expand_whole(0);
+    SCS_BARE_BARRIER();
+    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+
+    // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
+    // s_t[tl & 1]; the records of trees tl + 1 and tl + 2 are in place.  An early wave holds the
+    // column's query of tree tl in `pa` (landed: issued before the previous cell loop), a late
+    // wave holds (nb, vn) of tree tl and the query of tree tl + 1 in `pa` (in flight).
+    // ONE loop and ONE cell statement for both kinds of wave: a second inline-asm statement with
+    // 64 tied accumulators anywhere in the kernel makes the register allocator keep two sets.
+    for (int tl = 0; tl < nt; ++tl) {
+        if (!late) combine(pa, nb, vn);
+        stamp(0);
+        if (!late && active) column_issue(tl + 1, cpos_next, pa);
+        stamp(1);
+        const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_t[(
+            tl & 1) * DT_DOUBLES + nb * DV_LD];
+        // the wave's share of tree tl + 1's table goes into the other buffer, woven into the cells
+        // (the last tree expands its own table once more, into the buffer nobody reads any more)
+        const unsigned char *rb = s_rec + (min(tl + 1, nt - 1) % 3) * L::BYTES;
+        const double g_rank = ((const double *)(rb + L::G))[lane];
+        const int so_rank = rb[L::SORIG + lane];
+        const int rho = rb[L::RANK + lane];
+        const int b0 = L::seg(wave);
+        double cur = inf;
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
+        const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
+        const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
+        if (!late && tl + 3 < nt) issue_record(tl + 3);
+        stamp(2);
+        {
+            double tmp[SCS_CELLS_DEPTH];
+            unsigned x1, x2;
+            // (a missing sub-tile runs the same statement -- its waves owe their share of the
+            // table; its accumulators are never stored)
+            SCS_CELLS_EXPAND_ASM(acc, tmp, x1, x2, addr, vn, cur, (int)__double2loint(g_rank),
+                                 __double2hiint(g_rank), so_rank, rho, rowb, colb, b0, DV_LD * 8);
+        }
+        stamp(3);
+        if (late) {
+            combine(pa, nb, vn);  // tree tl + 1
+            if (active) column_issue(tl + 2, cpos_next, pa);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the record
+        }
+        stamp(4);
+        SCS_BARE_BARRIER();
+        stamp(5);
     }
 
     if (STAMPED && lane == 0 && p.stamps) {

@@ -86,6 +86,76 @@ def general():
 """
 
 
+def cells_expand():
+    """SCS_CELLS_EXPAND_ASM (k_accumulate_pipe): the 64 cells of tree t from one table buffer
+    with the wave's eight expansion steps of tree t + 1's table (the other buffer) woven in, one
+    step per eight cells.  A step (rank b = B0 + j): the gap value g[b] and the row of rank b
+    come out of the lanes that hold them (v_readlane -> SGPRs), the lanes whose rank is <= b
+    store their running minimum at (own row, row of b) and its mirror image, then take g[b] in.
+    Hazards are this generator's to keep (the compiler's recognizer does not look inside
+    inline asm; gfx940 family: a VALU-written SGPR needs 2 wait states before a VALU reads it,
+    a VALU-written EXEC 4 before v_readlane): the v_readlane results are consumed a cell (four
+    instructions) later, a step's v_cmpx is followed by seven cells before the next v_readlane.
+    The counted lgkmcnt waits are exact: the generator keeps the queue of LDS operations
+    (reads and stores return in order)."""
+    lines = ["s_waitcnt lgkmcnt(0)"]
+    queue = []  # outstanding LDS operations in issue order: ("r", k) reads into t{k}, ("w",)
+
+    def read(k, row):
+        lines.append(f"ds_read_b64 %[t{k}], %[addr] offset:{8 * row}")
+        queue.append(("r", k))
+
+    def consume(k):
+        # wait until the read into t{k} is done: everything up to it has left the queue
+        idx = next(i for i, op in enumerate(queue) if op == ("r", k))
+        younger = len(queue) - 1 - idx
+        lines.append(f"s_waitcnt lgkmcnt({younger})")
+        del queue[: idx + 1]
+
+    def store(addr_reg):
+        lines.append(f"ds_write_b64 {addr_reg}, %[cur]")
+        queue.append(("w",))
+
+    for k in range(DEPTH):
+        read(k, k)
+    for i in range(ROWS):
+        k = i % DEPTH
+        j, ph = divmod(i, 8)
+        if ph == 0:
+            # rank b of this step, the gap value and the row of rank b (SGPRs 92, 94:95, 96)
+            lines.append(f"s_add_u32 s92, %[b0], {j}")
+            lines.append("v_readlane_b32 s94, %[glo], s92")
+            lines.append("v_readlane_b32 s95, %[ghi], s92")
+            lines.append("v_readlane_b32 s96, %[so], s92")
+        consume(k)
+        lines.append(f"v_min_f64 %[t{k}], %[t{k}], %[vn]")
+        lines.append(f"v_add_f64 %[a{i}], %[a{i}], %[t{k}]")
+        if i + DEPTH < ROWS:
+            read(k, i + DEPTH)
+        if ph == 0:
+            lines.append("s_mul_i32 s97, s96, %[ld8]")
+            lines.append("v_lshl_add_u32 %[x1], s96, 3, %[rowb]")
+            lines.append("v_add_u32 %[x2], s97, %[colb]")
+            lines.append("v_cmpx_ge_u32 vcc, s92, %[rho]")
+            store("%[x1]")
+            store("%[x2]")
+            lines.append("v_min_f64 %[cur], %[cur], s[94:95]")
+            lines.append("s_mov_b64 exec, -1")
+    outs = ("," + BS).join(f'          [a{i}] "+v"(ACC[{i}])' for i in range(ROWS))
+    tmps = ("," + BS).join(f'          [t{k}] "=&v"(TMP[{k}])' for k in range(DEPTH))
+    return f"""#define SCS_CELLS_EXPAND_ASM(ACC, TMP, X1, X2, ADDR, VN, CUR, GLO, GHI, SO, RHO, ROWB, COLB, B0, LD8) \\
+    asm volatile( \\
+{quoted(lines)} \\
+        : \\
+{outs}, \\
+{tmps}, \\
+          [x1] "=&v"(X1), [x2] "=&v"(X2), [cur] "+v"(CUR) \\
+        : [addr] "v"(ADDR), [vn] "v"(VN), [glo] "v"(GLO), [ghi] "v"(GHI), [so] "v"(SO), \\
+          [rho] "v"(RHO), [rowb] "v"(ROWB), [colb] "v"(COLB), [b0] "s"(B0), [ld8] "s"(LD8) \\
+        : "memory", "vcc", "s92", "s94", "s95", "s96", "s97")
+"""
+
+
 def main(path):
     text = f"""// GENERATED by tools/gen_cells_asm.py -- do not edit.
 // SCS_CELLS_ASM(ACC, TMP, ADDR, VN): ACC double[{ROWS}] accumulators, TMP double[{DEPTH}] scratch,
@@ -94,11 +164,18 @@ def main(path):
 // monotone in the depth: rows whose sorted rank r has r - TLO <= TW (unsigned) take VV instead
 // of the table entry; RP int[{ROWS // 4}] wave-uniform, byte i & 3 of RP[i >> 2] = rank of row i;
 // TT (unsigned, vector) and SR (int, scalar) are scratch.  All 64 lanes must be active.
+// SCS_CELLS_EXPAND_ASM(ACC, TMP, X1, X2, ADDR, VN, CUR, GLO, GHI, SO, RHO, ROWB, COLB, B0, LD8): the
+// monotone cell loop with the wave's eight expansion steps of the NEXT tree's table woven in
+// (k_accumulate_pipe): CUR (double, in/out) the lane's running minimum, GLO / GHI the halves of
+// g[lane], SO the row of rank `lane`, RHO the lane's rank, ROWB / COLB the LDS byte addresses
+// of the lane's row and column of the other table buffer, B0 (scalar) the wave's first rank,
+// LD8 (scalar) the table's row stride in bytes; X1, X2 (unsigned, vector) are scratch.
 #pragma once
 #define SCS_CELLS_DEPTH {DEPTH}
 #define SCS_CELLS_GEN_DEPTH {GEN_DEPTH}
 {mono()}
-{general()}"""
+{general()}
+{cells_expand()}"""
     open(path, "w").write(text)
 
 
