@@ -689,7 +689,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // SCS_WIDE: 0 the 4-wave kernel, 1 the 12-wave kernel, 2 the pipelined 8-wave kernel
     int wide_mode = (monotone && !scatter && tiles.size() >= 3 * 256) ? 1 : 0;
     if (const char *e = getenv("SCS_WIDE")) wide_mode = (monotone && !scatter && !tiles.empty()) ? atoi(e) : 0;
-    const bool wide = wide_mode != 0, pipe = wide_mode == 2;
+    // (3: the producer / consumer kernel, same groups and records as 2)
+    const bool wide = wide_mode != 0, pipe = wide_mode == 2 || wide_mode == 3, spec = wide_mode == 3;
     const int group_tiles = pipe ? PIPE_NG : WIDE_NG;
     std::vector<int4> groups;
     dev_buf d_groups;
@@ -886,7 +887,13 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 // (more dynamic LDS than the default 64 KiB: per function and device, set every time)
 #define SCS_LAUNCH_WIDE(SYM_, STAMP_)                                                                   \
     do {                                                                                                \
-        if (pipe) {                                                                                     \
+        if (spec) {                                                                                     \
+            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_spec<SYM_, STAMP_>,            \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                              (int)spec_layout::LDS_BYTES));                            \
+            k_accumulate_spec<SYM_, STAMP_>                                                             \
+                <<<ng, spec_layout::THREADS, spec_layout::LDS_BYTES, s>>>(wp);                          \
+        } else if (pipe) {                                                                              \
             using PL = wide_layout<PIPE_NG>;                                                            \
             SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_pipe<PIPE_NG, SYM_, STAMP_>,   \
                                               hipFuncAttributeMaxDynamicSharedMemorySize,               \
@@ -915,7 +922,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                                            "cells", "wait loads+record", "barrier"};
                     const char *nm_p[7] = {"combine", "search + issue (early)", "table state + DMA issue",
                                            "cells + expansion", "search (late) / wait (early)", "barrier", "-"};
-                    const char **nm = pipe ? nm_p : nm_w;
+                    const char *nm_s[7] = {"producer: column step", "producer: records + wait", "consumer: pair + table state",
+                                           "consumer: cells + expansion", "barrier", "-", "-"};
+                    const char **nm = spec ? nm_s : (pipe ? nm_p : nm_w);
                     double tot = 0;
                     for (int i = 0; i < 7; ++i) tot += (double)h[i];
                     for (int i = 0; i < 7; ++i)

@@ -656,3 +656,274 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_pipe(wide_params w
     tile_store_wide<SYM>(p, acc, tile, active, ti, row0, col, self, ltid, lane, wl,
                          (double *)s_mem + (size_t)sub * MONO_TCW * 9);
 }
+
+// ---------------------------------------------------------------------------
+// k_accumulate_spec: producer and consumer waves
+// ---------------------------------------------------------------------------
+// tools/cells_probe.hip (profiles/r04_cells_probe.txt): twelve waves that do NOTHING but cells,
+// expansion stores and one barrier per tree keep the LDS 92 % busy (7.2e12 cell-trees/s);
+// k_accumulate_wide's waves reach 58 % -- each also searches its column among the tile's rows,
+// issues the range-minimum loads and waits for them, a chain of dependent LDS and memory round
+// trips during which it issues no cell reads, and the workgroup's waves do that in step.  Here
+// the roles are split: of a workgroup's twelve waves EIGHT (two tiles of one row block) are
+// consumers -- per tree: read the column's (table row address, own value) pair from LDS, then the
+// one woven statement (cells of tree t + the wave's expansion steps of tree t + 1) -- and FOUR are
+// producers: each runs the column step of k_accumulate_mono for the 128 columns of two consumer
+// waves, one tree ahead, and leaves the pairs in LDS; they also stage the records.  One barrier
+// per tree for all twelve.  Arithmetic as k_accumulate_mono: same addends, same order, same bits.
+struct spec_layout {
+    using L = wide_layout<2>;
+    static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
+    static constexpr size_t O_T = 0;                                      // double[2][DT_DOUBLES]
+    static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [3][L::BYTES]
+    static constexpr size_t O_VN = O_REC + 3 * (size_t)L::BYTES;         // double[2][512]
+    static constexpr size_t O_ADDR = O_VN + 2 * 512 * 8;                 // unsigned[2][512]
+    static constexpr size_t LDS_BYTES = O_ADDR + 2 * 512 * 4;
+    static_assert(O_VN % 16 == 0 && 3 * (size_t)MONO_TCW * 9 * 8 <= LDS_BYTES, "layout");
+};
+
+template <bool SYM, bool STAMPED>
+__global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_params wp) {
+    using S = spec_layout;
+    using L = wide_layout<2>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
+    double *const s_t = (double *)(s_mem + S::O_T);
+    unsigned char *const s_rec = s_mem + S::O_REC;
+    double *const s_vn = (double *)(s_mem + S::O_VN);
+    unsigned *const s_addr = (unsigned *)(s_mem + S::O_ADDR);
+    const mono_params &p = wp.m;
+
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto stamp = [&](int k) {
+        if (STAMPED) {
+            __builtin_amdgcn_sched_barrier(0);
+            unsigned long long tnow;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
+            ts[k] += tnow - tprev;
+            tprev = tnow;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= S::CONSUMERS;
+    const int pw = wave - S::CONSUMERS;  // producer index (0..3): the columns of consumer waves 2 pw, 2 pw + 1
+    const int4 grp = wp.groups[blockIdx.x];
+    const int nt = p.n_batch;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    // consumer geometry (a producer takes that of the first of its two consumer waves)
+    const int cw = producer ? 2 * pw : wave;
+    const int sub = cw >> 2, wl = cw & 3;
+    const int ltid = (cw & 3) * 64 + lane;
+    const int ti = sub == 0 ? grp.x : grp.y;
+    const bool active = ti >= 0;
+    const int2 tile = p.tiles[active ? ti : grp.x];
+    const int blk = tile.x;
+    const int row0 = p.row_begin + blk * SCS_TR;
+    const int col = tile.y * MONO_TCW + ltid;
+    const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
+
+    double acc[SCS_TR];
+#pragma unroll
+    for (int i = 0; i < SCS_TR; ++i) {
+        double v = 0.0;
+        if (!producer && active && p.load_w && p.tile_out)
+            v = p.tile_out[((int64_t)ti * SCS_TR + i) * MONO_TCW + ltid];
+        else if (!producer && active && p.load_w && col < p.n && row0 + i < p.row_end)
+            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
+        acc[i] = v;
+    }
+
+    const unsigned char *rec_base = p.rec + (int64_t)blk * nt * L::BYTES;
+    const scs_int4 rs_rec = {(int)(unsigned)(u64)rec_base, (int)(((u64)rec_base >> 32) & 0xffffu),
+                             nt * L::BYTES, 0x00020000};
+    const __amdgpu_buffer_rsrc_t r_pos =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.pos, 0, (int)(nt * p.npad * 4), 0x00020000);
+    const int lane16 = lane * 16;
+
+    // ---------------- producer side ----------------
+    // record of tree t lives in s_rec[t % 3]; producer pw copies pieces pw and pw + 4
+    auto issue_record = [&](int t) {
+#pragma unroll
+        for (int pc = 0; pc < L::PIECES; pc += S::PRODUCERS) {
+            const int piece = pc + pw;
+            if (piece < L::PIECES) {
+                const int left = (L::BYTES - piece * 1024) / 16;
+                if (lane < left)
+                    lds_dma16_asm(rs_rec,
+                                  (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
+                                      s_rec + (t % 3) * L::BYTES + piece * 1024),
+                                  lane16, t * L::BYTES + piece * 1024);
+            }
+        }
+    };
+    // the two columns of this lane (one per consumer wave served) and their positions in the
+    // tree the next column step is for
+    int pcol4[2], pself[2], cpos[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = tile.y * MONO_TCW + (((2 * pw + k) & 3) * 64) + lane;
+        pcol4[k] = c * 4;
+        pself[k] = (c >= row0 && c < row0 + SCS_TR && c < p.row_end) ? c - row0 : -1;
+        cpos[k] = -1;
+    }
+    // the column step of k_accumulate_mono for tree t and both columns: search, one range-minimum
+    // query each (all four loads in flight together), then the pair (table row address, value)
+    // goes to slot t & 1 of the hand-off arrays; also requests the positions in tree t + 1
+    auto produce = [&](int t) {
+        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
+        const int *s_spos = (const int *)(rb + L::SPOS);
+        const int *s_arg = (const int *)(rb + L::ARGPOS);
+        const unsigned char *s_sorig = rb + L::SORIG;
+        const int *s_piv = (const int *)(rb + L::PIV);
+        const int cnt = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::CNT));
+        const int m = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::M));
+        const unsigned so_lo = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF));
+        const unsigned so_hi = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF + 4));
+        const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
+        const int4 pa = *(const int4 *)&s_piv[0];
+        const int4 pb = *(const int4 *)&s_piv[4];
+        double qx[2], qy[2];
+        int cstate[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int cp = cpos[k];
+            const bool present = cp >= 0 && cnt > 0;
+            int lo = ((pa.x < cp) + (pa.y < cp) + (pa.z < cp) + (pa.w < cp) + (pb.x < cp) + (pb.y < cp) +
+                      (pb.z < cp) + (pb.w < cp)) * 8;
+            const int base = min(lo, 56);
+            const int4 qa = *(const int4 *)&s_spos[base];
+            const int4 qb = *(const int4 *)&s_spos[base + 4];
+            const int l2 = base + (qa.x < cp) + (qa.y < cp) + (qa.z < cp) + (qa.w < cp) + (qb.x < cp) +
+                           (qb.y < cp) + (qb.z < cp);
+            lo = lo == 64 ? 64 : l2;
+            const bool hasl = present && pself[k] < 0 && lo > 0;
+            const bool hasr = present && pself[k] < 0 && lo < cnt;
+            const int il = max(lo - 1, 0), ir = min(lo, 63);
+            const bool left = hasl && (!hasr || s_arg[il] >= cp);
+            const int q_anchor = s_spos[left ? il : ir];
+            const int nbrow = s_sorig[left ? il : ir];
+            cstate[k] = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && pself[k] >= 0) ? 512 : 0);
+            const bool any = hasl || hasr;
+            int o[2];
+            rmq_offsets(m, any ? (left ? q_anchor : cp) : 0, any ? (left ? cp : q_anchor) : 1, o);
+            qx[k] = *(const double *)(st + (unsigned)o[0] * 8u);
+            qy[k] = *(const double *)(st + (unsigned)o[1] * 8u);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], min(t + 1, nt - 1) * (int)p.npad * 4, 0);
+        const unsigned tbase =
+            (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_t[(t & 1) * DT_DOUBLES];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            int nb = 0;
+            double vn = 0.0;
+            if (cstate[k] & 256) {
+                vn = min_f64(qx[k], qy[k]);
+                nb = cstate[k] & 255;
+            } else if (cstate[k] & 512) {
+                nb = pself[k];
+                vn = inf;
+            }
+            const int slot = (t & 1) * 512 + (2 * pw + k) * 64 + lane;
+            s_vn[slot] = vn;
+            s_addr[slot] = tbase + (unsigned)nb * (DV_LD * 8);
+        }
+    };
+
+    // ---------------- consumer side ----------------
+    auto expand_whole = [&](int t) {
+        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
+        double *dv = s_t + (t & 1) * DT_DOUBLES;
+        const int b0 = L::seg(wave);
+        const double g_rank = ((const double *)(rb + L::G))[lane];
+        const int so_rank = rb[L::SORIG + lane];
+        const int rho = rb[L::RANK + lane];
+        double cur = inf;
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        double *row_a = &dv[lane * DV_LD];
+        double *col_a = &dv[lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int b = b0 + j;
+            const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_rank), b);
+            const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_rank), b);
+            const int so_b = __builtin_amdgcn_readlane(so_rank, b);
+            const double gb = __hiloint2double(hi32, lo32);
+            if (rho <= b) {
+                row_a[so_b] = cur;
+                col_a[so_b * DV_LD] = cur;
+                cur = min_f64(cur, gb);
+            }
+        }
+    };
+
+    // ---- prologue: records 0, 1, 2; tree 0's table and column pairs
+    if (producer) {
+        issue_record(0);
+        if (nt > 1) issue_record(1);
+        if (nt > 2) issue_record(2);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (producer) produce(0);
+    else expand_whole(0);
+    SCS_BARE_BARRIER();
+    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+
+    // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
+    // s_t[tl & 1], its column pairs in slot tl & 1; the records of trees tl + 1 and tl + 2 are in
+    // place.  Two loops, one per role, the same number of barriers in each: in ONE loop the
+    // accumulators would be live across the producers' branch as well and the register allocator
+    // keeps them in scratch memory between the steps; and ONE cell statement in the kernel (a
+    // second one with 64 tied accumulators makes it keep two sets).
+    if (producer) {
+        for (int tl = 0; tl < nt; ++tl) {
+            if (tl + 1 < nt) produce(tl + 1);
+            stamp(0);
+            if (tl + 3 < nt) issue_record(tl + 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(1);
+            SCS_BARE_BARRIER();
+            stamp(4);
+        }
+    } else {
+        for (int tl = 0; tl < nt; ++tl) {
+            const int slot = (tl & 1) * 512 + wave * 64 + lane;
+            const double vn = s_vn[slot];
+            const unsigned addr = s_addr[slot];
+            const unsigned char *rb = s_rec + (min(tl + 1, nt - 1) % 3) * L::BYTES;
+            const double g_rank = ((const double *)(rb + L::G))[lane];
+            const int so_rank = rb[L::SORIG + lane];
+            const int rho = rb[L::RANK + lane];
+            const int b0 = L::seg(wave);
+            double cur = inf;
+            if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+            double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
+            const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
+            const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
+            stamp(2);
+            double tmp[SCS_CELLS_DEPTH];
+            unsigned x1, x2;
+            SCS_CELLS_EXPAND_ASM(acc, tmp, x1, x2, addr, vn, cur, (int)__double2loint(g_rank),
+                                 __double2hiint(g_rank), so_rank, rho, rowb, colb, b0, DV_LD * 8);
+            stamp(3);
+            SCS_BARE_BARRIER();
+            stamp(4);
+        }
+    }
+
+    if (STAMPED && lane == 0 && p.stamps) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
+        atomicAdd(&p.stamps[7], 1ull);
+    }
+    // (the producers join the barriers of the mirror image with a staging region of their own)
+    tile_store_wide<SYM>(p, acc, tile, active && !producer, ti, row0, col, self, ltid, lane, wl,
+                         (double *)s_mem + (size_t)(producer ? 2 : sub) * MONO_TCW * 9);
+}

@@ -557,9 +557,10 @@ def test_shared_build_multi_batch(dev, monkeypatch):
 # It is chosen by itself once the groups fill the chip (the configs[2]-size tests and the
 # bench run it); SCS_WIDE=1 puts the small shapes through it, SCS_WIDE=2 through the pipelined
 # eight-wave kernel (k_accumulate_pipe: two tiles per workgroup, the table expansion woven into
-# the cell loop, the two sub-tiles half a step apart).
+# the cell loop, the two sub-tiles half a step apart), SCS_WIDE=3 through the producer / consumer
+# kernel (k_accumulate_spec: eight consumer waves, four producer waves).
 # ---------------------------------------------------------------------------
-WIDE_MODES = ["1", "2"]
+WIDE_MODES = ["1", "2", "3"]
 
 
 @pytest.mark.parametrize("wide", WIDE_MODES)
@@ -618,7 +619,7 @@ def test_wide_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
     # the two kernels against each other, whole matrix, and sampled rows against the oracle
     tables = synthetic.make_tables(3, 3000, 300, "branch", random_weights=True)
     got = {}
-    for wide in ("0", "1", "2"):
+    for wide in ("0", "1", "2", "3"):
         monkeypatch.setenv("SCS_WIDE", wide)
         dtab = dev.upload(tables)
         g = dtab.build()
@@ -626,7 +627,7 @@ def test_wide_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
         assert g.build_stats["n_batches"] > 1
         g.free()
         dtab.free()
-    assert np.array_equal(got["0"], got["1"]) and np.array_equal(got["0"], got["2"])
+    assert all(np.array_equal(got["0"], got[k]) for k in ("1", "2", "3"))
     rows = np.unique(np.random.RandomState(2).randint(0, 3000, size=12)).astype(np.int32)
     assert np.array_equal(got["1"][rows], to.pcg_rows(tables, rows))
     assert np.array_equal(got["1"], got["1"].T) and not np.any(np.diag(got["1"]))

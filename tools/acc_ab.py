@@ -25,7 +25,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    modes = os.environ.get("ACC_AB_MODES", "0,1,2,0,2").split(",")
+    modes = os.environ.get("ACC_AB_MODES", "0,3,0,3").split(",")
     tables = synthetic.make_tables(0, n, m, "branch", pinned=True)
     rows = np.unique(np.random.RandomState(1).randint(0, n, size=12)).astype(np.int32)
     want = to.pcg_rows(tables, rows)
