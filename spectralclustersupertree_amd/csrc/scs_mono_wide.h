@@ -769,10 +769,15 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         pself[k] = (c >= row0 && c < row0 + SCS_TR && c < p.row_end) ? c - row0 : -1;
         cpos[k] = -1;
     }
-    // the column step of k_accumulate_mono for tree t and both columns: search, one range-minimum
-    // query each (all four loads in flight together), then the pair (table row address, value)
-    // goes to slot t & 1 of the hand-off arrays; also requests the positions in tree t + 1
-    auto produce = [&](int t) {
+    // the column step of k_accumulate_mono for both columns, in two halves a whole step apart:
+    // `search` (tree t) finds the neighbours and ISSUES the one range-minimum query per column --
+    // four loads, in flight across the barrier -- and requests the positions in tree t + 1;
+    // `finish` (a step later) turns the answers into the pair (table row address, own value) in
+    // slot t & 1 of the hand-off arrays
+    double qx[2] = {0.0, 0.0}, qy[2] = {0.0, 0.0};
+    int cstate[2] = {0, 0};
+    auto search = [&](int t_raw) {
+        const int t = min(t_raw, nt - 1);
         const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
         const int *s_spos = (const int *)(rb + L::SPOS);
         const int *s_arg = (const int *)(rb + L::ARGPOS);
@@ -785,8 +790,6 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
         const int4 pa = *(const int4 *)&s_piv[0];
         const int4 pb = *(const int4 *)&s_piv[4];
-        double qx[2], qy[2];
-        int cstate[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int cp = cpos[k];
@@ -815,6 +818,8 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], min(t + 1, nt - 1) * (int)p.npad * 4, 0);
+    };
+    auto finish = [&](int t) {
         const unsigned tbase =
             (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_t[(t & 1) * DT_DOUBLES];
 #pragma unroll
@@ -871,8 +876,13 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (producer) produce(0);
-    else expand_whole(0);
+    if (producer) {
+        search(0);
+        finish(0);  // (waits for tree 0's answers: once per launch)
+        search(1);
+    } else {
+        expand_whole(0);
+    }
     SCS_BARE_BARRIER();
     if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 
@@ -883,11 +893,14 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // keeps them in scratch memory between the steps; and ONE cell statement in the kernel (a
     // second one with 64 tied accumulators makes it keep two sets).
     if (producer) {
+        // on entry: the queries of tree tl + 1 are in flight (issued a step ago)
         for (int tl = 0; tl < nt; ++tl) {
-            if (tl + 1 < nt) produce(tl + 1);
+            if (tl + 1 < nt) finish(tl + 1);
             stamp(0);
             if (tl + 3 < nt) issue_record(tl + 3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            search(tl + 2);  // six loads (four table entries, two positions), consumed a step later
+            // the record pieces are older than those six: they have landed, the queries stay in flight
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             stamp(1);
             SCS_BARE_BARRIER();
             stamp(4);
