@@ -675,8 +675,9 @@ struct spec_layout {
     using L = wide_layout<2>;
     static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
     static constexpr size_t O_T = 0;                                      // double[2][DT_DOUBLES]
-    static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [3][L::BYTES]
-    static constexpr size_t O_VN = O_REC + 3 * (size_t)L::BYTES;         // double[2][512]
+    static constexpr int NREC = 4;  // records of trees t + 1 ... t + 4 during step t
+    static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [NREC][L::BYTES]
+    static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[2][512]
     static constexpr size_t O_ADDR = O_VN + 2 * 512 * 8;                 // unsigned[2][512]
     static constexpr size_t LDS_BYTES = O_ADDR + 2 * 512 * 4;
     static_assert(O_VN % 16 == 0 && 3 * (size_t)MONO_TCW * 9 * 8 <= LDS_BYTES, "layout");
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     const int lane16 = lane * 16;
 
     // ---------------- producer side ----------------
-    // record of tree t lives in s_rec[t % 3]; producer pw copies pieces pw and pw + 4
+    // record of tree t lives in s_rec[t % NREC]; producer pw copies pieces pw and pw + 4
     auto issue_record = [&](int t) {
 #pragma unroll
         for (int pc = 0; pc < L::PIECES; pc += S::PRODUCERS) {
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
                 if (lane < left)
                     lds_dma16_asm(rs_rec,
                                   (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
-                                      s_rec + (t % 3) * L::BYTES + piece * 1024),
+                                      s_rec + (t % S::NREC) * L::BYTES + piece * 1024),
                                   lane16, t * L::BYTES + piece * 1024);
             }
         }
@@ -772,13 +773,16 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // the column step of k_accumulate_mono for both columns, in two halves a whole step apart:
     // `search` (tree t) finds the neighbours and ISSUES the one range-minimum query per column --
     // four loads, in flight across the barrier -- and requests the positions in tree t + 1;
-    // `finish` (a step later) turns the answers into the pair (table row address, own value) in
-    // slot t & 1 of the hand-off arrays
-    double qx[2] = {0.0, 0.0}, qy[2] = {0.0, 0.0};
-    int cstate[2] = {0, 0};
-    auto search = [&](int t_raw) {
+    // `finish` (TWO steps later: a step is about 2 us, a query that misses the L2 takes as long)
+    // turns the answers into the pair (table row address, own value) in slot t & 1 of the
+    // hand-off arrays
+    struct query {
+        double qx[2], qy[2];
+        int cstate[2];
+    };
+    auto search = [&](int t_raw, query &q) {
         const int t = min(t_raw, nt - 1);
-        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
+        const unsigned char *rb = s_rec + (t % S::NREC) * L::BYTES;
         const int *s_spos = (const int *)(rb + L::SPOS);
         const int *s_arg = (const int *)(rb + L::ARGPOS);
         const unsigned char *s_sorig = rb + L::SORIG;
@@ -808,28 +812,28 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
             const bool left = hasl && (!hasr || s_arg[il] >= cp);
             const int q_anchor = s_spos[left ? il : ir];
             const int nbrow = s_sorig[left ? il : ir];
-            cstate[k] = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && pself[k] >= 0) ? 512 : 0);
+            q.cstate[k] = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && pself[k] >= 0) ? 512 : 0);
             const bool any = hasl || hasr;
             int o[2];
             rmq_offsets(m, any ? (left ? q_anchor : cp) : 0, any ? (left ? cp : q_anchor) : 1, o);
-            qx[k] = *(const double *)(st + (unsigned)o[0] * 8u);
-            qy[k] = *(const double *)(st + (unsigned)o[1] * 8u);
+            q.qx[k] = *(const double *)(st + (unsigned)o[0] * 8u);
+            q.qy[k] = *(const double *)(st + (unsigned)o[1] * 8u);
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], min(t + 1, nt - 1) * (int)p.npad * 4, 0);
     };
-    auto finish = [&](int t) {
+    auto finish = [&](int t, const query &q) {
         const unsigned tbase =
             (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_t[(t & 1) * DT_DOUBLES];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             int nb = 0;
             double vn = 0.0;
-            if (cstate[k] & 256) {
-                vn = min_f64(qx[k], qy[k]);
-                nb = cstate[k] & 255;
-            } else if (cstate[k] & 512) {
+            if (q.cstate[k] & 256) {
+                vn = min_f64(q.qx[k], q.qy[k]);
+                nb = q.cstate[k] & 255;
+            } else if (q.cstate[k] & 512) {
                 nb = pself[k];
                 vn = inf;
             }
@@ -841,7 +845,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
 
     // ---------------- consumer side ----------------
     auto expand_whole = [&](int t) {
-        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
+        const unsigned char *rb = s_rec + (t % S::NREC) * L::BYTES;
         double *dv = s_t + (t & 1) * DT_DOUBLES;
         const int b0 = L::seg(wave);
         const double g_rank = ((const double *)(rb + L::G))[lane];
@@ -871,15 +875,18 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         issue_record(0);
         if (nt > 1) issue_record(1);
         if (nt > 2) issue_record(2);
+        if (nt > 3) issue_record(3);
 #pragma unroll
         for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa;
     if (producer) {
-        search(0);
-        finish(0);  // (waits for tree 0's answers: once per launch)
-        search(1);
+        search(0, qa);
+        finish(0, qa);  // (waits for tree 0's answers: once per launch)
+        search(1, qa);
+        search(2, qb);
     } else {
         expand_whole(0);
     }
@@ -893,24 +900,31 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // keeps them in scratch memory between the steps; and ONE cell statement in the kernel (a
     // second one with 64 tied accumulators makes it keep two sets).
     if (producer) {
-        // on entry: the queries of tree tl + 1 are in flight (issued a step ago)
-        for (int tl = 0; tl < nt; ++tl) {
-            if (tl + 1 < nt) finish(tl + 1);
+        __builtin_amdgcn_s_setprio(2);  // few instructions, all of them on the critical path of the step
+        // on entry of step tl: the queries of tree tl + 1 (in `q1`, issued two steps ago) and of tree
+        // tl + 2 (issued a step ago) are in flight; the two sets alternate
+        auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
+            // the record pieces first: they are the oldest loads when the step's wait comes
+            if (tl + 4 < nt) issue_record(tl + 4);
+            if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
-            if (tl + 3 < nt) issue_record(tl + 3);
-            search(tl + 2);  // six loads (four table entries, two positions), consumed a step later
-            // the record pieces are older than those six: they have landed, the queries stay in flight
+            search(tl + 3, q1);  // six loads (four table entries, two positions), consumed two steps on
+            // all but the six youngest: the record has landed (and the other set's answers)
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             stamp(1);
             SCS_BARE_BARRIER();
             stamp(4);
+        };
+        for (int tl = 0; tl < nt; tl += 2) {
+            step(tl, qa);
+            if (tl + 1 < nt) step(tl + 1, qb);
         }
     } else {
         for (int tl = 0; tl < nt; ++tl) {
             const int slot = (tl & 1) * 512 + wave * 64 + lane;
             const double vn = s_vn[slot];
             const unsigned addr = s_addr[slot];
-            const unsigned char *rb = s_rec + (min(tl + 1, nt - 1) % 3) * L::BYTES;
+            const unsigned char *rb = s_rec + (min(tl + 1, nt - 1) % S::NREC) * L::BYTES;
             const double g_rank = ((const double *)(rb + L::G))[lane];
             const int so_rank = rb[L::SORIG + lane];
             const int rho = rb[L::RANK + lane];
@@ -936,7 +950,19 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
         atomicAdd(&p.stamps[7], 1ull);
     }
-    // (the producers join the barriers of the mirror image with a staging region of their own)
-    tile_store_wide<SYM>(p, acc, tile, active && !producer, ti, row0, col, self, ltid, lane, wl,
-                         (double *)s_mem + (size_t)(producer ? 2 : sub) * MONO_TCW * 9);
+    // (a producer has no sums and must not appear to use the accumulators: 128 registers would be
+    // held through its loop, the queries would spill, and a spill is a vector-memory operation the
+    // counted vmcnt wait does not know about.  It only joins the barriers of the mirror image.)
+    if (producer) {
+        if (!p.tile_out && SYM && p.mirror) {
+#pragma unroll
+            for (int q = 0; q < SCS_TR / 8; ++q) {
+                SCS_BARE_BARRIER();
+                SCS_BARE_BARRIER();
+            }
+        }
+    } else {
+        tile_store_wide<SYM>(p, acc, tile, active, ti, row0, col, self, ltid, lane, wl,
+                             (double *)s_mem + (size_t)sub * MONO_TCW * 9);
+    }
 }
