@@ -726,17 +726,6 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     const int col = tile.y * MONO_TCW + ltid;
     const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
 
-    double acc[SCS_TR];
-#pragma unroll
-    for (int i = 0; i < SCS_TR; ++i) {
-        double v = 0.0;
-        if (!producer && active && p.load_w && p.tile_out)
-            v = p.tile_out[((int64_t)ti * SCS_TR + i) * MONO_TCW + ltid];
-        else if (!producer && active && p.load_w && col < p.n && row0 + i < p.row_end)
-            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
-        acc[i] = v;
-    }
-
     const unsigned char *rec_base = p.rec + (int64_t)blk * nt * L::BYTES;
     const scs_int4 rs_rec = {(int)(unsigned)(u64)rec_base, (int)(((u64)rec_base >> 32) & 0xffffu),
                              nt * L::BYTES, 0x00020000};
@@ -870,44 +859,36 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         }
     };
 
-    // ---- prologue: records 0, 1, 2; tree 0's table and column pairs
+    // Two code paths from here on, one per role, with the same sequence of barriers.  The
+    // accumulators exist in the consumers' path only: were they in scope of the producers' loop,
+    // 128 registers would be held through it, the queries would spill, and every reload of a spill
+    // is a vector-memory operation behind an s_waitcnt vmcnt(0) -- which drains the very loads the
+    // producer is there to keep in flight.  (And ONE cell statement in the kernel: a second one with
+    // 64 tied accumulators makes the register allocator keep two sets.)
     if (producer) {
+        // ---- prologue: records 0 ... 3, tree 0's column pairs, the queries of trees 1 and 2
         issue_record(0);
         if (nt > 1) issue_record(1);
         if (nt > 2) issue_record(2);
         if (nt > 3) issue_record(3);
 #pragma unroll
         for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa;
-    if (producer) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SCS_BARE_BARRIER();
+        query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa;
         search(0, qa);
         finish(0, qa);  // (waits for tree 0's answers: once per launch)
         search(1, qa);
         search(2, qb);
-    } else {
-        expand_whole(0);
-    }
-    SCS_BARE_BARRIER();
-    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-
-    // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
-    // s_t[tl & 1], its column pairs in slot tl & 1; the records of trees tl + 1 and tl + 2 are in
-    // place.  Two loops, one per role, the same number of barriers in each: in ONE loop the
-    // accumulators would be live across the producers' branch as well and the register allocator
-    // keeps them in scratch memory between the steps; and ONE cell statement in the kernel (a
-    // second one with 64 tied accumulators makes it keep two sets).
-    if (producer) {
+        SCS_BARE_BARRIER();
+        if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
         __builtin_amdgcn_s_setprio(2);  // few instructions, all of them on the critical path of the step
-        // on entry of step tl: the queries of tree tl + 1 (in `q1`, issued two steps ago) and of tree
-        // tl + 2 (issued a step ago) are in flight; the two sets alternate
+        // Step tl.  On entry: the queries of tree tl + 1 (in `q1`, issued two steps ago) and of tree
+        // tl + 2 (issued a step ago) are in flight; the two sets alternate.
         auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
-            // the record pieces first: they are the oldest loads when the step's wait comes
-            if (tl + 4 < nt) issue_record(tl + 4);
             if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
+            if (tl + 4 < nt) issue_record(tl + 4);
             search(tl + 3, q1);  // six loads (four table entries, two positions), consumed two steps on
             // all but the six youngest: the record has landed (and the other set's answers)
             asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -919,7 +900,37 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
             step(tl, qa);
             if (tl + 1 < nt) step(tl + 1, qb);
         }
+        if (STAMPED && lane == 0 && p.stamps) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
+            atomicAdd(&p.stamps[7], 1ull);
+        }
+        // the barriers of the consumers' mirror image
+        if (!p.tile_out && SYM && p.mirror) {
+#pragma unroll
+            for (int q = 0; q < SCS_TR / 8; ++q) {
+                SCS_BARE_BARRIER();
+                SCS_BARE_BARRIER();
+            }
+        }
     } else {
+        double acc[SCS_TR];
+#pragma unroll
+        for (int i = 0; i < SCS_TR; ++i) {
+            double v = 0.0;
+            if (active && p.load_w && p.tile_out)
+                v = p.tile_out[((int64_t)ti * SCS_TR + i) * MONO_TCW + ltid];
+            else if (active && p.load_w && col < p.n && row0 + i < p.row_end)
+                v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
+            acc[i] = v;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SCS_BARE_BARRIER();  // the records are in place
+        expand_whole(0);
+        SCS_BARE_BARRIER();
+        if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+        // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
+        // s_t[tl & 1], its column pairs in slot tl & 1; the record of tree tl + 1 is in place.
         for (int tl = 0; tl < nt; ++tl) {
             const int slot = (tl & 1) * 512 + wave * 64 + lane;
             const double vn = s_vn[slot];
@@ -943,25 +954,11 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
             SCS_BARE_BARRIER();
             stamp(4);
         }
-    }
-
-    if (STAMPED && lane == 0 && p.stamps) {
+        if (STAMPED && lane == 0 && p.stamps) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
-        atomicAdd(&p.stamps[7], 1ull);
-    }
-    // (a producer has no sums and must not appear to use the accumulators: 128 registers would be
-    // held through its loop, the queries would spill, and a spill is a vector-memory operation the
-    // counted vmcnt wait does not know about.  It only joins the barriers of the mirror image.)
-    if (producer) {
-        if (!p.tile_out && SYM && p.mirror) {
-#pragma unroll
-            for (int q = 0; q < SCS_TR / 8; ++q) {
-                SCS_BARE_BARRIER();
-                SCS_BARE_BARRIER();
-            }
+            for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
+            atomicAdd(&p.stamps[7], 1ull);
         }
-    } else {
         tile_store_wide<SYM>(p, acc, tile, active, ti, row0, col, self, ltid, lane, wl,
                              (double *)s_mem + (size_t)sub * MONO_TCW * 9);
     }
