@@ -27,7 +27,9 @@ struct wide_layout {
     static constexpr int NSEG = 4 * NG;  // expansion segments = waves
     static constexpr int SPOS = 0;       // int32[64]  sorted DFS positions (INT_MAX beyond cnt)
     static constexpr int G = 256;        // f64[64]    value of LCA(sorted k, sorted k+1); 0 beyond cnt-1
-    static constexpr int SEED = 768;     // f64[NSEG-1][64] seed[w-1][a] = min g[a .. seg(w)-1] for a < seg(w)
+    static constexpr int SEED = 768;     // f64[NSEG-1][64] seed[w-1][i] = min g[rank(i) .. seg(w)-1] for the ROW i
+                                         // whose rank lies below seg(w), +inf for the other rows: a lane of
+                                         // the tile kernels reads its own entry, no rank look-up in front
     static constexpr int ARGPOS = SEED + (NSEG - 1) * 512;  // int32[64]
     static constexpr int SORIG = ARGPOS + 256;              // u8[64]
     static constexpr int RANK = SORIG + 64;                 // u8[64]
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(64) void k_block_records_wide(
             const double other = __shfl_down(mine, off, 64);
             if (lane + off < end) mine = min_f64(mine, other);
         }
-        seed[(w - 1) * 64 + lane] = mine;
+        seed[(w - 1) * 64 + orig] = lane < end ? mine : inf;  // (absent rows take the ranks >= cnt: +inf or 0-chains, never read below seg)
     }
 }
 
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_wide(wide_params w
         const int so_rank = rb[L::SORIG + lane];
         const int rho = rb[L::RANK + lane];
         double cur = inf;
-        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
         double *row_a = &dv[lane * DV_LD];
         double *col_a = &dv[lane];
 #pragma unroll
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_pipe(wide_params w
         const int so_rank = rb[L::SORIG + lane];
         const int rho = rb[L::RANK + lane];
         double cur = inf;
-        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
         double *row_a = &dv[lane * DV_LD];
         double *col_a = &dv[lane];
 #pragma unroll
@@ -622,7 +624,7 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_pipe(wide_params w
         const int rho = rb[L::RANK + lane];
         const int b0 = L::seg(wave);
         double cur = inf;
-        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
         double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
         const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
         const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
@@ -735,19 +737,17 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     const int lane16 = lane * 16;
 
     // ---------------- producer side ----------------
-    // record of tree t lives in s_rec[t % NREC]; producer pw copies pieces pw and pw + 4
+    // record of tree t lives in s_rec[t % NREC]; CONSUMER wave w copies piece w.  (Loads return in
+    // order: behind a producer's range-minimum queries -- misses of the L2 at 50 000 leaves, 2-3 us --
+    // a record would wait for them, and the step with it; a consumer has no other load in flight.)
     auto issue_record = [&](int t) {
-#pragma unroll
-        for (int pc = 0; pc < L::PIECES; pc += S::PRODUCERS) {
-            const int piece = pc + pw;
-            if (piece < L::PIECES) {
-                const int left = (L::BYTES - piece * 1024) / 16;
-                if (lane < left)
-                    lds_dma16_asm(rs_rec,
-                                  (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
-                                      s_rec + (t % S::NREC) * L::BYTES + piece * 1024),
-                                  lane16, t * L::BYTES + piece * 1024);
-            }
+        if (wave < L::PIECES) {
+            const int left = (L::BYTES - wave * 1024) / 16;
+            if (lane < left)
+                lds_dma16_asm(rs_rec,
+                              (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
+                                  s_rec + (t % S::NREC) * L::BYTES + wave * 1024),
+                              lane16, t * L::BYTES + wave * 1024);
         }
     };
     // the two columns of this lane (one per consumer wave served) and their positions in the
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         const int so_rank = rb[L::SORIG + lane];
         const int rho = rb[L::RANK + lane];
         double cur = inf;
-        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
         double *row_a = &dv[lane * DV_LD];
         double *col_a = &dv[lane];
 #pragma unroll
@@ -867,12 +867,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // producer is there to keep in flight.  (And ONE cell statement in the kernel: a second one with
     // 64 tied accumulators makes the register allocator keep two sets.)
     if (producer) {
-        // ---- prologue: records 0 ... 4, the column pairs of trees 0 and 1, the queries of trees 2 and 3
-        issue_record(0);
-        if (nt > 1) issue_record(1);
-        if (nt > 2) issue_record(2);
-        if (nt > 3) issue_record(3);
-        if (nt > 4) issue_record(4);
+        // ---- prologue: the column pairs of trees 0 and 1, the queries of trees 2 and 3
 #pragma unroll
         for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -893,10 +888,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         auto step = [&](int tl, query &q2) __attribute__((always_inline)) {
             if (tl + 2 < nt) finish(tl + 2, q2);
             stamp(0);
-            if (tl + 5 < nt) issue_record(tl + 5);
             search(tl + 4, q2);  // six loads (four table entries, two positions), consumed two steps on
-            // all but the six youngest: the record has landed (and the other set's answers)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             stamp(1);
             SCS_BARE_BARRIER();
             stamp(4);
@@ -929,6 +921,11 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
                 v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
             acc[i] = v;
         }
+        issue_record(0);
+        if (nt > 1) issue_record(1);
+        if (nt > 2) issue_record(2);
+        if (nt > 3) issue_record(3);
+        if (nt > 4) issue_record(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SCS_BARE_BARRIER();  // the records are in place
         expand_whole(0);
@@ -952,13 +949,14 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
             so_rank = rb[L::SORIG + lane];
             rho = rb[L::RANK + lane];
             cur = inf;
-            if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
+            if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
         };
         fetch(0);
         for (int tl = 0; tl < nt; ++tl) {
             double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
             const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
             const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
+            if (tl + 5 < nt) issue_record(tl + 5);  // lands while the cells run
             stamp(2);
             {
                 double tmp[SCS_CELLS_DEPTH];
@@ -968,6 +966,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
             }
             stamp(3);
             fetch(tl + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's piece of the record
             SCS_BARE_BARRIER();
             stamp(4);
         }
