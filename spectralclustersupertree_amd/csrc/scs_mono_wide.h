@@ -27,9 +27,7 @@ struct wide_layout {
     static constexpr int NSEG = 4 * NG;  // expansion segments = waves
     static constexpr int SPOS = 0;       // int32[64]  sorted DFS positions (INT_MAX beyond cnt)
     static constexpr int G = 256;        // f64[64]    value of LCA(sorted k, sorted k+1); 0 beyond cnt-1
-    static constexpr int SEED = 768;     // f64[NSEG-1][64] seed[w-1][i] = min g[rank(i) .. seg(w)-1] for the ROW i
-                                         // whose rank lies below seg(w), +inf for the other rows: a lane of
-                                         // the tile kernels reads its own entry, no rank look-up in front
+    static constexpr int SEED = 768;     // f64[NSEG-1][64] seed[w-1][a] = min g[a .. seg(w)-1] for a < seg(w)
     static constexpr int ARGPOS = SEED + (NSEG - 1) * 512;  // int32[64]
     static constexpr int SORIG = ARGPOS + 256;              // u8[64]
     static constexpr int RANK = SORIG + 64;                 // u8[64]
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(64) void k_block_records_wide(
             const double other = __shfl_down(mine, off, 64);
             if (lane + off < end) mine = min_f64(mine, other);
         }
-        seed[(w - 1) * 64 + orig] = lane < end ? mine : inf;  // (absent rows take the ranks >= cnt: +inf or 0-chains, never read below seg)
+        seed[(w - 1) * 64 + lane] = mine;
     }
 }
 
@@ -324,7 +322,7 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_wide(wide_params w
         const int so_rank = rb[L::SORIG + lane];
         const int rho = rb[L::RANK + lane];
         double cur = inf;
-        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
         double *row_a = &dv[lane * DV_LD];
         double *col_a = &dv[lane];
 #pragma unroll
@@ -549,7 +547,7 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_pipe(wide_params w
         const int so_rank = rb[L::SORIG + lane];
         const int rho = rb[L::RANK + lane];
         double cur = inf;
-        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
         double *row_a = &dv[lane * DV_LD];
         double *col_a = &dv[lane];
 #pragma unroll
@@ -624,7 +622,7 @@ __global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_pipe(wide_params w
         const int rho = rb[L::RANK + lane];
         const int b0 = L::seg(wave);
         double cur = inf;
-        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
         double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
         const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
         const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
@@ -677,12 +675,11 @@ struct spec_layout {
     using L = wide_layout<2>;
     static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
     static constexpr size_t O_T = 0;                                      // double[2][DT_DOUBLES]
-    static constexpr int NREC = 5;  // records of trees t + 1 ... t + 5 during step t
-    static constexpr int NSLOT = 3; // hand-off slots: trees t (in use), t + 1 (being prefetched), t + 2 (being written)
+    static constexpr int NREC = 4;  // records of trees t + 1 ... t + 4 during step t
     static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [NREC][L::BYTES]
-    static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[NSLOT][512]
-    static constexpr size_t O_ADDR = O_VN + NSLOT * 512 * 8;             // unsigned[NSLOT][512]
-    static constexpr size_t LDS_BYTES = O_ADDR + NSLOT * 512 * 4;
+    static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[2][512]
+    static constexpr size_t O_ADDR = O_VN + 2 * 512 * 8;                 // unsigned[2][512]
+    static constexpr size_t LDS_BYTES = O_ADDR + 2 * 512 * 4;
     static_assert(O_VN % 16 == 0 && 3 * (size_t)MONO_TCW * 9 * 8 <= LDS_BYTES, "layout");
 };
 
@@ -737,17 +734,19 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     const int lane16 = lane * 16;
 
     // ---------------- producer side ----------------
-    // record of tree t lives in s_rec[t % NREC]; CONSUMER wave w copies piece w.  (Loads return in
-    // order: behind a producer's range-minimum queries -- misses of the L2 at 50 000 leaves, 2-3 us --
-    // a record would wait for them, and the step with it; a consumer has no other load in flight.)
+    // record of tree t lives in s_rec[t % NREC]; producer pw copies pieces pw and pw + 4
     auto issue_record = [&](int t) {
-        if (wave < L::PIECES) {
-            const int left = (L::BYTES - wave * 1024) / 16;
-            if (lane < left)
-                lds_dma16_asm(rs_rec,
-                              (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
-                                  s_rec + (t % S::NREC) * L::BYTES + wave * 1024),
-                              lane16, t * L::BYTES + wave * 1024);
+#pragma unroll
+        for (int pc = 0; pc < L::PIECES; pc += S::PRODUCERS) {
+            const int piece = pc + pw;
+            if (piece < L::PIECES) {
+                const int left = (L::BYTES - piece * 1024) / 16;
+                if (lane < left)
+                    lds_dma16_asm(rs_rec,
+                                  (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
+                                      s_rec + (t % S::NREC) * L::BYTES + piece * 1024),
+                                  lane16, t * L::BYTES + piece * 1024);
+            }
         }
     };
     // the two columns of this lane (one per consumer wave served) and their positions in the
@@ -764,8 +763,8 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // `search` (tree t) finds the neighbours and ISSUES the one range-minimum query per column --
     // four loads, in flight across the barrier -- and requests the positions in tree t + 1;
     // `finish` (TWO steps later: a step is about 2 us, a query that misses the L2 takes as long)
-    // turns the answers into the pair (table row address, own value) in slot t % 3 of the
-    // hand-off arrays -- a whole step before the consumers fetch it
+    // turns the answers into the pair (table row address, own value) in slot t & 1 of the
+    // hand-off arrays
     struct query {
         double qx[2], qy[2];
         int cstate[2];
@@ -827,7 +826,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
                 nb = pself[k];
                 vn = inf;
             }
-            const int slot = (t % S::NSLOT) * 512 + (2 * pw + k) * 64 + lane;
+            const int slot = (t & 1) * 512 + (2 * pw + k) * 64 + lane;
             s_vn[slot] = vn;
             s_addr[slot] = tbase + (unsigned)nb * (DV_LD * 8);
         }
@@ -842,7 +841,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         const int so_rank = rb[L::SORIG + lane];
         const int rho = rb[L::RANK + lane];
         double cur = inf;
-        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
         double *row_a = &dv[lane * DV_LD];
         double *col_a = &dv[lane];
 #pragma unroll
@@ -867,28 +866,32 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // producer is there to keep in flight.  (And ONE cell statement in the kernel: a second one with
     // 64 tied accumulators makes the register allocator keep two sets.)
     if (producer) {
-        // ---- prologue: the column pairs of trees 0 and 1, the queries of trees 2 and 3
+        // ---- prologue: records 0 ... 3, tree 0's column pairs, the queries of trees 1 and 2
+        issue_record(0);
+        if (nt > 1) issue_record(1);
+        if (nt > 2) issue_record(2);
+        if (nt > 3) issue_record(3);
 #pragma unroll
         for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SCS_BARE_BARRIER();
         query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa;
         search(0, qa);
-        search(1, qb);
-        finish(0, qa);  // (waits for the answers: once per launch)
-        if (nt > 1) finish(1, qb);
-        search(2, qa);
-        search(3, qb);
+        finish(0, qa);  // (waits for tree 0's answers: once per launch)
+        search(1, qa);
+        search(2, qb);
         SCS_BARE_BARRIER();
         if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
         __builtin_amdgcn_s_setprio(2);  // few instructions, all of them on the critical path of the step
-        // Step tl.  On entry: the pairs of trees tl and tl + 1 are in place; the queries of tree tl + 2
-        // (in `q2`, issued two steps ago) and of tree tl + 3 (a step ago) are in flight; the two sets
-        // alternate.
-        auto step = [&](int tl, query &q2) __attribute__((always_inline)) {
-            if (tl + 2 < nt) finish(tl + 2, q2);
+        // Step tl.  On entry: the queries of tree tl + 1 (in `q1`, issued two steps ago) and of tree
+        // tl + 2 (issued a step ago) are in flight; the two sets alternate.
+        auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
+            if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
-            search(tl + 4, q2);  // six loads (four table entries, two positions), consumed two steps on
+            if (tl + 4 < nt) issue_record(tl + 4);
+            search(tl + 3, q1);  // six loads (four table entries, two positions), consumed two steps on
+            // all but the six youngest: the record has landed (and the other set's answers)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             stamp(1);
             SCS_BARE_BARRIER();
             stamp(4);
@@ -921,52 +924,33 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
                 v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
             acc[i] = v;
         }
-        issue_record(0);
-        if (nt > 1) issue_record(1);
-        if (nt > 2) issue_record(2);
-        if (nt > 3) issue_record(3);
-        if (nt > 4) issue_record(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SCS_BARE_BARRIER();  // the records are in place
         expand_whole(0);
         SCS_BARE_BARRIER();
         if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
         // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
-        // s_t[tl & 1]; the column's pair of tree tl and the wave's expansion state of tree tl + 1 are
-        // in registers already -- fetched BEFORE the barrier (the pairs of tree tl + 1 were written a
-        // whole step earlier, the record of tree tl + 2 landed two steps ago), so a step opens with
-        // the cell loop, not with a round trip to an idle LDS.
-        const int b0 = L::seg(wave);
-        double vn, g_rank, cur;
-        unsigned addr;
-        int so_rank, rho;
-        auto fetch = [&](int t) {  // pair of tree t, expansion state of tree t + 1
-            const int slot = (min(t, nt - 1) % S::NSLOT) * 512 + wave * 64 + lane;
-            vn = s_vn[slot];
-            addr = s_addr[slot];
-            const unsigned char *rb = s_rec + (min(t + 1, nt - 1) % S::NREC) * L::BYTES;
-            g_rank = ((const double *)(rb + L::G))[lane];
-            so_rank = rb[L::SORIG + lane];
-            rho = rb[L::RANK + lane];
-            cur = inf;
-            if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
-        };
-        fetch(0);
+        // s_t[tl & 1], its column pairs in slot tl & 1; the record of tree tl + 1 is in place.
         for (int tl = 0; tl < nt; ++tl) {
+            const int slot = (tl & 1) * 512 + wave * 64 + lane;
+            const double vn = s_vn[slot];
+            const unsigned addr = s_addr[slot];
+            const unsigned char *rb = s_rec + (min(tl + 1, nt - 1) % S::NREC) * L::BYTES;
+            const double g_rank = ((const double *)(rb + L::G))[lane];
+            const int so_rank = rb[L::SORIG + lane];
+            const int rho = rb[L::RANK + lane];
+            const int b0 = L::seg(wave);
+            double cur = inf;
+            if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
             double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
             const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
             const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
-            if (tl + 5 < nt) issue_record(tl + 5);  // lands while the cells run
             stamp(2);
-            {
-                double tmp[SCS_CELLS_DEPTH];
-                unsigned x1, x2;
-                SCS_CELLS_EXPAND_ASM(acc, tmp, x1, x2, addr, vn, cur, (int)__double2loint(g_rank),
-                                     __double2hiint(g_rank), so_rank, rho, rowb, colb, b0, DV_LD * 8);
-            }
+            double tmp[SCS_CELLS_DEPTH];
+            unsigned x1, x2;
+            SCS_CELLS_EXPAND_ASM(acc, tmp, x1, x2, addr, vn, cur, (int)__double2loint(g_rank),
+                                 __double2hiint(g_rank), so_rank, rho, rowb, colb, b0, DV_LD * 8);
             stamp(3);
-            fetch(tl + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's piece of the record
             SCS_BARE_BARRIER();
             stamp(4);
         }
