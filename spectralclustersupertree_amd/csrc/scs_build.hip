@@ -681,22 +681,26 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                  hipMemcpyHostToDevice, s));
 
-    // ---- wide workgroups (scs_mono_wide.h): up to three tiles of ONE row block per workgroup,
-    // the row block's table expanded once for all of them.  Worth it once the groups fill the
-    // chip (one twelve-wave workgroup per CU); a handful of tiles -- a node of the deep recursion
-    // -- keeps one workgroup per tile.  SCS_WIDE=0 / 1 force either kernel (A/B runs).
-    constexpr int WIDE_NG = 3, PIPE_NG = 2;
-    // SCS_WIDE: 0 the 4-wave kernel, 1 the 12-wave kernel, 2 the pipelined 8-wave kernel
-    int wide_mode = (monotone && !scatter && tiles.size() >= 3 * 256) ? 1 : 0;
-    if (const char *e = getenv("SCS_WIDE")) wide_mode = (monotone && !scatter && !tiles.empty()) ? atoi(e) : 0;
-    // (3: the producer / consumer kernel, same groups and records as 2)
-    const bool wide = wide_mode != 0, pipe = wide_mode == 2 || wide_mode == 3, spec = wide_mode == 3;
-    const int group_tiles = pipe ? PIPE_NG : WIDE_NG;
+    // ---- producer / consumer workgroups (scs_mono_wide.h): two tiles of ONE row block per workgroup,
+    // the row block's table expanded once for both, four more waves running the column step ahead
+    // of the cells.  Worth it once the groups fill the chip (one twelve-wave workgroup per CU) and
+    // while the producers' range-minimum queries mostly hit the L2 (measured: -7.5 % at 10 000
+    // leaves per tree, +2.5 % at 50 000); a handful of tiles -- a node of the deep recursion --
+    // keeps one workgroup per tile.  SCS_WIDE=0 / 3 force either kernel (A/B runs, tests).
+    constexpr int PIPE_NG = 2;
+    int wide_mode = 0;
+    {
+        const double avg_leaves = (double)tb->n_leaves / std::max(tb->n_trees, 1);
+        if (monotone && !scatter && tiles.size() >= 3 * 256 && avg_leaves <= 20000.0) wide_mode = 3;
+    }
+    if (const char *e = getenv("SCS_WIDE")) wide_mode = (monotone && !scatter && !tiles.empty() && atoi(e)) ? 3 : 0;
+    const bool wide = wide_mode != 0;
+    const int group_tiles = PIPE_NG;
     std::vector<int4> groups;
     dev_buf d_groups;
     if (wide) {
-        rec_bytes = pipe ? wide_layout<PIPE_NG>::BYTES : wide_layout<WIDE_NG>::BYTES;
-        // the tiles of a row block in list order, three at a time; XCD x is handed the groups of
+        rec_bytes = wide_layout<PIPE_NG>::BYTES;
+        // the tiles of a row block in list order, two at a time; XCD x is handed the groups of
         // the row blocks b = x (mod 8), one row block after the other (as the tile order above)
         std::vector<std::vector<int>> of_block((size_t)n_blocks);
         for (size_t i = 0; i < tiles.size(); ++i) of_block[(size_t)tiles[i].x].push_back((int)i);
@@ -820,12 +824,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 k_sparse_level<double><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
                                                               (const int64_t *)d_stoff.p,
                                                               (double *)d_st.p);
-            if (pipe)
+            if (wide)
                 k_block_records_wide<PIPE_NG><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
-                    tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
-                    (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
-            else if (wide)
-                k_block_records_wide<WIDE_NG><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
                     tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
                     (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
             else if (!scatter)
@@ -873,7 +873,6 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.stamps = nullptr;
             static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
             if (wide) {
-                using WL = wide_layout<WIDE_NG>;
                 wide_params wp;
                 wp.m = mp;
                 wp.groups = (const int4 *)d_groups.p;
@@ -885,50 +884,32 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                     wp.m.stamps = (unsigned long long *)d_st8.p;
                 }
                 // (more dynamic LDS than the default 64 KiB: per function and device, set every time)
-#define SCS_LAUNCH_WIDE(SYM_, STAMP_)                                                                   \
+#define SCS_LAUNCH_SPEC(SYM_, STAMP_)                                                                   \
     do {                                                                                                \
-        if (spec) {                                                                                     \
-            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_spec<SYM_, STAMP_>,            \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                              (int)spec_layout::LDS_BYTES));                            \
-            k_accumulate_spec<SYM_, STAMP_>                                                             \
-                <<<ng, spec_layout::THREADS, spec_layout::LDS_BYTES, s>>>(wp);                          \
-        } else if (pipe) {                                                                              \
-            using PL = wide_layout<PIPE_NG>;                                                            \
-            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_pipe<PIPE_NG, SYM_, STAMP_>,   \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                              (int)PL::LDS_BYTES_PIPE));                                \
-            k_accumulate_pipe<PIPE_NG, SYM_, STAMP_>                                                    \
-                <<<ng, PIPE_NG * MONO_TCW, PL::LDS_BYTES_PIPE, s>>>(wp);                                \
-        } else {                                                                                        \
-            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_wide<WIDE_NG, SYM_, STAMP_>,   \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                              (int)WL::LDS_BYTES));                                     \
-            k_accumulate_wide<WIDE_NG, SYM_, STAMP_><<<ng, WIDE_NG * MONO_TCW, WL::LDS_BYTES, s>>>(wp); \
-        }                                                                                               \
+        SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_accumulate_spec<SYM_, STAMP_>,                \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,                   \
+                                          (int)spec_layout::LDS_BYTES));                                \
+        k_accumulate_spec<SYM_, STAMP_><<<ng, spec_layout::THREADS, spec_layout::LDS_BYTES, s>>>(wp);   \
     } while (0)
                 if (ng) {
-                    if (stamp && sym) SCS_LAUNCH_WIDE(true, true);
-                    else if (stamp) SCS_LAUNCH_WIDE(false, true);
-                    else if (sym) SCS_LAUNCH_WIDE(true, false);
-                    else SCS_LAUNCH_WIDE(false, false);
+                    if (stamp && sym) SCS_LAUNCH_SPEC(true, true);
+                    else if (stamp) SCS_LAUNCH_SPEC(false, true);
+                    else if (sym) SCS_LAUNCH_SPEC(true, false);
+                    else SCS_LAUNCH_SPEC(false, false);
                 }
-#undef SCS_LAUNCH_WIDE
+#undef SCS_LAUNCH_SPEC
                 if (stamp) {
                     unsigned long long h[8];
                     SCS_HIP_CHECK(hipMemcpyAsync(h, d_st8.p, 64, hipMemcpyDeviceToHost, s));
                     SCS_HIP_CHECK(hipStreamSynchronize(s));
-                    const char *nm_w[7] = {"combine", "search + issue", "expand (next tree)", "record DMA issue",
-                                           "cells", "wait loads+record", "barrier"};
-                    const char *nm_p[7] = {"combine", "search + issue (early)", "table state + DMA issue",
-                                           "cells + expansion", "search (late) / wait (early)", "barrier", "-"};
-                    const char *nm_s[7] = {"producer: column step", "producer: records + wait", "consumer: pair + table state",
-                                           "consumer: cells + expansion", "barrier", "-", "-"};
-                    const char **nm = spec ? nm_s : (pipe ? nm_p : nm_w);
+                    // (every wave adds its own phases: a producer phase is averaged over all twelve waves
+                    // -- times 3 for the producers' own figure, a consumer phase times 1.5)
+                    const char *nm[5] = {"producer: pairs of the next tree", "producer: records + search + wait",
+                                         "consumer: pair + table state", "consumer: cells + expansion", "barrier"};
                     double tot = 0;
-                    for (int i = 0; i < 7; ++i) tot += (double)h[i];
-                    for (int i = 0; i < 7; ++i)
-                        fprintf(stderr, "[stamp wide] %-24s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i],
+                    for (int i = 0; i < 5; ++i) tot += (double)h[i];
+                    for (int i = 0; i < 5; ++i)
+                        fprintf(stderr, "[stamp spec] %-36s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i],
                                 100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
                 }
             } else if (nt && stamp) {

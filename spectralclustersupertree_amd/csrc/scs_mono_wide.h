@@ -1,26 +1,31 @@
-// Wide variant of the monotone tile kernel (included by scs_build.hip after scs_mono.h).
+// k_accumulate_spec: the monotone tile kernel with producer and consumer waves (included by
+// scs_build.hip after scs_mono.h).  Round 4.
 //
-// Round 4.  profiles/r03_accumulate_phase_stamps.txt and the LDS cycle count of DESIGN.md 3.1:
-// of the ~1 900 LDS cycles a (64 x 256 tile, tree) step costs, 768 are the stores that expand
-// the tile's 64 x 64 row-row table -- and every one of the 40 (10 000 taxa) to 196 (50 000)
-// column tiles of a row block expands the SAME table again.  Here ONE workgroup of 4 NG waves
-// walks the trees for NG column tiles of one row block at once (NG = 3: 64 rows x 768 columns,
-// twelve waves = the three waves per SIMD the 128 accumulator registers allow): the record is
-// staged once, the table expanded once -- 64 / (4 NG) steps per wave -- and used by NG x 256
-// columns.  Round 2's first attempt at wider tiles kept the two barriers and the single table
-// buffer of the 4-wave kernel and lost (+22 % at 768 columns: with one workgroup per CU nothing
-// runs while its waves wait); this kernel has TWO table buffers and ONE barrier per tree: the
-// table of tree t + 1 is expanded into the other buffer before the cells of tree t are read, so
-// a wave meets the others once per tree, after its cell loop.
-//
-// The cells, the column step (one range-minimum query per column, issued one tree ahead) and
-// the arithmetic are those of k_accumulate_mono (scs_mono.h): same addends, same order, same
-// bits (reference: src/sc_supertree/scs.py:644-658).  The external tile geometry (64 x 256,
-// tile lists, packed tiles of the shared multi-rank build, mirror image) is unchanged: a
-// workgroup is handed up to NG tiles of one row block (`groups`).
+// profiles/r03_accumulate_phase_stamps.txt and the LDS cycle count of DESIGN.md 3.1: of the
+// ~1 900 LDS cycles a (64 x 256 tile, tree) step of k_accumulate_mono costs, 768 are the stores
+// that expand the tile's 64 x 64 row-row table -- and every one of the 40 (10 000 taxa) to 196
+// (50 000) column tiles of a row block expands the SAME table again; and the LDS is busy two
+// thirds of the time, because a wave's step is a chain of dependent phases (column search,
+// range-minimum loads, table expansion, cells) that it walks alone.  Three kernels were built
+// on the way here and measured against k_accumulate_mono, all bit-exact (profiles/
+// r04_wide_phase_stamps.txt, r04_cells_probe.txt):
+//   * twelve waves on three column tiles of one row block, two table buffers, one barrier per
+//     tree: the table is expanded once for 768 columns, yet the step is no shorter -- the twelve
+//     waves search, expand and read cells in step with each other and a quarter of the time goes
+//     to the barrier (+10 %);
+//   * eight waves on two tiles with the expansion WOVEN INTO the cell loop and the two tiles
+//     half a step apart: the woven statement runs at exactly the LDS cycles of the step, the LDS
+//     idles outside it (+24 %);
+//   * a microbenchmark of the inner loops alone: twelve waves that do nothing but cells,
+//     expansion stores and one barrier per tree keep the LDS 92 % busy (7.5e12 cell-trees/s); a
+//     ROW-lane cell loop (conflict-free reads, scalar operands through s_load) is slower than
+//     the column-lane one at every occupancy.
+// What is left is this kernel: the roles are split (below).  The external tile geometry
+// (64 x 256, tile lists, packed tiles of the shared multi-rank build, mirror image) is
+// unchanged: a workgroup is handed two tiles of one row block (`groups`).  Arithmetic as
+// k_accumulate_mono: same addends, same order, same bits (reference:
+// src/sc_supertree/scs.py:644-658).
 #pragma once
-
-#include <type_traits>
 
 template <int NG>
 struct wide_layout {
@@ -39,10 +44,7 @@ struct wide_layout {
     static constexpr int PIECES = (BYTES + 1023) / 1024;    // 1 KiB LDS-DMA pieces, one per wave
     __host__ __device__ static constexpr int seg(int w) { return 64 * w / NSEG; }
     static constexpr int MAXSEG = (64 + NSEG - 1) / NSEG;
-    static constexpr size_t LDS_BYTES = 2 * (size_t)DT_DOUBLES * 8 + 2 * (size_t)BYTES;
-    static constexpr size_t LDS_BYTES_PIPE = 2 * (size_t)DT_DOUBLES * 8 + 3 * (size_t)BYTES;  // k_accumulate_pipe
     static_assert(STOFF % 8 == 0 && PIECES <= NSEG, "record layout");
-    static_assert((size_t)NG * MONO_TCW * 9 * 8 <= LDS_BYTES, "mirror staging fits the table space");
 };
 
 // one wave per (local row block, tree): grid (n_blocks, trees in batch), 64 threads.  As
@@ -116,11 +118,14 @@ __global__ __launch_bounds__(64) void k_block_records_wide(
     }
 }
 
-// The same copy as inline asm: k_accumulate_pipe's waves of sub-tile 1 never issue one, yet in a
-// loop shared with the waves that do the compiler drains vmcnt in front of every LDS access that
-// may follow a pending LDS-DMA -- and with it the range-minimum loads those waves issued a moment
-// ago.  Hidden from the compiler, the copy is ordered by hand: s_waitcnt vmcnt(0) by the issuing
-// wave, then the workgroup barrier, before anyone reads the record.
+// 16 bytes per lane, global -> LDS at `lds_addr` + 16 * lane, no round trip through registers, as
+// inline asm: behind the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) the compiler drains
+// vmcnt in front of every LDS access that may follow a pending LDS-DMA -- and with it the
+// range-minimum loads the producer waves issued a moment ago and want in flight for two steps.
+// Hidden from the compiler, the copy is ordered by hand: a counted s_waitcnt vmcnt by the issuing
+// wave, then the workgroup barrier, before anyone reads the record.  (The builtin has a second
+// trap: inside a kernel TEMPLATE with value-dependent arguments the HOST pass, which does not know
+// it, drops the instantiation without a word and leaves the kernel's launch stub undefined.)
 typedef int scs_int4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_dma16_asm(const scs_int4 rsrc, const unsigned lds_addr,
                                               const int voffset, const int soffset) {
@@ -130,20 +135,9 @@ __device__ __forceinline__ void lds_dma16_asm(const scs_int4 rsrc, const unsigne
                  : "memory", "m0");
 }
 
-// 16 bytes per lane, global -> LDS at `dst` + 16 * lane, no round trip through registers.  (A plain
-// function on purpose: inside the kernel template the call would have value-dependent
-// arguments, be checked again when the template is instantiated -- also by the HOST pass, which
-// does not know the builtin, drops the instantiation without a word and leaves the kernel's
-// launch stub undefined.)
-__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, unsigned char *dst,
-                                          const int voffset, const int soffset) {
-    typedef __attribute__((address_space(3))) void *lds_ptr;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)dst, 16, voffset, soffset, 0, 0);
-}
-
 struct wide_params {
     mono_params m;
-    const int4 *groups;  // x, y, z: indices into m.tiles of up to three tiles of ONE row block (-1: none)
+    const int4 *groups;  // x, y: indices into m.tiles of up to two tiles of ONE row block (-1: none)
 };
 
 template <bool SYM>
@@ -196,486 +190,27 @@ __device__ __forceinline__ void tile_store_wide(const mono_params &p, double (&a
     }
 }
 
-template <int NG, bool SYM, bool STAMPED>
-__global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_wide(wide_params wp) {
-    using L = wide_layout<NG>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
-    double *const s_t = (double *)s_mem;                                // [2][DT_DOUBLES]
-    unsigned char *const s_rec = s_mem + 2 * (size_t)DT_DOUBLES * 8;  // [2][L::BYTES]
-    const mono_params &p = wp.m;
-
-    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int k) {
-        if (STAMPED) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long tnow;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
-            ts[k] += tnow - tprev;
-            tprev = tnow;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int ltid = tid & (MONO_TCW - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = wave >> 2, wl = wave & 3;
-    const int4 grp = wp.groups[blockIdx.x];
-    const int ti = sub == 0 ? grp.x : (sub == 1 ? grp.y : grp.z);
-    const bool active = ti >= 0;
-    // (a missing sub-tile takes the first tile's geometry: its waves expand their share of the
-    // table and join the barriers, nothing else)
-    const int2 tile = p.tiles[active ? ti : grp.x];
-    const int blk = tile.x;
-    const int row0 = p.row_begin + blk * SCS_TR;
-    const int col = tile.y * MONO_TCW + ltid;
-    const int nt = p.n_batch;
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
-
-    double acc[SCS_TR];
-#pragma unroll
-    for (int i = 0; i < SCS_TR; ++i) {
-        double v = 0.0;
-        if (active && p.load_w && p.tile_out)
-            v = p.tile_out[((int64_t)ti * SCS_TR + i) * MONO_TCW + ltid];
-        else if (active && p.load_w && col < p.n && row0 + i < p.row_end)
-            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
-        acc[i] = v;
-    }
-
-    const unsigned char *rec_base = p.rec + (int64_t)blk * nt * L::BYTES;
-    const __amdgpu_buffer_rsrc_t r_rec =
-        __builtin_amdgcn_make_buffer_rsrc((void *)rec_base, 0, nt * L::BYTES, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_pos =
-        __builtin_amdgcn_make_buffer_rsrc((void *)p.pos, 0, (int)(nt * p.npad * 4), 0x00020000);
-    const int lane16 = lane * 16;
-    const int col4 = col * 4;
-    // record of tree t lives in s_rec[t & 1]; wave w < PIECES copies its 1 KiB piece
-    auto issue_record = [&](int tl) {
-        if (wave < L::PIECES) {
-            const int left = (L::BYTES - wave * 1024) / 16;
-            if (lane < left)
-                lds_dma16(r_rec, s_rec + (tl & 1) * L::BYTES + wave * 1024, lane16,
-                          tl * L::BYTES + wave * 1024);
-        }
-    };
-
-    double qx = 0.0, qy = 0.0;
-    int cstate = 0;  // bits 0-7: row nb; bit 8: a neighbour exists; bit 9: self
-    int cpos_next = -1;
-
-    // the column step of scs_mono.h (k_accumulate_mono::column_issue), on the record of tree tl
-    auto column_issue = [&](int tl, int cpos) {
-        const unsigned char *rb = s_rec + (tl & 1) * L::BYTES;
-        const int *s_spos = (const int *)(rb + L::SPOS);
-        const int *s_arg = (const int *)(rb + L::ARGPOS);
-        const unsigned char *s_sorig = rb + L::SORIG;
-        const int *s_piv = (const int *)(rb + L::PIV);
-        const int cnt = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::CNT));
-        const bool present = cpos >= 0 && cnt > 0;
-        int lo;
-        {
-            const int4 pa = *(const int4 *)&s_piv[0];
-            const int4 pb = *(const int4 *)&s_piv[4];
-            lo = ((pa.x < cpos) + (pa.y < cpos) + (pa.z < cpos) + (pa.w < cpos) + (pb.x < cpos) +
-                  (pb.y < cpos) + (pb.z < cpos) + (pb.w < cpos)) * 8;
-            // (the octet's eight positions in two independent 16-byte reads: one LDS round trip
-            // where a binary descent makes three -- with one workgroup per CU the waves search at
-            // about the same time and nothing else hides the latency; its last position is the
-            // pivot itself, not below cpos unless lo == 64)
-            const int base = min(lo, 56);
-            const int4 qa = *(const int4 *)&s_spos[base];
-            const int4 qb = *(const int4 *)&s_spos[base + 4];
-            const int l2 = base + (qa.x < cpos) + (qa.y < cpos) + (qa.z < cpos) + (qa.w < cpos) +
-                           (qb.x < cpos) + (qb.y < cpos) + (qb.z < cpos);
-            lo = lo == 64 ? 64 : l2;
-        }
-        const bool hasl = present && self < 0 && lo > 0;
-        const bool hasr = present && self < 0 && lo < cnt;
-        const int il = max(lo - 1, 0), ir = min(lo, 63);
-        const bool left = hasl && (!hasr || s_arg[il] >= cpos);
-        const int q_anchor = s_spos[left ? il : ir];
-        const int nbrow = s_sorig[left ? il : ir];
-        cstate = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && self >= 0) ? 512 : 0);
-        const int m = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::M));
-        const unsigned so_lo = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF));
-        const unsigned so_hi = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF + 4));
-        const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
-        const bool any = hasl || hasr;
-        int o[2];
-        rmq_offsets(m, any ? (left ? q_anchor : cpos) : 0, any ? (left ? cpos : q_anchor) : 1, o);
-        qx = *(const double *)(st + (unsigned)o[0] * 8u);
-        qy = *(const double *)(st + (unsigned)o[1] * 8u);
-        cpos_next = __builtin_amdgcn_raw_buffer_load_b32(
-            r_pos, col4, min(tl + 1, nt - 1) * (int)p.npad * 4, 0);
-    };
-
-    // expansion of tree tl's row-row table into s_t[tl & 1] (k_accumulate_mono::expand); wave w
-    // walks the steps b in [seg(w), seg(w + 1))
-    auto expand = [&](int tl) {
-        const unsigned char *rb = s_rec + (tl & 1) * L::BYTES;
-        double *dv = s_t + (tl & 1) * DT_DOUBLES;
-        const int b0 = L::seg(wave), b1 = L::seg(wave + 1);
-        const double g_rank = ((const double *)(rb + L::G))[lane];
-        const int so_rank = rb[L::SORIG + lane];
-        const int rho = rb[L::RANK + lane];
-        double cur = inf;
-        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
-        double *row_a = &dv[lane * DV_LD];
-        double *col_a = &dv[lane];
-#pragma unroll
-        for (int j = 0; j < L::MAXSEG; ++j) {
-            const int b = b0 + j;
-            if (b >= b1) break;
-            const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_rank), b);
-            const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_rank), b);
-            const int so_b = __builtin_amdgcn_readlane(so_rank, b);
-            const double gb = __hiloint2double(hi32, lo32);
-            if (rho <= b) {
-                row_a[so_b] = cur;
-                col_a[so_b * DV_LD] = cur;
-                cur = min_f64(cur, gb);
-            }
-        }
-    };
-
-    // ---- prologue: records 0 and 1, the column's position in tree 0, tree 0's column step and table
-    issue_record(0);
-    if (nt > 1) issue_record(1);
-    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (active) column_issue(0, cpos_next);
-    expand(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SCS_BARE_BARRIER();
-    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-
-    // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
-    // s_t[tl & 1], the record of tree tl + 1 in s_rec[(tl + 1) & 1], this wave's range-minimum
-    // loads for tree tl have landed; s_rec[tl & 1] and s_t[(tl + 1) & 1] are free.
-    for (int tl = 0; tl < nt; ++tl) {
-        int nb = 0;
-        double vn = 0.0;
-        if (cstate & 256) {
-            vn = min_f64(qx, qy);
-            nb = cstate & 255;
-        } else if (cstate & 512) {
-            nb = self;
-            vn = inf;
-        }
-        stamp(0);
-        if (tl + 1 < nt) {
-            if (active) column_issue(tl + 1, cpos_next);  // loads stay in flight until the next step
-            stamp(1);
-            expand(tl + 1);
-            stamp(2);
-        }
-        // (the step's one LDS-DMA is issued after the last LDS access the compiler sees: it would
-        // drain vmcnt in front of every later one -- scs_mono.h)
-        if (tl + 2 < nt) issue_record(tl + 2);
-        stamp(3);
-        if (active) {
-            double tmp[SCS_CELLS_DEPTH];
-            const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_t[(
-                tl & 1) * DT_DOUBLES + nb * DV_LD];
-            SCS_CELLS_ASM(acc, tmp, addr, vn);
-        }
-        stamp(4);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(5);
-        SCS_BARE_BARRIER();
-        stamp(6);
-    }
-
-    if (STAMPED && lane == 0 && p.stamps) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
-        atomicAdd(&p.stamps[7], 1ull);
-    }
-    tile_store_wide<SYM>(p, acc, tile, active, ti, row0, col, self, ltid, lane, wl,
-                         (double *)s_mem + (size_t)sub * MONO_TCW * 9);
-}
-
-// ---------------------------------------------------------------------------
-// k_accumulate_pipe: the wide kernel with the phases of a step overlapped
-// ---------------------------------------------------------------------------
-// profiles/r04_wide_phase_stamps.txt: merely widening the tile bought nothing -- a wave's step is
-// a chain of dependent phases (column search, table expansion, cells) and every phase waits on
-// LDS operations queued behind the other waves' traffic: 7 250 cycles per step for 768 columns
-// against 3 x 2 500 for three 4-wave workgroups, a quarter of it at the barrier.  Here
-//   * the wave's expansion steps of tree t + 1's table are WOVEN INTO the cell loop of tree t
-//     (one inline-asm statement, scs_cells_asm.h: SCS_CELLS_EXPAND_ASM) -- the stores and the
-//     v_readlane broadcasts ride in the shadow of the cells' reads;
-//   * the two sub-tiles run half a step apart: the waves of sub-tile 0 search (tree t + 1) BEFORE
-//     their cell loop, the waves of sub-tile 1 AFTER it (tree t + 2: their range-minimum loads
-//     then have a whole step to come back), so the latency-bound search of one half runs beside
-//     the LDS-bound cell loop of the other -- what independent workgroups did by accident;
-//   * NG = 2: eight waves, two per SIMD, 256 registers each.
-// Three record buffers (trees t + 1 for the expansion and the early search, t + 2 for the late
-// search, t + 3 landing), two table buffers, one barrier per tree.  Arithmetic as
-// k_accumulate_mono: same addends, same order, same bits.
-template <int NG, bool SYM, bool STAMPED>
-__global__ __launch_bounds__(NG * MONO_TCW) void k_accumulate_pipe(wide_params wp) {
-    using L = wide_layout<NG>;
-    static_assert(NG == 2 && L::NSEG == 8 && L::seg(1) == 8,
-                  "eight waves, eight expansion steps each, woven into the cell loop");
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_mem[];
-    double *const s_t = (double *)s_mem;                                // [2][DT_DOUBLES]
-    unsigned char *const s_rec = s_mem + 2 * (size_t)DT_DOUBLES * 8;  // [3][L::BYTES]
-    const mono_params &p = wp.m;
-
-    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-    auto stamp = [&](int k) {
-        if (STAMPED) {
-            __builtin_amdgcn_sched_barrier(0);
-            unsigned long long tnow;
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tnow)::"memory");
-            ts[k] += tnow - tprev;
-            tprev = tnow;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int ltid = tid & (MONO_TCW - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int sub = wave >> 2, wl = wave & 3;
-    const int4 grp = wp.groups[blockIdx.x];
-    const int ti = sub == 0 ? grp.x : grp.y;
-    const bool active = ti >= 0;
-    const int2 tile = p.tiles[active ? ti : grp.x];
-    const int blk = tile.x;
-    const int row0 = p.row_begin + blk * SCS_TR;
-    const int col = tile.y * MONO_TCW + ltid;
-    const int nt = p.n_batch;
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
-
-    double acc[SCS_TR];
-#pragma unroll
-    for (int i = 0; i < SCS_TR; ++i) {
-        double v = 0.0;
-        if (active && p.load_w && p.tile_out)
-            v = p.tile_out[((int64_t)ti * SCS_TR + i) * MONO_TCW + ltid];
-        else if (active && p.load_w && col < p.n && row0 + i < p.row_end)
-            v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
-        acc[i] = v;
-    }
-
-    const unsigned char *rec_base = p.rec + (int64_t)blk * nt * L::BYTES;
-    const scs_int4 rs_rec = {(int)(unsigned)(u64)rec_base, (int)(((u64)rec_base >> 32) & 0xffffu),
-                             nt * L::BYTES, 0x00020000};
-    const __amdgpu_buffer_rsrc_t r_pos =
-        __builtin_amdgcn_make_buffer_rsrc((void *)p.pos, 0, (int)(nt * p.npad * 4), 0x00020000);
-    const int lane16 = lane * 16;
-    const int col4 = col * 4;
-    // record of tree t lives in s_rec[t % 3]; the four waves of sub-tile 0 copy its 1 KiB pieces
-    // (they are the ones whose step has no LDS access the compiler sees after this point)
-    auto issue_record = [&](int t) {
-#pragma unroll
-        for (int pc = 0; pc < L::PIECES; pc += 4) {
-            const int piece = pc + wave;
-            if (piece < L::PIECES) {
-                const int left = (L::BYTES - piece * 1024) / 16;
-                if (lane < left)
-                    lds_dma16_asm(rs_rec,
-                                  (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
-                                      s_rec + (t % 3) * L::BYTES + piece * 1024),
-                                  lane16, t * L::BYTES + piece * 1024);
-            }
-        }
-    };
-
-    struct pending {
-        double qx, qy;  // raw table values of the column's one range-minimum query
-        int cstate;     // bits 0-7: row nb; bit 8: a neighbour exists; bit 9: self
-    };
-    int cpos_next = -1;
-
-    // the column step of k_accumulate_mono on the record of tree t (clamped to the batch)
-    auto column_issue = [&](int t_raw, int cpos, pending &q) {
-        const int t = min(t_raw, nt - 1);
-        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
-        const int *s_spos = (const int *)(rb + L::SPOS);
-        const int *s_arg = (const int *)(rb + L::ARGPOS);
-        const unsigned char *s_sorig = rb + L::SORIG;
-        const int *s_piv = (const int *)(rb + L::PIV);
-        const int cnt = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::CNT));
-        const bool present = cpos >= 0 && cnt > 0;
-        int lo;
-        {
-            const int4 pa = *(const int4 *)&s_piv[0];
-            const int4 pb = *(const int4 *)&s_piv[4];
-            lo = ((pa.x < cpos) + (pa.y < cpos) + (pa.z < cpos) + (pa.w < cpos) + (pb.x < cpos) +
-                  (pb.y < cpos) + (pb.z < cpos) + (pb.w < cpos)) * 8;
-            const int base = min(lo, 56);
-            const int4 qa = *(const int4 *)&s_spos[base];
-            const int4 qb = *(const int4 *)&s_spos[base + 4];
-            const int l2 = base + (qa.x < cpos) + (qa.y < cpos) + (qa.z < cpos) + (qa.w < cpos) +
-                           (qb.x < cpos) + (qb.y < cpos) + (qb.z < cpos);
-            lo = lo == 64 ? 64 : l2;
-        }
-        const bool hasl = present && self < 0 && lo > 0;
-        const bool hasr = present && self < 0 && lo < cnt;
-        const int il = max(lo - 1, 0), ir = min(lo, 63);
-        const bool left = hasl && (!hasr || s_arg[il] >= cpos);
-        const int q_anchor = s_spos[left ? il : ir];
-        const int nbrow = s_sorig[left ? il : ir];
-        q.cstate = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && self >= 0) ? 512 : 0);
-        const int m = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::M));
-        const unsigned so_lo = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF));
-        const unsigned so_hi = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF + 4));
-        const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
-        const bool any = hasl || hasr;
-        int o[2];
-        rmq_offsets(m, any ? (left ? q_anchor : cpos) : 0, any ? (left ? cpos : q_anchor) : 1, o);
-        q.qx = *(const double *)(st + (unsigned)o[0] * 8u);
-        q.qy = *(const double *)(st + (unsigned)o[1] * 8u);
-        cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, min(t + 1, nt - 1) * (int)p.npad * 4, 0);
-    };
-
-    // whole expansion of tree 0's table (prologue only; the steady state weaves it into the cells)
-    auto expand_whole = [&](int t) {
-        const unsigned char *rb = s_rec + (t % 3) * L::BYTES;
-        double *dv = s_t + (t & 1) * DT_DOUBLES;
-        const int b0 = L::seg(wave);
-        const double g_rank = ((const double *)(rb + L::G))[lane];
-        const int so_rank = rb[L::SORIG + lane];
-        const int rho = rb[L::RANK + lane];
-        double cur = inf;
-        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
-        double *row_a = &dv[lane * DV_LD];
-        double *col_a = &dv[lane];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int b = b0 + j;
-            const int lo32 = __builtin_amdgcn_readlane((int)__double2loint(g_rank), b);
-            const int hi32 = __builtin_amdgcn_readlane(__double2hiint(g_rank), b);
-            const int so_b = __builtin_amdgcn_readlane(so_rank, b);
-            const double gb = __hiloint2double(hi32, lo32);
-            if (rho <= b) {
-                row_a[so_b] = cur;
-                col_a[so_b * DV_LD] = cur;
-                cur = min_f64(cur, gb);
-            }
-        }
-    };
-
-    // ---- prologue: records 0, 1, 2; tree 0's table; the first column steps
-    if (sub == 0) {
-        issue_record(0);
-        if (nt > 1) issue_record(1);
-        if (nt > 2) issue_record(2);
-    }
-    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    pending pa = {0.0, 0.0, 0};
-    const bool late = sub == 1;
-    // a column's query -> the tile row next to it and its own LCA value with that row
-    auto combine = [&](const pending &q, int &nb, double &vn) {
-        nb = 0;
-        vn = 0.0;
-        if (q.cstate & 256) {
-            vn = min_f64(q.qx, q.qy);
-            nb = q.cstate & 255;
-        } else if (q.cstate & 512) {
-            nb = self;
-            vn = inf;
-        }
-    };
-    int nb = 0;
-    double vn = 0.0;
-    if (active) column_issue(0, cpos_next, pa);
-    if (late) {
-        // a late wave combines a tree's query at the END of the step before (its loads were issued a
-        // whole step earlier) and only then issues the next one: nothing to wait for at the top
-        combine(pa, nb, vn);
-        if (active) column_issue(1, cpos_next, pa);
-    }
-    expand_whole(0);
-    SCS_BARE_BARRIER();
-    if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-
-    // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
-    // s_t[tl & 1]; the records of trees tl + 1 and tl + 2 are in place.  An early wave holds the
-    // column's query of tree tl in `pa` (landed: issued before the previous cell loop), a late
-    // wave holds (nb, vn) of tree tl and the query of tree tl + 1 in `pa` (in flight).
-    // ONE loop and ONE cell statement for both kinds of wave: a second inline-asm statement with
-    // 64 tied accumulators anywhere in the kernel makes the register allocator keep two sets.
-    for (int tl = 0; tl < nt; ++tl) {
-        if (!late) combine(pa, nb, vn);
-        stamp(0);
-        if (!late && active) column_issue(tl + 1, cpos_next, pa);
-        stamp(1);
-        const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_t[(
-            tl & 1) * DT_DOUBLES + nb * DV_LD];
-        // the wave's share of tree tl + 1's table goes into the other buffer, woven into the cells
-        // (the last tree expands its own table once more, into the buffer nobody reads any more)
-        const unsigned char *rb = s_rec + (min(tl + 1, nt - 1) % 3) * L::BYTES;
-        const double g_rank = ((const double *)(rb + L::G))[lane];
-        const int so_rank = rb[L::SORIG + lane];
-        const int rho = rb[L::RANK + lane];
-        const int b0 = L::seg(wave);
-        double cur = inf;
-        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
-        double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
-        const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
-        const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
-        if (!late && tl + 3 < nt) issue_record(tl + 3);
-        stamp(2);
-        {
-            double tmp[SCS_CELLS_DEPTH];
-            unsigned x1, x2;
-            // (a missing sub-tile runs the same statement -- its waves owe their share of the
-            // table; its accumulators are never stored)
-            SCS_CELLS_EXPAND_ASM(acc, tmp, x1, x2, addr, vn, cur, (int)__double2loint(g_rank),
-                                 __double2hiint(g_rank), so_rank, rho, rowb, colb, b0, DV_LD * 8);
-        }
-        stamp(3);
-        if (late) {
-            combine(pa, nb, vn);  // tree tl + 1
-            if (active) column_issue(tl + 2, cpos_next, pa);
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the record
-        }
-        stamp(4);
-        SCS_BARE_BARRIER();
-        stamp(5);
-    }
-
-    if (STAMPED && lane == 0 && p.stamps) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) atomicAdd(&p.stamps[k], ts[k]);
-        atomicAdd(&p.stamps[7], 1ull);
-    }
-    tile_store_wide<SYM>(p, acc, tile, active, ti, row0, col, self, ltid, lane, wl,
-                         (double *)s_mem + (size_t)sub * MONO_TCW * 9);
-}
-
 // ---------------------------------------------------------------------------
 // k_accumulate_spec: producer and consumer waves
 // ---------------------------------------------------------------------------
-// tools/cells_probe.hip (profiles/r04_cells_probe.txt): twelve waves that do NOTHING but cells,
-// expansion stores and one barrier per tree keep the LDS 92 % busy (7.2e12 cell-trees/s);
-// k_accumulate_wide's waves reach 58 % -- each also searches its column among the tile's rows,
-// issues the range-minimum loads and waits for them, a chain of dependent LDS and memory round
-// trips during which it issues no cell reads, and the workgroup's waves do that in step.  Here
-// the roles are split: of a workgroup's twelve waves EIGHT (two tiles of one row block) are
+// A wave that searches its column among the tile's rows, issues the range-minimum loads and
+// waits for them walks a chain of dependent LDS and memory round trips during which it issues
+// no cell reads -- and the waves of a wide workgroup do that in step.  Here the roles are
+// split: of a workgroup's twelve waves EIGHT (two tiles of one row block) are
 // consumers -- per tree: read the column's (table row address, own value) pair from LDS, then the
 // one woven statement (cells of tree t + the wave's expansion steps of tree t + 1) -- and FOUR are
 // producers: each runs the column step of k_accumulate_mono for the 128 columns of two consumer
-// waves, one tree ahead, and leaves the pairs in LDS; they also stage the records.  One barrier
-// per tree for all twelve.  Arithmetic as k_accumulate_mono: same addends, same order, same bits.
+// waves, TWO trees ahead (a step is about 2 us, a query that misses the L2 takes as long), and
+// leaves the pairs in LDS; they also stage the records.  One barrier per tree for all twelve.
+// Measured (tools/acc_ab.py, one MI355X): 10 000 taxa / 500 trees 6.40-6.46 ms against 6.92 for
+// k_accumulate_mono (4.2e12 cell-trees/s); 50 000 / 2 000: 698 against 681 ms -- the producers'
+// queries miss the L2 there and the producers, not the LDS, set the step: scs_pcg_build takes
+// this kernel up to 20 000 leaves per tree (SCS_WIDE=0 / 3 force either).
 struct spec_layout {
     using L = wide_layout<2>;
     static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
     static constexpr size_t O_T = 0;                                      // double[2][DT_DOUBLES]
-    static constexpr int NREC = 4;  // records of trees t + 1 ... t + 4 during step t
+    static constexpr int NREC = 5;  // records of trees t + 1 ... t + 5 during step t
     static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [NREC][L::BYTES]
     static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[2][512]
     static constexpr size_t O_ADDR = O_VN + 2 * 512 * 8;                 // unsigned[2][512]
@@ -866,11 +401,12 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // producer is there to keep in flight.  (And ONE cell statement in the kernel: a second one with
     // 64 tied accumulators makes the register allocator keep two sets.)
     if (producer) {
-        // ---- prologue: records 0 ... 3, tree 0's column pairs, the queries of trees 1 and 2
+        // ---- prologue: records 0 ... 4, tree 0's column pairs, the queries of trees 1 and 2
         issue_record(0);
         if (nt > 1) issue_record(1);
         if (nt > 2) issue_record(2);
         if (nt > 3) issue_record(3);
+        if (nt > 4) issue_record(4);
 #pragma unroll
         for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -888,10 +424,16 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
             if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
-            if (tl + 4 < nt) issue_record(tl + 4);
+            if (tl + 5 < nt) issue_record(tl + 5);
             search(tl + 3, q1);  // six loads (four table entries, two positions), consumed two steps on
-            // all but the six youngest: the record has landed (and the other set's answers)
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            // The record that must be in place when the barrier opens is the one requested a step ago
+            // (tree tl + 4: searched in the next step).  Loads return in order, so "it has landed" is
+            // "all but the loads issued after it are done": the six of the step before, this step's
+            // record pieces (two for producer 0, one for the others) and the six above -- the youngest
+            // queries (misses of the L2 at 50 000 leaves: 2-3 us) stay in flight.
+            if (tl + 5 >= nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (no pieces this step)
+            else if (pw == 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
             stamp(1);
             SCS_BARE_BARRIER();
             stamp(4);

@@ -553,34 +553,30 @@ def test_shared_build_multi_batch(dev, monkeypatch):
 
 
 # ---------------------------------------------------------------------------
-# the wide tile kernel (scs_mono_wide.h): three column tiles of a row block per workgroup.
-# It is chosen by itself once the groups fill the chip (the configs[2]-size tests and the
-# bench run it); SCS_WIDE=1 puts the small shapes through it, SCS_WIDE=2 through the pipelined
-# eight-wave kernel (k_accumulate_pipe: two tiles per workgroup, the table expansion woven into
-# the cell loop, the two sub-tiles half a step apart), SCS_WIDE=3 through the producer / consumer
-# kernel (k_accumulate_spec: eight consumer waves, four producer waves).
+# the producer / consumer tile kernel (scs_mono_wide.h: k_accumulate_spec -- two column tiles of a
+# row block per workgroup, eight consumer waves with the table expansion woven into the cell
+# loop, four producer waves running the column step two trees ahead).  scs_pcg_build takes it by
+# itself once the groups fill the chip (the configs[2]-size tests and the bench run it);
+# SCS_WIDE=1 puts the small shapes through it, SCS_WIDE=0 forces the 4-wave kernel.
 # ---------------------------------------------------------------------------
-WIDE_MODES = ["1", "2", "3"]
-
-
-@pytest.mark.parametrize("wide", WIDE_MODES)
 @pytest.mark.parametrize("strategy", ["one", "depth", "branch"])
 @pytest.mark.parametrize(("n", "m", "k"), [(37, 6, 20), (300, 12, 300), (700, 7, 512), (1100, 9, 900),
-                                           (1537, 5, 1537), (330, 300, 200)])
-def test_wide_kernel_bit_exact(dev, monkeypatch, wide, strategy, n, m, k):
-    # one, two, three (a full group), five and seven column tiles per row block: full and
-    # partial groups, ragged last tile, taxa missing from trees, a single tree batch of 300 trees
-    monkeypatch.setenv("SCS_WIDE", wide)
-    tables = synthetic.make_tables(200 + n, n, m, strategy, leaves_per_tree=k, random_weights=(n % 2 == 0))
+                                           (1537, 5, 1537), (330, 300, 200), (640, 1, 640), (640, 2, 600),
+                                           (900, 3, 700), (900, 4, 900), (900, 5, 650), (900, 6, 900)])
+def test_spec_kernel_bit_exact(dev, monkeypatch, strategy, n, m, k):
+    # one to seven column tiles per row block: full and half groups, ragged last tile, taxa
+    # missing from trees, a single tree batch of 300 trees -- and one to six trees: every length of
+    # the producers' and the records' pipelines (queries two trees ahead, records five)
+    monkeypatch.setenv("SCS_WIDE", "1")
+    tables = synthetic.make_tables(200 + n + m, n, m, strategy, leaves_per_tree=k, random_weights=(n % 2 == 0))
     assert tables.monotone
     _build_and_compare(dev, tables)
 
 
-@pytest.mark.parametrize("wide", WIDE_MODES)
-def test_wide_kernel_row_blocks_and_batches(dev, monkeypatch, wide):
+def test_spec_kernel_row_blocks_and_batches(dev, monkeypatch):
     # the non-symmetric schedule of row-partitioned ranks (no mirror image, every column tile of
     # a row block), and several tree batches through a tiny workspace (the sums travel through W)
-    monkeypatch.setenv("SCS_WIDE", wide)
+    monkeypatch.setenv("SCS_WIDE", "1")
     tables = synthetic.make_tables(6, 1000, 10, "branch", leaves_per_tree=800, random_weights=True)
     _build_and_compare(dev, tables, [(0, 100), (100, 1000), (64, 65), (7, 601)])
     monkeypatch.setenv("SCS_WS_LIMIT_MB", "1")
@@ -599,11 +595,10 @@ def test_wide_kernel_row_blocks_and_batches(dev, monkeypatch, wide):
     assert np.array_equal(w, w_ref)
 
 
-@pytest.mark.parametrize("wide", WIDE_MODES)
-def test_wide_kernel_shared_multi_rank_build(dev, monkeypatch, wide):
+def test_spec_kernel_shared_multi_rank_build(dev, monkeypatch):
     # packed tiles of the shared multi-rank build (a rank's tiles of a row block are every
-    # world-th column tile), several batches, and the upper-triangle job
-    monkeypatch.setenv("SCS_WIDE", wide)
+    # world-th column tile), several batches, and row-partitioned ranks
+    monkeypatch.setenv("SCS_WIDE", "1")
     monkeypatch.setenv("SCS_WS_LIMIT_MB", "2")
     tables = synthetic.make_tables(5, 1300, 30, "branch", leaves_per_tree=1200)
     w_ref, _ = to.pcg_dense(tables)
@@ -614,20 +609,24 @@ def test_wide_kernel_shared_multi_rank_build(dev, monkeypatch, wide):
     assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
 
 
-def test_wide_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
+def test_spec_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
     # 3 000 taxa / 300 trees: 12 column tiles per row block, two tree batches by the tree cap;
-    # the two kernels against each other, whole matrix, and sampled rows against the oracle
+    # the two kernels against each other, whole matrix, and sampled rows against the oracle;
+    # left to itself scs_pcg_build takes the producer / consumer kernel here
     tables = synthetic.make_tables(3, 3000, 300, "branch", random_weights=True)
     got = {}
-    for wide in ("0", "1", "2", "3"):
-        monkeypatch.setenv("SCS_WIDE", wide)
+    for wide in ("0", "1", None):
+        if wide is None:
+            monkeypatch.delenv("SCS_WIDE")
+        else:
+            monkeypatch.setenv("SCS_WIDE", wide)
         dtab = dev.upload(tables)
         g = dtab.build()
         got[wide] = g.download()
         assert g.build_stats["n_batches"] > 1
         g.free()
         dtab.free()
-    assert all(np.array_equal(got["0"], got[k]) for k in ("1", "2", "3"))
+    assert np.array_equal(got["0"], got["1"]) and np.array_equal(got["0"], got[None])
     rows = np.unique(np.random.RandomState(2).randint(0, 3000, size=12)).astype(np.int32)
     assert np.array_equal(got["1"][rows], to.pcg_rows(tables, rows))
     assert np.array_equal(got["1"], got["1"].T) and not np.any(np.diag(got["1"]))

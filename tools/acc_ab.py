@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the two monotone tile kernels on one device: the 4-wave kernel (one 64 x 256 tile per
-workgroup, scs_mono.h) against the wide kernel (three tiles of a row block per workgroup,
-scs_mono_wide.h), same tables, same process.  Prints accumulate ms, cell-trees/s and -- last
+workgroup, scs_mono.h; SCS_WIDE=0) against the producer / consumer kernel (two tiles of a row block
+per workgroup, scs_mono_wide.h; SCS_WIDE=1), same tables, same process.  Prints accumulate ms, cell-trees/s and -- last
 repetition -- sampled rows against the C oracle and the two matrices against each other.
 
     python tools/acc_ab.py [n_taxa n_trees [reps]]      (default 10000 500 5)
@@ -25,7 +25,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     m = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    modes = os.environ.get("ACC_AB_MODES", "0,3,0,3").split(",")
+    modes = os.environ.get("ACC_AB_MODES", "0,1,0,1").split(",")
     tables = synthetic.make_tables(0, n, m, "branch", pinned=True)
     rows = np.unique(np.random.RandomState(1).randint(0, n, size=12)).astype(np.int32)
     want = to.pcg_rows(tables, rows)
