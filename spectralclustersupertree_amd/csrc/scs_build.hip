@@ -805,6 +805,12 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         const size_t need_st = (size_t)st_off[nb] * entry_bytes + 64;
         const size_t need_stoff = (size_t)(nb + 1) * 8;
         const size_t need_rec = (size_t)n_blocks * nb * rec_bytes;
+        // A short batch (the first 64 trees of tables still on their way, a forest's last few trees)
+        // is the 4-wave kernel's: a twelve-wave workgroup has a CU to itself, nothing hides its
+        // prologue, its tile stores and the thin last round of its launch, and below ~100 trees
+        // that costs more than the shorter steps save (measured at 10 000 leaves: 64 + 218 + 218
+        // trees 6.93 ms either way, 218 + 218 with the 4-wave kernel in front 6.5).
+        const bool wide_b = wide && nb >= 96;
         SCS_TRY(d_pos.alloc(need_pos));
         SCS_TRY(d_st.alloc(need_st));
         SCS_TRY(d_stoff.alloc(need_stoff));
@@ -824,7 +830,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 k_sparse_level<double><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
                                                               (const int64_t *)d_stoff.p,
                                                               (double *)d_st.p);
-            if (wide)
+            if (wide_b)
                 k_block_records_wide<PIPE_NG><<<dim3((unsigned)n_blocks, (unsigned)nb), 64, 0, s>>>(
                     tb->d_tree_off, t0, nb, (const int32_t *)d_pos.p, npad, (const int64_t *)d_stoff.p,
                     (const double *)d_st.p, b_row_begin, b_row_end, (unsigned char *)d_rec.p);
@@ -872,7 +878,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
             mp.stamps = nullptr;
             static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
-            if (wide) {
+            if (wide_b) {
                 wide_params wp;
                 wp.m = mp;
                 wp.groups = (const int4 *)d_groups.p;
