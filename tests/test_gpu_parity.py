@@ -46,7 +46,7 @@ def dev():
 # ---------------------------------------------------------------------------
 # building blocks
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 24, 33, 48, 63, 64])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 11, 12, 13, 24, 33, 48, 63, 64])
 def test_jacobi_matches_lapack(dev, n):
     rs = np.random.RandomState(n)
     a = rs.standard_normal((n, n))
