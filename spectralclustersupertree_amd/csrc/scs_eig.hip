@@ -565,189 +565,12 @@ __device__ void jacobi_eig_fast(jacobi_lds &s, int n) {
     __syncthreads();
 }
 
-// ---- one-wave variant for n <= 12 (round 4): the 12 x 12 Rayleigh-Ritz problem of the block
-// width 4 loop and its 4 x 4 orthonormalisations are 108 / 12 work items -- two per lane of ONE
-// wave.  LDS operations of one wave are performed in order, so the hand-overs between the phases
-// of a step (rotations -> items -> next step's rotations) need no workgroup barrier, only the
-// compiler kept from reordering across them; the convergence test is a wave reduction.  The other
-// three waves of the workgroup wait at the barrier behind the solve.  Same items, same
-// arithmetic, same order of operations per item as jacobi_eig_fast (bitwise the same results);
-// a step costs about half: profiles/r04_jacobi_wave.txt.
-#define SCS_WAVE_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-__device__ void jacobi_eig_wave(jacobi_lds &s, int n) {
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        const int lane = tid & 63, wave = tid >> 6;
-        const int m = n + (n & 1), half = m / 2;
-        const int nblk = half * half, ne = m * half;
-        double *fa = &s.a[0][0];  // [2][nblk][4]: 2 x 2 blocks, row-major inside a block
-        double *fe = &s.e[0][0];  // [2][ne][2]:   E[r][2 kc], E[r][2 kc + 1]
-        // position after one round-robin move: 0 stays, the rest cycles 1 -> 3 -> ... -> m-1 ->
-        // m-2 -> ... -> 4 -> 2 -> 1
-        auto next_pos = [&](int i) {
-            if (i == 0 || m == 2) return i;
-            if (i & 1) return i == m - 1 ? m - 2 : i + 2;
-            return i == 2 ? 1 : i - 2;
-        };
-        int kind[2], ia[2], ib[2], dst[2][4];
-        double v[2][4];
-        // items of wave 0: the blocks first, the E items behind them, two per lane
-        const int nblk_pad = nblk;
-    #pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            const int e = tid + 64 * w;
-            kind[w] = 0;
-            ia[w] = ib[w] = 0;
-            if (e < nblk) {
-                kind[w] = 1;
-                const int kr = e / half, kc = e - kr * half;
-                ia[w] = kr;
-                ib[w] = kc;
-    #pragma unroll
-                for (int al = 0; al < 2; ++al)
-    #pragma unroll
-                    for (int be = 0; be < 2; ++be) {
-                        const int i = 2 * kr + al, j = 2 * kc + be;
-                        v[w][al * 2 + be] = (i < n && j < n) ? s.a[i][j] : 0.0;
-                        const int pi = next_pos(i), pj = next_pos(j);
-                        dst[w][al * 2 + be] = ((pi >> 1) * half + (pj >> 1)) * 4 + (pi & 1) * 2 + (pj & 1);
-                    }
-            } else if (e >= nblk_pad && e < nblk_pad + ne) {
-                kind[w] = 2;
-                const int r = (e - nblk_pad) / half, kc = (e - nblk_pad) - r * half;
-                ia[w] = r;
-                ib[w] = kc;
-    #pragma unroll
-                for (int be = 0; be < 2; ++be) {
-                    const int j = 2 * kc + be;
-                    v[w][be] = r == j ? 1.0 : 0.0;
-                    const int pj = next_pos(j);
-                    dst[w][be] = (r * half + (pj >> 1)) * 2 + (pj & 1);
-                }
-            }
-        }
-        SCS_WAVE_FENCE();  // (the flat copies overwrite the input matrix: every read above is in)
-    #pragma unroll
-        for (int w = 0; w < 2; ++w) {
-            if (kind[w] == 1) {
-    #pragma unroll
-                for (int k = 0; k < 4; ++k) fa[(ia[w] * half + ib[w]) * 4 + k] = v[w][k];
-            } else if (kind[w] == 2) {
-                fe[(ia[w] * half + ib[w]) * 2 + 0] = v[w][0];
-                fe[(ia[w] * half + ib[w]) * 2 + 1] = v[w][1];
-            }
-        }
-        SCS_WAVE_FENCE();
-        int cur = 0;
-        for (int sweep = 0; sweep < 30; ++sweep) {
-            const double *ac = fa + cur * nblk * 4;
-            // convergence: off-diagonal mass against the diagonal (dead directions carry -1e30 on
-            // the diagonal, k_small_rr: not part of the scale)
-            double off = 0.0, dia = 0.0;
-    #pragma unroll
-            for (int w = 0; w < 2; ++w)
-                if (kind[w] == 1) {
-                    const double *bp = ac + (ia[w] * half + ib[w]) * 4;
-                    const double b0 = bp[0], b1 = bp[1], b2 = bp[2], b3 = bp[3];
-                    if (ia[w] == ib[w]) {
-                        dia += (b0 > -1e29 ? b0 * b0 : 0.0) + (b3 > -1e29 ? b3 * b3 : 0.0);
-                        off += b1 * b1 + b2 * b2;
-                    } else {
-                        off += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
-                    }
-                }
-    #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                off += __shfl_xor(off, o, 64);
-                dia += __shfl_xor(dia, o, 64);
-            }
-            if (off <= 1.25e-32 * (double)(n * n) * dia || off == 0.0) break;
-
-            for (int step = 0; step < m - 1; ++step) {
-                const double *a0 = fa + cur * nblk * 4;
-                const double *e0 = fe + cur * ne * 2;
-                double *a1 = fa + (cur ^ 1) * nblk * 4;
-                double *e1 = fe + (cur ^ 1) * ne * 2;
-                // the rotation of pair k, once, from its diagonal block
-                if (tid < half) {
-                    const double *dc = a0 + (tid * half + tid) * 4;
-                    double c, sn;
-                    jacobi_rot(dc[0], dc[1], dc[3], c, sn);
-                    s.cs[tid][0] = c;
-                    s.cs[tid][1] = sn;
-                }
-                SCS_WAVE_FENCE();
-    #pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    if (kind[w] == 0) continue;
-                    const double c2 = s.cs[ib[w]][0], s2 = s.cs[ib[w]][1];
-                    if (kind[w] == 1) {
-                        const double c1 = s.cs[ia[w]][0], s1 = s.cs[ia[w]][1];
-                        const double *bp = a0 + (ia[w] * half + ib[w]) * 4;
-                        const double a00 = bp[0], a01 = bp[1], a10 = bp[2], a11 = bp[3];
-                        const double t00 = c2 * a00 - s2 * a01, t01 = s2 * a00 + c2 * a01;
-                        const double t10 = c2 * a10 - s2 * a11, t11 = s2 * a10 + c2 * a11;
-                        a1[dst[w][0]] = c1 * t00 - s1 * t10;
-                        a1[dst[w][1]] = c1 * t01 - s1 * t11;
-                        a1[dst[w][2]] = s1 * t00 + c1 * t10;
-                        a1[dst[w][3]] = s1 * t01 + c1 * t11;
-                    } else {
-                        const double *ep = e0 + (ia[w] * half + ib[w]) * 2;
-                        const double x = ep[0], y = ep[1];
-                        e1[dst[w][0]] = c2 * x - s2 * y;
-                        e1[dst[w][1]] = s2 * x + c2 * y;
-                    }
-                }
-                SCS_WAVE_FENCE();
-                cur ^= 1;
-            }
-        }
-        // back to the caller's layout: eigenvector of position j in column j of s.e, positions
-        // ranked by eigenvalue (descending); an odd n leaves out the padded coordinate, whose
-        // column is the only one with a non-zero in row n
-        const double *ac = fa + cur * nblk * 4;
-        const double *ec = fe + cur * ne * 2;
-    #pragma unroll
-        for (int w = 0; w < 2; ++w)
-            if (kind[w] == 2) {
-                v[w][0] = ec[(ia[w] * half + ib[w]) * 2 + 0];
-                v[w][1] = ec[(ia[w] * half + ib[w]) * 2 + 1];
-            }
-        double wi = 0.0;
-        int rank = -1;
-        if (tid < m) {
-            auto diag_at = [&](int i) { return ac[((i >> 1) * half + (i >> 1)) * 4 + (i & 1) * 3]; };
-            auto is_pad = [&](int i) { return m != n && ec[(n * half + (i >> 1)) * 2 + (i & 1)] != 0.0; };
-            if (!is_pad(tid)) {
-                wi = diag_at(tid);
-                rank = 0;
-                for (int j = 0; j < m; ++j) {
-                    if (is_pad(j)) continue;
-                    const double wj = diag_at(j);
-                    if (wj > wi || (wj == wi && j < tid)) ++rank;
-                }
-            }
-        }
-        SCS_WAVE_FENCE();  // all reads of the flat copies are in: s.e may be overwritten
-    #pragma unroll
-        for (int w = 0; w < 2; ++w)
-            if (kind[w] == 2 && ia[w] < n) {
-                s.e[ia[w]][2 * ib[w] + 0] = v[w][0];
-                s.e[ia[w]][2 * ib[w] + 1] = v[w][1];
-            }
-        if (rank >= 0) {
-            s.w[rank] = wi;
-            s.perm[rank] = tid;
-        }
-    }
-    __syncthreads();
-}
-
+// (Round 4: a ONE-wave variant of the above for n <= 12 -- two items per lane, no workgroup
+// barrier inside the sweeps, bitwise the same results -- was built and measured slower:
+// k_small_rr 50.6 us against 43.5, k_small_orth unchanged at 13.1: four waves with one item per
+// thread and two cheap barriers beat one wave that serialises two items and both item kinds;
+// profiles/r04_jacobi_wave.txt.)
 __device__ void jacobi_eig(jacobi_lds &s, int n) {
-    if (n <= 12) {
-        jacobi_eig_wave(s, n);
-        return;
-    }
     if (n <= 24) {
         jacobi_eig_fast(s, n);
         return;
