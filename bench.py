@@ -294,9 +294,18 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     # one v_add_f64 each) against 8 V^2 bytes written once: its HBM fraction is tiny by
     # construction and is reported as is, next to the fractions of the units that do bound it
     lds_gbs = 8.0 * cell_rate / 1e9
+    spec_b = int(bstats.get("spec_batches", 0))
+    if not tables.monotone:
+        acc_kernel = "k_accumulate_gen"
+    elif spec_b == 0:
+        acc_kernel = "k_accumulate_mono"
+    elif spec_b == n_batches:
+        acc_kernel = "k_accumulate_spec"
+    else:
+        acc_kernel = (f"k_accumulate_spec ({spec_b} of the {n_batches} tree batches; the short ones: "
+                      "k_accumulate_mono)")
     roof_acc = {
-        "kernel": ("k_accumulate_mono" if tables.monotone else "k_accumulate_gen") +
-                  " (PCG weights: tree-ordered sums of LCA values into 64 x 256 tiles)",
+        "kernel": acc_kernel + " (PCG weights: tree-ordered sums of LCA values into 64 x 256 tiles)",
         # the binding unit: every cell-tree evaluation is one 8-byte ds_read_b64 of the tile's
         # row-row table (plus one v_min_f64 and one v_add_f64); HBM sees W once
         "bound": "lds",
@@ -389,7 +398,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         for roof in (roof_symm, roof_acc):
             short = roof["kernel"].split("<")[0].split(" ")[0]
             for entry in pmc if isinstance(pmc, list) else [pmc]:
-                if entry and world == 1 and entry.get("kernel", "").startswith(short):
+                if entry and world == 1 and entry.get("kernel", "").split("<")[0] == short:
                     roof["traffic"] = entry["traffic"]
                     roof["traffic_source"] = entry["source"]
     except (OSError, ValueError, KeyError, AttributeError):

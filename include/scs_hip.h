@@ -69,7 +69,8 @@ typedef struct scs_build_stats {
     int32_t symmetric;          /* 1: upper tiles computed, lower mirrored; 2: shared */
     int32_t n_tiles;            /* workgroups of the accumulate kernel per batch     */
     int32_t n_batches;          /* tree batches (scratch bounded by ctx workspace)   */
-    int32_t reserved;
+    int32_t spec_batches;       /* of them walked by the producer / consumer tile kernel
+                                   (k_accumulate_spec; the others by the 4-wave kernels)   */
     double cell_trees;          /* (matrix cell, tree) evaluations performed         */
     double prep_ms;             /* position / sparse-table / block-record kernels    */
     double accumulate_ms;       /* the tile accumulate kernel(s)                     */

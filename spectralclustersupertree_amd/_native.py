@@ -77,7 +77,7 @@ class BuildStats(C.Structure):
         ("symmetric", C.c_int32),
         ("n_tiles", C.c_int32),
         ("n_batches", C.c_int32),
-        ("reserved", C.c_int32),
+        ("spec_batches", C.c_int32),
         ("cell_trees", C.c_double),
         ("prep_ms", C.c_double),
         ("accumulate_ms", C.c_double),

@@ -786,6 +786,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     float prep_ms = 0.f, acc_ms = 0.f;
     SCS_HIP_CHECK(hipEventRecord(ev_total.a, s));
 
+    int spec_batches = 0;
     pooled_buf d_pos(ctx, 1), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5);
     for (int bi = 0; bi < n_batches; ++bi) {
         const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
@@ -811,6 +812,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // that costs more than the shorter steps save (measured at 10 000 leaves: 64 + 218 + 218
         // trees 6.93 ms either way, 218 + 218 with the 4-wave kernel in front 6.5).
         const bool wide_b = wide && nb >= 96;
+        if (wide_b) ++spec_batches;
         SCS_TRY(d_pos.alloc(need_pos));
         SCS_TRY(d_st.alloc(need_st));
         SCS_TRY(d_stoff.alloc(need_stoff));
@@ -1063,6 +1065,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         stats->exchange_bytes = exch_bytes;
         stats->n_tiles = (int32_t)tiles.size();
         stats->n_batches = n_batches;
+        stats->spec_batches = spec_batches;
         stats->cell_trees = (double)tiles.size() * SCS_TR * cols_per_tile * (double)M;
         stats->prep_ms = prep_ms;
         stats->accumulate_ms = acc_ms;

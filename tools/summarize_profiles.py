@@ -34,8 +34,10 @@ if (raw / "bench_cfg4.json").exists():
     shutil.copy(raw / "bench_cfg4.json", out / f"{tag}_bench_cfg4_single_gpu.json")
 stamps = (raw / "stamps.txt").read_text()
 (out / f"{tag}_accumulate_phase_stamps.txt").write_text(
-    "In-kernel s_memtime phase shares of k_accumulate_mono (SCS_ACC_STAMP=1 diagnostic variant, configs[2]);\n"
-    "cycles are per wave per (tile, tree) step, three waves per SIMD interleaved; two tree batches.\n\n" + stamps)
+    "In-kernel s_memtime phase shares of the tile kernels (SCS_ACC_STAMP=1 diagnostic variants, configs[2]: the first,\n"
+    "short tree batch is k_accumulate_mono's, the two long ones k_accumulate_spec's); cycles are per wave per\n"
+    "(workgroup, tree) step, three waves per SIMD.  k_accumulate_spec: every wave adds its own phases, so a producer\n"
+    "phase is averaged over all twelve waves (x 3 for the producers' own figure), a consumer phase x 1.5.\n\n" + stamps)
 
 rows = list(csv.DictReader(open(stats_csv)))
 bench = json.load(open(raw / "bench_under_rocprof.json"))
@@ -44,7 +46,7 @@ default = json.load(open(raw / "bench_default.json"))
 
 def pmc(kind):
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-    f = newest(f"{kind}/*/*counter_collection.csv", "k_accumulate_mono")
+    f = newest(f"{kind}/*/*counter_collection.csv", "k_accumulate")
     for r in csv.DictReader(open(f)):
         a = acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]
         a[0] += 1
@@ -61,10 +63,12 @@ def key_of(acc, needle):
 
 
 k_symm = key_of(fetch, "k_symm")
-k_acc = key_of(fetch, "k_accumulate_mono")
 roofs = {r["kernel"].split(" ")[0].split("<")[0]: r for r in (bench["roofline"], bench["roofline_other"])}
+# the tile kernel that walked the long tree batches (round 4: k_accumulate_spec up to 20 000 leaves)
+ACC = next(k for k in roofs if k.startswith("k_accumulate"))
+k_acc = key_of(fetch, ACC)
 symm_alg = next(v for k, v in roofs.items() if k.startswith("k_symm"))["bytes_per_launch"]
-acc_alg = roofs["k_accumulate_mono"]["bytes_per_launch"]
+acc_alg = roofs[ACC]["bytes_per_launch"]
 alg = {k_symm: (symm_alg, "bytes of W tiles streamed + block in/out"),
        "k_degrees": (8.0 * n * n, "8 V^2"),
        k_acc: (acc_alg, "per tree batch: W tile sums written once + tables read once")}
@@ -119,15 +123,15 @@ lines += ["", f"Reading: the SYMM kernel moves {(corr + wr)/1e6:.0f} MB per laun
 try:
     sq = defaultdict(lambda: [0, 0.0])
     for kind in ("sq1", "sq2", "sq3"):
-        f = newest(f"{kind}/*/*counter_collection.csv", "k_accumulate_mono")
+        f = newest(f"{kind}/*/*counter_collection.csv", ACC)
         for r in csv.DictReader(open(f)):
-            if "k_accumulate_mono" in r["Kernel_Name"]:
+            if ACC in r["Kernel_Name"]:
                 a = sq[r["Counter_Name"]]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
     per = {k: v[1] / v[0] for k, v in sq.items()}
     cu_cycles = per["GRBM_GUI_ACTIVE"] / 8 * 256
-    lines += ["## SQ counters of `k_accumulate_mono` (per launch)", "",
+    lines += [f"## SQ counters of `{ACC}` (per launch)", "",
               f"CU cycles (GRBM_GUI_ACTIVE / 8 XCDs x 256 CUs): {cu_cycles:.3e}; LDS busy (SQ_LDS_IDX_ACTIVE): "
               f"{per['SQ_LDS_IDX_ACTIVE'] / cu_cycles:.2f} of them, bank-conflict cycles (SQ_LDS_BANK_CONFLICT): "
               f"{per['SQ_LDS_BANK_CONFLICT'] / cu_cycles:.2f}; VALU busy (4 x SQ_ACTIVE_INST_VALU / (4 SIMDs x CU cycles)): "
@@ -171,7 +175,7 @@ pj = {"_comment": "HBM-side bytes per launch from committed rocprofv3 PMC passes
       "cfg2": [
           {"kernel": k_symm.replace("void ", "").split("<")[0], "fetch_raw": round(fr), "fetch_corrected": round(corr),
            "write": round(wr), "traffic": round(corr + wr), "source": f"profiles/{tag}_bench_cfg2_summary.md"},
-          {"kernel": "k_accumulate_mono", "fetch_raw": round(afr), "fetch_corrected": round(acorr), "write": round(awr),
+          {"kernel": ACC, "fetch_raw": round(afr), "fetch_corrected": round(acorr), "write": round(awr),
            "traffic": round(acorr + awr), "source": f"profiles/{tag}_bench_cfg2_summary.md (fetches are 8-byte gathers: "
                                                      "uncalibrated width, quoted raw)"}]}
 (out / "pmc_traffic.json").write_text(json.dumps(pj, indent=1))
