@@ -8,6 +8,7 @@ thin: every number is produced by the HIP kernels behind include/scs_hip.h.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -84,7 +85,9 @@ class Device:
         return out
 
     # -- batched small nodes --------------------------------------------------
-    SMALL_MAX_TAXA = 64  # MAXS of the device Jacobi kernel
+    # largest node of the batched path (SMALL_MAXS of libscs_hip: two-sided Jacobi in LDS up to 64
+    # vertices, one-sided up to 128 -- SURVEY.md 8f rank 3).  SCS_SMALL_MAX_TAXA moves the limit down.
+    SMALL_MAX_TAXA = max(2, min(128, int(os.environ.get("SCS_SMALL_MAX_TAXA", "128") or 128)))
 
     def small_solve(self, nodes, want_w: bool = False):
         """K small recursion nodes in one launch (``scs_small_solve``; reference: scs.py:110-134
@@ -184,6 +187,12 @@ class SmallTicket:
             ticket, self._ticket = self._ticket, -1
             nv.check(self.dev._lib.scs_small_solve_end(self.dev._ctx, ticket, nv.dptr(maps), nv.dptr(lam),
                                                        nv.dptr(w) if want_w else None))
+            if not np.all(np.isfinite(lam)):
+                # (the one-sided Jacobi of a node of more than 64 vertices ran out of sweeps: refused, as
+                # the reference's ARPACK call raises rather than return a guess -- scs.py:252)
+                bad = [i for i in range(k) if not np.all(np.isfinite(lam[i]))]
+                msg = f"small-node eigen-solve did not converge (nodes {bad} of a batch of {k})"
+                raise RuntimeError(msg)
             out, at, wat = [], 0, 0
             for i in range(k):
                 v = int(n_groups[i])

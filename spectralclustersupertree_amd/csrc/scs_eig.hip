@@ -751,25 +751,16 @@ __global__ __launch_bounds__(256) void k_small_eig(const double *__restrict__ a,
 constexpr int DENSE2_MAX = 128;
 constexpr int DENSE2_LD = DENSE2_MAX + 1;
 
-__global__ __launch_bounds__(256) void k_dense_onesided(const double *__restrict__ sd, int n,
-                                                         double *__restrict__ w3,
-                                                         double *__restrict__ v2) {
-    extern __shared__ double dyn_lds[];
-    double(*a)[DENSE2_LD] = (double(*)[DENSE2_LD])dyn_lds;  // a[row][col]
-    __shared__ double s_norm[DENSE2_MAX];
-    __shared__ int s_rot, s_top[3];
+// The sweeps: columns of a (m x m, m even) rotated pairwise until mutually orthogonal.  All 256
+// threads of the workgroup call; returns false when 40 sweeps did not get there (never seen: the
+// method converges quadratically; a caller reports it rather than hand back a half-rotated basis).
+__device__ bool onesided_sweeps(double (*a)[DENSE2_LD], int m, int *s_rot) {
     const int tid = threadIdx.x;
-    const int m = n + (n & 1), half = m / 2;  // an odd n gets a zero column / row of padding
-    for (int e = tid; e < m * m; e += 256) {
-        const int i = e / m, j = e - i * m;
-        double v = 0.0;
-        if (i < n && j < n) v = i == j ? 1.0 : 0.5 * (sd[i * n + j] + sd[j * n + i]);
-        a[i][j] = v;
-    }
-    __syncthreads();
+    const int half = m / 2;
     const int pair = tid >> 2, part = tid & 3;
-    for (int sweep = 0; sweep < 40; ++sweep) {
-        if (tid == 0) s_rot = 0;
+    bool done = false;
+    for (int sweep = 0; sweep < 40 && !done; ++sweep) {
+        if (tid == 0) *s_rot = 0;
         __syncthreads();
         for (int step = 0; step < m - 1; ++step) {
             int rotated = 0;
@@ -811,13 +802,33 @@ __global__ __launch_bounds__(256) void k_dense_onesided(const double *__restrict
                     rotated = 1;
                 }
             }
-            if (rotated) s_rot = 1;  // (benign race: every writer stores 1)
+            if (rotated) *s_rot = 1;  // (benign race: every writer stores 1)
             __syncthreads();
         }
-        const int any = s_rot;
+        done = *s_rot == 0;
         __syncthreads();
-        if (!any) break;
     }
+    return done;
+}
+
+// w3: the three largest eigenvalues of S and, in w3[3], 1.0 when the sweeps converged (0.0: they did not)
+__global__ __launch_bounds__(256) void k_dense_onesided(const double *__restrict__ sd, int n,
+                                                         double *__restrict__ w3,
+                                                         double *__restrict__ v2) {
+    extern __shared__ double dyn_lds[];
+    double(*a)[DENSE2_LD] = (double(*)[DENSE2_LD])dyn_lds;  // a[row][col]
+    __shared__ double s_norm[DENSE2_MAX];
+    __shared__ int s_rot, s_top[3];
+    const int tid = threadIdx.x;
+    const int m = n + (n & 1);  // an odd n gets a zero column / row of padding
+    for (int e = tid; e < m * m; e += 256) {
+        const int i = e / m, j = e - i * m;
+        double v = 0.0;
+        if (i < n && j < n) v = i == j ? 1.0 : 0.5 * (sd[i * n + j] + sd[j * n + i]);
+        a[i][j] = v;
+    }
+    __syncthreads();
+    const bool ok = onesided_sweeps(a, m, &s_rot);
     // eigenvalues of S: column norms - 1; the three largest, the two leading unit columns
     if (tid < n) {
         double s2 = 0.0;
@@ -836,6 +847,7 @@ __global__ __launch_bounds__(256) void k_dense_onesided(const double *__restrict
     }
     __syncthreads();
     if (tid < 3) w3[tid] = tid < n ? s_norm[s_top[tid]] - 1.0 : 0.0;
+    if (tid == 3) w3[3] = ok ? 1.0 : 0.0;
     for (int e = tid; e < 2 * n; e += 256) {
         const int k = e / n, r = e - k * n;
         const int col = s_top[k];
@@ -1539,20 +1551,18 @@ static int fiedler_dense_onesided(scs_ctx *ctx, scs_graph *g, double *maps, scs_
     SCS_REQUIRE(ctx->comm.world == 1 && !g->upper, "dense path needs the whole matrix on one rank (V = %d)", n);
     dbuf sd, wv, vv;
     SCS_TRY(sd.alloc((size_t)n * n * 8));
-    SCS_TRY(wv.alloc(3 * 8));
+    SCS_TRY(wv.alloc(4 * 8));
     SCS_TRY(vv.alloc((size_t)n * 2 * 8));
     k_dense_s<<<(n * n + 255) / 256, 256, 0, s>>>(g->d_w, g->ld, n, g->d_dinv, sd.d());
     const size_t lds = (size_t)(n + (n & 1)) * DENSE2_LD * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
-        SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_dense_onesided, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          DENSE2_MAX * DENSE2_LD * (int)sizeof(double)));
-        attr_set = true;
-    }
+    // (the attribute is per function AND device: set on every call -- a process may drive several
+    // devices and threads, and a flag set once would cover only the first)
+    SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_dense_onesided, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DENSE2_MAX * DENSE2_LD * (int)sizeof(double)));
     k_dense_onesided<<<1, 256, lds, s>>>(sd.d(), n, wv.d(), vv.d());
     SCS_HIP_CHECK(hipGetLastError());
-    std::vector<double> w(3), v((size_t)n * 2), dinv(n);
-    SCS_HIP_CHECK(hipMemcpyAsync(w.data(), wv.p, 3 * 8, hipMemcpyDeviceToHost, s));
+    std::vector<double> w(4), v((size_t)n * 2), dinv(n);
+    SCS_HIP_CHECK(hipMemcpyAsync(w.data(), wv.p, 4 * 8, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipMemcpyAsync(v.data(), vv.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipMemcpyAsync(dinv.data(), g->d_dinv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));
@@ -1564,10 +1574,14 @@ static int fiedler_dense_onesided(scs_ctx *ctx, scs_graph *g, double *maps, scs_
     sign_flip_and_store(c0, c1, n, maps);
     if (st) {
         st->block = 0;
-        st->converged = 1;
+        st->converged = w[3] != 0.0 ? 1 : 0;
         st->lambda[0] = w[0];
         st->lambda[1] = w[1];
         st->lambda_next = w[2];
+    }
+    if (w[3] == 0.0) {
+        scs_set_error("scs_fiedler: the dense one-sided Jacobi did not converge in 40 sweeps (V = %d)", n);
+        return SCS_ENOCONV;
     }
     return SCS_OK;
 }
@@ -2026,18 +2040,104 @@ struct small_batch {
     double *w0;
 };
 
-constexpr int SMALL_Q = MAXS * MAXS / 256;  // cells of a thread at the largest node
+constexpr int SMALL_Q = MAXS * MAXS / 256;  // cells of a thread at the largest node of the one-wave form
+constexpr int SMALL_MAXS = 128;             // largest node of the batched path (round 4: was MAXS)
+
+// A node of 65 .. 128 taxa (round 4; SURVEY.md 8f rank 3 asks for V <= 128): the same three
+// launches.  A tree restricted to such a node has up to 128 leaves -- two per lane while a wave
+// stages it, the sparse table built level by level in LDS (seven levels, keys (depth << 7 | gap));
+// a thread owns the cells of one column y and every other row x < y.
+__device__ void small_addends_big(const small_batch &p, int k, int t0, int t1, unsigned (*s_sp)[7][SMALL_MAXS],
+                                  double (*s_val)[SMALL_MAXS], int (*s_pos)[SMALL_MAXS]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v0 = p.n_taxa[k];
+    const int ncell = v0 * v0;
+    const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
+    const int64_t lbase = p.leaf_ptr[k];
+    double *out = p.addends + p.add_ptr[k];
+    const int y = tid & 127, x0 = tid >> 7;
+    for (int g = t0; g < t1; g += 4) {
+        __syncthreads();  // the cells of the previous four trees are done with the buffers
+        const int ts = g + wave;
+        if (ts < t1) {
+            const int off = toff[ts], n = toff[ts + 1] - off;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = lane + 64 * h;
+                int f_dep = 0;
+                double f_val = 0.0;
+                if (i < n) {
+                    f_dep = p.adj_depth[lbase + off + i];
+                    f_val = p.adj_val[lbase + off + i];
+                }
+                // gap i = the LCA of leaves i and i + 1 (adj_* of leaf i), i < n - 1
+                s_sp[wave][0][i] = i + 1 < n ? ((unsigned)f_dep << 7) | (unsigned)i : 0xFFFFFFFFu;
+                s_val[wave][i] = f_val;
+                s_pos[wave][i] = -1;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: its LDS operations are performed in order)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = lane + 64 * h;
+                if (i < n) s_pos[wave][p.leaf_taxon[lbase + off + i]] = i;
+            }
+            for (int j = 1; j < 7; ++j) {
+                if ((1 << j) >= n) break;  // (uniform) no pair of this tree is 2^j gaps apart
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned nk[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = lane + 64 * h, i2 = i + (1 << (j - 1));
+                    const unsigned a = s_sp[wave][j - 1][i];
+                    const unsigned b = i2 < SMALL_MAXS ? s_sp[wave][j - 1][i2] : 0xFFFFFFFFu;
+                    nk[h] = b < a ? b : a;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) s_sp[wave][j][lane + 64 * h] = nk[h];
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < 4; ++j) {
+            const int t = g + j;
+            if (t >= t1) break;
+            const double wt = p.tree_w[p.tree_ptr[k] + t];
+            double *row = out + (int64_t)t * ncell;
+            const int py = y < v0 ? s_pos[j][y] : -1;
+            for (int x = x0; x < y && y < v0; x += 2) {
+                const int px = s_pos[j][x];
+                const bool live = px >= 0 && py >= 0;
+                const int lo = live ? (px < py ? px : py) : 0, hi = live ? (px < py ? py : px) : 1;
+                const int lv = 31 - __clz(hi - lo);
+                const unsigned ka = s_sp[j][lv][lo], kb = s_sp[j][lv][hi - (1 << lv)];
+                // (leftmost on ties, as a left-to-right sweep finds it)
+                const unsigned key = kb < ka ? kb : ka;
+                const double mv = s_val[j][key & 127u];
+                double add = 0.0;
+                // the root (depth 0) separates the two: nothing to add
+                if (live && (key >> 7) != 0) {
+#pragma clang fp contract(off)
+                    add = mv * wt;  // rounded on its own, never fused into the sum
+                }
+                row[x * v0 + y] = add;
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void k_small_addends(small_batch p) {
     // per wave one staged tree: sparse table over the gaps' (depth << 6 | gap) keys, the gaps'
     // values, the position of every taxon (-1: absent)
-    __shared__ unsigned s_sp[4][6][MAXS];
-    __shared__ double s_val[4][MAXS];
-    __shared__ int s_pos[4][MAXS];
+    __shared__ unsigned s_sp[4][7][SMALL_MAXS];
+    __shared__ double s_val[4][SMALL_MAXS];
+    __shared__ int s_pos[4][SMALL_MAXS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = p.item_node[blockIdx.x];
     const int t0 = p.item_t0[blockIdx.x], t1 = p.item_t1[blockIdx.x];
     const int v0 = p.n_taxa[k];
+    if (v0 > MAXS) {
+        small_addends_big(p, k, t0, t1, s_sp, s_val, s_pos);
+        return;
+    }
     const int ncell = v0 * v0;
     const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
     const int64_t lbase = p.leaf_ptr[k];
@@ -2141,6 +2241,7 @@ __global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
     const int tid = threadIdx.x;
     const int k = blockIdx.x;
     const int v = p.n_groups[k], v0 = p.n_taxa[k];
+    if (v0 > MAXS) return;  // k_small_finish_big's
     double(*w0)[SLD] = s.e;  // the uncontracted weights live where Jacobi later keeps its vectors
     if (tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
     {
@@ -2207,6 +2308,103 @@ __global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
     if (tid < 3) p.lambda[k * 3 + tid] = tid < v ? s.w[tid] : 0.0;
 }
 
+// The nodes of 65 .. 128 taxa of a batch, one workgroup each: contraction straight from the
+// uncontracted weights in device memory into the one LDS array the one-sided Jacobi works in
+// (dense path of scs_fiedler: (V + 1) x V doubles, 132 KB at 128), scipy's degree scaling in
+// place (the contracted matrix is symmetric bit for bit, so every cell's two orders of division
+// need only the cell itself), A = S + I, the sweeps, scikit-learn's embedding conventions.  A
+// batch's workgroups of this kind run side by side on as many CUs: what the recursion's walk
+// used to solve one node after the other with ~35 latency-bound LOBPCG iterations each.
+__global__ __launch_bounds__(256) void k_small_finish_big(small_batch p) {
+    extern __shared__ double dyn_lds[];
+    double(*a)[DENSE2_LD] = (double(*)[DENSE2_LD])dyn_lds;
+    __shared__ double s_dd[SMALL_MAXS], s_norm[SMALL_MAXS];
+    __shared__ int s_gs[SMALL_MAXS + 1];
+    __shared__ int s_rot, s_top[3];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x;
+    const int v = p.n_groups[k], v0 = p.n_taxa[k];
+    if (v0 <= MAXS) return;  // k_small_finish's
+    const int m = v + (v & 1);
+    if (tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
+    __syncthreads();
+    // ---- contraction: vertex g = taxa [gs[g], gs[g+1]); weight = max over member pairs
+    // (reference: scs.py:336-387), diagonal 0; the padding row / column of an odd V is zero
+    const double *w0 = p.w0 + p.w0_ptr[k];
+    for (int e = tid; e < m * m; e += 256) {
+        const int g = e / m, h = e - g * m;
+        double best = 0.0;
+        if (g != h && g < v && h < v) {
+            best = w0[s_gs[g] * v0 + s_gs[h]];
+            for (int r = s_gs[g]; r < s_gs[g + 1]; ++r)
+                for (int c = s_gs[h]; c < s_gs[h + 1]; ++c) {
+                    const double x = w0[r * v0 + c];
+                    best = x > best ? x : best;
+                }
+        }
+        a[g][h] = best;
+    }
+    __syncthreads();
+    if (p.w_out)
+        for (int e = tid; e < v * v; e += 256) p.w_out[p.w_ptr[k] + e] = a[e / v][e % v];
+    // ---- degrees as scipy takes them (column sums, rows in order; isolated -> 1)
+    if (tid < v) {
+        double d = 0.0;
+        for (int i = 0; i < v; ++i) d = d + a[i][tid];
+        s_dd[tid] = d == 0.0 ? 1.0 : sqrt(d);
+    }
+    __syncthreads();
+    // S = (W / dd) / dd^T: two successive divisions (scipy/sparse/csgraph/_laplacian.py:552-557),
+    // then the symmetric part (the two orders of division may differ in the last bit); + I
+    for (int e = tid; e < v * v; e += 256) {
+        const int g = e / v, h = e - g * v;
+        const double w = a[g][h];  // == a[h][g]
+        const double x = (w / s_dd[h]) / s_dd[g];
+        const double y = (w / s_dd[g]) / s_dd[h];
+        a[g][h] = g == h ? 1.0 : 0.5 * (x + y);
+    }
+    __syncthreads();
+    const bool ok = onesided_sweeps(a, m, &s_rot);
+    // eigenvalues of S: column norms - 1 (the padding column of an odd V has norm 0: last)
+    if (tid < v) {
+        double s2 = 0.0;
+        for (int r = 0; r < v; ++r) s2 = fma(a[r][tid], a[r][tid], s2);
+        s_norm[tid] = sqrt(s2);
+    }
+    __syncthreads();
+    if (tid < v) {
+        const double mine = s_norm[tid];
+        int rank = 0;
+        for (int j = 0; j < v; ++j) {
+            const double o = s_norm[j];
+            if (o > mine || (o == mine && j < tid)) ++rank;
+        }
+        if (rank < 3) s_top[rank] = tid;
+    }
+    __syncthreads();
+    // ---- embedding: unit eigenvectors / dd, largest |entry| of each column positive, column 0
+    // <-> the largest eigenvalue (sklearn/manifold/_spectral_embedding.py:373-376, 463)
+    if (tid < 2) {
+        const int col = s_top[tid];
+        const double nrm = s_norm[col];
+        int arg = 0;
+        double best = -1.0;
+        for (int i = 0; i < v; ++i) {
+            const double x = fabs((a[i][col] / nrm) / s_dd[i]);
+            if (x > best) {
+                best = x;
+                arg = i;
+            }
+        }
+        const double sg = a[arg][col] < 0.0 ? -1.0 : 1.0;
+        double *out = p.maps + (int64_t)p.vertex_ptr[k] * 2 + tid;
+        for (int i = 0; i < v; ++i) out[2 * i] = sg * ((a[i][col] / nrm) / s_dd[i]);
+    }
+    // (sweeps that did not converge: NaN eigenvalues -- the host refuses the node)
+    if (tid < 3) p.lambda[k * 3 + tid] = !ok ? __longlong_as_double(0x7FF8000000000000ll)
+                                             : (tid < v ? s_norm[s_top[tid]] - 1.0 : 0.0);
+}
+
 extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
                                      const int32_t *n_trees, const int32_t *n_groups,
                                      const int32_t *tree_off, const int32_t *leaf_taxon,
@@ -2226,9 +2424,11 @@ extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_
     std::vector<int32_t> tree_ptr(K + 1, 0), vertex_ptr(K + 1, 0);
     std::vector<int64_t> leaf_ptr(K + 1, 0), w_ptr(K + 1, 0);
     int64_t toff_at = 0;
+    bool any_big = false;  // nodes of more than MAXS taxa: k_small_finish_big
     for (int k = 0; k < K; ++k) {
-        SCS_REQUIRE(n_taxa[k] >= 2 && n_taxa[k] <= MAXS, "scs_small_solve: node %d has %d taxa (2..%d)",
-                    k, n_taxa[k], MAXS);
+        SCS_REQUIRE(n_taxa[k] >= 2 && n_taxa[k] <= SMALL_MAXS, "scs_small_solve: node %d has %d taxa (2..%d)",
+                    k, n_taxa[k], SMALL_MAXS);
+        any_big = any_big || n_taxa[k] > MAXS;
         SCS_REQUIRE(n_groups[k] >= 2 && n_groups[k] <= n_taxa[k], "scs_small_solve: node %d: bad group count %d",
                     k, n_groups[k]);
         SCS_REQUIRE(n_trees[k] >= 1, "scs_small_solve: node %d has no tree", k);
@@ -2386,6 +2586,12 @@ extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_
     k_small_addends<<<(unsigned)n_items, 256, 0, s>>>(sb);
     k_small_sum<<<(unsigned)n_sums, 256, 0, s>>>(sb);
     k_small_finish<<<K, 256, 0, s>>>(sb);
+    if (any_big) {
+        // (every node gets a workgroup of either kind; the one that is not its own returns at once)
+        SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_small_finish_big, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          DENSE2_MAX * DENSE2_LD * (int)sizeof(double)));
+        k_small_finish_big<<<K, 256, (size_t)DENSE2_MAX * DENSE2_LD * sizeof(double), s>>>(sb);
+    }
     SCS_HIP_CHECK(hipGetLastError());
     SCS_HIP_CHECK(hipMemcpyAsync(h + o_maps, d + o_maps, total - o_maps, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipEventRecord(slot.done, s));

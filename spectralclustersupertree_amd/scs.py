@@ -206,7 +206,7 @@ def spectral_bipartition_device(
     all-gather of the Krylov block per iteration; every rank receives the whole embedding and
     draws the same labels.  Smaller nodes run on the rank's own single-device context.
 
-    A node of at most 64 taxa goes through ``scs_small_solve`` (one fused launch);
+    A node of at most 128 taxa goes through ``scs_small_solve`` (three launches, batched);
     ``presolved`` carries the embedding of a node whose device work was already done in a
     batch with its siblings, or queued ahead of the walk (``_construct``, ``ahead.Ahead``).
 
@@ -700,7 +700,7 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
 
 def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahead=None) -> None:
     """Flatten every child problem, and run the device work of those that are one component of
-    at most 64 taxa as ONE ``scs_small_solve`` launch; fills the ``pre`` slot of each child
+    at most 128 taxa as ONE ``scs_small_solve`` batch; fills the ``pre`` slot of each child
     (present taxa, tables, components, embedding-or-None).  With ``ahead`` every small child's
     solve is BEGUN as soon as its tables are flattened (``scs_small_solve_begin``: the next child
     is flattened meanwhile, the result is fetched at the visit), and every larger single-component

@@ -761,8 +761,9 @@ def test_small_solve_equals_the_per_node_path(dev):
     # the fused kernel against build + contract + fiedler on the same nodes, one at a time
     rs = np.random.RandomState(4)
     nodes = []
-    for i in range(12):
-        n = int(rs.randint(3, 65))
+    for i in range(20):
+        # (up to 64 taxa: two-sided Jacobi in LDS; 65 .. 128: the one-sided one, round 4)
+        n = int(rs.randint(3, 65)) if i < 12 else int(rs.randint(65, 129))
         nodes.append((synthetic.make_tables(500 + i, n, int(rs.randint(2, 30)), ["one", "depth", "branch", "bootstrap"][i % 4],
                                             leaves_per_tree=max(2, n - int(rs.randint(0, 3))),
                                             random_weights=bool(i % 2)), None))
@@ -783,7 +784,10 @@ def test_small_solve_equals_the_per_node_path(dev):
 
 
 @pytest.mark.parametrize("n,m,k,strategy", [(5, 1500, 4, "branch"), (12, 700, 9, "bootstrap"), (40, 333, 25, "branch"),
-                                            (64, 150, 64, "depth"), (33, 37, 20, "one")])
+                                            (64, 150, 64, "depth"), (33, 37, 20, "one"),
+                                            # 65 .. 128 taxa (round 4): trees of up to 128 leaves, odd and even sizes
+                                            (65, 90, 65, "branch"), (96, 120, 90, "branch"), (127, 40, 127, "bootstrap"),
+                                            (128, 200, 128, "depth"), (100, 1500, 70, "branch"), (113, 17, 66, "one")])
 def test_small_solve_many_trees_bit_exact(dev, n, m, k, strategy):
     # one node spread over many workgroups (runs of trees -> addends -> tree-ordered sums):
     # W bit for bit the oracle's, in a batch with a second node of another shape
@@ -795,6 +799,44 @@ def test_small_solve_many_trees_bit_exact(dev, n, m, k, strategy):
         assert np.array_equal(w, w_ref)
         assert np.array_equal(w, w.T)
     assert np.array_equal(out[0][0], out[2][0])  # the same node twice: the same bits
+
+
+def test_small_solve_nodes_of_65_to_128_taxa_match_sklearn(dev):
+    # the batched path above the two-sided Jacobi's 64 vertices (V <= 128):
+    # W bit for bit incl. contraction (planted twins), eigenvalues and embedding against
+    # scikit-learn at 1e-10, several such nodes and small ones in one batch
+    import warnings
+
+    rs = np.random.RandomState(11)
+    nodes = []
+    for i, n in enumerate([65, 66, 80, 97, 111, 128, 30, 128]):
+        m = int(rs.randint(8, 60))
+        tables = synthetic.make_tables(1300 + i, n, m, ["branch", "depth", "bootstrap", "one"][i % 4],
+                                       leaves_per_tree=max(2, n - int(rs.randint(0, 9))), random_weights=bool(i % 2))
+        gs = None
+        if i in (2, 5):  # contraction groups: some consecutive taxa merged
+            cuts = np.sort(rs.choice(np.arange(1, n), size=n - 1 - 7, replace=False))
+            gs = np.concatenate(([0], cuts, [n])).astype(np.int32)
+        nodes.append((tables, gs))
+    out = dev.small_solve(nodes, want_w=True)
+    worst = 0.0
+    for (tables, gs), (maps, lam, w) in zip(nodes, out):
+        w_ref, _ = to.pcg_dense(tables)
+        if gs is not None:
+            w_ref = to.contract_dense(w_ref, gs)
+        assert np.array_equal(w, w_ref), tables.n_taxa
+        s_ref, _ = to.normalized_operator(w_ref)
+        ev = np.sort(np.linalg.eigvalsh(s_ref))[::-1]
+        assert np.max(np.abs(lam - ev[:3])) <= 1e-12, (tables.n_taxa, lam, ev[:3])
+        if ev[1] - ev[2] < 1e-6 or ev[0] - ev[1] < 1e-6:
+            continue
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = to.sign_flip_columns(so.spectral_maps(w_ref, np.random.RandomState(0)))
+        err = float(np.max(np.abs(maps - ref)))
+        worst = max(worst, err)
+        assert err <= FIEDLER_TOL, (tables.n_taxa, err)
+    print("SMALL BATCH 65..128 taxa: worst |maps - sklearn|", worst)
 
 
 def test_small_solve_begin_end_tickets(dev):
