@@ -683,16 +683,12 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
 
     // ---- producer / consumer workgroups (scs_mono_wide.h): two tiles of ONE row block per workgroup,
     // the row block's table expanded once for both, four more waves running the column step ahead
-    // of the cells.  Worth it once the groups fill the chip (one twelve-wave workgroup per CU) and
-    // while the producers' range-minimum queries mostly hit the L2 (measured: -7.5 % at 10 000
-    // leaves per tree, +2.5 % at 50 000); a handful of tiles -- a node of the deep recursion --
-    // keeps one workgroup per tile.  SCS_WIDE=0 / 3 force either kernel (A/B runs, tests).
+    // of the cells.  Worth it once the groups fill the chip (one twelve-wave workgroup per CU) --
+    // measured with the long tree batches it prefers (below): -11 % at 10 000 leaves per tree, -12 %
+    // at 50 000; a handful of tiles -- a node of the deep recursion -- keeps one workgroup per tile.
+    // SCS_WIDE=0 / 1 force either kernel (A/B runs, tests).
     constexpr int PIPE_NG = 2;
-    int wide_mode = 0;
-    {
-        const double avg_leaves = (double)tb->n_leaves / std::max(tb->n_trees, 1);
-        if (monotone && !scatter && tiles.size() >= 3 * 256 && avg_leaves <= 20000.0) wide_mode = 3;
-    }
+    int wide_mode = (monotone && !scatter && tiles.size() >= 3 * 256) ? 3 : 0;
     if (const char *e = getenv("SCS_WIDE")) wide_mode = (monotone && !scatter && !tiles.empty() && atoi(e)) ? 3 : 0;
     const bool wide = wide_mode != 0;
     const int group_tiles = PIPE_NG;
@@ -752,10 +748,22 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // (a node of the deep recursion -- a few hundred taxa, thousands of tiny trees -- is a
         // handful of tiles whose tables sit in L2: one batch, one set of launches)
         if (n <= 2048) max_batch_trees = 4096;
-        if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
         // tables whose later trees are still on their way (page-locked source, scs_tables_upload): the
         // trees that have arrived make a first, short batch -- the copy of the rest runs beside it
         const int arrived = tb->late_start.empty() ? M : tb->late_start[0];
+        if (wide) {
+            // The producer / consumer kernel wants LONG batches: its range-minimum queries are off the
+            // cells' critical path (the locality of a short batch buys it little), while every launch
+            // costs it a prologue, tile loads and stores and a thin last round that no second
+            // workgroup on the CU hides.  Measured (profiles/r04_spec_batch_sweep.txt), 50 000 leaves:
+            // 93 trees per batch 705 ms, 186: 633, 256: 613, 400: 602, 667: 617, 1 000: 603, 2 000: 645
+            // (the 4-wave kernel: 682 at 93, 715 at 186); 10 000 leaves: 250: 6.48 ms, 500: 6.2.
+            // Up to 512 trees, the batches behind the first of equal length.
+            const int rest = M - (arrived < M ? arrived : 0);
+            const int k = std::max(1, (rest + 511) / 512);
+            max_batch_trees = std::max(96, (rest + k - 1) / k);
+        }
+        if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
         size_t used = 0;
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
@@ -811,7 +819,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // prologue, its tile stores and the thin last round of its launch, and below ~100 trees
         // that costs more than the shorter steps save (measured at 10 000 leaves: 64 + 218 + 218
         // trees 6.93 ms either way, 218 + 218 with the 4-wave kernel in front 6.5).
-        const bool wide_b = wide && nb >= 96;
+        static const int wide_min_trees = getenv("SCS_WIDE_MIN_TREES") ? atoi(getenv("SCS_WIDE_MIN_TREES")) : 96;
+        const bool wide_b = wide && nb >= wide_min_trees;
         if (wide_b) ++spec_batches;
         SCS_TRY(d_pos.alloc(need_pos));
         SCS_TRY(d_st.alloc(need_st));

@@ -210,7 +210,7 @@ struct spec_layout {
     using L = wide_layout<2>;
     static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
     static constexpr size_t O_T = 0;                                      // double[2][DT_DOUBLES]
-    static constexpr int NREC = 5;  // records of trees t + 1 ... t + 5 during step t
+    static constexpr int NREC = 6;  // records of trees t + 1 ... t + 6 during step t
     static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [NREC][L::BYTES]
     static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[2][512]
     static constexpr size_t O_ADDR = O_VN + 2 * 512 * 8;                 // unsigned[2][512]
@@ -401,46 +401,49 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // producer is there to keep in flight.  (And ONE cell statement in the kernel: a second one with
     // 64 tied accumulators makes the register allocator keep two sets.)
     if (producer) {
-        // ---- prologue: records 0 ... 4, tree 0's column pairs, the queries of trees 1 and 2
+        // ---- prologue: records 0 ... 5, tree 0's column pairs, the queries of trees 1, 2 and 3
         issue_record(0);
         if (nt > 1) issue_record(1);
         if (nt > 2) issue_record(2);
         if (nt > 3) issue_record(3);
         if (nt > 4) issue_record(4);
+        if (nt > 5) issue_record(5);
 #pragma unroll
         for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SCS_BARE_BARRIER();
-        query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa;
+        query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa, qc = qa;
         search(0, qa);
         finish(0, qa);  // (waits for tree 0's answers: once per launch)
         search(1, qa);
         search(2, qb);
+        search(3, qc);
         SCS_BARE_BARRIER();
         if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
         __builtin_amdgcn_s_setprio(2);  // few instructions, all of them on the critical path of the step
-        // Step tl.  On entry: the queries of tree tl + 1 (in `q1`, issued two steps ago) and of tree
-        // tl + 2 (issued a step ago) are in flight; the two sets alternate.
+        // Step tl.  On entry: the queries of trees tl + 1 (in `q1`, issued three steps ago), tl + 2 and
+        // tl + 3 are in flight; the three sets take turns.
         auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
             if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
-            if (tl + 5 < nt) issue_record(tl + 5);
-            search(tl + 3, q1);  // six loads (four table entries, two positions), consumed two steps on
+            if (tl + 6 < nt) issue_record(tl + 6);
+            search(tl + 4, q1);  // six loads (four table entries, two positions), consumed three steps on
             // The record that must be in place when the barrier opens is the one requested a step ago
-            // (tree tl + 4: searched in the next step).  Loads return in order, so "it has landed" is
+            // (tree tl + 5: searched in the next step).  Loads return in order, so "it has landed" is
             // "all but the loads issued after it are done": the six of the step before, this step's
-            // record pieces (two for producer 0, one for the others) and the six above -- the youngest
-            // queries (misses of the L2 at 50 000 leaves: 2-3 us) stay in flight.
-            if (tl + 5 >= nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (no pieces this step)
+            // record pieces (two for producer 0, one for the others) and the six above -- the two
+            // youngest sets of queries (misses of the L2 at 50 000 leaves: 2-3 us) stay in flight.
+            if (tl + 6 >= nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (no pieces this step)
             else if (pw == 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
             stamp(1);
             SCS_BARE_BARRIER();
             stamp(4);
         };
-        for (int tl = 0; tl < nt; tl += 2) {
+        for (int tl = 0; tl < nt; tl += 3) {
             step(tl, qa);
             if (tl + 1 < nt) step(tl + 1, qb);
+            if (tl + 2 < nt) step(tl + 2, qc);
         }
         if (STAMPED && lane == 0 && p.stamps) {
 #pragma unroll
