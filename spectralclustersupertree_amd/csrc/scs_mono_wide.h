@@ -32,9 +32,7 @@ struct wide_layout {
     static constexpr int NSEG = 4 * NG;  // expansion segments = waves
     static constexpr int SPOS = 0;       // int32[64]  sorted DFS positions (INT_MAX beyond cnt)
     static constexpr int G = 256;        // f64[64]    value of LCA(sorted k, sorted k+1); 0 beyond cnt-1
-    static constexpr int SEED = 768;     // f64[NSEG-1][64] seed[w-1][i] = min g[rank(i) .. seg(w)-1] for the ROW i whose
-                                         // rank lies below seg(w), +inf for the other rows: a lane reads its own
-                                         // entry, no look-up of its rank in front (a dependent LDS round trip)
+    static constexpr int SEED = 768;     // f64[NSEG-1][64] seed[w-1][a] = min g[a .. seg(w)-1] for a < seg(w)
     static constexpr int ARGPOS = SEED + (NSEG - 1) * 512;  // int32[64]
     static constexpr int SORIG = ARGPOS + 256;              // u8[64]
     static constexpr int RANK = SORIG + 64;                 // u8[64]
@@ -116,7 +114,7 @@ __global__ __launch_bounds__(64) void k_block_records_wide(
             const double other = __shfl_down(mine, off, 64);
             if (lane + off < end) mine = min_f64(mine, other);
         }
-        seed[(w - 1) * 64 + orig] = lane < end ? mine : inf;
+        seed[(w - 1) * 64 + lane] = mine;
     }
 }
 
@@ -212,13 +210,11 @@ struct spec_layout {
     using L = wide_layout<2>;
     static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
     static constexpr size_t O_T = 0;                                      // double[2][DT_DOUBLES]
-    static constexpr int NREC = 7;   // records of trees t + 1 ... t + 7 during step t
-    static constexpr int NSLOT = 3;  // hand-off slots: tree t in use, t + 1 being prefetched, t + 2 being written
+    static constexpr int NREC = 6;  // records of trees t + 1 ... t + 6 during step t
     static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [NREC][L::BYTES]
-    static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[NSLOT][512]
-    static constexpr size_t O_ADDR = O_VN + NSLOT * 512 * 8;             // unsigned[NSLOT][512]
-    static constexpr size_t O_INF = O_ADDR + NSLOT * 512 * 4;            // double[64] of +inf (wave 0's "seeds")
-    static constexpr size_t LDS_BYTES = O_INF + 64 * 8;
+    static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[2][512]
+    static constexpr size_t O_ADDR = O_VN + 2 * 512 * 8;                 // unsigned[2][512]
+    static constexpr size_t LDS_BYTES = O_ADDR + 2 * 512 * 4;
     static_assert(O_VN % 16 == 0 && 3 * (size_t)MONO_TCW * 9 * 8 <= LDS_BYTES, "layout");
 };
 
@@ -365,7 +361,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
                 nb = pself[k];
                 vn = inf;
             }
-            const int slot = (t % S::NSLOT) * 512 + (2 * pw + k) * 64 + lane;
+            const int slot = (t & 1) * 512 + (2 * pw + k) * 64 + lane;
             s_vn[slot] = vn;
             s_addr[slot] = tbase + (unsigned)nb * (DV_LD * 8);
         }
@@ -380,7 +376,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         const int so_rank = rb[L::SORIG + lane];
         const int rho = rb[L::RANK + lane];
         double cur = inf;
-        if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
+        if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
         double *row_a = &dv[lane * DV_LD];
         double *col_a = &dv[lane];
 #pragma unroll
@@ -405,38 +401,39 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // producer is there to keep in flight.  (And ONE cell statement in the kernel: a second one with
     // 64 tied accumulators makes the register allocator keep two sets.)
     if (producer) {
-        // ---- prologue: records 0 ... 6, the column pairs of trees 0 and 1, the queries of trees 2, 3, 4
-        for (int t = 0; t < 7; ++t)
-            if (t < nt) issue_record(t);
+        // ---- prologue: records 0 ... 5, tree 0's column pairs, the queries of trees 1, 2 and 3
+        issue_record(0);
+        if (nt > 1) issue_record(1);
+        if (nt > 2) issue_record(2);
+        if (nt > 3) issue_record(3);
+        if (nt > 4) issue_record(4);
+        if (nt > 5) issue_record(5);
 #pragma unroll
         for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SCS_BARE_BARRIER();
         query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa, qc = qa;
         search(0, qa);
-        search(1, qb);
-        finish(0, qa);  // (waits for the answers: once per launch)
-        if (nt > 1) finish(1, qb);
-        search(2, qa);
-        search(3, qb);
-        search(4, qc);
+        finish(0, qa);  // (waits for tree 0's answers: once per launch)
+        search(1, qa);
+        search(2, qb);
+        search(3, qc);
         SCS_BARE_BARRIER();
         if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
         __builtin_amdgcn_s_setprio(2);  // few instructions, all of them on the critical path of the step
-        // Step tl.  On entry: the pairs of trees tl and tl + 1 are in place (the consumers fetch the
-        // latter inside this step's cell loop); the queries of trees tl + 2 (in `q2`, issued three steps
-        // ago), tl + 3 and tl + 4 are in flight; the three sets take turns.
-        auto step = [&](int tl, query &q2) __attribute__((always_inline)) {
-            if (tl + 2 < nt) finish(tl + 2, q2);
+        // Step tl.  On entry: the queries of trees tl + 1 (in `q1`, issued three steps ago), tl + 2 and
+        // tl + 3 are in flight; the three sets take turns.
+        auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
+            if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
-            if (tl + 7 < nt) issue_record(tl + 7);
-            search(tl + 5, q2);  // six loads (four table entries, two positions), consumed three steps on
+            if (tl + 6 < nt) issue_record(tl + 6);
+            search(tl + 4, q1);  // six loads (four table entries, two positions), consumed three steps on
             // The record that must be in place when the barrier opens is the one requested a step ago
-            // (tree tl + 6: searched in the next step).  Loads return in order, so "it has landed" is
+            // (tree tl + 5: searched in the next step).  Loads return in order, so "it has landed" is
             // "all but the loads issued after it are done": the six of the step before, this step's
             // record pieces (two for producer 0, one for the others) and the six above -- the two
             // youngest sets of queries (misses of the L2 at 50 000 leaves: 2-3 us) stay in flight.
-            if (tl + 7 >= nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (no pieces this step)
+            if (tl + 6 >= nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (no pieces this step)
             else if (pw == 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
             stamp(1);
@@ -472,57 +469,32 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
                 v = p.w[(int64_t)(row0 - p.row_begin + i) * p.ld + col];
             acc[i] = v;
         }
-        if (wave == 0) ((double *)(s_mem + S::O_INF))[lane] = inf;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         SCS_BARE_BARRIER();  // the records are in place
         expand_whole(0);
         SCS_BARE_BARRIER();
         if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
         // Step tl.  On entry (all waves past the barrier): the table of tree tl is complete in
-        // s_t[tl & 1]; the column's pair of tree tl and the wave's expansion state of tree tl + 1 ARE IN
-        // REGISTERS -- fetched inside the previous step's cell statement, behind its last expansion
-        // step, into the registers whose contents had just had their last use (the pairs of tree
-        // tl + 1 were written a whole step earlier, the record of tree tl + 2 landed long ago): a step
-        // opens with its cell loop, not with two round trips to an idle LDS.
-        static_assert(L::G == SCS_CELLS_EXPAND_PF_G && L::SORIG == SCS_CELLS_EXPAND_PF_SORIG &&
-                          L::RANK == SCS_CELLS_EXPAND_PF_RANK, "record offsets baked into the generated statement");
-        const int b0 = L::seg(wave);
-        auto lds_addr = [](const void *q) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)q; };
-        double vn, cur;
-        unsigned addr;
-        int g_lo, g_hi, so_rank, rho;
-        {  // the first step's operands
-            const int slot = wave * 64 + lane;
-            vn = s_vn[slot];
-            addr = s_addr[slot];
-            const unsigned char *rb = s_rec + (min(1, nt - 1) % S::NREC) * L::BYTES;
-            const double g_rank = ((const double *)(rb + L::G))[lane];
-            g_lo = (int)__double2loint(g_rank);
-            g_hi = __double2hiint(g_rank);
-            so_rank = rb[L::SORIG + lane];
-            rho = rb[L::RANK + lane];
-            cur = inf;
-            if (wave > 0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + lane];
-        }
+        // s_t[tl & 1], its column pairs in slot tl & 1; the record of tree tl + 1 is in place.
         for (int tl = 0; tl < nt; ++tl) {
+            const int slot = (tl & 1) * 512 + wave * 64 + lane;
+            const double vn = s_vn[slot];
+            const unsigned addr = s_addr[slot];
+            const unsigned char *rb = s_rec + (min(tl + 1, nt - 1) % S::NREC) * L::BYTES;
+            const double g_rank = ((const double *)(rb + L::G))[lane];
+            const int so_rank = rb[L::SORIG + lane];
+            const int rho = rb[L::RANK + lane];
+            const int b0 = L::seg(wave);
+            double cur = inf;
+            if (rho < b0) cur = ((const double *)(rb + L::SEED))[(wave - 1) * 64 + rho];
             double *dv = s_t + ((tl + 1) & 1) * DT_DOUBLES;
-            const unsigned tbo = lds_addr(dv);
-            const unsigned rowb = tbo + (unsigned)lane * (DV_LD * 8), colb = tbo + (unsigned)lane * 8;
-            // next step's operands: pair of tree tl + 1, expansion state of tree tl + 2 (clamped)
-            const unsigned char *rbn = s_rec + (min(tl + 2, nt - 1) % S::NREC) * L::BYTES;
-            const unsigned recn = lds_addr(rbn);
-            const unsigned seedn = wave > 0 ? recn + L::SEED + (unsigned)(wave - 1) * 512u : lds_addr(s_mem + S::O_INF);
-            const int nslot = (min(tl + 1, nt - 1) % S::NSLOT) * 512 + wave * 64;
-            const unsigned hvn = lds_addr(&s_vn[nslot]), haddr = lds_addr(&s_addr[nslot]);
+            const unsigned rowb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane * DV_LD];
+            const unsigned colb = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&dv[lane];
             stamp(2);
-            double vnn;
-            {
-                double tmp[SCS_CELLS_DEPTH];
-                unsigned x1, x2;
-                SCS_CELLS_EXPAND_PF_ASM(acc, tmp, x1, x2, addr, vn, vnn, cur, g_lo, g_hi, so_rank, rho, rowb, colb, b0,
-                                        DV_LD * 8, tbo, recn, seedn, hvn, haddr);
-            }
-            vn = vnn;
+            double tmp[SCS_CELLS_DEPTH];
+            unsigned x1, x2;
+            SCS_CELLS_EXPAND_ASM(acc, tmp, x1, x2, addr, vn, cur, (int)__double2loint(g_rank),
+                                 __double2hiint(g_rank), so_rank, rho, rowb, colb, b0, DV_LD * 8);
             stamp(3);
             SCS_BARE_BARRIER();
             stamp(4);

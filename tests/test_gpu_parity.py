@@ -612,8 +612,7 @@ def test_spec_kernel_shared_multi_rank_build(dev, monkeypatch):
 def test_spec_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
     # 3 000 taxa / 600 trees: 12 column tiles per row block, several tree batches by the tree cap
     # (256 for the 4-wave kernel, 512 -- equal lengths -- for the producer / consumer kernel);
-    # the two kernels against each other, whole matrix, and sampled rows against the oracle;
-    # left to itself scs_pcg_build takes the producer / consumer kernel here
+    # the two kernels against each other, whole matrix, and sampled rows against the oracle
     tables = synthetic.make_tables(3, 3000, 600, "branch", random_weights=True)
     got = {}
     for wide in ("0", "1", None):
@@ -625,7 +624,9 @@ def test_spec_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
         g = dtab.build()
         got[wide] = g.download()
         assert g.build_stats["n_batches"] > 1
-        assert g.build_stats["spec_batches"] == (0 if wide == "0" else g.build_stats["n_batches"])
+        # (left to itself scs_pcg_build keeps the 4-wave kernel here: 300 tiles do not fill the chip
+        # with twelve-wave workgroups)
+        assert g.build_stats["spec_batches"] == (g.build_stats["n_batches"] if wide == "1" else 0)
         g.free()
         dtab.free()
     assert np.array_equal(got["0"], got["1"]) and np.array_equal(got["0"], got[None])

@@ -156,100 +156,6 @@ def cells_expand():
 """
 
 
-def cells_expand_prefetch():
-    """SCS_CELLS_EXPAND_PF_ASM (k_accumulate_spec, consumers): SCS_CELLS_EXPAND_ASM plus, behind the
-    wave's last expansion step, the loads of the NEXT step's operands -- the column's (table row
-    address, own value) pair of tree t + 1 and the expansion state of tree t + 2 -- into the very
-    registers whose current contents have just had their last use (the pair's value goes into a
-    register pair of its own: the current one is needed to the last cell).  A step then opens with
-    its cell loop instead of two round trips to an idle LDS.  Record offsets are the layout's
-    (wide_layout<2>: G 256, SORIG 4608, RANK 4672; the kernel static_asserts them)."""
-    G, SORIG, RANK = 256, 4608, 4672
-    lines = []
-    queue = []
-
-    def read(k, row):
-        lines.append(f"ds_read_b64 %[t{k}], %[addr] offset:{8 * row}")
-        queue.append(("r", k))
-
-    def consume(k):
-        idx = next(i for i, op in enumerate(queue) if op == ("r", k))
-        younger = len(queue) - 1 - idx
-        lines.append(f"s_waitcnt lgkmcnt({younger})")
-        del queue[: idx + 1]
-
-    def other(text):
-        lines.append(text)
-        queue.append(("x",))
-
-    for k in range(DEPTH):
-        read(k, k)
-    for i in range(ROWS):
-        k = i % DEPTH
-        j, ph = divmod(i, 8)
-        if ph == 0:
-            lines.append(f"s_add_u32 s92, %[b0], {j}")
-            lines.append("v_readlane_b32 s94, %[glo], s92")
-            lines.append("v_readlane_b32 s95, %[ghi], s92")
-            lines.append("v_readlane_b32 s96, %[so], s92")
-        consume(k)
-        lines.append(f"v_min_f64 %[t{k}], %[t{k}], %[vn]")
-        lines.append(f"v_add_f64 %[a{i}], %[a{i}], %[t{k}]")
-        if i + DEPTH < ROWS:
-            read(k, i + DEPTH)
-        if ph == 0:
-            lines.append("s_mul_i32 s97, s96, %[ld8]")
-            lines.append("v_lshl_add_u32 %[x1], s96, 3, %[rowb]")
-            lines.append("v_add_u32 %[x2], s97, %[colb]")
-            lines.append("v_cmpx_ge_u32 vcc, s92, %[rho]")
-            other("ds_write_b64 %[x1], %[cur]")
-            other("ds_write_b64 %[x2], %[cur]")
-            lines.append("v_min_f64 %[cur], %[cur], s[94:95]")
-            lines.append("s_mov_b64 exec, -1")
-        if i == ROWS - 8 + 1:
-            # the last expansion step is a cell behind us (its v_cmpx well clear of anything lane-crossing;
-            # nothing below crosses lanes) and the last cell read has been issued: glo, ghi, so, rho,
-            # cur, x1, x2 and addr are free
-            assert not any(op[0] == "r" and False for op in queue)
-            lines.append("v_subrev_u32 %[x1], %[tbo], %[colb]")    # lane * 8
-            lines.append("v_add_u32 %[x2], %[recn], %[x1]")
-            other(f"ds_read_b32 %[glo], %[x2] offset:{G}")
-            other(f"ds_read_b32 %[ghi], %[x2] offset:{G + 4}")
-            lines.append("v_add_u32 %[x2], %[seedn], %[x1]")
-            other("ds_read_b64 %[cur], %[x2]")
-            lines.append("v_add_u32 %[x2], %[hvn], %[x1]")
-            other("ds_read_b64 %[vnn], %[x2]")
-            lines.append("v_lshrrev_b32 %[x1], 1, %[x1]")          # lane * 4
-            lines.append("v_add_u32 %[x2], %[haddr], %[x1]")
-            other("ds_read_b32 %[addr], %[x2]")
-            lines.append("v_lshrrev_b32 %[x1], 2, %[x1]")          # lane
-            lines.append("v_add_u32 %[x2], %[recn], %[x1]")
-            other(f"ds_read_u8 %[so], %[x2] offset:{SORIG}")
-            other(f"ds_read_u8 %[rho], %[x2] offset:{RANK}")
-    lines.append("s_waitcnt lgkmcnt(0)")
-    # the address register must not be re-loaded while a cell read that uses it is still to be issued
-    last_read_issue = max(n for n, ln in enumerate(lines) if ln.startswith("ds_read_b64 %[t"))
-    first_addr_load = next(n for n, ln in enumerate(lines) if ln.startswith("ds_read_b32 %[addr]"))
-    assert first_addr_load > last_read_issue
-    outs = ("," + BS).join(f'          [a{i}] "+v"(ACC[{i}])' for i in range(ROWS))
-    tmps = ("," + BS).join(f'          [t{k}] "=&v"(TMP[{k}])' for k in range(DEPTH))
-    return f"""#define SCS_CELLS_EXPAND_PF_G {G}
-#define SCS_CELLS_EXPAND_PF_SORIG {SORIG}
-#define SCS_CELLS_EXPAND_PF_RANK {RANK}
-#define SCS_CELLS_EXPAND_PF_ASM(ACC, TMP, X1, X2, ADDR, VN, VNN, CUR, GLO, GHI, SO, RHO, ROWB, COLB, B0, LD8, TBO, RECN, SEEDN, HVN, HADDR) \\
-    asm volatile( \\
-{quoted(lines)} \\
-        : \\
-{outs}, \\
-{tmps}, \\
-          [x1] "=&v"(X1), [x2] "=&v"(X2), [cur] "+v"(CUR), [addr] "+v"(ADDR), [vnn] "=&v"(VNN), \\
-          [glo] "+v"(GLO), [ghi] "+v"(GHI), [so] "+v"(SO), [rho] "+v"(RHO) \\
-        : [vn] "v"(VN), [rowb] "v"(ROWB), [colb] "v"(COLB), [b0] "s"(B0), [ld8] "s"(LD8), \\
-          [tbo] "s"(TBO), [recn] "s"(RECN), [seedn] "s"(SEEDN), [hvn] "s"(HVN), [haddr] "s"(HADDR) \\
-        : "memory", "vcc", "s92", "s94", "s95", "s96", "s97")
-"""
-
-
 def main(path):
     text = f"""// GENERATED by tools/gen_cells_asm.py -- do not edit.
 // SCS_CELLS_ASM(ACC, TMP, ADDR, VN): ACC double[{ROWS}] accumulators, TMP double[{DEPTH}] scratch,
@@ -269,8 +175,7 @@ def main(path):
 #define SCS_CELLS_GEN_DEPTH {GEN_DEPTH}
 {mono()}
 {general()}
-{cells_expand()}
-{cells_expand_prefetch()}"""
+{cells_expand()}"""
     open(path, "w").write(text)
 
 
