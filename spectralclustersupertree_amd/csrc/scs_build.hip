@@ -893,6 +893,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 wide_params wp;
                 wp.m = mp;
                 wp.groups = (const int4 *)d_groups.p;
+                static const int spec_prio = getenv("SCS_SPEC_PRIO") ? atoi(getenv("SCS_SPEC_PRIO")) : 2;
+                wp.producer_prio = spec_prio;
                 const unsigned ng = (unsigned)groups.size();
                 dev_buf d_st8;
                 if (stamp) {

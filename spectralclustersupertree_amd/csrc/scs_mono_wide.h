@@ -138,6 +138,7 @@ __device__ __forceinline__ void lds_dma16_asm(const scs_int4 rsrc, const unsigne
 struct wide_params {
     mono_params m;
     const int4 *groups;  // x, y: indices into m.tiles of up to two tiles of ONE row block (-1: none)
+    int producer_prio;   // s_setprio of the producer waves (0: as the consumers)
 };
 
 template <bool SYM>
@@ -200,12 +201,19 @@ __device__ __forceinline__ void tile_store_wide(const mono_params &p, double (&a
 // consumers -- per tree: read the column's (table row address, own value) pair from LDS, then the
 // one woven statement (cells of tree t + the wave's expansion steps of tree t + 1) -- and FOUR are
 // producers: each runs the column step of k_accumulate_mono for the 128 columns of two consumer
-// waves, TWO trees ahead (a step is about 2 us, a query that misses the L2 takes as long), and
-// leaves the pairs in LDS; they also stage the records.  One barrier per tree for all twelve.
-// Measured (tools/acc_ab.py, one MI355X): 10 000 taxa / 500 trees 6.40-6.46 ms against 6.92 for
-// k_accumulate_mono (4.2e12 cell-trees/s); 50 000 / 2 000: 698 against 681 ms -- the producers'
-// queries miss the L2 there and the producers, not the LDS, set the step: scs_pcg_build takes
-// this kernel up to 20 000 leaves per tree (SCS_WIDE=0 / 3 force either).
+// waves, THREE trees ahead (a step is about 2 us, a query that misses the L2 takes as long; three
+// sets of answers in flight), and leaves the pairs in LDS; they also stage the records.  One barrier
+// per tree for all twelve.  The kernel wants LONG tree batches (scs_pcg_build gives it up to 512
+// trees): its queries are off the cells' critical path, so the cache locality of a short batch
+// buys it little, while every launch costs a one-workgroup-per-CU kernel a prologue, tile loads /
+// stores and a thin last round.  Measured (tools/acc_ab.py, one MI355X, same process and tables as
+// k_accumulate_mono; profiles/r04_spec_long_batches.txt, r04_spec_batch_sweep.txt):
+//   10 000 taxa /   500 trees   6.1 ms against 7.0   (4.4e12 cell-trees/s against 3.85e12)
+//   50 000 taxa / 2 000 trees   600 ms against 681   (4.2e12 against 3.7e12)
+//  100 000 taxa / 5 000 trees   6.52 s against 7.37  (3.85e12 against 3.4e12)
+// scs_pcg_build takes it whenever its groups fill the chip (SCS_WIDE=0 / 1 force either kernel) and
+// leaves tree batches shorter than 96 trees (the first 64 trees of tables still on their way) to
+// the 4-wave kernel.
 struct spec_layout {
     using L = wide_layout<2>;
     static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
@@ -310,14 +318,18 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         const int *s_spos = (const int *)(rb + L::SPOS);
         const int *s_arg = (const int *)(rb + L::ARGPOS);
         const unsigned char *s_sorig = rb + L::SORIG;
-        const int *s_piv = (const int *)(rb + L::PIV);
-        const int cnt = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::CNT));
-        const int m = __builtin_amdgcn_readfirstlane(*(const int *)(rb + L::M));
-        const unsigned so_lo = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF));
-        const unsigned so_hi = __builtin_amdgcn_readfirstlane(*(const unsigned *)(rb + L::STOFF + 4));
+        // the record's pivots and scalars through the SCALAR path, from the record's copy in device
+        // memory (constant for the kernel's duration: address space 4, a uniform address -> s_load):
+        // one LDS round trip less in a search whose every LDS access queues behind the consumers'
+        // cell reads
+        typedef const __attribute__((address_space(4))) int *cint;
+        cint gpiv = (cint)(size_t)(rec_base + (int64_t)t * L::BYTES + L::PIV);
+        const int4 pa = make_int4(gpiv[0], gpiv[1], gpiv[2], gpiv[3]);
+        const int4 pb = make_int4(gpiv[4], gpiv[5], gpiv[6], gpiv[7]);
+        const int cnt = gpiv[8], m = gpiv[9];  // (CNT and M follow the pivots, STOFF follows them)
+        const unsigned so_lo = (unsigned)gpiv[10], so_hi = (unsigned)gpiv[11];
+        static_assert(L::CNT == L::PIV + 32 && L::M == L::PIV + 36 && L::STOFF == L::PIV + 40, "record tail");
         const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
-        const int4 pa = *(const int4 *)&s_piv[0];
-        const int4 pb = *(const int4 *)&s_piv[4];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int cp = cpos[k];
@@ -420,7 +432,10 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         search(3, qc);
         SCS_BARE_BARRIER();
         if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
-        __builtin_amdgcn_s_setprio(2);  // few instructions, all of them on the critical path of the step
+        // (few instructions, all of them on the critical path of the step -- unless the consumers are)
+        if (wp.producer_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (wp.producer_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (wp.producer_prio == 3) __builtin_amdgcn_s_setprio(3);
         // Step tl.  On entry: the queries of trees tl + 1 (in `q1`, issued three steps ago), tl + 2 and
         // tl + 3 are in flight; the three sets take turns.
         auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
