@@ -99,6 +99,32 @@ __global__ void k_sparse_level(const int64_t *__restrict__ tree_off, int t0, int
     base[(int64_t)k * m + p] = a < b ? a : b;
 }
 
+// ALL levels k >= 1 of a tree's sparse table by ONE workgroup per tree (grid = trees in the batch):
+// a launch per level is a dozen launches of a few microseconds of work each for trees of up to a
+// few 10^4 leaves -- 0.56 ms of a 19 ms step at configs[2] (profiles/r04_bench_cfg2_kernel_stats.csv:
+// 63 launches of k_sparse_level per pass).  Level k reads what the same workgroup wrote as level
+// k - 1: __syncthreads() orders that (workgroup-scope release / acquire on global memory: the
+// workgroup's waves share one L1).  MIN(a, b) is `a < b ? a : b` on values, gap_min on pairs.
+template <typename K, typename MIN>
+__global__ __launch_bounds__(1024) void k_sparse_levels_fused(const int64_t *__restrict__ tree_off, int t0,
+                                                               const int64_t *__restrict__ st_off,
+                                                               K *__restrict__ st, MIN pick) {
+    const int tl = blockIdx.x;
+    const int m = (int)(tree_off[t0 + tl + 1] - tree_off[t0 + tl]) - 1;
+    K *base = st + st_off[tl];
+    for (int k = 1; (1 << k) <= m; ++k) {
+        const K *prev = base + (int64_t)(k - 1) * m;
+        K *cur = base + (int64_t)k * m;
+        const int half = 1 << (k - 1), last = m - (1 << k);
+        for (int p = threadIdx.x; p <= last; p += 1024) cur[p] = pick(prev[p], prev[p + half]);
+        __syncthreads();
+    }
+}
+constexpr int SPARSE_FUSED_MAX_LEAVES = 32768;  // beyond: a launch per level has real work and more parallelism
+struct pick_smaller_value {
+    __device__ double operator()(double a, double b) const { return a < b ? a : b; }
+};
+
 // one v_min_f64 (the builtin fmin adds a canonicalising v_max_f64 in front of it);
 // operands are finite non-negative values or +inf, so IEEE minNum semantics are moot
 __device__ __forceinline__ double min_f64(double a, double b) {
@@ -114,6 +140,9 @@ __device__ __forceinline__ double min_f64(double a, double b) {
 #include "scs_mono.h"  // monotone fast path: k_block_records_mono, k_accumulate_mono
 #include "scs_mono_wide.h"  // the same walk for three column tiles of a row block per workgroup
 #include "scs_gen.h"   // general path on the same tile structure: k_block_records_gen, k_accumulate_gen
+struct pick_shallower_pair {
+    __device__ gap_entry operator()(const gap_entry a, const gap_entry b) const { return gap_min(a, b); }
+};
 
 // ---------------------------------------------------------------------------
 // comparison variant: input-stationary scatter with global fp64 atomics (SCS_BUILD_SCATTER)
@@ -837,6 +866,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                                                       tb->d_adj_depth, tb->d_adj_val, tb->d_tree_w,
                                                       t0, (int32_t *)d_pos.p, npad,
                                                       (const int64_t *)d_stoff.p, (double *)d_st.p);
+            if (max_n <= SPARSE_FUSED_MAX_LEAVES && max_levels > 1)
+                k_sparse_levels_fused<double><<<(unsigned)nb, 1024, 0, s>>>(
+                    tb->d_tree_off, t0, (const int64_t *)d_stoff.p, (double *)d_st.p, pick_smaller_value{});
+            else
             for (int k = 1; k < max_levels; ++k)
                 k_sparse_level<double><<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
                                                               (const int64_t *)d_stoff.p,
@@ -854,6 +887,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                                                      tb->d_adj_depth, tb->d_adj_val, tb->d_tree_w,
                                                      t0, (int32_t *)d_pos.p, npad,
                                                      (const int64_t *)d_stoff.p, (gap_entry *)d_st.p);
+            if (max_n <= SPARSE_FUSED_MAX_LEAVES && max_levels > 1)
+                k_sparse_levels_fused<gap_entry><<<(unsigned)nb, 1024, 0, s>>>(
+                    tb->d_tree_off, t0, (const int64_t *)d_stoff.p, (gap_entry *)d_st.p, pick_shallower_pair{});
+            else
             for (int k = 1; k < max_levels; ++k)
                 k_sparse_level_pairs<<<grid_l, 256, 0, s>>>(tb->d_tree_off, t0, k,
                                                             (const int64_t *)d_stoff.p,
