@@ -469,7 +469,10 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
                     f"eig = sklearn.manifold.spectral_embedding (the reference's ARPACK shift-invert "
                     f"path) on the full {n} x {n} matrix, {blas} BLAS threads, {t_eig:.2f} s.  One thread: "
                     f"trees [0,{legs['one_thread_sample_trees']}) in {legs['one_thread_sample_s']:.2f} s, "
-                    f"x{m / legs['one_thread_sample_trees']:.1f} -> {legs['one_thread_scaled_s']:.1f} s"
+                    f"x{m / legs['one_thread_sample_trees']:.1f} -> {legs['one_thread_scaled_s']:.1f} s (scaled).  "
+                    f"The reference's literal dict-of-tuples build (reference_style_build): a "
+                    f"{ref_leg['seconds']:.2f} s sample of {ref_leg['pair_updates']} pair updates, EXTRAPOLATED to "
+                    f"{ref_leg['extrapolated_s_at_workload']:.0f} s for this workload -- not part of `value`"
                 ),
                 "build_s": round(legs["all_core_s"], 3),
                 "build_one_thread_scaled_s": round(legs["one_thread_scaled_s"], 2),

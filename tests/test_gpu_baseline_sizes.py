@@ -372,7 +372,10 @@ def test_page_locked_tables_arrive_behind_the_first_tree_batch(dev):
             dtab = dev.upload(tables)
             graph = dtab.build()
             try:
-                assert graph.build_stats["n_batches"] > 1
+                # (pageable monotone tables: ONE batch of 500 trees for the producer / consumer kernel;
+                # page-locked ones: the 64 trees that have arrived, then the rest)
+                if tables is pinned or strategy == "bootstrap":
+                    assert graph.build_stats["n_batches"] > 1
                 got.append(_check_rows_bit_exact(graph, tables, rows))
                 if tables is pinned:  # the tables are complete now: a second build reads them as they are
                     again = dtab.build()
