@@ -333,9 +333,9 @@ __global__ void k_sum_parts(const double *__restrict__ parts, int world, int n, 
 // one-workgroup parallel Jacobi eigensolver (n <= 64), LDS resident
 // ---------------------------------------------------------------------------
 struct jacobi_lds {
-    double a[MAXS][SLD];
-    double e[MAXS][SLD];
-    double cs[MAXS / 2][2];
+    alignas(16) double a[MAXS][SLD];
+    alignas(16) double e[MAXS][SLD];
+    alignas(16) double cs[MAXS / 2][2];
     int pq[MAXS / 2][2];
     double red[256];
     double w[MAXS];
@@ -361,32 +361,39 @@ struct jacobi_lds {
 //     root) and hands it to the items through LDS: a second barrier per step, but the long
 //     rotation chain is off the path of the threads that own two items.
 // At most two items per thread (256 threads).  Interface as jacobi_eig.
+// 1 / sqrt(x) to full precision: the hardware seed (2^-23) and ONE third-order step
+// y (1 + h / 2 + 3 h^2 / 8), h = 1 - x y^2 -- four dependent operations
+__device__ __forceinline__ double rsq_full(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double xy = x * y;
+    const double h = fma(-xy, y, 1.0);
+    const double p = fma(0.375, h, 0.5);
+    return fma(y * h, p, y);
+}
+
+// The rotation (c, s) that annihilates a_pq, |angle| <= pi / 4:  tan 2t = a_pq / dl with
+// dl = (a_qq - a_pp) / 2, taken through cos 2t = |dl| / hypot(dl, a_pq):
+//   c^2 = (1 + cos 2t) / 2,   s = sin 2t / (2 c).
+// A Jacobi step of a lone wave is bound by the LENGTH of this dependent chain (about ten clocks
+// an operation), so it is written for depth: two reciprocal square roots, no division, 17
+// operations deep (the textbook t = sign / (|theta| + sqrt(theta^2 + 1)) form with refined
+// rsq / rcp seeds was 31).  Straight-line (selects, no branch).
 __device__ __forceinline__ void jacobi_rot(double app, double apq, double aqq, double &c,
                                            double &sn) {
-    c = 1.0;
-    sn = 0.0;
-    if (apq != 0.0) {
-        const double dl = 0.5 * (aqq - app);
-        const double x = fma(dl, dl, apq * apq);
-        double y = __builtin_amdgcn_rsq(x);
-        double r = x * y;                      // sqrt(x), refined once
-        r = fma(fma(-r, r, x), 0.5 * y, r);
-        const double den = fabs(dl) + r;
-        double inv = __builtin_amdgcn_rcp(den);
-        inv = inv * fma(-den, inv, 2.0);
-        inv = inv * fma(-den, inv, 2.0);
-        double t = apq * inv;
-        t = dl >= 0.0 ? t : -t;
-        // |t| <= 1 by construction; a rounding excess is clamped, anything else means x
-        // overflowed or vanished: no rotation
-        if (!(fabs(t) <= 1.0)) t = fabs(t) <= 1.0000001 ? copysign(1.0, t) : 0.0;
-        const double x2 = fma(t, t, 1.0);
-        double y2 = __builtin_amdgcn_rsq(x2);
-        y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
-        y2 = y2 * fma(-0.5 * x2 * y2, y2, 1.5);
-        c = y2;
-        sn = t * y2;
-    }
+    const double dl = 0.5 * (aqq - app);
+    const double x = fma(dl, dl, apq * apq);
+    const double y = rsq_full(x);                   // 1 / hypot(dl, apq)
+    const double c2 = fma(0.5 * fabs(dl), y, 0.5);  // in [0.5, 1]
+    const double z = rsq_full(c2);
+    const double hs = (0.5 * apq) * y;
+    const double cc = c2 * z;
+    double ss = hs * z;
+    ss = dl >= 0.0 ? ss : -ss;
+    // nothing to rotate, or hypot^2 outside the range the seed handles (never seen: the
+    // matrices are O(1) and dead directions carry -1e30): identity
+    const bool rot = apq != 0.0 && x >= 1e-290 && x <= 1e290;
+    c = rot ? cc : 1.0;
+    sn = rot ? ss : 0.0;
 }
 
 __device__ void jacobi_eig_fast(jacobi_lds &s, int n) {
@@ -570,7 +577,193 @@ __device__ void jacobi_eig_fast(jacobi_lds &s, int n) {
 // k_small_rr 50.6 us against 43.5, k_small_orth unchanged at 13.1: four waves with one item per
 // thread and two cheap barriers beat one wave that serialises two items and both item kinds;
 // profiles/r04_jacobi_wave.txt.)
+// The same sum when only the first 16 (ROWS = 1) or 32 (ROWS = 2) lanes carry non-zero terms and
+// only they need the result: four DPP steps inside a row of 16 lanes (quad swaps, then the two
+// mirrors) instead of six trips through the LDS crossbar; every lane of the rows that count
+// ends with bitwise the same total.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+template <int ROWS>
+__device__ __forceinline__ double row_sum(double v) {
+    v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);  // row_half_mirror
+    v += dpp_f64<0x140>(v);  // row_mirror
+    if (ROWS == 2) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
+// ---- wave-specialised variant for n = 4, 8, 12 (the sizes the fused b = 4 loop solves in
+// every iteration: the 12 x 12 Rayleigh-Ritz problem and the 4 x 4 SVQB ones)
+// The variant above spends 1 200 clocks on a step at n = 12 -- two workgroup barriers, three
+// dependent LDS round trips, the rotation chain -- for 36 + 72 work items.  Here wave 0 alone
+// iterates on A: its lanes own the (n/2)^2 2 x 2 blocks in registers, every lane computes the
+// rotation of its own block (only the diagonal blocks' ones mean anything: they are published,
+// 16 bytes each), applies the two it needs and writes its four results to their round-robin
+// positions, in place -- a wave's LDS operations execute in order, so the step needs no barrier
+// at all.  The rotations of a sweep are also logged; wave 1, one lane per ROW of the eigenvector
+// matrix with the row in registers (the round-robin moves are compile-time renamings over the
+// unrolled sweep), replays the log one sweep behind wave 0, concurrently: one workgroup barrier
+// per sweep.  Same rotations, same arithmetic, same order as the variant above.
+typedef double jw_d2 __attribute__((ext_vector_type(2)));
+constexpr int jw_next_pos(int i, int m) {
+    if (i == 0 || m == 2) return i;
+    if (i & 1) return i == m - 1 ? m - 2 : i + 2;
+    return i == 2 ? 1 : i - 2;
+}
+
+template <int M>
+__device__ void jacobi_eig_waves(jacobi_lds &s) {
+    constexpr int H = M / 2, NB = H * H, SPS = M - 1;
+    static_assert(M % 2 == 0 && NB <= 64 && M <= 16, "one wave holds the blocks");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    double *fa = &s.a[0][0];                 // [NB][4]: 2 x 2 blocks, row-major inside a block
+    double *rlog = &s.e[16][0];              // [2][SPS][H][2]: (c, s) of a sweep's rotations
+    volatile int *flag = &s.pq[0][0];        // [2]: wave 0's verdict before sweep k, at k & 1
+    const int kr = lane / H, kc = lane - kr * H;
+    const bool blk = wave == 0 && lane < NB;
+    double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+    int d00 = 0, d01 = 0, d10 = 0, d11 = 0;
+    if (blk) {
+        a00 = s.a[2 * kr][2 * kc];
+        a01 = s.a[2 * kr][2 * kc + 1];
+        a10 = s.a[2 * kr + 1][2 * kc];
+        a11 = s.a[2 * kr + 1][2 * kc + 1];
+        const int r0 = jw_next_pos(2 * kr, M), r1 = jw_next_pos(2 * kr + 1, M);
+        const int c0 = jw_next_pos(2 * kc, M), c1 = jw_next_pos(2 * kc + 1, M);
+        auto at = [&](int pi, int pj) { return ((pi >> 1) * H + (pj >> 1)) * 4 + (pi & 1) * 2 + (pj & 1); };
+        d00 = at(r0, c0);
+        d01 = at(r0, c1);
+        d10 = at(r1, c0);
+        d11 = at(r1, c1);
+    }
+    // row `lane` of E (wave 1), by position
+    double e[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) e[i] = i == lane ? 1.0 : 0.0;
+    __syncthreads();  // the input matrix has been read: its memory now holds the flat blocks
+    if (blk) {
+        double *bp = fa + lane * 4;
+        bp[0] = a00;
+        bp[1] = a01;
+        bp[2] = a10;
+        bp[3] = a11;
+    }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        if (wave == 0) {
+            // convergence: off-diagonal mass against the diagonal (dead directions carry -1e30 on
+            // the diagonal, k_small_rr: not part of the scale)
+            double off = 0.0, dia = 0.0;
+            if (blk) {
+                if (kr == kc) {
+                    dia = (a00 > -1e29 ? a00 * a00 : 0.0) + (a11 > -1e29 ? a11 * a11 : 0.0);
+                    off = a01 * a01 + a10 * a10;
+                } else {
+                    off = (a00 * a00 + a01 * a01) + (a10 * a10 + a11 * a11);
+                }
+            }
+            off = row_sum<1>(off);
+            dia = row_sum<1>(dia);
+            if (NB > 16) {
+                off += __shfl_xor(off, 16, 64);
+                dia += __shfl_xor(dia, 16, 64);
+            }
+            if (NB > 32) {
+                off += __shfl_xor(off, 32, 64);
+                dia += __shfl_xor(dia, 32, 64);
+            }
+            const bool done = off <= 1.25e-32 * (double)(M * M) * dia || off == 0.0;
+            if (lane == 0) flag[sweep & 1] = done ? 1 : 0;
+            if (!done) {
+                double *lg = rlog + (sweep & 1) * SPS * H * 2;
+                for (int step = 0; step < SPS; ++step) {
+                    double c, sn;
+                    jacobi_rot(a00, a01, a11, c, sn);
+                    if (blk && kr == kc) {
+                        const jw_d2 v = {c, sn};
+                        *(jw_d2 *)&s.cs[kr][0] = v;
+                        *(jw_d2 *)&lg[(step * H + kr) * 2] = v;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (blk) {
+                        const jw_d2 r1 = *(const jw_d2 *)&s.cs[kr][0], r2 = *(const jw_d2 *)&s.cs[kc][0];
+                        const double c1 = r1.x, s1 = r1.y;
+                        const double c2 = r2.x, s2 = r2.y;
+                        const double t00 = c2 * a00 - s2 * a01, t01 = s2 * a00 + c2 * a01;
+                        const double t10 = c2 * a10 - s2 * a11, t11 = s2 * a10 + c2 * a11;
+                        fa[d00] = c1 * t00 - s1 * t10;
+                        fa[d01] = c1 * t01 - s1 * t11;
+                        fa[d10] = s1 * t00 + c1 * t10;
+                        fa[d11] = s1 * t01 + c1 * t11;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    if (blk) {
+                        const jw_d2 *bp = (const jw_d2 *)(fa + lane * 4);
+                        const jw_d2 lo = bp[0], hi = bp[1];
+                        a00 = lo.x;
+                        a01 = lo.y;
+                        a10 = hi.x;
+                        a11 = hi.y;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+        }
+        __syncthreads();
+        if (flag[sweep & 1]) break;
+        if (wave == 1 && lane < M) {
+            const double *lg = rlog + (sweep & 1) * SPS * H * 2;
+#pragma unroll
+            for (int step = 0; step < SPS; ++step) {
+                double t[M];
+#pragma unroll
+                for (int k = 0; k < H; ++k) {
+                    const jw_d2 r = *(const jw_d2 *)&lg[(step * H + k) * 2];
+                    const double c2 = r.x, s2 = r.y;
+                    const double x = e[2 * k], y = e[2 * k + 1];
+                    t[jw_next_pos(2 * k, M)] = c2 * x - s2 * y;
+                    t[jw_next_pos(2 * k + 1, M)] = s2 * x + c2 * y;
+                }
+#pragma unroll
+                for (int i = 0; i < M; ++i) e[i] = t[i];
+            }
+        }
+    }
+    // back to the caller's layout: eigenvector of position j in column j of s.e, positions
+    // ranked by eigenvalue (descending)
+    if (wave == 1 && lane < M) {
+#pragma unroll
+        for (int i = 0; i < M; ++i) s.e[lane][i] = e[i];
+    }
+    double wi = 0.0;
+    int rank = -1;
+    if (tid < M) {
+        auto diag_at = [&](int i) { return fa[((i >> 1) * H + (i >> 1)) * 4 + (i & 1) * 3]; };
+        wi = diag_at(tid);
+        rank = 0;
+        for (int j = 0; j < M; ++j) {
+            const double wj = diag_at(j);
+            if (wj > wi || (wj == wi && j < tid)) ++rank;
+        }
+    }
+    __syncthreads();
+    if (rank >= 0) {
+        s.w[rank] = wi;
+        s.perm[rank] = tid;
+    }
+    __syncthreads();
+}
+
 __device__ void jacobi_eig(jacobi_lds &s, int n) {
+    if (n == 12) return jacobi_eig_waves<12>(s);
+    if (n == 8) return jacobi_eig_waves<8>(s);
+    if (n == 4) return jacobi_eig_waves<4>(s);
     if (n <= 24) {
         jacobi_eig_fast(s, n);
         return;
@@ -702,12 +895,31 @@ __device__ __forceinline__ void sum_partials(const double *__restrict__ partial,
                                              int nout, double (*tmp)[3 * MAXB * 3 * MAXB / 4],
                                              F out) {
     // tmp: [8][>= nout] doubles of LDS
-    for (int f = threadIdx.x; f < nout * 8; f += 256) {
-        const int slice = f / nout, e = f - slice * nout;
-        double v = 0.0;
-#pragma unroll 8
-        for (int p = slice; p < nparts; p += 8) v += partial[(int64_t)p * nout + e];
-        tmp[slice][e] = v;
+    // (two outputs per thread at a time, sixteen loads of each in flight before the first add:
+    // the kernel is one workgroup, nothing else hides the latency of a load)
+    const int total = nout * 8;
+    for (int f0 = threadIdx.x; f0 < total; f0 += 512) {
+        const int f1 = f0 + 256;
+        const bool two = f1 < total;
+        const int s0 = f0 / nout, e0 = f0 - s0 * nout;
+        const int s1 = two ? f1 / nout : s0, e1 = two ? f1 - s1 * nout : e0;
+        double v0 = 0.0, v1 = 0.0;
+        for (int base = 0; base < nparts; base += 128) {
+            double x0[16], x1[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int p0 = base + s0 + 8 * k, p1 = base + s1 + 8 * k;
+                x0[k] = p0 < nparts ? partial[(int64_t)p0 * nout + e0] : 0.0;
+                x1[k] = (two && p1 < nparts) ? partial[(int64_t)p1 * nout + e1] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v0 += x0[k];
+                v1 += x1[k];
+            }
+        }
+        tmp[s0][e0] = v0;
+        if (two) tmp[s1][e1] = v1;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nout; e += 256) {
@@ -917,7 +1129,7 @@ __device__ void rr_directions_wave(const jacobi_lds &s, int nq, double drop_tol,
 #pragma unroll
         for (int a = 0; a < B; ++a)
 #pragma unroll
-            for (int k = 0; k < B; ++k) g[a][k] = wave_sum(c[a] * d[k]);
+            for (int k = 0; k < B; ++k) g[a][k] = row_sum<(3 * B + 15) / 16>(c[a] * d[k]);
 #pragma unroll
         for (int k = 0; k < B; ++k)
 #pragma unroll
@@ -925,7 +1137,7 @@ __device__ void rr_directions_wave(const jacobi_lds &s, int nq, double drop_tol,
     }
     double n0[B];
 #pragma unroll
-    for (int k = 0; k < B; ++k) n0[k] = wave_sum(d[k] * d[k]);
+    for (int k = 0; k < B; ++k) n0[k] = row_sum<(3 * B + 15) / 16>(d[k] * d[k]);
     int keep_mask = 0;
 #pragma unroll
     for (int k = 0; k < B; ++k) {
@@ -933,11 +1145,11 @@ __device__ void rr_directions_wave(const jacobi_lds &s, int nq, double drop_tol,
         for (int pass = 0; pass < 2; ++pass) {
             double r[B];
 #pragma unroll
-            for (int j = 0; j < k; ++j) r[j] = wave_sum(d[j] * d[k]);
+            for (int j = 0; j < k; ++j) r[j] = row_sum<(3 * B + 15) / 16>(d[j] * d[k]);
 #pragma unroll
             for (int j = 0; j < k; ++j) d[k] -= r[j] * d[j];
         }
-        const double n1 = wave_sum(d[k] * d[k]);
+        const double n1 = row_sum<(3 * B + 15) / 16>(d[k] * d[k]);
         const bool keep = n0[k] > 1e-290 && n1 > drop_tol * n0[k];
         const double sc = keep ? 1.0 / sqrt(n1) : 0.0;
         d[k] *= sc;
