@@ -576,7 +576,8 @@ __device__ void jacobi_eig_fast(jacobi_lds &s, int n) {
 // barrier inside the sweeps, bitwise the same results -- was built and measured slower:
 // k_small_rr 50.6 us against 43.5, k_small_orth unchanged at 13.1: four waves with one item per
 // thread and two cheap barriers beat one wave that serialises two items and both item kinds;
-// profiles/r04_jacobi_wave.txt.)
+// profiles/r04_jacobi_wave.txt.  What did work is to split the two item KINDS over two waves:
+// jacobi_eig_waves below.)
 // The same sum when only the first 16 (ROWS = 1) or 32 (ROWS = 2) lanes carry non-zero terms and
 // only they need the result: four DPP steps inside a row of 16 lanes (quad swaps, then the two
 // mirrors) instead of six trips through the LDS crossbar; every lane of the rows that count
@@ -895,31 +896,41 @@ __device__ __forceinline__ void sum_partials(const double *__restrict__ partial,
                                              int nout, double (*tmp)[3 * MAXB * 3 * MAXB / 4],
                                              F out) {
     // tmp: [8][>= nout] doubles of LDS
-    // (two outputs per thread at a time, sixteen loads of each in flight before the first add:
-    // the kernel is one workgroup, nothing else hides the latency of a load)
+    // (up to five outputs per thread at a time, sixteen loads of each in flight before the first
+    // add: the kernel is one workgroup, nothing else hides the latency of a load, and the
+    // partials come from the other XCDs' workgroups, i.e. from memory -- the 12 x 12 Rayleigh-Ritz
+    // matrix, 1 152 slice sums, is then ONE round trip instead of ten)
+    constexpr int IT = 5;
     const int total = nout * 8;
-    for (int f0 = threadIdx.x; f0 < total; f0 += 512) {
-        const int f1 = f0 + 256;
-        const bool two = f1 < total;
-        const int s0 = f0 / nout, e0 = f0 - s0 * nout;
-        const int s1 = two ? f1 / nout : s0, e1 = two ? f1 - s1 * nout : e0;
-        double v0 = 0.0, v1 = 0.0;
-        for (int base = 0; base < nparts; base += 128) {
-            double x0[16], x1[16];
+    for (int f0 = threadIdx.x; f0 < total; f0 += 256 * IT) {
+        int sl[IT], el[IT];
+        bool on[IT];
+        double v[IT];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int p0 = base + s0 + 8 * k, p1 = base + s1 + 8 * k;
-                x0[k] = p0 < nparts ? partial[(int64_t)p0 * nout + e0] : 0.0;
-                x1[k] = (two && p1 < nparts) ? partial[(int64_t)p1 * nout + e1] : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                v0 += x0[k];
-                v1 += x1[k];
-            }
+        for (int j = 0; j < IT; ++j) {
+            const int f = f0 + 256 * j;
+            on[j] = f < total;
+            sl[j] = on[j] ? f / nout : 0;
+            el[j] = on[j] ? f - sl[j] * nout : 0;
+            v[j] = 0.0;
         }
-        tmp[s0][e0] = v0;
-        if (two) tmp[s1][e1] = v1;
+        for (int base = 0; base < nparts; base += 128) {
+            double x[IT][16];
+#pragma unroll
+            for (int j = 0; j < IT; ++j)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int p = base + sl[j] + 8 * k;
+                    x[j][k] = (on[j] && p < nparts) ? partial[(int64_t)p * nout + el[j]] : 0.0;
+                }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+#pragma unroll
+                for (int j = 0; j < IT; ++j) v[j] += x[j][k];
+        }
+#pragma unroll
+        for (int j = 0; j < IT; ++j)
+            if (on[j]) tmp[sl[j]][el[j]] = v[j];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < nout; e += 256) {
@@ -1171,11 +1182,10 @@ __device__ void rr_directions_wave(const jacobi_lds &s, int nq, double drop_tol,
 //     SVQB-orthonormalise with rank-revealing drop; mask_p[k] = 0 marks a dropped direction.
 //   nparts > 0: tm holds nparts per-workgroup partials of T (k_gram_qaq), summed here in
 //   fixed order.
-__global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm, int nparts,
-                                                   int nq, int b, const int *__restrict__ mask,
-                                                   double *__restrict__ c, double *__restrict__ d,
-                                                   double *__restrict__ theta,
-                                                   int *__restrict__ mask_p, double drop_tol) {
+// (mask, c, d, theta, mask_p may live in LDS: k_panel_rr_solve runs this in front of its panel pass)
+__device__ __forceinline__ void small_rr_body(const double *__restrict__ tm, int nparts, int nq, int b,
+                              const int *mask, double *c, double *d, double *theta, int *mask_p,
+                              double drop_tol) {
     __shared__ jacobi_lds s;
     __shared__ double cc[3 * MAXB][MAXB];
     __shared__ double dd[3 * MAXB][MAXB];
@@ -1265,6 +1275,14 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
     }
 }
 
+__global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm, int nparts,
+                                                   int nq, int b, const int *__restrict__ mask,
+                                                   double *__restrict__ c, double *__restrict__ d,
+                                                   double *__restrict__ theta,
+                                                   int *__restrict__ mask_p, double drop_tol) {
+    small_rr_body(tm, nparts, nq, b, mask, c, d, theta, mask_p, drop_tol);
+}
+
 // Projected SVQB (fused path, b <= 8).  Input: per-workgroup partials of
 //   Cxp = [x p]^T r (2b x b),  G = r^T r (b x b),  cu = u^T r (1 x b)
 // for an orthonormal [u x p].  With M = G - Cxp^T Cxp - cu^T cu (the Gram matrix of r
@@ -1275,12 +1293,10 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
 // k_panel_tf; mask[c] = 0 marks a dropped direction (zero column).
 // report (mapped host memory, may be null): [0, b) squared residual norms diag(G),
 // [16, 16 + b] the current Ritz values, [40] the caller's sequence number, written last.
-__global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ partial,
-                                                     int nparts, int b, double drop_tol,
-                                                     double *__restrict__ coef,
-                                                     int *__restrict__ mask,
-                                                     const double *__restrict__ theta,
-                                                     double *report, double seq) {
+// (coef may live in LDS, mask may be null: k_panel_tf_solve runs this in front of its panel pass)
+__device__ __forceinline__ void small_orth_body(const double *__restrict__ partial, int nparts, int b,
+                                double drop_tol, double *coef, int *mask,
+                                const double *__restrict__ theta, double *report, double seq) {
     __shared__ jacobi_lds s;
     __shared__ double cxp[16][8], gm[9][8], mm[8][8], tt[8][8], dsc[8];
     const int tid = threadIdx.x;
@@ -1295,14 +1311,18 @@ __global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ p
     if (report) {
         // hand the norms to the host through mapped memory: data, system-scope fence, then the
         // sequence number the host is polling for (no stream event: recording one costs the
-        // device a ~6 us bubble)
+        // device a ~6 us bubble).  seq < 0: the caller sends the sequence number itself, later
+        // (report_sequence): the fence then finds the stores long done instead of waiting a PCIe
+        // round trip for them in front of the workgroup's rows.
         if (tid < b) report[tid] = gm[tid][tid];
         if (tid <= b) report[16 + tid] = theta[tid];
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) {
-            ((volatile double *)report)[40] = seq;
+        if (seq >= 0.0) {
             __threadfence_system();
+            __syncthreads();
+            if (tid == 0) {
+                ((volatile double *)report)[40] = seq;
+                __threadfence_system();
+            }
         }
     }
     for (int e = tid; e < b * b; e += 256) {
@@ -1332,7 +1352,7 @@ __global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ p
         const bool keep = wmax > 0.0 && lam > drop_tol * wmax;
         tt[i][c] = keep ? dsc[i] * s.e[i][s.perm[c]] / sqrt(lam) : 0.0;
     }
-    if (tid < b) mask[tid] = (wmax > 0.0 && s.w[tid] > drop_tol * wmax) ? 1 : 0;
+    if (mask && tid < b) mask[tid] = (wmax > 0.0 && s.w[tid] > drop_tol * wmax) ? 1 : 0;
     __syncthreads();
     for (int e = tid; e < (3 * b + 4) * b; e += 256) {
         const int k = e / b, c = e - k * b;
@@ -1345,6 +1365,81 @@ __global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ p
             for (int i = 0; i < b; ++i) v -= gm[b][i] * tt[i][c];
         }
         coef[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ partial,
+                                                     int nparts, int b, double drop_tol,
+                                                     double *__restrict__ coef,
+                                                     int *__restrict__ mask,
+                                                     const double *__restrict__ theta,
+                                                     double *report, double seq) {
+    small_orth_body(partial, nparts, b, drop_tol, coef, mask, theta, report, seq);
+}
+
+// ---- the small solves in FRONT of the tall kernels that consume them
+// A one-workgroup kernel between two tall ones costs its launch and the drain of the one before
+// (~5 us a time, three times an iteration).  The tall kernel's workgroups can each run the small
+// solve themselves, redundantly -- same partials, same code, same bits in every workgroup --
+// and go straight on to their rows with the coefficients in LDS; workgroup 0 also publishes what
+// later kernels and the host read (Ritz values, masks, the residual report).  Nothing is shared
+// between the workgroups inside the kernel, so there is no release / acquire across XCDs (the
+// variant that ran the solve in the TAIL of the producing kernel paid for exactly that,
+// scs_panel.h).  Partials alternate between two buffers: a workgroup still summing the incoming
+// ones must not see another one's outgoing ones; the search-direction mask alternates likewise.
+template <int B>
+__global__ __launch_bounds__(256) void k_panel_rr_solve(double *q, double *aq,
+                                                         const double *__restrict__ u,
+                                                         const double *__restrict__ tm, int nparts_in,
+                                                         int solve, double *theta_g,
+                                                         const int *__restrict__ maskp_in,
+                                                         const int *__restrict__ mask_r,
+                                                         int *maskp_out, double drop_tol, int n,
+                                                         double *__restrict__ partial) {
+    __shared__ double c_s[3 * B * B], d_s[3 * B * B], th_s[B + 4];
+    __shared__ int live_s[3 * B], mp_s[B];
+    const int tid = threadIdx.x;
+    if (solve) {
+        if (tid < 3 * B) live_s[tid] = tid < B ? 1 : (tid < 2 * B ? maskp_in[tid - B] : mask_r[tid - 2 * B]);
+        __syncthreads();
+        small_rr_body(tm, nparts_in, 3 * B, B, live_s, c_s, d_s, th_s, mp_s, drop_tol);
+    } else {
+        // first iteration, and after a refresh: X stays, no search directions
+        for (int e = tid; e < 3 * B * B; e += 256) {
+            c_s[e] = (e / B == e % B) ? 1.0 : 0.0;
+            d_s[e] = 0.0;
+        }
+        if (tid <= B) th_s[tid] = theta_g[tid];
+        if (tid < B) mp_s[tid] = 0;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (solve && tid <= B) theta_g[tid] = th_s[tid];
+        if (tid < B) maskp_out[tid] = mp_s[tid];
+    }
+    panel_rr_body<B>(q, aq, u, c_s, d_s, th_s, n, partial);
+}
+
+template <int B, bool GRAM, bool WRITE_Z>
+__global__ __launch_bounds__(256) void k_panel_tf_solve(double *q, const double *__restrict__ u,
+                                                         const double *__restrict__ part_in,
+                                                         int nparts_in, double drop_tol, int *mask_r,
+                                                         const double *__restrict__ theta_g,
+                                                         double *report, double seq, int n,
+                                                         double *__restrict__ partial,
+                                                         const double *__restrict__ dinv,
+                                                         double *__restrict__ zt, int64_t ldz) {
+    __shared__ double coef_s[PANEL_COEF_ROWS<B> * B];
+    const bool lead = blockIdx.x == 0;
+    small_orth_body(part_in, nparts_in, B, drop_tol, coef_s, lead ? mask_r : nullptr, theta_g,
+                    lead ? report : nullptr, -1.0);
+    __syncthreads();
+    panel_tf_body<B, GRAM, WRITE_Z>(q, u, coef_s, n, partial, dinv, zt, ldz);
+    if (lead && report) {
+        // the report's sequence number, after the rows (the end of the kernel makes it visible)
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) ((volatile double *)report)[40] = seq;
     }
 }
 
@@ -1399,7 +1494,7 @@ struct solver {
     hipStream_t s = nullptr;
     int n = 0, b = 0, rows = 0, world = 1;
     bool use_mfma = true;
-    dbuf q, aq, z, ypart, yloc, yfull, recv, u, part, small, splits_d;
+    dbuf q, aq, z, ypart, yloc, yfull, recv, u, part, part2, small, splits_d;
     size_t ypart_cap = 0;
     int64_t chunk = 0;
     int gram_blocks = 0;
@@ -1678,8 +1773,29 @@ struct solver {
 
     // AR = S R (R's scaled transpose already sits in z) into AQ's R slot, then the
     // partials of Q^T AQ; returns their count
+    // The same front with the small solves inside the tall kernels (k_panel_rr_solve,
+    // k_panel_tf_solve): three launches instead of five, and the Rayleigh-Ritz kernel that used
+    // to close the iteration is the head of the next one's first launch.  `solve` = 0: X stays
+    // and the search directions are cleared (first iteration, after a refresh).
     template <int B>
-    int fused_back(int *nparts) {
+    int fused_front_solve(const double *uvec, int nparts_in, int solve, double *theta,
+                          const int *maskp_in, int *mask_r, int *maskp_out, double drop_tol,
+                          double *report, double seq) {
+        const int nb = panel_blocks16();
+        k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part2.d(), nparts_in, solve, theta,
+                                               maskp_in, mask_r, maskp_out, drop_tol, n, part.d());
+        k_panel_tf_solve<B, true, false><<<nb, 256, 0, s>>>(q.d(), uvec, part.d(), nb, drop_tol, mask_r,
+                                                            theta, report, seq, n, part2.d(), nullptr,
+                                                            nullptr, 0);
+        k_panel_tf_solve<B, false, true><<<nb, 256, 0, s>>>(q.d(), uvec, part2.d(), nb, 0.0, mask_r, theta,
+                                                            nullptr, 0.0, n, nullptr, g->d_dinv, z.d(),
+                                                            ldz);
+        SCS_HIP_CHECK(hipGetLastError());
+        return SCS_OK;
+    }
+
+    template <int B>
+    int fused_back(int *nparts, double *pout) {
         // k_symm is timed with HIP events on every fourth launch only: recording an event costs
         // the device a ~6 us bubble
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1699,14 +1815,14 @@ struct solver {
             SCS_TRY(launch_symm(z.d(), nullptr));
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
-            k_gram_qaq<B, 3><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, part.d());
+            k_gram_qaq<B, 3><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, pout);
         } else if (world == 1) {
             if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
             SCS_TRY(launch_symm(z.d(), nullptr));
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
             k_gram_qaq<B, 1><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
-                                                   g->d_dinv, part.d());
+                                                   g->d_dinv, pout);
         } else {
             if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
             SCS_TRY(launch_symm(z.d(), yloc.d()));
@@ -1714,7 +1830,7 @@ struct solver {
             ++n_apply;
             SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
             // (the gathered slices go straight into AQ's R slot inside the Gram kernel)
-            k_gram_qaq<B, 2><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, part.d(),
+            k_gram_qaq<B, 2><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, pout,
                                                 (int64_t)chunk, (const int32_t *)splits_d.p);
         }
         SCS_HIP_CHECK(hipGetLastError());
@@ -1920,6 +2036,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_TRY(sv.yloc.alloc((size_t)sv.chunk * 8));
     SCS_TRY(sv.u.alloc((size_t)n * 8));
     SCS_TRY(sv.part.alloc((size_t)1024 * q3 * q3 * 8));
+    SCS_TRY(sv.part2.alloc((size_t)1024 * q3 * q3 * 8));
     SCS_TRY(sv.small.alloc((size_t)SM_TOTAL * 8));
     if (sv.world > 1 && !sv.part_mode) {
         SCS_TRY(sv.yfull.alloc((size_t)n * b * 8));
@@ -2016,6 +2133,10 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         k_unit_coeffs<<<(3 * b * b + 255) / 256, 256, 0, s>>>(T, D, b);
     }
     const double *uvec = constrained ? sv.u.d() : nullptr;
+    // SCS_SPLIT_SMALL=1: the small solves as one-workgroup kernels of their own (the round-3 loop)
+    const bool split_small = getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"));
+    int rr_solve = 0, rr_parts = 0, mpar = 0;
+    int *maskp[2] = {MASK + b, MASK + 32};
 
     for (iter = 0; iter < max_iter; ++iter) {
         if (fused) {
@@ -2024,15 +2145,32 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             // after that kernel touches X, so on a stop X is the block the norms belong to.
             int nparts = 0;
             const double seq = (double)(++ctx->report_seq);
-            if (b == 4) {
-                SCS_TRY(sv.fused_front<4>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, seq));
-                SCS_TRY(sv.fused_back<4>(&nparts));
+            if (!split_small) {
+                // (the Rayleigh-Ritz solve on the previous iteration's Gram partials opens the
+                // first launch)
+                if (b == 4) {
+                    SCS_TRY(sv.fused_front_solve<4>(uvec, rr_parts, rr_solve, TH, maskp[mpar], MASK + 2 * b,
+                                                    maskp[mpar ^ 1], drop_tol, ctx->d_report, seq));
+                    SCS_TRY(sv.fused_back<4>(&nparts, sv.part2.d()));
+                } else {
+                    SCS_TRY(sv.fused_front_solve<8>(uvec, rr_parts, rr_solve, TH, maskp[mpar], MASK + 2 * b,
+                                                    maskp[mpar ^ 1], drop_tol, ctx->d_report, seq));
+                    SCS_TRY(sv.fused_back<8>(&nparts, sv.part2.d()));
+                }
+                rr_parts = nparts;
+                rr_solve = 1;
+                mpar ^= 1;
             } else {
-                SCS_TRY(sv.fused_front<8>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, seq));
-                SCS_TRY(sv.fused_back<8>(&nparts));
+                if (b == 4) {
+                    SCS_TRY(sv.fused_front<4>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, seq));
+                    SCS_TRY(sv.fused_back<4>(&nparts, sv.part.d()));
+                } else {
+                    SCS_TRY(sv.fused_front<8>(uvec, T, D, TH, C, MASK + 2 * b, drop_tol, ctx->d_report, seq));
+                    SCS_TRY(sv.fused_back<8>(&nparts, sv.part.d()));
+                }
+                k_small_rr<<<1, 256, 0, s>>>(sv.part.d(), nparts, q3, b, MASK, T, D, TH, MASK + b,
+                                             drop_tol);
             }
-            k_small_rr<<<1, 256, 0, s>>>(sv.part.d(), nparts, q3, b, MASK, T, D, TH, MASK + b,
-                                         drop_tol);
             SCS_HIP_CHECK(hipGetLastError());
             {
                 // wait for this iteration's report (the device is already working on the rest of
@@ -2113,6 +2251,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 best_res = w2;
                 since_best = 0;
                 if (fused) k_unit_coeffs<<<(3 * b * b + 255) / 256, 256, 0, s>>>(T, D, b);
+                rr_solve = 0;
             } else {
                 converged = worst <= tol;
                 break;

@@ -8,8 +8,8 @@
 //   k_panel_rr        X' = Q c, P' = Q d, AX' = AQ c, AP' = AQ d, R = AX' - X' theta,
 //                     and the Gram products [u X' P']^T R, R^T R          (one pass over Q, AQ)
 //   k_small_orth      projected SVQB: from those Gram products the transform that makes R
-//                     orthonormal and orthogonal to [u X P]  (one workgroup; also hands the
-//                     residual norms to the host)
+//                     orthonormal and orthogonal to [u X P]  (also hands the residual norms to
+//                     the host)
 //   k_panel_tf        R <- R T + [u X P] K, again with the Gram products     (second pass)
 //   k_small_orth
 //   k_panel_tf        final transform, also emits Z = D^-1/2 R k-major for k_symm
@@ -17,11 +17,16 @@
 //   k_gram_qaq        combines k_symm's column segments into AR and forms Q^T AQ
 //   k_small_rr        Rayleigh-Ritz (scs_eig.hip)
 //
-// (Running a small solve in the tail of the tall kernel before it -- the workgroup whose
-// agent-scope ticket add comes last sums the partials and solves, no launch of its own -- was
-// tried: bit-identical results, but no faster: 10 000 vertices 14.0 ms per solve against 13.6 ms,
+// Since round 4 the three small solves run in FRONT of the tall kernel that consumes them, in
+// every one of its workgroups (k_panel_rr_solve, k_panel_tf_solve in scs_eig.hip: same partials,
+// same code, same bits everywhere; workgroup 0 publishes what later kernels and the host read):
+// six launches an iteration instead of nine, 17.8 -> 17.2 ms per step at 10 000 vertices.
+// SCS_SPLIT_SMALL=1 keeps them as one-workgroup kernels of their own.
+// (Running a small solve in the TAIL of the tall kernel before it -- the workgroup whose
+// agent-scope ticket add comes last sums the partials and solves -- was tried in round 2:
+// bit-identical results, but no faster: 10 000 vertices 14.0 ms per solve against 13.6 ms,
 // 1 000 vertices 4.97 against 5.04 ms.  Every workgroup's release has to write its XCD's L2
-// back, which costs what the launch saved.)
+// back, which costs what the launch saved; the redundant solve in front shares nothing.)
 //
 // The tall kernels are MFMA pipelines (v_mfma_f64_16x16x4_f64): a wave owns groups of 16
 // rows; the row transform is a 16 x K x 16 product whose accumulator layout (register r
@@ -81,13 +86,11 @@ __device__ __forceinline__ void panel_store_partials(panel_v4d g1, panel_v4d g2,
 // Rayleigh-Ritz update + residual + Gram products.  q, aq: n x 3B (ld 3B), updated in
 // place (a group of 16 rows is read completely by its wave before it is written).
 // c, d: 3B x B row-major; theta: B; u: n or null.
+// (c, d, theta may live in LDS: the solve-in-front kernels of scs_eig.hip pass their own)
 template <int B>
-__global__ __launch_bounds__(256) void k_panel_rr(double *q, double *aq,
-                                                   const double *__restrict__ u,
-                                                   const double *__restrict__ c,
-                                                   const double *__restrict__ d,
-                                                   const double *__restrict__ theta, int n,
-                                                   double *__restrict__ partial) {
+__device__ __forceinline__ void panel_rr_body(double *q, double *aq, const double *__restrict__ u,
+                                              const double *c, const double *d, const double *theta,
+                                              int n, double *__restrict__ partial) {
     static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
     constexpr int LD = 3 * B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -112,6 +115,12 @@ __global__ __launch_bounds__(256) void k_panel_rr(double *q, double *aq,
             q_op[k] = ra < n ? q[(int64_t)ra * LD + 4 * k + kk] : 0.0;
             aq_op[k] = ra < n ? aq[(int64_t)ra * LD + 4 * k + kk] : 0.0;
         }
+        double u_in[4];  // (read before the stores below: see k_panel_tf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = base + kk + 4 * r;
+            u_in[r] = (cc == B && u && row < n) ? u[row] : 0.0;
+        }
 #pragma unroll
         for (int k = 0; k < LD / 4; ++k) {
             dq = __builtin_amdgcn_mfma_f64_16x16x4f64(q_op[k], coef[k], dq, 0, 0, 0);
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256) void k_panel_rr(double *q, double *aq,
             const bool live = row < n;
             const double res = cc < B ? da[r] - dq[r] * th : 0.0;
             double ru = res;
-            if (cc == B) ru = (u && live) ? u[row] : 0.0;
+            if (cc == B) ru = u_in[r];
             if (live && cc < 2 * B) {
                 q[(int64_t)row * LD + cc] = dq[r];
                 aq[(int64_t)row * LD + cc] = da[r];
@@ -136,14 +145,24 @@ __global__ __launch_bounds__(256) void k_panel_rr(double *q, double *aq,
     panel_store_partials<B>(g1, g2, partial);
 }
 
+template <int B>
+__global__ __launch_bounds__(256) void k_panel_rr(double *q, double *aq,
+                                                   const double *__restrict__ u,
+                                                   const double *__restrict__ c,
+                                                   const double *__restrict__ d,
+                                                   const double *__restrict__ theta, int n,
+                                                   double *__restrict__ partial) {
+    panel_rr_body<B>(q, aq, u, c, d, theta, n, partial);
+}
+
 // R <- R T + [u X P] K (coefficients: PANEL_COEF_ROWS<B> x B, rows [x | p | r | u | pad]).
 // GRAM: also the Gram products of the new R.  WRITE_Z: also zt[k][row] = dinv[row] R[row][k].
 template <int B, bool GRAM, bool WRITE_Z>
-__global__ __launch_bounds__(256) void k_panel_tf(double *q, const double *__restrict__ u,
-                                                   const double *__restrict__ coefm, int n,
-                                                   double *__restrict__ partial,
-                                                   const double *__restrict__ dinv,
-                                                   double *__restrict__ zt, int64_t ldz) {
+__device__ __forceinline__ void panel_tf_body(double *q, const double *__restrict__ u,
+                                              const double *coefm, int n,
+                                              double *__restrict__ partial,
+                                              const double *__restrict__ dinv,
+                                              double *__restrict__ zt, int64_t ldz) {
     static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
     constexpr int LD = 3 * B;
     constexpr int KC = PANEL_COEF_ROWS<B> / 4;
@@ -161,6 +180,18 @@ __global__ __launch_bounds__(256) void k_panel_tf(double *q, const double *__res
 #pragma unroll
         for (int k = 0; k < KC - 1; ++k) a_op[k] = ra < n ? q[(int64_t)ra * LD + 4 * k + kk] : 0.0;
         a_op[KC - 1] = (kk == 0 && u && ra < n) ? u[ra] : 0.0;
+        // the [x p] entries of the Gram products, read with the operands: after the stores of
+        // the new R below a load from q would have to wait for them (they cannot alias, the
+        // compiler cannot know) -- a memory round trip per four rows in a kernel that is all latency
+        double xp_in[4], u_in[4];
+        if (GRAM) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = base + kk + 4 * r;
+                xp_in[r] = (row < n && cc < 2 * B) ? q[(int64_t)row * LD + cc] : 0.0;
+                u_in[r] = (cc == B && u && row < n) ? u[row] : 0.0;
+            }
+        }
         panel_v4d dr = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int k = 0; k < KC; ++k)
@@ -175,15 +206,24 @@ __global__ __launch_bounds__(256) void k_panel_tf(double *q, const double *__res
                 if (WRITE_Z) zt[(int64_t)cc * ldz + row] = dinv[row] * res;
             }
             if (GRAM) {
-                const double xp = (live && cc < 2 * B) ? q[(int64_t)row * LD + cc] : 0.0;
+                const double xp = xp_in[r];
                 double ru = res;
-                if (cc == B) ru = (u && live) ? u[row] : 0.0;
+                if (cc == B) ru = u_in[r];
                 g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xp, res, g1, 0, 0, 0);
                 g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ru, res, g2, 0, 0, 0);
             }
         }
     }
     if (GRAM) panel_store_partials<B>(g1, g2, partial);
+}
+
+template <int B, bool GRAM, bool WRITE_Z>
+__global__ __launch_bounds__(256) void k_panel_tf(double *q, const double *__restrict__ u,
+                                                   const double *__restrict__ coefm, int n,
+                                                   double *__restrict__ partial,
+                                                   const double *__restrict__ dinv,
+                                                   double *__restrict__ zt, int64_t ldz) {
+    panel_tf_body<B, GRAM, WRITE_Z>(q, u, coefm, n, partial, dinv, zt, ldz);
 }
 
 // T = Q^T AQ (3B x 3B) as per-workgroup partials.  FINISH selects where AR, the R slot of AQ,
