@@ -1013,7 +1013,13 @@ __device__ bool onesided_sweeps(double (*a)[DENSE2_LD], int m, int *s_rot) {
                 // (the four threads of a pair hold the same sums: the same decision); columns
                 // whose cosine is at the rounding floor of a 128-term dot product (~ n eps = 3e-14)
                 // are orthogonal: rotating them again would never end
-                if (ga * ga > 1e-27 * al * be) {
+                // -- and a column whose squared norm is below 1e-24 IS zero: an eigenvalue -1 of S
+                // (a bipartite component) is a null direction of A = S + I, its column shrinks to
+                // rounding noise whose "cosine" with the other columns is anything, and the pair
+                // would be rotated for ever (seen: a 2-tree bootstrap forest in the recursion sweep).
+                // The wanted columns have norms near 2; what a 1e-12 column still overlaps with them
+                // moves their eigenvalues by 1e-24.
+                if (ga * ga > 1e-27 * al * be && al > 1e-24 && be > 1e-24) {
                     const double zeta = (be - al) / (2.0 * ga);
                     const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
                     const double c = 1.0 / sqrt(fma(t, t, 1.0)), sn = c * t;

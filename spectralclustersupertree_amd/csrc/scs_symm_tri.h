@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ 
         for (int s = 0; s < CT; ++s) {
 #pragma unroll
             for (int k = 0; k < B; ++k) {
+                // (loop-invariant over the unrolled groups: the compiler keeps these in registers)
                 const double2 zz = *(const double2 *)&zc[k][s * 128 + 2 * lane];
 #pragma unroll
                 for (int i = 0; i < RPW; ++i) {

@@ -244,6 +244,15 @@ def test_whole_recursion_bootstrap():
     assert not ties
 
 
+def test_two_tree_bootstrap_forest_with_a_bipartite_node_of_65_to_128_taxa():
+    # found by tests/fuzz_recursion.py --seed 404: a node of 65..128 taxa whose graph has a
+    # bipartite component (eigenvalue -1 of S, a null direction of the one-sided Jacobi's S + I)
+    # used to end as "small-node eigen-solve did not converge"
+    trees, weights = recursion_input(676767675 % 100000, 260, 2, 260, 0, weighted=False)
+    trace, _ = compare_with_oracle(trees, weights, "bootstrap", seed=676767675 % 9973, ties_allowed=True)
+    assert any(64 < sum(len(v) for v in e["vertices"]) or 64 < len(e["vertices"]) for e in trace)
+
+
 @pytest.mark.parametrize("strategy", ["one", "depth"])
 def test_whole_recursion_integer_strategies_from_tree_arrays(strategy):
     trees, weights = recursion_input(2, 400, 16, 300, 30, weighted=True)
