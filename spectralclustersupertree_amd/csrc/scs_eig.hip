@@ -1777,8 +1777,6 @@ struct solver {
         return SCS_OK;
     }
 
-    // AR = S R (R's scaled transpose already sits in z) into AQ's R slot, then the
-    // partials of Q^T AQ; returns their count
     // The same front with the small solves inside the tall kernels (k_panel_rr_solve,
     // k_panel_tf_solve): three launches instead of five, and the Rayleigh-Ritz kernel that used
     // to close the iteration is the head of the next one's first launch.  `solve` = 0: X stays
@@ -1800,6 +1798,12 @@ struct solver {
         return SCS_OK;
     }
 
+    // AR = S R (R's scaled transpose already sits in z) into AQ's R slot, then the
+    // partials of Q^T AQ (into pout); returns their count.
+    // (Folding k_symm_tri_finish into k_gram_qaq -- every lane of the Gram kernel sums the ~60
+    // tile partials of one AR entry, same order, same bits, 32 loads in flight -- was measured:
+    // 25.1 us against 7.7 + 7.8 for the two launches: 128 workgroups cannot hide the latency of
+    // that many dependent rounds of loads; the finish kernel spreads them over 625.)
     template <int B>
     int fused_back(int *nparts, double *pout) {
         // k_symm is timed with HIP events on every fourth launch only: recording an event costs
