@@ -120,7 +120,10 @@ __global__ __launch_bounds__(64) void k_block_records_mono(
     if (lane < cnt - 1) {
         g = rmq_min<double>(st, m, spos, next_pos);
         // a position in [spos, next_pos) where the minimum is attained: halve the range,
-        // keeping a half whose minimum is still g
+        // keeping a half whose minimum is still g.  (Eight sub-ranges a step -- seven prefix minima
+        // in flight together, a third of the dependent round trips -- was measured: 587 us
+        // against 450 for the 436-tree batch of 10 000 leaves: the kernel is bound by the number
+        // of table gathers, not by their latency.)
         int lo = spos, hi = next_pos;
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
