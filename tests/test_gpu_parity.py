@@ -272,6 +272,24 @@ def test_fiedler_block_widths(dev, block):
     _fiedler_case(dev, tables, block=block)
 
 
+@pytest.mark.parametrize(("n", "block"), [(600, 4), (5000, 4), (700, 8)])
+def test_small_solves_in_front_of_the_tall_kernels_change_no_bit(dev, n, block, monkeypatch):
+    # the LOBPCG loop with its three small solves inside the tall kernels (the default) against
+    # the same loop with one-workgroup kernels of their own (SCS_SPLIT_SMALL=1): same partial
+    # sums, same solves -- the same iterates, bit for bit
+    tables = synthetic.make_tables(n + 1, n, 12, "branch", random_weights=True)
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    monkeypatch.delenv("SCS_SPLIT_SMALL", raising=False)
+    maps_a, stats_a = g.fiedler(None, block=block)
+    monkeypatch.setenv("SCS_SPLIT_SMALL", "1")
+    maps_b, stats_b = g.fiedler(None, block=block)
+    g.free()
+    dtab.free()
+    assert stats_a["iterations"] == stats_b["iterations"] > 3
+    assert np.array_equal(maps_a, maps_b)
+
+
 @pytest.mark.parametrize("n", [3, 4, 8, 33, 64, 65, 80, 96])
 def test_fiedler_small_dense_path(dev, n):
     # generic (random tree weights, branch lengths) so that no eigenvalue is repeated
