@@ -721,8 +721,14 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
         const int32_t per = (int32_t)std::min(256.0, std::max(64.0, 600e6 / table_bytes));
         if (n_trees >= 2 * per || n_trees - per >= 32) {
             // the call waits for 64 trees only (scs_pcg_build then makes them a first, short batch:
-            // an extra launch is cheaper than waiting for the other three quarters of a batch)
-            first = std::min(per, 64);
+            // an extra launch is cheaper than waiting for the other three quarters of a batch).
+            // (Balancing the first batch's build against the copy of the rest -- a tree of L leaves
+            // takes ~1.45e-13 L^2 s to accumulate and 16 L bytes at ~50 GB/s to arrive: F / M =
+            // 1 / (1 + L / 2200), ~90 trees at 10 000 x 500 -- was measured with SCS_FIRST_TREES:
+            // 64 / 80 / 96 / 112 trees first give 17.17 / 17.07 / 17.11 / 17.16 ms a step: within the
+            // run-to-run spread, the rule stays.)
+            static const int first_env = getenv("SCS_FIRST_TREES") ? atoi(getenv("SCS_FIRST_TREES")) : 0;
+            first = std::min(per, first_env > 0 ? first_env : 64);
             chunk = per;
         }
     }
