@@ -244,13 +244,14 @@ int scs_fiedler(scs_ctx *ctx, scs_graph *graph, const double *x_init, double tol
 /* ---- batched small nodes ----------------------------------------------- */
 
 /* Deep recursion levels (reference: scs.py:110-134 at depth): K
- * independent nodes of at most 64 taxa each, one workgroup per node, one launch.  Every node
- * goes from its flattened tables to the V x 2 embedding in LDS: proper-cluster-graph weights
+ * independent nodes of at most 128 taxa each (round 4; 64 before), the batch spread over the
+ * chip in three launches.  Every node goes from its flattened tables to the V x 2 embedding: proper-cluster-graph weights
  * (bit-identical to scs_pcg_build's W), contraction of consecutive id ranges (max over member
- * pairs, scs.py:336-387), scipy's degree scaling, full Jacobi eigen-decomposition,
+ * pairs, scs.py:336-387), scipy's degree scaling, full Jacobi eigen-decomposition in LDS
+ * (two-sided up to 64 vertices, one-sided up to 128),
  * scikit-learn's embedding conventions (as scs_fiedler).  Replaces, per node,
  * scs_tables_upload + scs_pcg_build + scs_graph_contract + scs_fiedler.
- *   n_taxa, n_trees, n_groups  int32 [K]   (2 <= n_groups <= n_taxa <= 64)
+ *   n_taxa, n_trees, n_groups  int32 [K]   (2 <= n_groups <= n_taxa <= 128)
  *   tree_off    int32, per node n_trees+1 leaf offsets starting at 0, nodes concatenated
  *   leaf_taxon / adj_depth / adj_val       the nodes' tables, concatenated (taxon ids 0..n_taxa-1,
  *                                          numbered so that every contraction group is a
