@@ -2222,6 +2222,8 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         double worst = 0.0;
         for (int j = 0; j < want; ++j) worst = std::max(worst, std::sqrt(h_rn[j]));
         for (int j = 0; j < want; ++j) final_res[constrained ? 1 : j] = std::sqrt(h_rn[j]);
+        static const bool trace_res = getenv("SCS_TRACE_RESIDUAL") && atoi(getenv("SCS_TRACE_RESIDUAL"));
+        if (trace_res) fprintf(stderr, "[lobpcg] it %3d  residual %.3e  theta %.12g %.12g\n", iter, worst, h_th[0], h_th[1]);
         if (!(worst == worst)) {
             scs_set_error("scs_fiedler: NaN residual at iteration %d", iter);
             return SCS_EHIP;
