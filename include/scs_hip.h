@@ -79,6 +79,10 @@ typedef struct scs_build_stats {
     double bytes_w;             /* algorithmic bytes: W written once (8 * rows * V)  */
     double bytes_tables;        /* algorithmic bytes: tables read once               */
     double exchange_bytes;      /* shared build: bytes of packed tiles this rank received */
+    int32_t tree_parallel_batches; /* batches of a small node built tree-parallel: a workgroup
+                                      per (tile, tree), the trees' cells added up in order
+                                      afterwards (k_sum_tree_tiles) -- same bits as the walk */
+    int32_t reserved;
 } scs_build_stats;
 
 int scs_version(void);

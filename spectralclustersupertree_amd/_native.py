@@ -86,6 +86,8 @@ class BuildStats(C.Structure):
         ("bytes_w", C.c_double),
         ("bytes_tables", C.c_double),
         ("exchange_bytes", C.c_double),
+        ("tree_parallel_batches", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

@@ -710,6 +710,17 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipMemcpyAsync(d_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                  hipMemcpyHostToDevice, s));
 
+    // ---- tree-parallel build (scs_mono.h, k_sum_tree_tiles): a node of a few tiles and many trees --
+    // the mid-size nodes of the recursion -- gives every (tile, tree) pair its own workgroup and adds
+    // the trees' cells up in order afterwards.  SCS_TREE_PARALLEL=0 / 1 force either way (tests).
+    // Measured (tools/node_profile2.py, 5 000 trees): 200 taxa 10.8 -> 1.2 ms, 400 taxa (11 tiles) 11 ->
+    // 3.1 ms = 0.056 us per tile and tree against 1.9 us per tree for the producer / consumer walk:
+    // up to 24 tiles.
+    bool tree_par = sym && monotone && !scatter && !tiles.empty() && tiles.size() <= 24 && tb->n_trees >= 128;
+    if (const char *e = getenv("SCS_TREE_PARALLEL"))
+        tree_par = sym && monotone && !scatter && !tiles.empty() && atoi(e) != 0;
+    const size_t cells_per_tree = tiles.size() * (size_t)SCS_TR * cols_per_tile * 8;
+
     // ---- producer / consumer workgroups (scs_mono_wide.h): two tiles of ONE row block per workgroup,
     // the row block's table expanded once for both, four more waves running the column step ahead
     // of the cells.  Worth it once the groups fill the chip (one twelve-wave workgroup per CU) --
@@ -717,8 +728,14 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // at 50 000; a handful of tiles -- a node of the deep recursion -- keeps one workgroup per tile.
     // SCS_WIDE=0 / 1 force either kernel (A/B runs, tests).
     constexpr int PIPE_NG = 2;
-    int wide_mode = (monotone && !scatter && tiles.size() >= 3 * 256) ? 3 : 0;
+    // (Round 4, later: it also pays on a few dozen tiles -- a node of 1 000 to 5 000 taxa in the
+    // recursion, where the walk is bound by the latency of a tree's step, not by the chip:
+    // 1 000 taxa x 5 000 trees 11.1 -> 9.5 ms, 3 000 x 5 000 15.5 -> 11.2, 3 000 x 300 1.03 -> 0.78;
+    // up to 24 tiles the tree-parallel build below is faster still when the trees are many.)
+    static const size_t wide_min_tiles = getenv("SCS_WIDE_MIN_TILES") ? (size_t)atoi(getenv("SCS_WIDE_MIN_TILES")) : 13;
+    int wide_mode = (monotone && !scatter && !tree_par && tiles.size() >= wide_min_tiles) ? 3 : 0;
     if (const char *e = getenv("SCS_WIDE")) wide_mode = (monotone && !scatter && !tiles.empty() && atoi(e)) ? 3 : 0;
+    if (wide_mode) tree_par = false;  // (SCS_WIDE=1 wins over a tree-parallel build)
     const bool wide = wide_mode != 0;
     const int group_tiles = PIPE_NG;
     std::vector<int4> groups;
@@ -792,6 +809,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             const int k = std::max(1, (rest + 511) / 512);
             max_batch_trees = std::max(96, (rest + k - 1) / k);
         }
+        // (tree-parallel: the cells of a batch's trees stay within the 1 GiB scratch the context keeps)
+        if (tree_par)
+            max_batch_trees = (int)std::max<size_t>(16, std::min<size_t>((size_t)max_batch_trees,
+                                                                         SCS_SCRATCH_KEEP / cells_per_tree));
         if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
         size_t used = 0;
         for (int t = 0; t < M; ++t) {
@@ -824,7 +845,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_HIP_CHECK(hipEventRecord(ev_total.a, s));
 
     int spec_batches = 0;
-    pooled_buf d_pos(ctx, 1), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5);
+    pooled_buf d_pos(ctx, 1), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5), d_cells(ctx, 6);
     for (int bi = 0; bi < n_batches; ++bi) {
         const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
         const int nb = t1 - t0;
@@ -925,6 +946,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.mirror = (sym && bi == n_batches - 1) ? 1 : 0;
             mp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
             mp.stamps = nullptr;
+            mp.split_tiles = 0;
             static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
             if (wide_b) {
                 wide_params wp;
@@ -985,6 +1007,15 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 for (int i = 0; i < 7; ++i)
                     fprintf(stderr, "[stamp] %-24s %6.2f %%  (%.0f cycles per wave-step)\n", nm[i],
                             100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
+            } else if (nt && tree_par) {
+                SCS_TRY(d_cells.alloc((size_t)nb * cells_per_tree));
+                mono_params ap = mp;  // the addends: one workgroup per (tile, tree), from zero, no W
+                ap.split_tiles = (int)nt;
+                ap.load_w = 0;
+                ap.mirror = 0;
+                ap.tile_out = (double *)d_cells.p;
+                k_accumulate_mono<true, false><<<nt * (unsigned)nb, MONO_TCW, 0, s>>>(ap);
+                k_sum_tree_tiles<true><<<nt * SCS_TR, MONO_TCW, 0, s>>>(mp, (const double *)d_cells.p, (int)nt);
             } else if (nt) {
                 if (sym) k_accumulate_mono<true, false><<<nt, MONO_TCW, 0, s>>>(mp);
                 else k_accumulate_mono<false, false><<<nt, MONO_TCW, 0, s>>>(mp);
@@ -1114,6 +1145,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         stats->n_tiles = (int32_t)tiles.size();
         stats->n_batches = n_batches;
         stats->spec_batches = spec_batches;
+        stats->tree_parallel_batches = tree_par ? n_batches : 0;
+        stats->reserved = 0;
         stats->cell_trees = (double)tiles.size() * SCS_TR * cols_per_tile * (double)M;
         stats->prep_ms = prep_ms;
         stats->accumulate_ms = acc_ms;

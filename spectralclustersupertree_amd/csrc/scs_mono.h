@@ -179,6 +179,9 @@ struct mono_params {
     int mirror;                  // 1: last batch of a symmetric build: write the mirror image too
     double *tile_out;            // shared multi-rank build: packed 64 x 256 tiles (else null)
     unsigned long long *stamps;  // diagnostic build only (SCS_ACC_STAMP), else null
+    int split_tiles;             // > 0: tree-parallel build of a small node (k_sum_tree_tiles): the
+                                 // grid is split_tiles x n_batch, workgroup x takes tile x % split_tiles
+                                 // of tree x / split_tiles ALONE and leaves its cells in tile_out slot x
 };
 
 // ---- end of a tile (shared by the monotone and the general tile kernel): write the sums once,
@@ -260,11 +263,15 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
     // (the wave index and everything read from the record are wave-uniform: saying so keeps
     // them in scalar registers)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int2 tile = p.tiles[blockIdx.x];
+    const int split = p.split_tiles;
+    const int2 tile = p.tiles[split > 0 ? (int)blockIdx.x % split : (int)blockIdx.x];
     const int blk = tile.x;
     const int row0 = p.row_begin + blk * SCS_TR;
     const int col = tile.y * MONO_TCW + tid;
     const int nt = p.n_batch;
+    // the trees this workgroup walks: all of the batch, or (tree-parallel build) one
+    const int tl0 = split > 0 ? (int)blockIdx.x / split : 0;
+    const int tl1 = split > 0 ? tl0 + 1 : nt;
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     // a column that is one of the tile's own rows (tiles on the diagonal): its cells are the
     // row-row table itself, no search or range-minimum needed; W[c][c] stays 0
@@ -391,13 +398,14 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         }
     };
 
-    // ---- prologue: records 0 and 1, the column's position in tree 0; then tree 0's column step
-    issue_record(0, 0);
-    issue_record(min(1, nt - 1), 1);
-    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, 0, 0);
+    // ---- prologue: the records of the first two trees, the column's position in the first one;
+    // then its column step
+    issue_record(tl0, tl0 & 1);
+    issue_record(min(tl0 + 1, nt - 1), (tl0 + 1) & 1);
+    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, tl0 * (int)p.npad * 4, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    column_issue(0, cpos_next);  // 3 operations in flight: 2 table loads + the next position
+    column_issue(tl0, cpos_next);  // 3 operations in flight: 2 table loads + the next position
     if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 
     // Order inside a step (tree tl).  The compiler cannot tell an LDS-DMA in flight from the
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
     // follows one, so the step's only DMA -- the record of tree tl + 2 -- is issued after the
     // last LDS access the compiler sees (the cell loop is opaque to it); the table loads of
     // the column step have the whole cell loop to come back.
-    for (int tl = 0; tl < nt; ++tl) {
+    for (int tl = tl0; tl < tl1; ++tl) {
         // the column's loads for tree tl, its position in tree tl + 1, this wave's piece of
         // the record of tree tl + 1 (all issued a cell loop ago)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -451,4 +459,41 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         atomicAdd(&p.stamps[7], 1ull);
     }
     tile_store<SYM>(p, acc, tile, row0, col, self, tid, lane, wave, s_dv);
+}
+
+// ---- tree-parallel build of a small node (mid-size recursion nodes)
+// A node of a few hundred taxa is a handful of tiles, and a tile's workgroup walks the batch's
+// trees one after the other -- ~2 us a tree whatever the tile holds (barriers, the gathers of one
+// range-minimum query, the table expansion): 10 ms for 5 000 trees with 250 CUs idle.  The sum
+// has to be formed in tree order, but the ADDENDS need no order: k_accumulate_mono with
+// p.split_tiles > 0 gives every (tile, tree) pair a workgroup of its own that leaves the tree's
+// cells (0.0 + v = v: exact) in `cells` [tree][tile][64][MONO_TCW], and this kernel adds them up:
+// one thread per cell, the trees in order, sixteen loads in flight -- the same additions in the
+// same order as the walk, the same bits.  Pays while the cells' round trip through HBM (2 x 128 KB
+// per tile and tree) is cheaper than the walk's step: up to ~12 tiles (scs_pcg_build decides).
+template <bool SYM>
+__global__ __launch_bounds__(MONO_TCW) void k_sum_tree_tiles(mono_params p, const double *__restrict__ cells,
+                                                             int n_tiles) {
+    const int tile_i = (int)blockIdx.x / SCS_TR, i = (int)blockIdx.x % SCS_TR;
+    const int2 tile = p.tiles[tile_i];
+    const int row = p.row_begin + tile.x * SCS_TR + i;
+    const int col = tile.y * MONO_TCW + (int)threadIdx.x;
+    if (row >= p.row_end || col >= p.n) return;
+    double *wcell = p.w + (int64_t)(row - p.row_begin) * p.ld + col;
+    double acc = p.load_w ? *wcell : 0.0;
+    const double *src = cells + ((int64_t)tile_i * SCS_TR + i) * MONO_TCW + threadIdx.x;
+    const int64_t stride = (int64_t)n_tiles * SCS_TR * MONO_TCW;
+    int t = 0;
+    for (; t + 16 <= p.n_batch; t += 16) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)(t + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+    for (; t < p.n_batch; ++t) acc += src[(int64_t)t * stride];
+    *wcell = acc;
+    // the mirror image of the cells no tile of the schedule owns (tile_store's rule), last batch
+    if (SYM && p.mirror && (row / MONO_TCW + 1) * MONO_TCW <= (col / SCS_TR) * SCS_TR)
+        p.w[(int64_t)col * p.ld + row] = acc;
 }

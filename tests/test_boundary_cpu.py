@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizes the header implies (int32 fields then doubles, natural alignment)
     assert nv.C.sizeof(nv.Stats) == 6 * 4 + 9 * 8
-    assert nv.C.sizeof(nv.BuildStats) == 8 * 4 + 8 * 8
+    assert nv.C.sizeof(nv.BuildStats) == 8 * 4 + 8 * 8 + 2 * 4  # (+ tree_parallel_batches, reserved)
 
 
 def test_no_device_means_loud_failure():

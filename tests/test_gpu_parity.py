@@ -272,6 +272,41 @@ def test_fiedler_block_widths(dev, block):
     _fiedler_case(dev, tables, block=block)
 
 
+@pytest.mark.parametrize(("n", "m", "strategy", "k"), [(130, 150, "branch", None), (200, 300, "depth", 150),
+                                                       (450, 260, "one", None), (700, 600, "branch", 500)])
+def test_tree_parallel_build_of_a_small_node_is_the_walk_bit_for_bit(dev, n, m, strategy, k, monkeypatch):
+    # a workgroup per (tile, tree) and the trees' cells added up in order afterwards
+    # (k_sum_tree_tiles) against one workgroup per tile walking the trees: the same additions in
+    # the same order -- and both the oracle's W.  700 x 600 needs two batches of cells (1 GiB each).
+    tables = synthetic.make_tables(n + m, n, m, strategy, leaves_per_tree=k, random_weights=True)
+    w_ref, _ = to.pcg_dense(tables)
+    got = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SCS_TREE_PARALLEL", mode)
+        dtab = dev.upload(tables)
+        g = dtab.build()
+        assert (g.build_stats["tree_parallel_batches"] > 0) == (mode == "1"), g.build_stats
+        if n == 700 and mode == "1":
+            assert g.build_stats["n_batches"] >= 2
+        got[mode] = g.download()
+        g.free()
+        dtab.free()
+    assert np.array_equal(got["0"], got["1"])
+    assert np.array_equal(got["1"], w_ref)
+
+
+def test_mid_size_nodes_with_many_trees_are_built_tree_parallel_by_default(dev, monkeypatch):
+    monkeypatch.delenv("SCS_TREE_PARALLEL", raising=False)
+    for n, m, expect in ((300, 200, True), (300, 60, False), (1500, 200, False)):
+        tables = synthetic.make_tables(5, n, m, "branch")
+        dtab = dev.upload(tables)
+        g = dtab.build()
+        assert (g.build_stats["tree_parallel_batches"] > 0) == expect, (n, m, g.build_stats)
+        assert np.array_equal(g.download(), to.pcg_dense(tables)[0])
+        g.free()
+        dtab.free()
+
+
 @pytest.mark.parametrize(("n", "block"), [(600, 4), (5000, 4), (700, 8)])
 def test_small_solves_in_front_of_the_tall_kernels_change_no_bit(dev, n, block, monkeypatch):
     # the LOBPCG loop with its three small solves inside the tall kernels (the default) against
@@ -642,9 +677,9 @@ def test_spec_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
         g = dtab.build()
         got[wide] = g.download()
         assert g.build_stats["n_batches"] > 1
-        # (left to itself scs_pcg_build keeps the 4-wave kernel here: 300 tiles do not fill the chip
-        # with twelve-wave workgroups)
-        assert g.build_stats["spec_batches"] == (g.build_stats["n_batches"] if wide == "1" else 0)
+        # (left to itself scs_pcg_build takes the producer / consumer kernel from 25 tiles on since
+        # round 4: a walk of a few hundred tiles is bound by the latency of a tree's step)
+        assert g.build_stats["spec_batches"] == (0 if wide == "0" else g.build_stats["n_batches"])
         g.free()
         dtab.free()
     assert np.array_equal(got["0"], got["1"]) and np.array_equal(got["0"], got[None])
