@@ -716,9 +716,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // Measured (tools/node_profile2.py, 5 000 trees): 200 taxa 10.8 -> 1.2 ms, 400 taxa (11 tiles) 11 ->
     // 3.1 ms = 0.056 us per tile and tree against 1.9 us per tree for the producer / consumer walk:
     // up to 24 tiles.
-    bool tree_par = sym && monotone && !scatter && !tiles.empty() && tiles.size() <= 24 && tb->n_trees >= 128;
-    if (const char *e = getenv("SCS_TREE_PARALLEL"))
-        tree_par = sym && monotone && !scatter && !tiles.empty() && atoi(e) != 0;
+    bool tree_par = sym && !scatter && !tiles.empty() && tiles.size() <= 24 && tb->n_trees >= 128;
+    if (const char *e = getenv("SCS_TREE_PARALLEL")) tree_par = sym && !scatter && !tiles.empty() && atoi(e) != 0;
     const size_t cells_per_tree = tiles.size() * (size_t)SCS_TR * cols_per_tile * 8;
 
     // ---- producer / consumer workgroups (scs_mono_wide.h): two tiles of ONE row block per workgroup,
@@ -1015,7 +1014,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 ap.mirror = 0;
                 ap.tile_out = (double *)d_cells.p;
                 k_accumulate_mono<true, false><<<nt * (unsigned)nb, MONO_TCW, 0, s>>>(ap);
-                k_sum_tree_tiles<true><<<nt * SCS_TR, MONO_TCW, 0, s>>>(mp, (const double *)d_cells.p, (int)nt);
+                k_sum_tree_tiles<true, mono_params><<<nt * SCS_TR, MONO_TCW, 0, s>>>(mp, (const double *)d_cells.p,
+                                                                                    (int)nt);
             } else if (nt) {
                 if (sym) k_accumulate_mono<true, false><<<nt, MONO_TCW, 0, s>>>(mp);
                 else k_accumulate_mono<false, false><<<nt, MONO_TCW, 0, s>>>(mp);
@@ -1036,7 +1036,18 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             gp.load_w = bi > 0;
             gp.mirror = (sym && bi == n_batches - 1) ? 1 : 0;
             gp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
-            if (nt) {
+            gp.split_tiles = 0;
+            if (nt && tree_par) {
+                SCS_TRY(d_cells.alloc((size_t)nb * cells_per_tree));
+                gen_params ap = gp;  // the addends: one workgroup per (tile, tree), from zero, no W
+                ap.split_tiles = (int)nt;
+                ap.load_w = 0;
+                ap.mirror = 0;
+                ap.tile_out = (double *)d_cells.p;
+                k_accumulate_gen<true><<<nt * (unsigned)nb, MONO_TCW, 0, s>>>(ap);
+                k_sum_tree_tiles<true, gen_params><<<nt * SCS_TR, MONO_TCW, 0, s>>>(gp, (const double *)d_cells.p,
+                                                                                   (int)nt);
+            } else if (nt) {
                 if (sym) k_accumulate_gen<true><<<nt, MONO_TCW, 0, s>>>(gp);
                 else k_accumulate_gen<false><<<nt, MONO_TCW, 0, s>>>(gp);
             }

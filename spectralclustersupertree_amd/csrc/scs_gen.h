@@ -216,6 +216,7 @@ struct gen_params {
     int load_w;                  // 1: continue a sum started by an earlier batch
     int mirror;                  // 1: last batch of a symmetric build: write the mirror image too
     double *tile_out;            // shared multi-rank build: packed 64 x 256 tiles (else null)
+    int split_tiles;             // > 0: tree-parallel build (scs_mono.h, k_sum_tree_tiles)
 };
 
 template <bool SYM>
@@ -227,11 +228,15 @@ __global__ __launch_bounds__(MONO_TCW, 3) void k_accumulate_gen(gen_params p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int2 tile = p.tiles[blockIdx.x];
+    const int split = p.split_tiles;
+    const int2 tile = p.tiles[split > 0 ? (int)blockIdx.x % split : (int)blockIdx.x];
     const int blk = tile.x;
     const int row0 = p.row_begin + blk * SCS_TR;
     const int col = tile.y * MONO_TCW + tid;
     const int nt = p.n_batch;
+    // the trees this workgroup walks: all of the batch, or (tree-parallel build) one
+    const int tl0 = split > 0 ? (int)blockIdx.x / split : 0;
+    const int tl1 = split > 0 ? tl0 + 1 : nt;
     // a column that is one of the tile's own rows (tiles on the diagonal): its cells are the
     // row-row table itself, no search or range-minimum needed; W[c][c] stays 0
     const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
@@ -367,16 +372,16 @@ __global__ __launch_bounds__(MONO_TCW, 3) void k_accumulate_gen(gen_params p) {
     };
 
     // ---- prologue: records 0 and 1, the column's position in tree 0; then tree 0's column step
-    issue_record(0, 0);
-    issue_record(min(1, nt - 1), 1);
-    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, 0, 0);
+    issue_record(tl0, tl0 & 1);
+    issue_record(min(tl0 + 1, nt - 1), (tl0 + 1) & 1);
+    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, tl0 * (int)p.npad * 4, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    column_issue(0, cpos_next);
+    column_issue(tl0, cpos_next);
 
     // Order inside a step as in k_accumulate_mono: the step's only LDS-DMA (the record of tree
     // tl + 2) is issued after the last LDS access the compiler sees.
-    for (int tl = 0; tl < nt; ++tl) {
+    for (int tl = tl0; tl < tl1; ++tl) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // A: every wave is done with the cells of tree tl - 1 (s_dv); the record of tree
         // tl + 1 is complete

@@ -465,15 +465,14 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
 // A node of a few hundred taxa is a handful of tiles, and a tile's workgroup walks the batch's
 // trees one after the other -- ~2 us a tree whatever the tile holds (barriers, the gathers of one
 // range-minimum query, the table expansion): 10 ms for 5 000 trees with 250 CUs idle.  The sum
-// has to be formed in tree order, but the ADDENDS need no order: k_accumulate_mono with
+// has to be formed in tree order, but the ADDENDS need no order: k_accumulate_mono / _gen with
 // p.split_tiles > 0 gives every (tile, tree) pair a workgroup of its own that leaves the tree's
 // cells (0.0 + v = v: exact) in `cells` [tree][tile][64][MONO_TCW], and this kernel adds them up:
 // one thread per cell, the trees in order, sixteen loads in flight -- the same additions in the
 // same order as the walk, the same bits.  Pays while the cells' round trip through HBM (2 x 128 KB
 // per tile and tree) is cheaper than the walk's step: up to ~12 tiles (scs_pcg_build decides).
-template <bool SYM>
-__global__ __launch_bounds__(MONO_TCW) void k_sum_tree_tiles(mono_params p, const double *__restrict__ cells,
-                                                             int n_tiles) {
+template <bool SYM, typename P>
+__global__ __launch_bounds__(MONO_TCW) void k_sum_tree_tiles(P p, const double *__restrict__ cells, int n_tiles) {
     const int tile_i = (int)blockIdx.x / SCS_TR, i = (int)blockIdx.x % SCS_TR;
     const int2 tile = p.tiles[tile_i];
     const int row = p.row_begin + tile.x * SCS_TR + i;

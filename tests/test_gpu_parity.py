@@ -273,7 +273,8 @@ def test_fiedler_block_widths(dev, block):
 
 
 @pytest.mark.parametrize(("n", "m", "strategy", "k"), [(130, 150, "branch", None), (200, 300, "depth", 150),
-                                                       (450, 260, "one", None), (700, 600, "branch", 500)])
+                                                       (450, 260, "one", None), (700, 600, "branch", 500),
+                                                       (300, 200, "bootstrap", 220), (140, 330, "bootstrap", None)])
 def test_tree_parallel_build_of_a_small_node_is_the_walk_bit_for_bit(dev, n, m, strategy, k, monkeypatch):
     # a workgroup per (tile, tree) and the trees' cells added up in order afterwards
     # (k_sum_tree_tiles) against one workgroup per tile walking the trees: the same additions in
@@ -297,8 +298,9 @@ def test_tree_parallel_build_of_a_small_node_is_the_walk_bit_for_bit(dev, n, m, 
 
 def test_mid_size_nodes_with_many_trees_are_built_tree_parallel_by_default(dev, monkeypatch):
     monkeypatch.delenv("SCS_TREE_PARALLEL", raising=False)
-    for n, m, expect in ((300, 200, True), (300, 60, False), (1500, 200, False)):
-        tables = synthetic.make_tables(5, n, m, "branch")
+    for n, m, expect, strategy in ((300, 200, True, "branch"), (300, 60, False, "branch"), (1500, 200, False, "branch"),
+                                   (260, 150, True, "bootstrap")):
+        tables = synthetic.make_tables(5, n, m, strategy)
         dtab = dev.upload(tables)
         g = dtab.build()
         assert (g.build_stats["tree_parallel_batches"] > 0) == expect, (n, m, g.build_stats)
