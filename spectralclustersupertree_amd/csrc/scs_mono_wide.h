@@ -41,7 +41,7 @@ struct wide_layout {
     static constexpr int M = CNT + 4;                       // int32
     static constexpr int STOFF = M + 4;                     // int64
     static constexpr int BYTES = (STOFF + 8 + 15) / 16 * 16;
-    static constexpr int PIECES = (BYTES + 1023) / 1024;    // 1 KiB LDS-DMA pieces, one per wave
+    static constexpr int PIECES = (BYTES + 1023) / 1024;    // 1 KiB pieces of a record, one or two per producer wave
     __host__ __device__ static constexpr int seg(int w) { return 64 * w / NSEG; }
     static constexpr int MAXSEG = (64 + NSEG - 1) / NSEG;
     static_assert(STOFF % 8 == 0 && PIECES <= NSEG, "record layout");
@@ -118,22 +118,7 @@ __global__ __launch_bounds__(64) void k_block_records_wide(
     }
 }
 
-// 16 bytes per lane, global -> LDS at `lds_addr` + 16 * lane, no round trip through registers, as
-// inline asm: behind the builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) the compiler drains
-// vmcnt in front of every LDS access that may follow a pending LDS-DMA -- and with it the
-// range-minimum loads the producer waves issued a moment ago and want in flight for two steps.
-// Hidden from the compiler, the copy is ordered by hand: a counted s_waitcnt vmcnt by the issuing
-// wave, then the workgroup barrier, before anyone reads the record.  (The builtin has a second
-// trap: inside a kernel TEMPLATE with value-dependent arguments the HOST pass, which does not know
-// it, drops the instantiation without a word and leaves the kernel's launch stub undefined.)
 typedef int scs_int4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void lds_dma16_asm(const scs_int4 rsrc, const unsigned lds_addr,
-                                              const int voffset, const int soffset) {
-    asm volatile("s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[voff], %[rsrc], %[soff] offen lds"
-                 :
-                 : [lds] "s"(lds_addr), [voff] "v"(voffset), [rsrc] "s"(rsrc), [soff] "s"(soffset)
-                 : "memory", "m0");
-}
 
 struct wide_params {
     mono_params m;
@@ -218,7 +203,7 @@ struct spec_layout {
     using L = wide_layout<2>;
     static constexpr int CONSUMERS = 8, PRODUCERS = 4, THREADS = 64 * (CONSUMERS + PRODUCERS);
     static constexpr size_t O_T = 0;                                      // double[2][DT_DOUBLES]
-    static constexpr int NREC = 6;  // records of trees t + 1 ... t + 6 during step t
+    static constexpr int NREC = 6;  // a record is in LDS from step t - 5 (stored) to step t - 1 (the consumers' expansion state)
     static constexpr size_t O_REC = 2 * (size_t)DT_DOUBLES * 8;          // [NREC][L::BYTES]
     static constexpr size_t O_VN = O_REC + NREC * (size_t)L::BYTES;      // double[2][512]
     static constexpr size_t O_ADDR = O_VN + 2 * 512 * 8;                 // unsigned[2][512]
@@ -270,37 +255,64 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     const int self = (col >= row0 && col < row0 + SCS_TR && col < p.row_end) ? col - row0 : -1;
 
     const unsigned char *rec_base = p.rec + (int64_t)blk * nt * L::BYTES;
-    const scs_int4 rs_rec = {(int)(unsigned)(u64)rec_base, (int)(((u64)rec_base >> 32) & 0xffffu),
-                             nt * L::BYTES, 0x00020000};
     const __amdgpu_buffer_rsrc_t r_pos =
         __builtin_amdgcn_make_buffer_rsrc((void *)p.pos, 0, (int)(nt * p.npad * 4), 0x00020000);
     const int lane16 = lane * 16;
 
     // ---------------- producer side ----------------
-    // record of tree t lives in s_rec[t % NREC]; producer pw copies pieces pw and pw + 4
-    auto issue_record = [&](int t) {
+    // record of tree t lives in s_rec[t % NREC]; producer pw copies pieces pw and pw + 4 -- THROUGH
+    // REGISTERS, loaded three steps before they are stored.  (The first version sent the pieces
+    // straight to LDS -- buffer_load ... lds in inline asm, invisible to the compiler, ordered by
+    // hand-counted s_waitcnt vmcnt -- and the compiler, counting only the loads it could see, put
+    // waits in front of the uses of the range-minimum values and the positions that were too
+    // strict by the number of DMA operations in flight: a search waited for loads one step old.
+    // Harmless while those hit the L2 -- 10 000 leaves --, a quarter of the step at 50 000.  With
+    // every vector-memory operation visible the compiler's own counts are exact: loads return in
+    // order, a use waits for exactly the loads issued before its own.)
+    const __amdgpu_buffer_rsrc_t r_rec =
+        __builtin_amdgcn_make_buffer_rsrc((void *)rec_base, 0, nt * L::BYTES, 0x00020000);
+    struct pieces {
+        scs_int4 v[2];
+    };
+    auto load_record = [&](int t, pieces &r) {
+        if (t >= nt) return;
 #pragma unroll
         for (int pc = 0; pc < L::PIECES; pc += S::PRODUCERS) {
             const int piece = pc + pw;
             if (piece < L::PIECES) {
                 const int left = (L::BYTES - piece * 1024) / 16;
                 if (lane < left)
-                    lds_dma16_asm(rs_rec,
-                                  (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)(
-                                      s_rec + (t % S::NREC) * L::BYTES + piece * 1024),
-                                  lane16, t * L::BYTES + piece * 1024);
+                    r.v[pc / S::PRODUCERS] =
+                        __builtin_amdgcn_raw_buffer_load_b128(r_rec, lane16, t * L::BYTES + piece * 1024, 0);
+            }
+        }
+    };
+    auto store_record = [&](int t, const pieces &r) {
+        if (t >= nt) return;
+#pragma unroll
+        for (int pc = 0; pc < L::PIECES; pc += S::PRODUCERS) {
+            const int piece = pc + pw;
+            if (piece < L::PIECES) {
+                const int left = (L::BYTES - piece * 1024) / 16;
+                if (lane < left)
+                    *(scs_int4 *)(s_rec + (t % S::NREC) * L::BYTES + piece * 1024 + lane16) = r.v[pc / S::PRODUCERS];
             }
         }
     };
     // the two columns of this lane (one per consumer wave served) and their positions in the
     // tree the next column step is for
-    int pcol4[2], pself[2], cpos[2];
+    // (cpos: in the tree the next search is for; cpos2: in the tree after that -- a position is
+    // requested TWO searches ahead and in front of the search's own table loads: loads return in
+    // order, so a search that waits for positions requested at the end of the search before it
+    // waits for that search's range-minimum loads too, and at 50 000 leaves those come from HBM)
+    int pcol4[2], pself[2], cpos[2], cpos2[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int c = tile.y * MONO_TCW + (((2 * pw + k) & 3) * 64) + lane;
         pcol4[k] = c * 4;
         pself[k] = (c >= row0 && c < row0 + SCS_TR && c < p.row_end) ? c - row0 : -1;
         cpos[k] = -1;
+        cpos2[k] = -1;
     }
     // the column step of k_accumulate_mono for both columns, in two halves a whole step apart:
     // `search` (tree t) finds the neighbours and ISSUES the one range-minimum query per column --
@@ -312,27 +324,44 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         double qx[2], qy[2];
         int cstate[2];
     };
+    // the record's pivots and scalars come through the SCALAR path, from the record's copy in device
+    // memory (constant for the kernel's duration: address space 4, a uniform address -> s_load): one
+    // LDS round trip less in a search whose every LDS access queues behind the consumers' cell
+    // reads.  They are requested a whole step before the search that needs them (`tail`, twelve
+    // SGPRs carried from one search to the next): the records of a batch are gigabytes at 50 000
+    // leaves, the load misses every cache, and waiting for it inside the search (1-2 us of a 2 us
+    // step) made the producers the slower side there.
+    typedef const __attribute__((address_space(4))) int *cint;
+    int tail[12];
+    auto request_tail = [&](int t) {
+        cint gpiv = (cint)(size_t)(rec_base + (int64_t)min(t, nt - 1) * L::BYTES + L::PIV);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tail[k] = gpiv[k];
+    };
     auto search = [&](int t_raw, query &q) {
         const int t = min(t_raw, nt - 1);
         const unsigned char *rb = s_rec + (t % S::NREC) * L::BYTES;
         const int *s_spos = (const int *)(rb + L::SPOS);
         const int *s_arg = (const int *)(rb + L::ARGPOS);
         const unsigned char *s_sorig = rb + L::SORIG;
-        // the record's pivots and scalars through the SCALAR path, from the record's copy in device
-        // memory (constant for the kernel's duration: address space 4, a uniform address -> s_load):
-        // one LDS round trip less in a search whose every LDS access queues behind the consumers'
-        // cell reads
-        typedef const __attribute__((address_space(4))) int *cint;
-        cint gpiv = (cint)(size_t)(rec_base + (int64_t)t * L::BYTES + L::PIV);
-        const int4 pa = make_int4(gpiv[0], gpiv[1], gpiv[2], gpiv[3]);
-        const int4 pb = make_int4(gpiv[4], gpiv[5], gpiv[6], gpiv[7]);
-        const int cnt = gpiv[8], m = gpiv[9];  // (CNT and M follow the pivots, STOFF follows them)
-        const unsigned so_lo = (unsigned)gpiv[10], so_hi = (unsigned)gpiv[11];
+        // (the searches run over consecutive trees: `tail` holds tree t's, requested by the search before)
+        const int4 pa = make_int4(tail[0], tail[1], tail[2], tail[3]);
+        const int4 pb = make_int4(tail[4], tail[5], tail[6], tail[7]);
+        const int cnt = tail[8], m = tail[9];  // (CNT and M follow the pivots, STOFF follows them)
+        const unsigned so_lo = (unsigned)tail[10], so_hi = (unsigned)tail[11];
         static_assert(L::CNT == L::PIV + 32 && L::M == L::PIV + 36 && L::STOFF == L::PIV + 40, "record tail");
         const unsigned char *st = (const unsigned char *)(p.stv + (((u64)so_hi << 32) | so_lo));
+        // this search's positions; the next one's move up; the one after that is requested now
+        int cp_now[2];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int cp = cpos[k];
+            cp_now[k] = cpos[k];
+            cpos[k] = cpos2[k];
+            cpos2[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], min(t + 2, nt - 1) * (int)p.npad * 4, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int cp = cp_now[k];
             const bool present = cp >= 0 && cnt > 0;
             int lo = ((pa.x < cp) + (pa.y < cp) + (pa.z < cp) + (pa.w < cp) + (pb.x < cp) + (pb.y < cp) +
                       (pb.z < cp) + (pb.w < cp)) * 8;
@@ -345,9 +374,15 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
             const bool hasl = present && pself[k] < 0 && lo > 0;
             const bool hasr = present && pself[k] < 0 && lo < cnt;
             const int il = max(lo - 1, 0), ir = min(lo, 63);
-            const bool left = hasl && (!hasr || s_arg[il] >= cp);
-            const int q_anchor = s_spos[left ? il : ir];
-            const int nbrow = s_sorig[left ? il : ir];
+            // (both neighbours' entries in ONE round trip, chosen afterwards: every LDS access of a
+            // producer queues behind the consumers' cell reads -- ~700 clocks a trip at 50 000 leaves,
+            // and three dependent ones made the search the longest thing in the step)
+            const int a_il = s_arg[il];
+            const int sp_il = s_spos[il], sp_ir = s_spos[ir];
+            const int so_il = s_sorig[il], so_ir = s_sorig[ir];
+            const bool left = hasl && (!hasr || a_il >= cp);
+            const int q_anchor = left ? sp_il : sp_ir;
+            const int nbrow = left ? so_il : so_ir;
             q.cstate[k] = nbrow | ((hasl || hasr) ? 256 : 0) | ((present && pself[k] >= 0) ? 512 : 0);
             const bool any = hasl || hasr;
             int o[2];
@@ -355,9 +390,7 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
             q.qx[k] = *(const double *)(st + (unsigned)o[0] * 8u);
             q.qy[k] = *(const double *)(st + (unsigned)o[1] * 8u);
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-            cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], min(t + 1, nt - 1) * (int)p.npad * 4, 0);
+        request_tail(t_raw + 1);
     };
     auto finish = [&](int t, const query &q) {
         const unsigned tbase =
@@ -413,18 +446,27 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
     // producer is there to keep in flight.  (And ONE cell statement in the kernel: a second one with
     // 64 tied accumulators makes the register allocator keep two sets.)
     if (producer) {
-        // ---- prologue: records 0 ... 5, tree 0's column pairs, the queries of trees 1, 2 and 3
-        issue_record(0);
-        if (nt > 1) issue_record(1);
-        if (nt > 2) issue_record(2);
-        if (nt > 3) issue_record(3);
-        if (nt > 4) issue_record(4);
-        if (nt > 5) issue_record(5);
+        // ---- prologue: records 0 ... 4 into LDS, 5 ... 7 on their way (one per register set), tree 0's
+        // column pairs, the queries of trees 1, 2 and 3
+        pieces ra = {{{0, 0, 0, 0}, {0, 0, 0, 0}}}, rb = ra, rc = ra;
+        {
+            pieces first[5] = {ra, ra, ra, ra, ra};  // (all five loads in flight together)
 #pragma unroll
-        for (int k = 0; k < 2; ++k) cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        SCS_BARE_BARRIER();
+            for (int t = 0; t < 5; ++t) load_record(t, first[t]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) store_record(t, first[t]);
+        }
+        load_record(5, ra);
+        load_record(6, rb);
+        load_record(7, rc);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            cpos[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], 0, 0);
+            cpos2[k] = __builtin_amdgcn_raw_buffer_load_b32(r_pos, pcol4[k], min(1, nt - 1) * (int)p.npad * 4, 0);
+        }
+        SCS_BARE_BARRIER();  // (records 0 ... 4 are stores of this wave: drained by the barrier's lgkmcnt wait)
         query qa = {{0.0, 0.0}, {0.0, 0.0}, {0, 0}}, qb = qa, qc = qa;
+        request_tail(0);
         search(0, qa);
         finish(0, qa);  // (waits for tree 0's answers: once per launch)
         search(1, qa);
@@ -438,27 +480,22 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         else if (wp.producer_prio == 3) __builtin_amdgcn_s_setprio(3);
         // Step tl.  On entry: the queries of trees tl + 1 (in `q1`, issued three steps ago), tl + 2 and
         // tl + 3 are in flight; the three sets take turns.
-        auto step = [&](int tl, query &q1) __attribute__((always_inline)) {
+        auto step = [&](int tl, query &q1, pieces &r1) __attribute__((always_inline)) {
             if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
-            if (tl + 6 < nt) issue_record(tl + 6);
-            search(tl + 4, q1);  // six loads (four table entries, two positions), consumed three steps on
-            // The record that must be in place when the barrier opens is the one requested a step ago
-            // (tree tl + 5: searched in the next step).  Loads return in order, so "it has landed" is
-            // "all but the loads issued after it are done": the six of the step before, this step's
-            // record pieces (two for producer 0, one for the others) and the six above -- the two
-            // youngest sets of queries (misses of the L2 at 50 000 leaves: 2-3 us) stay in flight.
-            if (tl + 6 >= nt) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // (no pieces this step)
-            else if (pw == 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            // the record of tree tl + 5 (searched in the next step), loaded three steps ago, goes to
+            // LDS; its registers take the record of tree tl + 8
+            store_record(tl + 5, r1);
+            load_record(tl + 8, r1);
+            search(tl + 4, q1);  // six loads (two positions, four table entries), consumed two / three steps on
             stamp(1);
             SCS_BARE_BARRIER();
             stamp(4);
         };
         for (int tl = 0; tl < nt; tl += 3) {
-            step(tl, qa);
-            if (tl + 1 < nt) step(tl + 1, qb);
-            if (tl + 2 < nt) step(tl + 2, qc);
+            step(tl, qa, ra);
+            if (tl + 1 < nt) step(tl + 1, qb, rb);
+            if (tl + 2 < nt) step(tl + 2, qc, rc);
         }
         if (STAMPED && lane == 0 && p.stamps) {
 #pragma unroll
