@@ -21,12 +21,16 @@ warnings.simplefilter("ignore")
 rng = np.random.RandomState(args.seed)
 dev = Device(0)
 t_end = time.time() + args.seconds
-n_cases = n_fiedler = n_multi = n_small = n_upper = 0
+n_cases = n_fiedler = n_multi = n_small = n_upper = n_treepar = n_spec = 0
 worst = 0.0
 fails = []
 while time.time() < t_end:
     n = int(rng.choice([rng.randint(3, 65), rng.randint(65, 400), rng.randint(400, 2500)]))
     m = int(rng.randint(1, 30))
+    if n > 128 and n <= 900 and rng.randint(0, 4) == 0:
+        # (forests of many trees on a few tiles: the tree-parallel build; above ~800 taxa the
+        # producer / consumer kernel on a few dozen tiles)
+        m = int(rng.randint(128, 420))
     strategy = str(rng.choice(["one", "depth", "branch", "bootstrap"]))
     k = int(rng.randint(max(2, n // 2), n + 1))
     rw = bool(rng.randint(0, 2))
@@ -40,6 +44,10 @@ while time.time() < t_end:
     if not np.array_equal(w, w_ref):
         fails.append(f"W mismatch: {tag}: {int(np.sum(w != w_ref))} cells")
     n_cases += 1
+    if g.build_stats["tree_parallel_batches"]:
+        n_treepar += 1
+    if g.build_stats["spec_batches"]:
+        n_spec += 1
     if n <= dev.SMALL_MAX_TAXA:
         # the fused small-node kernel on the same input: same W, same embedding as the general path
         (maps_s, lam_s, w_s), = dev.small_solve([(tables, None)], want_w=True)
@@ -131,7 +139,7 @@ while time.time() < t_end:
 dev.close()
 print(f"fuzz: {n_cases} builds bit-exact checked, {n_fiedler} Fiedler comparisons, worst |diff| {worst:.2e}, "
       f"{n_multi} multi-rank builds + solves ({n_upper} rank-blocks of upper-triangle jobs), {n_small} fused small-node "
-      f"solves, {len(fails)} failures")
+      f"solves, {n_treepar} tree-parallel builds, {n_spec} builds by the producer / consumer kernel, {len(fails)} failures")
 for f in fails[:20]:
     print("  ", f)
 sys.exit(1 if fails else 0)
