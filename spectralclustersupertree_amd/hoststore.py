@@ -25,6 +25,33 @@ import time
 _MAGIC = b"SCSRDZV1"
 _PROBES = 16
 
+# What travels is plain data -- None, numbers, strings, bytes (the RCCL id), tuples / lists /
+# dicts of those (flat trees), numpy scalars and arrays.  The sockets are unauthenticated (the
+# handshake only tells jobs apart), so nothing received is allowed to name any other global: a
+# pickle that asks for one is refused instead of executed.
+_SAFE_GLOBALS = {
+    ("builtins", "complex"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "bytearray"),
+    ("builtins", "slice"), ("builtins", "range"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+}
+
+
+class _DataUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _SAFE_GLOBALS:
+            return super().find_class(module, name)
+        msg = f"rendezvous: refused to unpickle {module}.{name} (only plain data travels between the ranks)"
+        raise pickle.UnpicklingError(msg)
+
+
+def _loads(blob: bytes):
+    import io
+
+    return _DataUnpickler(io.BytesIO(blob)).load()
+
 
 def _send(sock: socket.socket, payload: bytes) -> None:
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
@@ -143,13 +170,13 @@ class HostGroup:
         if self.rank == 0:
             out = [obj] + [None] * (self.world - 1)
             for r in range(1, self.world):
-                out[r] = pickle.loads(_recv(self._peers[r]))
+                out[r] = _loads(_recv(self._peers[r]))
             blob = pickle.dumps(out, protocol=pickle.HIGHEST_PROTOCOL)
             for r in range(1, self.world):
                 _send(self._peers[r], blob)
             return out
         _send(self._sock, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
-        return pickle.loads(_recv(self._sock))
+        return _loads(_recv(self._sock))
 
     def broadcast(self, obj):
         """Rank 0's object on every rank."""

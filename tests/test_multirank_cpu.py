@@ -409,3 +409,26 @@ def test_host_group_three_ranks_skips_a_stranger_on_the_first_port():
     assert err == [None, None, None], err
     for got, top, word in out:
         assert got == [("rank", 0), ("rank", 1), ("rank", 2)] and top == 20.0 and word == "hello"
+
+
+def test_rendezvous_unpickles_plain_data_only():
+    # the sockets are unauthenticated: a message that names a global outside the whitelist
+    # (here os.system through __reduce__) is refused, not executed; what the ranks really send
+    # -- None, numbers, bytes, flat trees, numpy values -- round-trips
+    import os
+    import pickle
+
+    from spectralclustersupertree_amd import hoststore as hs
+
+    for obj in (None, 1.5, 3, "a", b"\x00" * 128, ({4: ([-1, 0, 0], ["r", "a", "b"], [None, 1.0, 2.5], [None, None, None])}, None),
+                np.float64(2.0)):
+        assert hs._loads(pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)) == obj
+    arr = np.arange(7, dtype=np.int32)
+    assert np.array_equal(hs._loads(pickle.dumps(arr, protocol=pickle.HIGHEST_PROTOCOL)), arr)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+
+    with pytest.raises(pickle.UnpicklingError, match="refused to unpickle"):
+        hs._loads(pickle.dumps(Evil()))
