@@ -539,18 +539,47 @@ class _warm_allocator:
         return False
 
 
+_switch_users = 0
+_switch_saved = None
+_switch_lock = threading.Lock()
+
+
+class _short_switch_interval:
+    """The interpreter's switch interval lowered to 200 us while a recursion runs with its
+    look-ahead worker (the worker comes back from a library call every few hundred microseconds
+    and needs the interpreter for a few lines each time: it must not wait the default 5 ms for
+    it).  Process-wide state: counted, so that recursions on several threads enter and leave in
+    any order and the LAST one out restores what the FIRST one in found."""
+
+    def __enter__(self):
+        import sys
+
+        global _switch_users, _switch_saved
+        with _switch_lock:
+            if _switch_users == 0:
+                _switch_saved = sys.getswitchinterval()
+                sys.setswitchinterval(min(_switch_saved, 2e-4))
+            _switch_users += 1
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        global _switch_users, _switch_saved
+        with _switch_lock:
+            _switch_users -= 1
+            if _switch_users == 0 and _switch_saved is not None:
+                sys.setswitchinterval(_switch_saved)
+                _switch_saved = None
+        return False
+
+
 def _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre):
     single = team is None or team.world == 1
     if bipartition is None and single and _small_path() and _ahead_enabled():
-        import sys
-
         from spectralclustersupertree_amd.ahead import Ahead
 
-        # the worker comes back from a library call every few hundred microseconds and needs the
-        # interpreter for a few lines each time: do not let it wait 5 ms (the default) for it
-        interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(interval, 2e-4))
-        try:
+        with _short_switch_interval():
             # (the worker's context is made when the first job arrives -- by then the walk has solved
             # the root on its own; a recursion that never reaches the spectral step touches no device)
             def second_context():
@@ -563,8 +592,6 @@ def _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipart
                                            queue)
                 finally:
                     _last_ahead_stats = dict(queue.stats)
-        finally:
-            sys.setswitchinterval(interval)
     return _construct_node(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre, None)
 
 
