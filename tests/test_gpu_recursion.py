@@ -253,6 +253,16 @@ def test_two_tree_bootstrap_forest_with_a_bipartite_node_of_65_to_128_taxa():
     assert any(64 < sum(len(v) for v in e["vertices"]) or 64 < len(e["vertices"]) for e in trace)
 
 
+@pytest.mark.parametrize("strategy", ["branch", "bootstrap"])
+def test_whole_recursion_of_a_forest_of_many_trees_on_a_few_tiles(strategy):
+    # 230 taxa / 150 trees: the nodes above 128 taxa are built tree-parallel (a workgroup per tile and
+    # tree), the ones below go through the batched small-node path with 150 trees each
+    trees, weights = recursion_input(31, 230, 150, 200, 12, weighted=True)
+    trace, ties = compare_with_oracle(trees, weights, strategy, seed=3, ties_allowed=True)
+    assert len(ties) <= len(trace) // 10
+    assert max(len(e["vertices"]) for e in trace) > 128
+
+
 @pytest.mark.parametrize("strategy", ["one", "depth"])
 def test_whole_recursion_integer_strategies_from_tree_arrays(strategy):
     trees, weights = recursion_input(2, 400, 16, 300, 30, weighted=True)
