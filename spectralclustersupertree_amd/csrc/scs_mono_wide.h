@@ -479,7 +479,9 @@ __global__ __launch_bounds__(spec_layout::THREADS) void k_accumulate_spec(wide_p
         else if (wp.producer_prio == 2) __builtin_amdgcn_s_setprio(2);
         else if (wp.producer_prio == 3) __builtin_amdgcn_s_setprio(3);
         // Step tl.  On entry: the queries of trees tl + 1 (in `q1`, issued three steps ago), tl + 2 and
-        // tl + 3 are in flight; the three sets take turns.
+        // tl + 3 are in flight; the three sets take turns.  (Four sets, four steps ahead: measured, no
+        // faster at 50 000 leaves -- 579 against 573 ms: what the producers wait for there is not the
+        // age of a load.)
         auto step = [&](int tl, query &q1, pieces &r1) __attribute__((always_inline)) {
             if (tl + 1 < nt) finish(tl + 1, q1);
             stamp(0);
