@@ -869,7 +869,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // that costs more than the shorter steps save (measured at 10 000 leaves: 64 + 218 + 218
         // trees 6.93 ms either way, 218 + 218 with the 4-wave kernel in front 6.5).
         static const int wide_min_trees = getenv("SCS_WIDE_MIN_TREES") ? atoi(getenv("SCS_WIDE_MIN_TREES")) : 96;
-        const bool wide_b = wide && nb >= wide_min_trees;
+        // (with many rounds of workgroups per launch -- 50 000 leaves: 150 -- the prologue and the thin
+        // last round are noise and the short first batch is the producer / consumer kernel's too:
+        // 64 trees 25 -> 18 ms there)
+        const bool wide_b = wide && (nb >= wide_min_trees || (groups.size() >= 8 * 256 && nb >= 16));
         if (wide_b) ++spec_batches;
         SCS_TRY(d_pos.alloc(need_pos));
         SCS_TRY(d_st.alloc(need_st));
