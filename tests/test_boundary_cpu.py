@@ -37,6 +37,36 @@ def test_struct_layouts_match_header():
     assert nv.C.sizeof(nv.BuildStats) == 8 * 4 + 8 * 8 + 2 * 4  # (+ tree_parallel_batches, reserved)
 
 
+def test_struct_fields_match_header_in_name_type_and_order():
+    # the ctypes mirrors against include/scs_hip.h, field by field
+    import re
+
+    text = (ROOT / "include" / "scs_hip.h").read_text()
+    for c_name, mirror in (("scs_stats", nv.Stats), ("scs_build_stats", nv.BuildStats)):
+        body = re.search(r"typedef struct " + c_name + r" \{(.*?)\} " + c_name + ";", text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            ctype, names = decl.split(None, 1)
+            for name in names.split(","):
+                name = name.strip()
+                count = 1
+                m = re.match(r"(\w+)\[(\d+)\]", name)
+                if m:
+                    name, count = m.group(1), int(m.group(2))
+                fields.append((name, ctype, count))
+        want = {"int32_t": nv.C.c_int32, "double": nv.C.c_double, "int64_t": nv.C.c_int64}
+        got = list(mirror._fields_)
+        assert len(got) == len(fields), (c_name, [f[0] for f in fields], [g[0] for g in got])
+        for (name, ctype, count), (py_name, py_type) in zip(fields, got):
+            assert py_name.rstrip("_") == name.rstrip("_"), (c_name, name, py_name)
+            expect = want[ctype] * count if count > 1 else want[ctype]
+            assert py_type is expect or (count > 1 and py_type._type_ is want[ctype] and py_type._length_ == count), (c_name, name)
+
+
 def test_no_device_means_loud_failure():
     lib = nv.load_library()
     if lib.scs_device_count() > 0:
