@@ -85,6 +85,10 @@ typedef struct scs_build_stats {
     int32_t reserved;
 } scs_build_stats;
 
+/* ABI version of this header: 101.  100 -> 101: scs_build_stats is 8 bytes longer
+ * (tree_parallel_batches; the old `reserved` slot became spec_batches), scs_tables_split*
+ * added.  Callers compare it with the value they were compiled against before passing
+ * structs (the Python binding refuses a library of another version at load). */
 int scs_version(void);
 const char *scs_last_error(void);
 

@@ -102,6 +102,8 @@ _I32 = C.c_int32
 # per argument (``data_as``) costs more than the call itself for the tiny nodes of a deep recursion;
 # dptr / iptr / lptr below check the dtype instead
 _DP = _IP = _LP = C.c_void_p
+ABI_VERSION = 101  # scs_version() of the header these bindings were written against
+
 SIGNATURES = {
     "scs_version": (C.c_int, []),
     "scs_last_error": (C.c_char_p, []),
@@ -155,6 +157,12 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = restype
         fn.argtypes = argtypes
+    # the ctypes mirrors of the stats structs follow include/scs_hip.h of THIS version: a library
+    # built from another header would be handed structs of the wrong size
+    have = int(lib.scs_version())
+    if have != ABI_VERSION:
+        msg = f"{LIB_PATH} reports ABI version {have}, this package binds {ABI_VERSION}: rebuild the library"
+        raise ImportError(msg)
     _lib = lib
     return lib
 

@@ -132,7 +132,7 @@ class Device:
             self._ctx, k, nv.iptr(n_taxa), nv.iptr(n_trees), nv.iptr(n_groups), nv.iptr(toff_a),
             nv.iptr(lt_a), nv.iptr(ad_a), nv.dptr(av_a), nv.dptr(tw_a), nv.iptr(gs_a), int(want_w),
             C.byref(ticket)))
-        return SmallTicket(self, ticket.value, n_groups, want_w)
+        return SmallTicket(self, ticket.value, n_groups, want_w, list(nodes))
 
     def copy_bandwidth(self, nbytes: int = 1 << 30, reps: int = 6) -> float:
         """Measured device-to-device copy rate of this GPU in GB/s (read + write bytes over
@@ -173,9 +173,38 @@ class SmallTicket:
     """An ``scs_small_solve_begin`` that has not been ended: ``result()`` waits and returns one
     ``(maps, lambdas[, W])`` per node (once; kept).  Dropped unasked-for, it releases its slot."""
 
-    def __init__(self, dev: Device, ticket: int, n_groups: np.ndarray, want_w: bool) -> None:
+    def __init__(self, dev: Device, ticket: int, n_groups: np.ndarray, want_w: bool, nodes=None) -> None:
         self.dev, self._ticket, self._n_groups, self._want_w = dev, ticket, n_groups, want_w
+        self._nodes = nodes
         self._out = None
+
+    def _general_path(self, i: int):
+        """Node ``i`` once more through the general per-node path (upload, build, contract, LOBPCG
+        with an explicit block width -- which keeps scs_fiedler off the dense one-sided solve that
+        has just failed): ``(maps, lambdas, W or None)``.  Raises RuntimeError if that fails too."""
+        tables, group_start = self._nodes[i]
+        dtab = self.dev.upload(tables)
+        try:
+            graph = dtab.build()
+        finally:
+            dtab.free()
+        try:
+            if group_start is not None:
+                graph = graph.contract(group_start)
+            last = None
+            for block, iters in ((4, DEFAULT_MAX_ITER), (8, 4 * DEFAULT_MAX_ITER)):
+                if graph.shape[0] <= 3 * block + 2:
+                    continue
+                try:
+                    maps, stats = graph.fiedler(None, block=block, max_iter=iters)
+                    lam = np.array([stats["lambda"][0], stats["lambda"][1], stats["lambda_next"]])
+                    return maps, lam, (graph.download() if self._want_w else None)
+                except nv.ConvergenceError as exc:
+                    last = exc
+            msg = f"small-node eigen-solve did not converge, nor did the general path ({last})"
+            raise RuntimeError(msg)
+        finally:
+            graph.free()
 
     def result(self):
         if self._out is None:
@@ -187,21 +216,34 @@ class SmallTicket:
             ticket, self._ticket = self._ticket, -1
             nv.check(self.dev._lib.scs_small_solve_end(self.dev._ctx, ticket, nv.dptr(maps), nv.dptr(lam),
                                                        nv.dptr(w) if want_w else None))
+            redo = {}
+            if os.environ.get("SCS_DEBUG_SMALL_FAIL"):  # test hook: pretend the one-sided Jacobi gave up
+                lam[n_groups > 64] = np.nan
             if not np.all(np.isfinite(lam)):
-                # (the one-sided Jacobi of a node of more than 64 vertices ran out of sweeps: refused, as
-                # the reference's ARPACK call raises rather than return a guess -- scs.py:252)
+                # the one-sided Jacobi of a node of more than 64 vertices ran out of sweeps (NaN
+                # eigenvalues, never a half-rotated basis): only THAT node goes through the general
+                # path again; if that fails too the call raises, as the reference's ARPACK call
+                # raises rather than return a guess (scs.py:252)
                 bad = [i for i in range(k) if not np.all(np.isfinite(lam[i]))]
-                msg = f"small-node eigen-solve did not converge (nodes {bad} of a batch of {k})"
-                raise RuntimeError(msg)
+                if self._nodes is None:
+                    msg = f"small-node eigen-solve did not converge (nodes {bad} of a batch of {k})"
+                    raise RuntimeError(msg)
+                for i in bad:
+                    redo[i] = self._general_path(i)
             out, at, wat = [], 0, 0
             for i in range(k):
                 v = int(n_groups[i])
-                item = (maps[at:at + v], lam[i])
+                if i in redo:
+                    item = (redo[i][0], redo[i][1]) + ((redo[i][2],) if want_w else ())
+                else:
+                    item = (maps[at:at + v], lam[i])
+                    if want_w:
+                        item += (w[wat:wat + v * v].reshape(v, v),)
                 if want_w:
-                    item += (w[wat:wat + v * v].reshape(v, v),)
                     wat += v * v
                 out.append(item)
                 at += v
+            self._nodes = None
             self._out = out
         return self._out
 

@@ -731,9 +731,19 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // recursion, where the walk is bound by the latency of a tree's step, not by the chip:
     // 1 000 taxa x 5 000 trees 11.1 -> 9.5 ms, 3 000 x 5 000 15.5 -> 11.2, 3 000 x 300 1.03 -> 0.78;
     // up to 24 tiles the tree-parallel build below is faster still when the trees are many.)
-    static const size_t wide_min_tiles = getenv("SCS_WIDE_MIN_TILES") ? (size_t)atoi(getenv("SCS_WIDE_MIN_TILES")) : 13;
+    // (diagnostic switches are read on every call: tests and A/B tools set them in-process)
+    const size_t wide_min_tiles = getenv("SCS_WIDE_MIN_TILES") ? (size_t)atoi(getenv("SCS_WIDE_MIN_TILES")) : 13;
     int wide_mode = (monotone && !scatter && !tree_par && tiles.size() >= wide_min_tiles) ? 3 : 0;
-    if (const char *e = getenv("SCS_WIDE")) wide_mode = (monotone && !scatter && !tiles.empty() && atoi(e)) ? 3 : 0;
+    bool wide_forced = false;  // an explicit SCS_WIDE=1 also lifts the trees-per-batch gate below
+    if (const char *e = getenv("SCS_WIDE")) {
+        wide_mode = (monotone && !scatter && !tiles.empty() && atoi(e)) ? 3 : 0;
+        wide_forced = wide_mode != 0;
+    }
+    // the producer / consumer kernel needs more dynamic LDS than every device offers
+    if (wide_mode && ctx->max_lds_bytes < (int)spec_layout::LDS_BYTES) {
+        wide_mode = 0;
+        wide_forced = false;
+    }
     if (wide_mode) tree_par = false;  // (SCS_WIDE=1 wins over a tree-parallel build)
     const bool wide = wide_mode != 0;
     const int group_tiles = PIPE_NG;
@@ -782,7 +792,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // slower -- 50 000 leaves: 785 ms instead of 697 ms at any stream priority: the
         // preparation kernels take CU slots a few at a time, the tiles fall out of step and the
         // new tables push the current ones out of the caches.  The batches stay sequential.)
-        static const int batch_trees_env = getenv("SCS_BATCH_TREES") ? atoi(getenv("SCS_BATCH_TREES")) : 0;
+        const int batch_trees_env = getenv("SCS_BATCH_TREES") ? atoi(getenv("SCS_BATCH_TREES")) : 0;
         int max_batch_trees = 256;
         {
             const double avg_leaves = (double)tb->n_leaves / std::max(M, 1);
@@ -813,6 +823,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             max_batch_trees = (int)std::max<size_t>(16, std::min<size_t>((size_t)max_batch_trees,
                                                                          SCS_SCRATCH_KEEP / cells_per_tree));
         if (batch_trees_env > 0) max_batch_trees = batch_trees_env;
+        // (a forced tree-parallel build or batch length still keeps a batch's cells within the scratch)
+        if (tree_par)
+            max_batch_trees = (int)std::max<size_t>(1, std::min<size_t>((size_t)max_batch_trees,
+                                                                        SCS_SCRATCH_KEEP / std::max<size_t>(cells_per_tree, 1)));
         size_t used = 0;
         for (int t = 0; t < M; ++t) {
             const int64_t nt = tb->h_tree_off[t + 1] - tb->h_tree_off[t];
@@ -868,7 +882,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // prologue, its tile stores and the thin last round of its launch, and below ~100 trees
         // that costs more than the shorter steps save (measured at 10 000 leaves: 64 + 218 + 218
         // trees 6.93 ms either way, 218 + 218 with the 4-wave kernel in front 6.5).
-        static const int wide_min_trees = getenv("SCS_WIDE_MIN_TREES") ? atoi(getenv("SCS_WIDE_MIN_TREES")) : 96;
+        const int wide_min_trees = wide_forced ? 1 : (getenv("SCS_WIDE_MIN_TREES") ? atoi(getenv("SCS_WIDE_MIN_TREES")) : 96);
         // (with many rounds of workgroups per launch -- 50 000 leaves: 150 -- the prologue and the thin
         // last round are noise and the short first batch is the producer / consumer kernel's too:
         // 64 trees 25 -> 18 ms there)
@@ -949,12 +963,12 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
             mp.stamps = nullptr;
             mp.split_tiles = 0;
-            static const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
+            const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
             if (wide_b) {
                 wide_params wp;
                 wp.m = mp;
                 wp.groups = (const int4 *)d_groups.p;
-                static const int spec_prio = getenv("SCS_SPEC_PRIO") ? atoi(getenv("SCS_SPEC_PRIO")) : 2;
+                const int spec_prio = getenv("SCS_SPEC_PRIO") ? atoi(getenv("SCS_SPEC_PRIO")) : 2;
                 wp.producer_prio = spec_prio;
                 const unsigned ng = (unsigned)groups.size();
                 dev_buf d_st8;

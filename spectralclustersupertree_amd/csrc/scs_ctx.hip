@@ -31,7 +31,8 @@ void scs_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *scs_last_error(void) { return g_last_error.c_str(); }
-extern "C" int scs_version(void) { return 100; }
+// 101 (round 5): scs_build_stats grew by tree_parallel_batches / spec_batches (round 4), scs_tables_split added
+extern "C" int scs_version(void) { return 101; }
 
 extern "C" int scs_device_count(void) {
     int n = 0;
@@ -414,6 +415,11 @@ static int ctx_common(int device, scs_ctx **out) {
     auto *ctx = new scs_ctx();
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+            ctx->max_lds_bytes = lds;
+    }
     hipError_t se = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (se != hipSuccess) {
         delete ctx;
@@ -727,7 +733,7 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
             // 1 / (1 + L / 2200), ~90 trees at 10 000 x 500 -- was measured with SCS_FIRST_TREES:
             // 64 / 80 / 96 / 112 trees first give 17.17 / 17.07 / 17.11 / 17.16 ms a step: within the
             // run-to-run spread, the rule stays.)
-            static const int first_env = getenv("SCS_FIRST_TREES") ? atoi(getenv("SCS_FIRST_TREES")) : 0;
+            const int first_env = getenv("SCS_FIRST_TREES") ? atoi(getenv("SCS_FIRST_TREES")) : 0;
             first = std::min(per, first_env > 0 ? first_env : 64);
             chunk = per;
         }

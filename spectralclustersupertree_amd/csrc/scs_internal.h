@@ -84,6 +84,7 @@ struct scs_ctx {
     hipStream_t copy_stream = nullptr;  // late chunks of a table upload (created on first use)
     scs_comm comm;
     int n_cu = 256;
+    int max_lds_bytes = 65536;  // dynamic LDS one workgroup may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock)
     size_t ws_limit = 0;  // bytes of build scratch allowed per tree batch
     // 64 doubles of mapped, coherent host memory the eigensolver's small kernel reports
     // residual norms into (allocated on first use)

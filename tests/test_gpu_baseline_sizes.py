@@ -326,8 +326,11 @@ def test_config3_fiedler_against_the_reference_solve():
 
 @pytest.mark.slow
 def test_config4_single_device_properties(dev):
-    """configs[4] on ONE device: 100 000 taxa / 5 000 weighted trees / branch (W = 80 GB)."""
-    _large_config_properties(dev, 100000, 5000, True, 24, [(0, 99000)])
+    """configs[4] on ONE device: 100 000 taxa / 5 000 weighted trees / branch (W = 80 GB).  As at
+    configs[3] the 1e-10 bar rests on two solves that share nothing but the matrix (block widths
+    8 and 4, different start vectors) agreeing within 1e-11 on the unit-norm scale -- the sampled
+    residual alone bounds an entry only through the gap (1.1e-4 here)."""
+    _large_config_properties(dev, 100000, 5000, True, 24, [(0, 99000)], second_solve=True)
 
 
 @pytest.mark.slow

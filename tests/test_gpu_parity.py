@@ -73,13 +73,15 @@ def test_gram_kernels(dev, use_mfma, n, ka, kb):
 # ---------------------------------------------------------------------------
 # proper cluster graph
 # ---------------------------------------------------------------------------
-def _build_and_compare(dev, tables, row_ranges=None):
+def _build_and_compare(dev, tables, row_ranges=None, expect_spec=False):
     w_ref, _ = to.pcg_dense(tables)
     dtab = dev.upload(tables)
     try:
         for rb, re_ in row_ranges or [(0, tables.n_taxa)]:
             g = dtab.build(rb, re_)
             w = g.download()
+            if expect_spec:  # every tree batch went through k_accumulate_spec (SCS_WIDE=1 lifts the gates)
+                assert g.build_stats["spec_batches"] == g.build_stats["n_batches"] >= 1, g.build_stats
             g.free()
             assert w.shape == (re_ - rb, tables.n_taxa)
             diff = w != w_ref[rb:re_]
@@ -176,6 +178,7 @@ def test_build_batched_matches_single_batch(dev, monkeypatch):
         dtab = small.upload(tables)
         g = dtab.build()
         assert g.build_stats["n_batches"] > 1
+        assert g.build_stats["spec_batches"] == g.build_stats["n_batches"], g.build_stats
         w = g.download()
         g.free()
         dtab.free()
@@ -625,7 +628,7 @@ def test_spec_kernel_bit_exact(dev, monkeypatch, strategy, n, m, k):
     monkeypatch.setenv("SCS_WIDE", "1")
     tables = synthetic.make_tables(200 + n + m, n, m, strategy, leaves_per_tree=k, random_weights=(n % 2 == 0))
     assert tables.monotone
-    _build_and_compare(dev, tables)
+    _build_and_compare(dev, tables, expect_spec=True)
 
 
 def test_spec_kernel_row_blocks_and_batches(dev, monkeypatch):
@@ -633,7 +636,7 @@ def test_spec_kernel_row_blocks_and_batches(dev, monkeypatch):
     # a row block), and several tree batches through a tiny workspace (the sums travel through W)
     monkeypatch.setenv("SCS_WIDE", "1")
     tables = synthetic.make_tables(6, 1000, 10, "branch", leaves_per_tree=800, random_weights=True)
-    _build_and_compare(dev, tables, [(0, 100), (100, 1000), (64, 65), (7, 601)])
+    _build_and_compare(dev, tables, [(0, 100), (100, 1000), (64, 65), (7, 601)], expect_spec=True)
     monkeypatch.setenv("SCS_WS_LIMIT_MB", "1")
     small = Device(0)
     try:
@@ -641,6 +644,7 @@ def test_spec_kernel_row_blocks_and_batches(dev, monkeypatch):
         dtab = small.upload(tables)
         g = dtab.build()
         assert g.build_stats["n_batches"] > 1
+        assert g.build_stats["spec_batches"] == g.build_stats["n_batches"], g.build_stats
         w = g.download()
         g.free()
         dtab.free()
@@ -659,8 +663,10 @@ def test_spec_kernel_shared_multi_rank_build(dev, monkeypatch):
     w_ref, _ = to.pcg_dense(tables)
     out = _run_local_group(tables, [0, 500, 1300], True, None)
     assert out[0][3]["n_batches"] > 1
+    assert all(o[3]["spec_batches"] == o[3]["n_batches"] for o in out), [o[3] for o in out]
     assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
     out = _run_local_group(tables, [0, 333, 800, 1300], False, None)
+    assert all(o[3]["spec_batches"] == o[3]["n_batches"] for o in out), [o[3] for o in out]
     assert np.array_equal(np.vstack([o[0] for o in out]), w_ref)
 
 
@@ -688,6 +694,21 @@ def test_spec_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
     rows = np.unique(np.random.RandomState(2).randint(0, 3000, size=12)).astype(np.int32)
     assert np.array_equal(got["1"][rows], to.pcg_rows(tables, rows))
     assert np.array_equal(got["1"], got["1"].T) and not np.any(np.diag(got["1"]))
+
+
+def test_small_node_that_fails_is_solved_again_on_the_general_path(dev, monkeypatch):
+    # a node of 65 .. 128 taxa whose batched one-sided Jacobi reports NaN eigenvalues (forced here:
+    # SCS_DEBUG_SMALL_FAIL) goes through upload + build + LOBPCG instead of failing the whole batch;
+    # its neighbours in the batch keep their batched results
+    nodes = [(synthetic.make_tables(70 + i, n, 12, "branch"), None) for i, n in enumerate((40, 90, 120))]
+    want = dev.small_solve(nodes, want_w=True)
+    monkeypatch.setenv("SCS_DEBUG_SMALL_FAIL", "1")
+    got = dev.small_solve(nodes, want_w=True)
+    assert np.array_equal(got[0][0], want[0][0]) and np.array_equal(got[0][1], want[0][1])
+    for g, w in zip(got[1:], want[1:]):
+        assert np.array_equal(g[2], w[2])  # the same W
+        assert np.max(np.abs(g[1][:2] - w[1][:2])) <= 1e-12  # the same eigenvalues
+        assert np.max(np.abs(g[0][:, 1] - w[0][:, 1])) <= 1e-10 * np.max(np.abs(w[0][:, 1]))
 
 
 def test_rccl_world_of_one(dev):
