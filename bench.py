@@ -78,16 +78,21 @@ def parse_args():
     ap.add_argument("--tol", type=float, default=1e-13)
     ap.add_argument("--max-iter", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--multi-rank-mode", default="upper", choices=["upper", "shared", "rows"],
-                    help="N > 1: 'upper' = the job keeps only the upper triangle of W (no exchange, the "
-                         "solve adds the ranks' partial products); 'shared' = row-partitioned W, upper tiles "
-                         "computed once and exchanged; 'rows' = every rank evaluates all cells of its rows")
+    ap.add_argument("--multi-rank-mode", default="shared", choices=["upper", "shared", "rows"],
+                    help="N > 1, the headline layout: 'shared' (default: north_star's row-partitioned W, upper "
+                         "tiles computed once and exchanged, RCCL all-gather of the Krylov block per iteration); "
+                         "'upper' = the job keeps only the upper triangle of W (no exchange, the solve adds the "
+                         "ranks' partial products); 'rows' = every rank evaluates all cells of its rows.  The "
+                         "other one of shared / upper is timed too and printed under other_modes")
     ap.add_argument("--no-parity", action="store_true",
                     help="profiling runs: skip the oracle gates (never for a reported number)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip seeds 1/2, the planted input and the other single-GPU configs")
     ap.add_argument("--cpu-seconds", type=float, default=8.0,
                     help="target CPU time of the one-thread leg of cpu_baseline")
+    ap.add_argument("--quick-reference-leg", action="store_true",
+                    help="cpu_baseline.reference_style_build on 300 taxa / 30 trees (seconds) instead of the "
+                         "full configs[1] (a minute or two)")
     return ap.parse_args()
 
 
@@ -147,26 +152,29 @@ def sklearn_gates(w, maps, labels_dev):
     }, t_eig, int(blas)
 
 
-def reference_style_leg(n, m, strategy, sample_taxa=300, sample_trees=30):
+def reference_style_leg(n, m, strategy, sample_taxa=1000, sample_trees=100, sample_strategy="depth"):
     """The reference's LITERAL loop structure -- dicts keyed by tuples of names, one Python
-    update per leaf pair (scs.py:569-658, restated in oracle/scs_oracle.build_pcg) -- on a
-    bounded sample (300 taxa / 30 trees, a second or two), with its cost per pair update and
-    what that extrapolates to at the workload's 0.336 N^2 M pair updates."""
+    update per leaf pair (scs.py:569-658, restated in oracle/scs_oracle.build_pcg) -- TIMED IN FULL
+    at BASELINE.json configs[1] (1 000 taxa / 100 trees / depth: SURVEY.md 8d "timed only where
+    feasible (config 1 ...)", a minute or two of one CPython thread), with its cost per pair update
+    and what that extrapolates to at the workload's 0.336 N^2 M pair updates."""
     from oracle import scs_oracle as so
     from spectralclustersupertree_amd import synthetic
 
     trees = synthetic.tree_objects(0, sample_taxa, sample_trees)
     names = sorted(so._all_tips(trees))
     t0 = time.perf_counter()
-    _, weight, _, together = so.build_pcg({(x,) for x in names}, trees, [1.0] * sample_trees, strategy)
+    _, weight, _, together = so.build_pcg({(x,) for x in names}, trees, [1.0] * sample_trees, sample_strategy)
     secs = time.perf_counter() - t0
     updates = int(sum(together.values()))
     per = secs / max(updates, 1)
     return {"kind": "reference-style (oracle/scs_oracle.build_pcg: the reference's dict-of-tuples loops)",
-            "sample": f"{sample_taxa} taxa / {sample_trees} trees / {strategy}, one thread (CPython)",
+            "sample": (f"BASELINE.json configs[1] in full: {sample_taxa} taxa / {sample_trees} trees / "
+                       f"{sample_strategy}, one thread (CPython), measured -- not a sample of it"),
             "seconds": round(secs, 3), "pair_updates": updates, "us_per_pair_update": round(per * 1e6, 3),
             "extrapolated_s_at_workload": round(per * 0.336 * n * n * m, 0),
-            "extrapolation": "us_per_pair_update x 0.336 N^2 M pair updates of the full workload"}
+            "extrapolation": "us_per_pair_update x 0.336 N^2 M pair updates of THIS workload "
+                             f"({n} taxa / {m} trees / {strategy})"}
 
 
 def cpu_build_legs(tables, args, n, m):
@@ -192,11 +200,12 @@ def cpu_build_legs(tables, args, n, m):
             "one_thread_sample_trees": sample, "one_thread_scaled_s": t_one_sample * m / sample}
 
 
-def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=None, planted=False):
-    """Time `steps` passes of build + solve on one named workload; returns the report."""
+def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=None, planted=False, mode=None):
+    """Time `steps` passes of build + solve on one named workload; returns the report (`_maps`: the
+    last step's embedding, for the callers that compare layouts with each other)."""
     seed = args.seed if seed is None else seed
     tables, (n, m, strategy, rw, cfg_idx), t_gen = make_input(name, args, seed, planted)
-    mode = args.multi_rank_mode if world > 1 else "single"
+    mode = (mode or args.multi_rank_mode) if world > 1 else "single"
     splits = even_splits(n, world, upper=(mode == "upper"))
     rb, re_ = splits[rank], splits[rank + 1]
 
@@ -233,7 +242,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         protocol_step()
 
     acc = {"apply_ms": 0.0, "n_apply": 0, "iters": 0, "build_ms": 0.0, "acc_ms": 0.0, "prep_ms": 0.0,
-           "solve_ms": 0.0, "exch_ms": 0.0}
+           "solve_ms": 0.0, "exch_ms": 0.0, "spec_ms": 0.0, "ag_ms": 0.0, "n_ag": 0}
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -249,6 +258,9 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         acc["prep_ms"] += bstats["prep_ms"]
         acc["exch_ms"] += bstats["exchange_ms"]
         acc["solve_ms"] += stats["solve_ms"]
+        acc["spec_ms"] += bstats.get("spec_ms", 0.0)
+        acc["ag_ms"] += stats.get("allgather_ms_total", 0.0)
+        acc["n_ag"] += stats.get("n_allgather", 0)
         last = (maps, stats, bstats)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -293,8 +305,30 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     # the PCG accumulation does 0.5 V^2 M cell-tree evaluations (one ds_read_b64, one v_min_f64,
     # one v_add_f64 each) against 8 V^2 bytes written once: its HBM fraction is tiny by
     # construction and is reported as is, next to the fractions of the units that do bound it
-    lds_gbs = 8.0 * cell_rate / 1e9
     spec_b = int(bstats.get("spec_batches", 0))
+    # the launches of the producer / consumer kernel and those of the 4-wave kernels, apart: each
+    # with the average duration of ITS launches (what a rocprofv3 kernel-stats row shows)
+    spec_ms = acc["spec_ms"] / steps
+    spec_trees = int(bstats.get("spec_trees", 0))
+    cells_per_tree = bstats["cell_trees"] / max(int(bstats["n_trees"]), 1)
+    launches = []
+    if spec_b:
+        launches.append({"kernel": "k_accumulate_spec", "launches_per_step": spec_b, "trees": spec_trees,
+                         "avg_launch_ms": round(spec_ms / spec_b, 4),
+                         "cell_trees_per_s": round(cells_per_tree * spec_trees / (spec_ms * 1e-3), 0) if spec_ms > 0 else 0.0})
+    if n_batches > spec_b:
+        rest_ms, rest_trees = acc_ms - spec_ms, int(bstats["n_trees"]) - spec_trees
+        launches.append({"kernel": "k_accumulate_mono" if tables.monotone else "k_accumulate_gen",
+                         "launches_per_step": n_batches - spec_b, "trees": rest_trees,
+                         "avg_launch_ms": round(rest_ms / (n_batches - spec_b), 4),
+                         "cell_trees_per_s": round(cells_per_tree * rest_trees / (rest_ms * 1e-3), 0) if rest_ms > 0 else 0.0})
+    main_launch = max(launches, key=lambda e: e["avg_launch_ms"] * e["launches_per_step"]) if launches else None
+    if main_launch and main_launch["cell_trees_per_s"]:
+        # the roofline of the DOMINANT kernel is that of its own launches (the other kind is listed beside it)
+        cell_rate_k = main_launch["cell_trees_per_s"]
+    else:
+        cell_rate_k = cell_rate
+    lds_gbs = 8.0 * cell_rate_k / 1e9
     if not tables.monotone:
         acc_kernel = "k_accumulate_gen"
     elif spec_b == 0:
@@ -318,19 +352,25 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
                 "frac": round(build_gbs / HBM_PEAK_GBS, 5),
                 "bytes_per_launch": build_bytes / n_batches},
         "bytes_per_launch": build_bytes / n_batches,
-        "avg_launch_ms": round(acc_ms / n_batches, 4),
-        "launches_per_step": n_batches,
+        "avg_launch_ms": main_launch["avg_launch_ms"] if main_launch else round(acc_ms / n_batches, 4),
+        "launches_per_step": main_launch["launches_per_step"] if main_launch else n_batches,
+        "launches": launches,
         "device_ms_per_step": round(acc_ms, 3),
         "cell_trees_per_step": bstats["cell_trees"],
-        "cell_trees_per_s": round(cell_rate, 0),
-        "frac_f64_valu": round(2.0 * cell_rate / (F64_VALU_TOPS * 1e12), 4),
-        "frac_lds": round(8.0 * cell_rate / (LDS_PEAK_TBS * 1e12), 4),
+        "cell_trees_per_s": round(cell_rate_k, 0),
+        "cell_trees_per_s_all_launches": round(cell_rate, 0),
+        "frac_f64_valu": round(2.0 * cell_rate_k / (F64_VALU_TOPS * 1e12), 4),
+        "frac_lds": round(8.0 * cell_rate_k / (LDS_PEAK_TBS * 1e12), 4),
         "note": "not HBM-bound by construction (SURVEY.md 8d): 0.5 V^2 M cell-tree evaluations against "
                 "8 V^2 bytes of W written once.  frac = LDS bytes of the cell loop (8 per cell-tree, "
                 "ds_read_b64) over ~150 TB/s; the reads are 2-way bank-conflicted by construction (64 "
                 "table rows over 32 eight-byte bank pairs), so 0.5 is the ceiling of this fraction; "
                 "frac_f64_valu prices the 2 fp64 VALU ops per cell-tree against 39.3 Tops/s; hbm.* is the "
-                "algorithmic HBM figure (W + tables once per build)",
+                "algorithmic HBM figure (W + tables once per build).  achieved / avg_launch_ms are those of the "
+                "kernel named first in `launches` by device time (its own launches: a rocprofv3 kernel-stats "
+                "row), the other kind of launch is listed beside it.  Round 5 measured the inner loops alone "
+                "(profiles/r05_cells_probe_rank_halved.txt): a conflict-free table layout runs no faster, the "
+                "loop is bound by how fast 2-3 waves per SIMD issue its dependent ds_read / min / add stream",
     }
     dominant, other = (roof_acc, roof_symm) if acc_ms >= symm_ms_step else (roof_symm, roof_acc)
     report = {
@@ -390,8 +430,18 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
             "tables_generate_s": round(t_gen, 3),
         },
     }
+    report["_maps"] = maps
     if world > 1:
         report["stages"]["build_exchange_bytes_received"] = bstats.get("exchange_bytes", 0.0)
+        # the one collective of an iteration: device time (HIP events around every fourth, scaled)
+        # and the bytes it delivers to a rank -- shared: world x rows x b x 8 (the Krylov block's
+        # slices), upper: world x V x b x 8 (the ranks' partial products)
+        n_ag = max(acc["n_ag"], 1)
+        report["stages"]["allgather_ms_per_iteration"] = round(acc["ag_ms"] / n_ag, 5)
+        report["stages"]["allgather_ms_per_step"] = round(acc["ag_ms"] / steps, 4)
+        report["stages"]["allgathers_per_step"] = acc["n_ag"] / steps
+        report["stages"]["allgather_bytes_received_per_rank"] = stats.get("allgather_bytes", 0.0)
+        report["stages"]["multi_rank_mode"] = mode
     # HBM traffic from the committed PMC passes of this workload, if any
     try:
         pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(name, [])
@@ -457,7 +507,8 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
             report["parity"]["w_symmetric"] = bool(np.array_equal(w, w.T))
             del w
             legs = cpu_build_legs(tables, args, n, m)
-            ref_leg = reference_style_leg(n, m, strategy)
+            ref_leg = (reference_style_leg(n, m, strategy, 300, 30, strategy) if args.quick_reference_leg
+                       else reference_style_leg(n, m, strategy))
             report["cpu_baseline"] = {
                 "value": round(legs["all_core_s"] + t_eig, 3),
                 "unit": "s",
@@ -470,8 +521,8 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
                     f"path) on the full {n} x {n} matrix, {blas} BLAS threads, {t_eig:.2f} s.  One thread: "
                     f"trees [0,{legs['one_thread_sample_trees']}) in {legs['one_thread_sample_s']:.2f} s, "
                     f"x{m / legs['one_thread_sample_trees']:.1f} -> {legs['one_thread_scaled_s']:.1f} s (scaled).  "
-                    f"The reference's literal dict-of-tuples build (reference_style_build): a "
-                    f"{ref_leg['seconds']:.2f} s sample of {ref_leg['pair_updates']} pair updates, EXTRAPOLATED to "
+                    f"The reference's literal dict-of-tuples build (reference_style_build): {ref_leg['sample']}, "
+                    f"{ref_leg['seconds']:.2f} s for {ref_leg['pair_updates']} pair updates; EXTRAPOLATED to "
                     f"{ref_leg['extrapolated_s_at_workload']:.0f} s for this workload -- not part of `value`"
                 ),
                 "build_s": round(legs["all_core_s"], 3),
@@ -592,6 +643,19 @@ def main() -> int:
         print(f"bench.py: copy bandwidth not measured: {exc}", file=sys.stderr)
     main_rep = run_workload(name, args, dev, dist, rank, world, args.steps, args.warmup, full=True,
                             planted=args.planted)
+    maps_by_mode = {main_rep["stages"].get("multi_rank_mode", "single"): main_rep.pop("_maps", None)}
+    other_modes = {}
+    if world > 1 and not args.no_extra and args.multi_rank_mode in ("shared", "upper"):
+        # the other layout in the same invocation (a first real multi-GPU run then decides between
+        # them): timed, rows of W against the oracle, embedding against the one-GPU run below
+        alt = "upper" if args.multi_rank_mode == "shared" else "shared"
+        try:
+            rep = run_workload(name, args, dev, dist, rank, world, min(args.steps, 3), 1, full=False, mode=alt)
+            maps_by_mode[alt] = rep.pop("_maps", None)
+            other_modes[alt] = {k: rep[k] for k in ("value", "ms_per_step", "steps", "config", "roofline",
+                                                    "roofline_other", "stages", "parity") if k in rep}
+        except Exception as exc:  # noqa: BLE001 - report, never hide the main line
+            other_modes[alt] = {"error": f"{type(exc).__name__}: {exc}"}
 
     result = {
         "metric": "top-level PCG build + Fiedler solve wall-time (s) at N taxa, 1/2/4/8 MI355X",
@@ -603,9 +667,10 @@ def main() -> int:
         "ms_per_step": main_rep["ms_per_step"],
         "higher_is_better": False,
         "scaling": "strong",
-        "scaling_note": "N > 1 runs BASELINE.json configs[3]; its one-GPU time, the strong-scaling "
-                        "baseline, is other_workloads.cfg3.value of the N = 1 line and "
-                        "same_workload_on_one_gpu.value of every N > 1 line",
+        "scaling_note": "N > 1 runs BASELINE.json configs[3] in the row-partitioned layout north_star names "
+                        "(--multi-rank-mode shared; the upper-triangle job is other_modes.upper of the same "
+                        "line); its one-GPU time, the strong-scaling baseline, is other_workloads.cfg3.value "
+                        "of the N = 1 line and same_workload_on_one_gpu.value of every N > 1 line",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -624,6 +689,14 @@ def main() -> int:
                 "parity", "cpu_baseline"):
         if key in main_rep:
             result[key] = main_rep[key]
+    if other_modes:
+        result["other_modes"] = other_modes
+    if world > 1:
+        try:
+            result["communicator"] = dev.comm_info()  # RCCL's own rank count beside WORLD_SIZE
+            result["communicator"]["launcher_world_size"] = world
+        except Exception as exc:  # noqa: BLE001 - a report field, never fatal
+            result["communicator"] = {"error": str(exc)}
     if copy_gbs:
         # every HBM roofline of the line also against what this box's copy engine-free DtoD copy reaches
         result["hbm_copy_measured_gbs"] = round(copy_gbs, 1)
@@ -643,6 +716,7 @@ def main() -> int:
         for sd in (1, 2):
             try:
                 rep = run_workload(name, args, dev, dist, rank, world, 3, 1, full=False, seed=sd)
+                rep.pop("_maps", None)
                 seeds[str(sd)] = {"value": rep["value"], "lambda2": rep["stages"]["lambda2"],
                                   "lambda3": rep["stages"]["lambda3"],
                                   "iterations": rep["stages"]["lobpcg_iterations"],
@@ -654,6 +728,7 @@ def main() -> int:
         result["seeds"] = seeds
         try:
             rep = run_workload(name, args, dev, dist, rank, world, 3, 1, full=False, planted=True)
+            rep.pop("_maps", None)
             result["planted"] = {k: rep[k] for k in ("value", "config", "stages", "parity") if k in rep}
         except Exception as exc:  # noqa: BLE001
             result["planted"] = {"error": str(exc)}
@@ -663,6 +738,7 @@ def main() -> int:
         for extra, st in (("cfg1", 3), ("cfg3", 1)):
             try:
                 rep = run_workload(extra, args, dev, dist, rank, world, st, 1, full=False)
+                rep.pop("_maps", None)
                 others[extra] = {k: rep[k] for k in ("value", "steps", "config", "roofline", "roofline_other",
                                                      "roofline_path", "stages", "parity") if k in rep}
             except Exception as exc:  # noqa: BLE001 - report, never hide the main line
@@ -680,8 +756,20 @@ def main() -> int:
             solo = Device(dev_index, 0, 1)
             try:
                 rep = run_workload(name, args, solo, None, 0, 1, 1, 1, full=False)
+                maps_one = rep.pop("_maps", None)
                 result["same_workload_on_one_gpu"] = {k: rep[k] for k in ("value", "stages", "roofline", "parity")
                                                       if k in rep}
+                # the embedding of every multi-rank layout against the one-GPU run of the same input
+                # (Fiedler column; the 1e-10 bar of north_star is on the unit-norm eigenvector, of
+                # which the embedding is a row-scaled copy: both are printed where the degrees allow)
+                for md, mp in maps_by_mode.items():
+                    where = result if md == args.multi_rank_mode else result.get("other_modes", {}).get(md)
+                    if mp is None or maps_one is None or not isinstance(where, dict):
+                        continue
+                    d = float(np.max(np.abs(mp[:, 1] - maps_one[:, 1])))
+                    scale = float(np.max(np.abs(maps_one[:, 1])))
+                    where.setdefault("parity", {})["embedding_vs_one_gpu_max_abs"] = d
+                    where["parity"]["embedding_vs_one_gpu_rel_to_largest_entry"] = d / scale if scale > 0 else None
             finally:
                 solo.close()
         except Exception as exc:  # noqa: BLE001 - report, never hide the main line

@@ -59,6 +59,11 @@ typedef struct scs_stats {
     double apply_ms_min;     /* fastest single SYMM launch                           */
     double solve_ms;         /* whole scs_fiedler call, device time                  */
     double apply_bytes;      /* algorithmic HBM bytes of ONE SYMM launch on this rank */
+    double allgather_ms_total; /* multi-rank solves: device time of the per-iteration all-gathers
+                                * (timed every 4th, scaled to all n_allgather)            */
+    double allgather_bytes;  /* bytes ONE all-gather delivers to this rank (world x chunk x 8) */
+    int32_t n_allgather;     /* all-gathers enqueued by the solve                      */
+    int32_t reserved;
 } scs_stats;
 
 /* Per-call report of scs_pcg_build. */
@@ -82,12 +87,13 @@ typedef struct scs_build_stats {
     int32_t tree_parallel_batches; /* batches of a small node built tree-parallel: a workgroup
                                       per (tile, tree), the trees' cells added up in order
                                       afterwards (k_sum_tree_tiles) -- same bits as the walk */
-    int32_t reserved;
+    int32_t spec_trees;            /* trees the spec_batches walked (the rest: 4-wave kernels)       */
+    double spec_ms;                /* device time of the k_accumulate_spec launches (of accumulate_ms) */
 } scs_build_stats;
 
 /* ABI version of this header: 101.  100 -> 101: scs_build_stats is 8 bytes longer
- * (tree_parallel_batches; the old `reserved` slot became spec_batches), scs_tables_split*
- * added.  Callers compare it with the value they were compiled against before passing
+ * (tree_parallel_batches; the old `reserved` slot became spec_batches) and again by spec_trees /
+ * spec_ms; scs_forest_* added.  Callers compare it with the value they were compiled against before passing
  * structs (the Python binding refuses a library of another version at load). */
 int scs_version(void);
 const char *scs_last_error(void);
@@ -118,6 +124,11 @@ int scs_ctx_create_local(int device, int rank, scs_local_group *group, scs_ctx *
 
 int scs_ctx_destroy(scs_ctx *ctx);
 int scs_ctx_synchronize(scs_ctx *ctx);
+/* The communicator as it sees itself: kind (0 none, 1 RCCL, 2 in-process team), the world / rank
+ * it was created with, and what ncclCommCount / ncclCommUserRank report (-1: not available).
+ * No reference counterpart (the reference has no parallelism, scs.py:239 n_jobs = 1). */
+int scs_ctx_comm_info(scs_ctx *ctx, int32_t *kind, int32_t *world, int32_t *rank,
+                      int32_t *reported_world, int32_t *reported_rank);
 
 /* ---- tables ------------------------------------------------------------ */
 

@@ -58,6 +58,10 @@ class Stats(C.Structure):
         ("apply_ms_min", C.c_double),
         ("solve_ms", C.c_double),
         ("apply_bytes", C.c_double),
+        ("allgather_ms_total", C.c_double),
+        ("allgather_bytes", C.c_double),
+        ("n_allgather", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -87,7 +91,8 @@ class BuildStats(C.Structure):
         ("bytes_tables", C.c_double),
         ("exchange_bytes", C.c_double),
         ("tree_parallel_batches", C.c_int32),
-        ("reserved", C.c_int32),
+        ("spec_trees", C.c_int32),
+        ("spec_ms", C.c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -115,6 +120,7 @@ SIGNATURES = {
     "scs_ctx_create_local": (C.c_int, [C.c_int, C.c_int, _P, _PP]),
     "scs_ctx_destroy": (C.c_int, [_P]),
     "scs_ctx_synchronize": (C.c_int, [_P]),
+    "scs_ctx_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "scs_host_alloc": (C.c_int, [C.c_size_t, _PP]),
     "scs_host_free": (C.c_int, [_P]),
     "scs_tables_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _PP]),

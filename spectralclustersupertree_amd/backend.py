@@ -67,6 +67,15 @@ class Device:
     def synchronize(self) -> None:
         nv.check(self._lib.scs_ctx_synchronize(self._ctx))
 
+    def comm_info(self) -> dict:
+        """The communicator as it sees itself (``scs_ctx_comm_info``): kind, the world / rank it was
+        created with and what ncclCommCount / ncclCommUserRank report (-1: not available)."""
+        v = [C.c_int32(0) for _ in range(5)]
+        nv.check(self._lib.scs_ctx_comm_info(self._ctx, *[C.byref(x) for x in v]))
+        kind, world, rank, rep_world, rep_rank = (int(x.value) for x in v)
+        return {"kind": {0: "none", 1: "rccl", 2: "in-process team"}.get(kind, str(kind)), "world": world,
+                "rank": rank, "reported_world": rep_world, "reported_rank": rep_rank}
+
     # -- tables ------------------------------------------------------------
     def upload(self, tables: TreeTables) -> "DeviceTables":
         tables.validate(ranges=False)  # (ranges: checked by a kernel on the uploaded copy)

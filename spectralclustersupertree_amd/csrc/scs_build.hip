@@ -857,7 +857,9 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     float prep_ms = 0.f, acc_ms = 0.f;
     SCS_HIP_CHECK(hipEventRecord(ev_total.a, s));
 
-    int spec_batches = 0;
+    int spec_batches = 0, spec_trees = 0;
+    float spec_ms = 0.f;
+    bool single_batch_spec = false;
     pooled_buf d_pos(ctx, 1), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5), d_cells(ctx, 6);
     for (int bi = 0; bi < n_batches; ++bi) {
         const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
@@ -887,7 +889,11 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // last round are noise and the short first batch is the producer / consumer kernel's too:
         // 64 trees 25 -> 18 ms there)
         const bool wide_b = wide && (nb >= wide_min_trees || (groups.size() >= 8 * 256 && nb >= 16));
-        if (wide_b) ++spec_batches;
+        if (wide_b) {
+            ++spec_batches;
+            spec_trees += nb;
+            single_batch_spec = true;
+        }
         SCS_TRY(d_pos.alloc(need_pos));
         SCS_TRY(d_st.alloc(need_st));
         SCS_TRY(d_stoff.alloc(need_stoff));
@@ -1081,6 +1087,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             prep_ms += ms;
             SCS_HIP_CHECK(hipEventElapsedTime(&ms, ev_acc.a, ev_acc.b));
             acc_ms += ms;
+            if (wide_b) spec_ms += ms;
         }
     }
     float exch_ms = 0.f;
@@ -1159,6 +1166,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     if (n_batches == 1) {
         SCS_HIP_CHECK(hipEventElapsedTime(&prep_ms, ev_prep.a, ev_prep.b));
         SCS_HIP_CHECK(hipEventElapsedTime(&acc_ms, ev_acc.a, ev_acc.b));
+        if (single_batch_spec) spec_ms = acc_ms;
     }
 
     if (stats) {
@@ -1174,7 +1182,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         stats->n_batches = n_batches;
         stats->spec_batches = spec_batches;
         stats->tree_parallel_batches = tree_par ? n_batches : 0;
-        stats->reserved = 0;
+        stats->spec_trees = spec_trees;
+        stats->spec_ms = spec_ms;
         stats->cell_trees = (double)tiles.size() * SCS_TR * cols_per_tile * (double)M;
         stats->prep_ms = prep_ms;
         stats->accumulate_ms = acc_ms;

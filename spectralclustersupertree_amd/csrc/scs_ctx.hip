@@ -56,6 +56,7 @@ typedef int (*fn_send)(const void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_recv)(void *, size_t, int, int, void *, hipStream_t);
 typedef int (*fn_group)(void);
 typedef const char *(*fn_errstr)(int);
+typedef int (*fn_count)(void *, int *);
 
 struct rccl_api {
     void *handle = nullptr;
@@ -67,6 +68,7 @@ struct rccl_api {
     fn_recv recv = nullptr;
     fn_group group_start = nullptr, group_end = nullptr;
     fn_errstr errstr = nullptr;
+    fn_count comm_count = nullptr, comm_user_rank = nullptr;
 };
 
 rccl_api g_rccl;
@@ -94,6 +96,8 @@ int load_rccl() {
     g_rccl.group_start = (fn_group)dlsym(h, "ncclGroupStart");
     g_rccl.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
     g_rccl.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+    g_rccl.comm_count = (fn_count)dlsym(h, "ncclCommCount");
+    g_rccl.comm_user_rank = (fn_count)dlsym(h, "ncclCommUserRank");
     if (!g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allgather) {
         scs_set_error("librccl lacks an expected symbol");
         dlclose(h);
@@ -134,6 +138,29 @@ int scs_comm_init_rccl(scs_comm *comm, int rank, int world, const void *uid_byte
     comm->world = world;
     comm->kind = 1;
     comm->rccl_comm = c;
+    return SCS_OK;
+}
+
+// What the communicator itself says: kind (0 none, 1 RCCL, 2 in-process team), and -- RCCL -- the
+// rank count and this rank's number as ncclCommCount / ncclCommUserRank report them (-1 when the
+// library has no such entry point).  bench.py prints it with every multi-GPU line.
+extern "C" int scs_ctx_comm_info(scs_ctx *ctx, int32_t *kind, int32_t *world, int32_t *rank,
+                                 int32_t *reported_world, int32_t *reported_rank) {
+    SCS_REQUIRE(ctx && kind && world && rank && reported_world && reported_rank, "scs_ctx_comm_info: null argument");
+    *kind = ctx->comm.kind;
+    *world = ctx->comm.world;
+    *rank = ctx->comm.rank;
+    *reported_world = -1;
+    *reported_rank = -1;
+    if (ctx->comm.kind == 1 && ctx->comm.rccl_comm) {
+        int v = -1;
+        if (g_rccl.comm_count && g_rccl.comm_count(ctx->comm.rccl_comm, &v) == 0) *reported_world = v;
+        v = -1;
+        if (g_rccl.comm_user_rank && g_rccl.comm_user_rank(ctx->comm.rccl_comm, &v) == 0) *reported_rank = v;
+    } else if (ctx->comm.kind == 2) {
+        *reported_world = ctx->comm.world;
+        *reported_rank = ctx->comm.rank;
+    }
     return SCS_OK;
 }
 

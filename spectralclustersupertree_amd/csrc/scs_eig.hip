@@ -1507,11 +1507,19 @@ struct solver {
     std::vector<int32_t> splits;
     // timing of SYMM launches
     std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev_ag;  // pairs around the timed all-gathers (multi-rank solves)
+    bool time_ag = false;           // set by fused_back for the launches it times
+    int n_allgather = 0;
     int n_apply = 0;
 
     ~solver() {
-        if (ctx) ctx->event_pool.insert(ctx->event_pool.end(), ev.begin(), ev.end());
-        else for (auto e : ev) hipEventDestroy(e);
+        if (ctx) {
+            ctx->event_pool.insert(ctx->event_pool.end(), ev.begin(), ev.end());
+            ctx->event_pool.insert(ctx->event_pool.end(), ev_ag.begin(), ev_ag.end());
+        } else {
+            for (auto e : ev) hipEventDestroy(e);
+            for (auto e : ev_ag) hipEventDestroy(e);
+        }
     }
     int new_event(hipEvent_t *e) {
         if (ctx && !ctx->event_pool.empty()) {
@@ -1524,6 +1532,22 @@ struct solver {
     }
 
     double *small_at(int off) const { return small.d() + off; }
+
+    // the all-gather of an iteration, timed with its own event pair when fused_back times the launch
+    int gather(const double *send, double *recvb, size_t count) {
+        hipEvent_t a = nullptr, b = nullptr;
+        if (time_ag) {
+            SCS_TRY(new_event(&a));
+            SCS_TRY(new_event(&b));
+            ev_ag.push_back(a);
+            ev_ag.push_back(b);
+            SCS_HIP_CHECK(hipEventRecord(a, s));
+        }
+        SCS_TRY(scs_comm_allgather_f64(&ctx->comm, send, recvb, count, s));
+        if (time_ag) SCS_HIP_CHECK(hipEventRecord(b, s));
+        ++n_allgather;
+        return SCS_OK;
+    }
 
     int last_nseg = 1;  // column segments of the most recent k_symm launch
 
@@ -1571,7 +1595,7 @@ struct solver {
             k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), ptr_eff, n, b, tw, tri_nct,
                                                                   nullptr, ysend.d(), tri_rb_lo, tri_rb_hi);
             SCS_HIP_CHECK(hipGetLastError());
-            SCS_TRY(scs_comm_allgather_f64(&ctx->comm, ysend.d(), recv.d(), (size_t)n * b, s));
+            SCS_TRY(gather(ysend.d(), recv.d(), (size_t)n * b));
             if (yout) {
                 k_sum_parts<<<(n * b + 255) / 256, 256, 0, s>>>(recv.d(), world, n, b, g->d_dinv, yout);
                 SCS_HIP_CHECK(hipGetLastError());
@@ -1715,7 +1739,7 @@ struct solver {
             // (launch_symm_tri gathered the ranks' partial products and yloc holds their scaled
             // sum for all V rows)
         } else if (world > 1) {
-            SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
+            SCS_TRY(gather(yloc.d(), recv.d(), (size_t)chunk));
             k_unpack<<<(nb + 255) / 256, 256, 0, s>>>(recv.d(), chunk, b,
                                                       (const int32_t *)splits_d.p, world, n,
                                                       yfull.d());
@@ -1810,6 +1834,7 @@ struct solver {
         // the device a ~6 us bubble
         hipEvent_t e0 = nullptr, e1 = nullptr;
         const bool timed = (n_apply & 3) == 0;
+        time_ag = timed && world > 1;
         if (timed) {
             SCS_TRY(new_event(&e0));
             SCS_TRY(new_event(&e1));
@@ -1838,11 +1863,12 @@ struct solver {
             SCS_TRY(launch_symm(z.d(), yloc.d()));
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
-            SCS_TRY(scs_comm_allgather_f64(&ctx->comm, yloc.d(), recv.d(), (size_t)chunk, s));
+            SCS_TRY(gather(yloc.d(), recv.d(), (size_t)chunk));
             // (the gathered slices go straight into AQ's R slot inside the Gram kernel)
             k_gram_qaq<B, 2><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, pout,
                                                 (int64_t)chunk, (const int32_t *)splits_d.p);
         }
+        time_ag = false;
         SCS_HIP_CHECK(hipGetLastError());
         return SCS_OK;
     }
@@ -2346,6 +2372,22 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // W bytes one application streams (all of this rank's rows, or the upper tiles of the
     // symmetric schedule) + the block in and out
     st->apply_bytes = sv.w_bytes_per_apply + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;
+    {
+        // the timed all-gathers (every fourth iteration of the fused loop), scaled to all of them
+        double ag = 0.0;
+        int n_ag = 0;
+        for (size_t i = 0; i + 1 < sv.ev_ag.size(); i += 2) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, sv.ev_ag[i], sv.ev_ag[i + 1]) == hipSuccess) {
+                ag += t;
+                ++n_ag;
+            }
+        }
+        st->n_allgather = sv.n_allgather;
+        st->allgather_ms_total = n_ag ? ag * (double)sv.n_allgather / n_ag : 0.0;
+        // bytes one all-gather delivers to this rank: `world` chunks of `chunk` doubles
+        st->allgather_bytes = sv.world > 1 ? 8.0 * (double)sv.chunk * sv.world : 0.0;
+    }
     if (!converged) {
         // maps_out and stats are filled: the caller decides whether the block is usable
         scs_set_error("scs_fiedler: residual %.3e above tol %.3e after %d iterations (V = %d, block %d)",

@@ -235,10 +235,13 @@ def spectral_bipartition_device(
         from spectralclustersupertree_amd.partition import row_splits, row_splits_upper
 
         try:
-            if group_start is None and os.environ.get("SCS_MULTI_MODE", "upper") != "shared":
-                # nothing contracts: the job keeps only the upper triangle of the symmetric
-                # matrix -- no tile exchange, half the bytes per operator application
-                # (SCS_MULTI_MODE=shared keeps whole rows on every rank, as for nodes that contract)
+            if group_start is None and os.environ.get("SCS_MULTI_MODE", "shared") == "upper":
+                # SCS_MULTI_MODE=upper, nothing contracts: the job keeps only the upper triangle of the
+                # symmetric matrix -- no tile exchange, half the bytes per operator application.
+                # The DEFAULT since round 5 is the row-partitioned layout BASELINE.json's north_star
+                # names (whole rows on every rank, the Krylov block's slices all-gathered: the smaller
+                # collective) until a run on N > 1 real GPUs has shown the upper-triangle job's rows
+                # bit-equal there (bench.py --gpus N times both and prints both parities)
                 splits = row_splits_upper(n, team.world)
                 upper = True
             else:

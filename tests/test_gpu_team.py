@@ -205,8 +205,9 @@ def test_upper_triangle_job_build_apply_fiedler(world, strategy, n):
     assert cells <= 0.5 * n * n * tables.n_trees * 1.6
 
 
-def test_bipartition_through_a_team_takes_the_upper_triangle_when_nothing_contracts():
+def test_bipartition_through_a_team_takes_the_upper_triangle_when_nothing_contracts(monkeypatch):
     # (60 full trees: no two taxa share a root side in every one of them, nothing contracts)
+    monkeypatch.setenv("SCS_MULTI_MODE", "upper")  # (round 5: the default is the row-partitioned layout)
     tables = synthetic.make_tables(5, 1100, 60, "depth")
     assert int(fl.contraction_groups(tables).max()) + 1 == tables.n_taxa
     with Device(0) as dev:
@@ -235,7 +236,7 @@ def test_upper_triangle_job_equals_the_row_partitioned_job(monkeypatch):
     """The two multi-rank layouts against each other (two in-process ranks, nothing contracts):
     the stored cells of the upper-triangle job are the row-partitioned job's, bit for bit, the
     embeddings agree within the Fiedler tolerance and both give the single-device labels;
-    SCS_MULTI_MODE=shared is the switch back to whole rows."""
+    SCS_MULTI_MODE=upper / shared select the layout (default since round 5: shared)."""
     from spectralclustersupertree_amd.partition import row_splits_upper
 
     n = 1500
@@ -268,6 +269,8 @@ def test_upper_triangle_job_equals_the_row_partitioned_job(monkeypatch):
         for mode in ("upper", "shared"):
             monkeypatch.setenv("SCS_MULTI_MODE", mode)
             by_mode[mode] = teams.run(rank_bipartition)
+        monkeypatch.delenv("SCS_MULTI_MODE")
+        by_mode["default"] = teams.run(rank_bipartition)
     finally:
         teams.close()
     out = [(out_got[r], {mode: by_mode[mode][r] for mode in by_mode}) for r in range(2)]
@@ -284,6 +287,8 @@ def test_upper_triangle_job_equals_the_row_partitioned_job(monkeypatch):
             assert np.array_equal(w_u[i - lo_u, c0:], w_s[i - lo_s, c0:])
         assert np.max(np.abs(maps_u - maps_s)) <= 1e-10
         assert reports["upper"][1]["upper"] and not reports["shared"][1]["upper"]
+        assert not reports["default"][1]["upper"] and reports["default"][1]["sharded"]  # the default layout
+        assert np.array_equal(reports["default"][0], want_labels)
         for mode in ("upper", "shared"):
             assert reports[mode][1]["sharded"]
             assert np.array_equal(reports[mode][0], want_labels)

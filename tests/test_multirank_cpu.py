@@ -216,7 +216,8 @@ def _bench_worker(rank: int, world: int, port: int, out_dir: str) -> None:
             return maps, {"n_vertices": n, "block": 4, "iterations": 7, "n_apply": 8, "converged": 1,
                           "used_constraint": 1, "lambda": [1.0, 0.5], "resid": [0.0, 1e-14], "lambda_next": 0.4,
                           "apply_ms_total": 0.8, "apply_ms_min": 0.1, "solve_ms": 2.0,
-                          "apply_bytes": 8.0 * (self.re - self.rb) * n}
+                          "apply_bytes": 8.0 * (self.re - self.rb) * n, "allgather_ms_total": 0.07,
+                          "allgather_bytes": 8.0 * n * 4, "n_allgather": 7}
 
         def download_rows(self, first, count):
             return self.w[first:first + count].copy()
@@ -254,15 +255,19 @@ def _bench_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         def synchronize(self):
             pass
 
+        def comm_info(self):
+            return {"kind": "rccl", "world": self.world, "rank": self.rank, "reported_world": self.world,
+                    "reported_rank": self.rank}
+
         def close(self):
             pass
 
     backend.Device = FakeDevice
     import bench
 
-    # the default multi-rank mode (the job keeps the upper triangle only) ...
+    # the upper-triangle job (the job keeps the upper triangle only) ...
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--workload", "custom",
-                "--taxa", "600", "--trees", "4", "--strategy", "depth", "--no-extra"]
+                "--taxa", "600", "--trees", "4", "--strategy", "depth", "--no-extra", "--multi-rank-mode", "upper"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         rc = bench.main()
@@ -271,9 +276,10 @@ def _bench_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         line = json.loads(buf.getvalue().strip().splitlines()[-1])
         assert "upper triangle" in line["config"]["parallelism"] and line["parity"]["w_cells_mismatched"] == 0
         assert line["stages"]["build_exchange_ms"] == 0
-    # ... and the row-partitioned one with the tile exchange
+    # ... and the DEFAULT, the row-partitioned one with the tile exchange -- which also times the other
+    # layout (other_modes.upper) and holds both embeddings against the one-GPU run of the same input
     sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--workload", "custom",
-                "--taxa", "200", "--trees", "5", "--strategy", "depth", "--multi-rank-mode", "shared"]
+                "--taxa", "600", "--trees", "5", "--strategy", "depth"]
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
         rc = bench.main()
@@ -288,6 +294,14 @@ def _bench_worker(rank: int, world: int, port: int, out_dir: str) -> None:
         assert line["parity"]["w_cells_mismatched"] == 0
         assert line["stages"]["build_exchange_ms"] > 0 and line["stages"]["build_exchange_bytes_received"] > 0
         assert "workload" in line["config"] and "parallelism" in line["config"]
+        assert line["stages"]["multi_rank_mode"] == "shared" and "row-partitioned" in line["config"]["parallelism"]
+        assert line["communicator"]["reported_world"] == world == line["communicator"]["launcher_world_size"]
+        assert line["stages"]["allgather_bytes_received_per_rank"] > 0 and line["stages"]["allgathers_per_step"] == 7
+        alt = line["other_modes"]["upper"]
+        assert "upper triangle" in alt["config"]["parallelism"] and alt["parity"]["w_cells_mismatched"] == 0
+        assert alt["stages"]["build_exchange_ms"] == 0
+        for rep in (line, alt):  # (the fake solver returns one embedding whatever the layout)
+            assert rep["parity"]["embedding_vs_one_gpu_max_abs"] == 0.0
     else:
         assert buf.getvalue().strip() == ""
     Path(out_dir, f"bench_ok{rank}").write_text("ok")
