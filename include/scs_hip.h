@@ -130,6 +130,53 @@ int scs_ctx_synchronize(scs_ctx *ctx);
 int scs_ctx_comm_info(scs_ctx *ctx, int32_t *kind, int32_t *world, int32_t *rank,
                       int32_t *reported_world, int32_t *reported_rank);
 
+/* ---- source forests in HBM (round 5) ------------------------------------ */
+
+/* The source trees as preorder node arrays, resident on the device: what the recursion restricts
+ * at every node (reference: src/sc_supertree/scs.py:139-171 with :411-455 --
+ * `_generate_induced_trees_with_weights`, cogent3's get_sub_tree per tree and part).
+ * Arrays as spectralclustersupertree_amd/treearrays.py: tree t owns nodes [node_off[t],
+ * node_off[t+1]) in preorder; parent relative to the tree's first node (-1 root); taxon -1 for
+ * inner nodes; length / support NaN for None; n_leaves = nodes with taxon >= 0. */
+typedef struct scs_forest scs_forest;
+typedef struct scs_forest_info {
+    int32_t n_trees;  /* trees that keep two or more leaves of the part       */
+    int32_t monotone; /* `branch`: 1 unless a merged inner length is negative  */
+    int64_t n_nodes;
+    int64_t n_leaves;
+} scs_forest_info;
+
+int scs_forest_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, const int64_t *node_off,
+                      const int32_t *parent, const int32_t *taxon, const double *length,
+                      const double *support, const double *weights, int64_t n_leaves, scs_forest **out);
+int scs_forest_free(scs_ctx *ctx, scs_forest *forest);
+
+/* The forests induced on up to 8 disjoint taxon sets, all from ONE sweep of `forest`, each with
+ * its flattened tables (scs.py:411-455 + the strategy values of :555-564): part_of[x] = part of
+ * taxon x or -1, new_id[x] = its id inside the part (children number their taxa 0 .. k-1),
+ * part_taxa[c] = k of part c, strategy 0 one / 1 depth / 2 branch / 3 bootstrap.  Dropped
+ * leaves, spliced unary nodes with merged lengths (folded bottom-up, the parent's length in
+ * front), collapsed unary roots, trees left with fewer than two leaves of a part dropped --
+ * bit for bit what libscs_host.so's scs_host_split_* + scs_host_flatten produce.
+ * SCS_EUNSUP: bootstrap weighting met an inner node without support (the reference fails in
+ * `length * tree_weight`, scs.py:656). */
+int scs_forest_split(scs_ctx *ctx, const scs_forest *forest, const int32_t *part_of,
+                     const int32_t *new_id, int32_t n_parts, const int32_t *part_taxa, int32_t strategy,
+                     scs_forest **out_forests, scs_forest_info *info);
+
+/* The tables of a child of scs_forest_split to the host (any pointer may be null): tree_off
+ * [n_trees + 1], leaf_taxon / adj_depth / adj_val [n_leaves], tree_index [n_trees] (the tree's
+ * index in the parent forest), tree_w [n_trees], present [n_taxa] (1: the taxon occurs). */
+int scs_forest_tables_download(scs_ctx *ctx, const scs_forest *forest, int64_t *tree_off,
+                               int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val,
+                               int32_t *tree_index, double *tree_w, uint8_t *present);
+
+/* Node arrays of the trees [t_begin, t_end) to the host (node_off [t_end - t_begin + 1], made
+ * relative to the first of them; the other pointers may be null). */
+int scs_forest_download(scs_ctx *ctx, const scs_forest *forest, int32_t t_begin, int32_t t_end,
+                        int64_t *node_off, int32_t *parent, int32_t *taxon, double *length,
+                        double *support, double *weights);
+
 /* ---- tables ------------------------------------------------------------ */
 
 /* Page-locked host memory (hipHostMalloc) for callers that want scs_tables_upload to run at

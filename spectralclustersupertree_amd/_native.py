@@ -32,6 +32,7 @@ class ScsError(RuntimeError):
 
 EINVAL = -1  # SCS_EINVAL
 ENOCONV = -5  # SCS_ENOCONV: scs_fiedler stopped above tol (maps and stats are still filled)
+EUNSUP = -6  # SCS_EUNSUP
 
 
 class ConvergenceError(ScsError):
@@ -70,6 +71,15 @@ class Stats(C.Structure):
             v = getattr(self, name)
             out[name.rstrip("_")] = list(v) if hasattr(v, "__len__") else v
         return out
+
+
+class ForestInfo(C.Structure):
+    _fields_ = [
+        ("n_trees", C.c_int32),
+        ("monotone", C.c_int32),
+        ("n_nodes", C.c_int64),
+        ("n_leaves", C.c_int64),
+    ]
 
 
 class BuildStats(C.Structure):
@@ -121,6 +131,11 @@ SIGNATURES = {
     "scs_ctx_destroy": (C.c_int, [_P]),
     "scs_ctx_synchronize": (C.c_int, [_P]),
     "scs_ctx_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
+    "scs_forest_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP, C.c_int64, _PP]),
+    "scs_forest_free": (C.c_int, [_P, _P]),
+    "scs_forest_split": (C.c_int, [_P, _P, _IP, _IP, _I32, _IP, _I32, _P, _P]),
+    "scs_forest_tables_download": (C.c_int, [_P, _P, _LP, _IP, _IP, _DP, _IP, _DP, _P]),
+    "scs_forest_download": (C.c_int, [_P, _P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP]),
     "scs_host_alloc": (C.c_int, [C.c_size_t, _PP]),
     "scs_host_free": (C.c_int, [_P]),
     "scs_tables_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _PP]),

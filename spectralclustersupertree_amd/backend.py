@@ -178,6 +178,89 @@ class Device:
         return out
 
 
+class DeviceForest:
+    """A source forest resident in HBM (``scs_forest``): preorder node arrays, and -- for the
+    children of ``split`` -- their flattened tables.  See ``treearrays.ResidentArrays``."""
+
+    def __init__(self, dev: Device, handle, n_taxa: int, n_trees: int, n_nodes: int, n_leaves: int,
+                 monotone_flag: bool = True) -> None:
+        self.dev, self._h = dev, handle
+        self.n_taxa, self.n_trees, self.n_nodes, self.n_leaves = n_taxa, n_trees, n_nodes, n_leaves
+        self.monotone_flag = monotone_flag
+
+    @classmethod
+    def upload(cls, dev: Device, n_taxa, node_off, parent, taxon, length, support, weights, n_leaves) -> "DeviceForest":
+        handle = C.c_void_p()
+        nv.check(dev._lib.scs_forest_upload(dev._ctx, int(n_taxa), len(weights), nv.lptr(node_off), nv.iptr(parent),
+                                            nv.iptr(taxon), nv.dptr(length), nv.dptr(support), nv.dptr(weights),
+                                            int(n_leaves), C.byref(handle)))
+        return cls(dev, handle, int(n_taxa), len(weights), int(node_off[-1]), int(n_leaves))
+
+    def free(self) -> None:
+        if self._h:
+            self.dev._lib.scs_forest_free(self.dev._ctx, self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self) -> None:
+        try:
+            if self.dev._ctx:
+                self.free()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def split(self, part_of: np.ndarray, new_id: np.ndarray, part_taxa, strategy_code: int) -> list["DeviceForest"]:
+        """``scs_forest_split``: one child per part, each with its tables (reference: scs.py:411-455)."""
+        n_parts = len(part_taxa)
+        handles = (C.c_void_p * n_parts)()
+        info = (nv.ForestInfo * n_parts)()
+        pt = np.ascontiguousarray(part_taxa, dtype=np.int32)
+        rc = self.dev._lib.scs_forest_split(self.dev._ctx, self._h, nv.iptr(part_of), nv.iptr(new_id), n_parts,
+                                            nv.iptr(pt), int(strategy_code), handles, info)
+        if rc == nv.EUNSUP:
+            # the reference fails in ``length * tree_weight`` with a missing support (scs.py:656)
+            msg = "unsupported operand type(s) for *: 'NoneType' and 'float'"
+            raise TypeError(msg)
+        nv.check(rc)
+        return [DeviceForest(self.dev, C.c_void_p(handles[c]), int(pt[c]), int(info[c].n_trees), int(info[c].n_nodes),
+                             int(info[c].n_leaves), bool(info[c].monotone)) for c in range(n_parts)]
+
+    def tables(self):
+        """``(tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present)`` of a child of ``split``."""
+        m, l = self.n_trees, self.n_leaves
+        tree_off = np.zeros(m + 1, dtype=np.int64)
+        leaf_taxon = np.empty(l, dtype=np.int32)
+        adj_depth = np.empty(l, dtype=np.int32)
+        adj_val = np.empty(l, dtype=np.float64)
+        tree_index = np.empty(m, dtype=np.int32)
+        tree_w = np.empty(m, dtype=np.float64)
+        present = np.zeros(max(self.n_taxa, 1), dtype=np.uint8)
+        nv.check(self.dev._lib.scs_forest_tables_download(
+            self.dev._ctx, self._h, nv.lptr(tree_off), nv.iptr(leaf_taxon) if l else None,
+            nv.iptr(adj_depth) if l else None, nv.dptr(adj_val) if l else None, nv.iptr(tree_index) if m else None,
+            nv.dptr(tree_w) if m else None, present.ctypes.data))
+        return tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present
+
+    def download(self, t_begin: int = 0, t_end: int | None = None):
+        """Node arrays of the trees ``[t_begin, t_end)``: ``(node_off, parent, taxon, length, support, weights)``."""
+        t_end = self.n_trees if t_end is None else t_end
+        m = t_end - t_begin
+        node_off = np.zeros(m + 1, dtype=np.int64)
+        # (sizes are known only after the offsets arrive: two calls)
+        nv.check(self.dev._lib.scs_forest_download(self.dev._ctx, self._h, t_begin, t_end, nv.lptr(node_off),
+                                                   None, None, None, None, None))
+        n = int(node_off[-1])
+        parent = np.empty(n, dtype=np.int32)
+        taxon = np.empty(n, dtype=np.int32)
+        length = np.empty(n, dtype=np.float64)
+        support = np.empty(n, dtype=np.float64)
+        weights = np.empty(m, dtype=np.float64)
+        nv.check(self.dev._lib.scs_forest_download(self.dev._ctx, self._h, t_begin, t_end, nv.lptr(node_off),
+                                                   nv.iptr(parent) if n else None, nv.iptr(taxon) if n else None,
+                                                   nv.dptr(length) if n else None, nv.dptr(support) if n else None,
+                                                   nv.dptr(weights) if m else None))
+        return node_off, parent, taxon, length, support, weights
+
+
 class SmallTicket:
     """An ``scs_small_solve_begin`` that has not been ended: ``result()`` waits and returns one
     ``(maps, lambdas[, W])`` per node (once; kept).  Dropped unasked-for, it releases its slot."""

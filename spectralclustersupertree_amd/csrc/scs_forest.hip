@@ -1,0 +1,572 @@
+// Source forests resident in HBM, and their restriction on the device (round 5).
+//
+// The recursion of construct_supertree restricts every source tree to every part of a node's
+// partition (reference: src/sc_supertree/scs.py:139-171 with :411-455, cogent3's get_sub_tree per
+// tree and part).  Rounds 2-4 did that on the host (csrc/scs_host.c: one preorder sweep per tree
+// serves all parts; then scs_host_flatten turns each child forest into the tables of
+// include/scs_hip.h) -- 12 ns per tree node and level, which at configs[4]'s shape (10^9 tree
+// nodes per level, 61 000 nodes of 5 000 trees each) was three quarters of the whole recursion.
+// Here the forest stays in device memory as the same preorder node arrays and a split is three
+// launches:
+//   k_split_count   one THREAD per tree: subtree ends, the sweep with the root path on a stack
+//                   (the LCA of a part's consecutive leaves = the deepest stack entry at or before
+//                   the earlier leaf: binary search), one mark bit per part on every node a part
+//                   keeps; leaves and nodes per (part, tree);
+//   k_split_scan    one workgroup: exclusive scans over the trees -- child tree index, node and leaf
+//                   offsets, totals, per part;
+//   k_split_fill    one thread per tree again: per part the marked nodes in index order = the
+//                   restricted tree in preorder; parents by the interval test, merged branch
+//                   lengths folded bottom-up with the parent's length in front (the SAME order of
+//                   additions as scs_host.c / tree.py:get_sub_tree: same bits), taxa renumbered --
+//                   and, in the same pass, the child's TABLES (leaf_taxon, adj_depth, adj_val by
+//                   weighting strategy, as scs_host_flatten: same bits), weights, present taxa.
+// Trees are independent, so the parallelism is across trees (thousands); a thread walks its tree
+// alone.  The host keeps what north_star leaves to it: labels, tie-breaks, contraction groups,
+// components, tree assembly -- it downloads a child's tables (16 bytes per leaf) for that and hands
+// them on exactly as the host path does.
+#include <cmath>
+#include <memory>
+
+#include "scs_internal.h"
+
+namespace {
+
+// device arrays a split leaves behind for ALL children: one allocation each, children are slices
+struct forest_region {
+    scs_ctx *ctx = nullptr;
+    std::vector<void *> blocks;
+    ~forest_region() {
+        for (void *p : blocks) scs_block_release(ctx, p);
+    }
+    int alloc(size_t bytes, void **out) {
+        SCS_TRY(scs_block_alloc(ctx, bytes, out));
+        blocks.push_back(*out);
+        return SCS_OK;
+    }
+};
+
+}  // namespace
+
+struct scs_forest {
+    int32_t n_taxa = 0, n_trees = 0;
+    int64_t n_nodes = 0, n_leaves = 0;
+    std::shared_ptr<forest_region> region;  // (owner of every pointer below)
+    int64_t *node_off = nullptr;            // [n_trees + 1], relative to this forest's arrays
+    int32_t *parent = nullptr, *taxon = nullptr;
+    double *length = nullptr, *support = nullptr;
+    double *weights = nullptr;  // [n_trees]
+    // children of a split also carry their flattened tables
+    bool has_tables = false;
+    int64_t *tree_off = nullptr;  // [n_trees + 1]
+    int32_t *leaf_taxon = nullptr, *adj_depth = nullptr, *tree_index = nullptr;
+    double *adj_val = nullptr;
+    unsigned char *present = nullptr;  // [n_taxa]
+};
+
+namespace {
+
+constexpr int SPLIT_MAX_PARTS = 8;
+constexpr int SPLIT_THREADS = 128;
+
+struct split_params {
+    int32_t n_trees, n_parts, strategy;
+    const int64_t *node_off;
+    const int32_t *parent, *taxon;
+    const double *length, *support, *weights;
+    const int32_t *part_of, *new_id;
+    // scratch, sized like the parent's node arrays
+    int32_t *sub_end, *stk_a, *stk_b, *cdepth;
+    unsigned char *mark;
+    double *cval;
+    // per (part, tree)
+    int32_t *leaves_cnt, *nodes_cnt, *tree_pos;
+    int64_t *node_start, *leaf_start;  // absolute positions in the children's shared arrays
+    int64_t *totals;                   // [n_parts][4]: trees, nodes, leaves, first node of the part
+    // children (shared arrays; a part's slice starts at totals[part][3] / leaf base)
+    int64_t *c_node_off, *c_tree_off;  // [n_parts][n_trees + 1]
+    int32_t *c_parent, *c_taxon, *c_tree_index;
+    double *c_length, *c_support, *c_weights;
+    int32_t *c_leaf_taxon, *c_adj_depth;
+    double *c_adj_val;
+    unsigned char *c_present;  // [n_parts][n_taxa_parent] (only the first part_taxa entries are used)
+    int32_t present_ld;
+    int32_t *flags;  // [0]: error code, [1 + part]: monotone (1 until a negative length is met)
+};
+
+__global__ __launch_bounds__(SPLIT_THREADS) void k_split_count(split_params p) {
+    __shared__ int32_t s_last[SPLIT_MAX_PARTS][SPLIT_THREADS];
+    __shared__ int32_t s_cnt[SPLIT_MAX_PARTS][SPLIT_THREADS];
+    const int t = blockIdx.x * SPLIT_THREADS + threadIdx.x;
+    if (t >= p.n_trees) return;
+    const int tid = threadIdx.x;
+    const int np = p.n_parts;
+    const int64_t off = p.node_off[t];
+    const int32_t k = (int32_t)(p.node_off[t + 1] - off);
+    const int32_t *par = p.parent + off, *tax = p.taxon + off;
+    int32_t *se = p.sub_end + off, *st = p.stk_a + off;
+    unsigned char *mk = p.mark + off;
+    for (int b = 0; b < np; ++b) {
+        s_last[b][tid] = 0;
+        s_cnt[b][tid] = 0;
+    }
+    for (int32_t i = 0; i < k; ++i) se[i] = i;
+    for (int32_t i = k - 1; i > 0; --i) {
+        const int32_t q = par[i];
+        if (q < 0 || q >= i) {  // not preorder
+            atomicExch(&p.flags[0], SCS_EINVAL);
+            return;
+        }
+        if (se[i] > se[q]) se[q] = se[i];
+    }
+    int32_t sp = 0;
+    for (int32_t i = 0; i < k; ++i) {
+        while (sp > 0 && i > se[st[sp - 1]]) --sp;
+        const int32_t x = tax[i];
+        if (x < 0) {
+            st[sp++] = i;
+            continue;
+        }
+        const int32_t pc = p.part_of[x];
+        if (pc < 0) continue;
+        const int32_t xl = s_last[pc][tid] - 1;
+        if (xl >= 0) {
+            // deepest ancestor of i whose index is <= xl: the LCA of xl and i (st[0] = root <= xl)
+            int32_t lo = 0, hi = sp - 1;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi + 1) >> 1;
+                if (st[mid] <= xl) lo = mid;
+                else hi = mid - 1;
+            }
+            mk[st[lo]] |= (unsigned char)(1u << pc);
+        }
+        mk[i] |= (unsigned char)(1u << pc);
+        s_last[pc][tid] = i + 1;
+        s_cnt[pc][tid] += 1;
+    }
+    // nodes a part keeps (a part with fewer than two leaves is dropped: nothing counted)
+    int32_t nodes[SPLIT_MAX_PARTS];
+#pragma unroll
+    for (int b = 0; b < SPLIT_MAX_PARTS; ++b) nodes[b] = 0;
+    for (int32_t i = 0; i < k; ++i) {
+        const unsigned m = mk[i];
+#pragma unroll
+        for (int b = 0; b < SPLIT_MAX_PARTS; ++b) nodes[b] += (int32_t)((m >> b) & 1u);
+    }
+#pragma unroll
+    for (int b = 0; b < SPLIT_MAX_PARTS; ++b) {
+        if (b < np) {
+            const int32_t c = s_cnt[b][tid];
+            const bool keep = c >= 2;
+            p.leaves_cnt[(int64_t)b * p.n_trees + t] = keep ? c : 0;
+            p.nodes_cnt[(int64_t)b * p.n_trees + t] = keep ? nodes[b] : 0;
+        }
+    }
+}
+
+// one workgroup of 1024: per part, exclusive scans over the trees
+__global__ __launch_bounds__(1024) void k_split_scan(split_params p) {
+    __shared__ int64_t s_a[1024], s_b[1024], s_c[1024];
+    __shared__ int64_t s_node_base, s_leaf_base;
+    const int tid = threadIdx.x;
+    const int M = p.n_trees;
+    const int per = (M + 1023) / 1024;
+    if (tid == 0) {
+        s_node_base = 0;
+        s_leaf_base = 0;
+    }
+    __syncthreads();
+    for (int b = 0; b < p.n_parts; ++b) {
+        const int32_t *lc = p.leaves_cnt + (int64_t)b * M, *nc = p.nodes_cnt + (int64_t)b * M;
+        const int t0 = tid * per, t1 = min(M, t0 + per);
+        int64_t a = 0, n = 0, l = 0;
+        for (int t = t0; t < t1; ++t) {
+            a += lc[t] > 0;
+            n += nc[t];
+            l += lc[t];
+        }
+        s_a[tid] = a;
+        s_b[tid] = n;
+        s_c[tid] = l;
+        __syncthreads();
+        // inclusive scan of the 1024 partial sums (Hillis-Steele)
+        for (int d = 1; d < 1024; d <<= 1) {
+            int64_t xa = 0, xb = 0, xc = 0;
+            if (tid >= d) {
+                xa = s_a[tid - d];
+                xb = s_b[tid - d];
+                xc = s_c[tid - d];
+            }
+            __syncthreads();
+            s_a[tid] += xa;
+            s_b[tid] += xb;
+            s_c[tid] += xc;
+            __syncthreads();
+        }
+        const int64_t node_base = s_node_base, leaf_base = s_leaf_base;
+        int64_t ea = s_a[tid] - a, eb = s_b[tid] - n, ec = s_c[tid] - l;  // exclusive
+        int64_t *cno = p.c_node_off + (int64_t)b * (M + 1), *cto = p.c_tree_off + (int64_t)b * (M + 1);
+        for (int t = t0; t < t1; ++t) {
+            const bool keep = lc[t] > 0;
+            p.tree_pos[(int64_t)b * M + t] = keep ? (int32_t)ea : -1;
+            p.node_start[(int64_t)b * M + t] = node_base + eb;
+            p.leaf_start[(int64_t)b * M + t] = leaf_base + ec;
+            if (keep) {
+                cno[ea] = eb;  // relative to the child's own arrays
+                cto[ea] = ec;
+            }
+            ea += keep;
+            eb += nc[t];
+            ec += lc[t];
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            const int64_t trees = s_a[1023], nodes = s_b[1023], leaves = s_c[1023];
+            p.totals[b * 4 + 0] = trees;
+            p.totals[b * 4 + 1] = nodes;
+            p.totals[b * 4 + 2] = leaves;
+            p.totals[b * 4 + 3] = node_base;
+            cno[trees] = nodes;
+            cto[trees] = leaves;
+            s_node_base = node_base + nodes;
+            s_leaf_base = leaf_base + leaves;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SPLIT_THREADS) void k_split_fill(split_params p) {
+    const int t = blockIdx.x * SPLIT_THREADS + threadIdx.x;
+    if (t >= p.n_trees) return;
+    if (p.flags[0] != 0) return;
+    const int np = p.n_parts;
+    const int M = p.n_trees;
+    const int64_t off = p.node_off[t];
+    const int32_t k = (int32_t)(p.node_off[t + 1] - off);
+    const int32_t *par = p.parent + off, *tax = p.taxon + off;
+    const double *len = p.length + off, *sup = p.support + off;
+    const int32_t *se = p.sub_end + off;
+    int32_t *sv = p.stk_a + off, *sj = p.stk_b + off;
+    unsigned char *mk = p.mark + off;
+    const double wt = p.weights[t];
+    for (int b = 0; b < np; ++b) {
+        const int32_t pos = p.tree_pos[(int64_t)b * M + t];
+        if (pos < 0) continue;
+        const int64_t base = p.node_start[(int64_t)b * M + t];
+        int64_t slot = p.leaf_start[(int64_t)b * M + t];
+        const int64_t slot_end = slot + p.leaves_cnt[(int64_t)b * M + t];
+        const int64_t tbase = p.totals[b * 4 + 0];  // (unused: kept for symmetry)
+        (void)tbase;
+        // child arrays of this part
+        int64_t tree_base = 0;
+        for (int c = 0; c < b; ++c) tree_base += p.totals[c * 4 + 0];
+        p.c_weights[tree_base + pos] = wt;
+        p.c_tree_index[tree_base + pos] = t;
+        unsigned char *present = p.c_present + (int64_t)b * p.present_ld;
+        int32_t vs = 0, j = 0;
+        bool first_leaf = true;
+        int32_t pend_depth = 0;
+        double pend_val = 0.0;
+        const unsigned bit = 1u << b;
+        for (int32_t v = 0; v < k; ++v) {
+            if (!(mk[v] & bit)) continue;
+            while (vs > 0 && v > se[sv[vs - 1]]) --vs;
+            const int32_t upj = vs > 0 ? sj[vs - 1] : -1;
+            const int32_t up = vs > 0 ? sv[vs - 1] : -1;
+            const int32_t x = tax[v];
+            const int32_t ctx_ = x >= 0 ? p.new_id[x] : -1;
+            double acc = len[v];
+            for (int32_t u = v == 0 ? -1 : par[v]; u >= 0 && u != up; u = par[u])
+                if (!isnan(len[u]) && !isnan(acc)) acc = len[u] + acc;
+            const double sp_ = sup[v];
+            p.c_parent[base + j] = upj;
+            p.c_taxon[base + j] = ctx_;
+            p.c_length[base + j] = acc;
+            p.c_support[base + j] = sp_;
+            // ---- the child's tables, as scs_host_flatten walks the child in preorder
+            if (j == 0) {
+                p.cdepth[base] = 0;
+                p.cval[base] = 0.0;
+            } else {
+                if (j != upj + 1) {  // not the first child: the next leaf's LCA with the previous one is upj
+                    pend_depth = p.cdepth[base + upj];
+                    pend_val = p.cval[base + upj];
+                }
+                if (x >= 0) {
+                    if (!first_leaf) {
+                        p.c_adj_depth[slot - 1] = pend_depth;
+                        p.c_adj_val[slot - 1] = pend_val;
+                    }
+                    first_leaf = false;
+                    if (slot < slot_end) p.c_leaf_taxon[slot] = ctx_;
+                    ++slot;
+                    present[ctx_] = 1;
+                } else {
+                    const double pv = p.cval[base + upj];
+                    double val;
+                    switch (p.strategy) {
+                        case 0:
+                            val = 1.0;
+                            break;
+                        case 1:
+                            val = pv + 1.0;
+                            break;
+                        case 2:
+                            val = pv + (isnan(acc) ? 1.0 : acc);
+                            if (!isnan(acc) && acc < 0.0) p.flags[1 + b] = 0;
+                            break;
+                        default:
+                            val = sp_;
+                            if (isnan(val)) {
+                                // (every internal node of a restricted tree has two or more children)
+                                atomicExch(&p.flags[0], -3);
+                                val = 0.0;
+                            }
+                            break;
+                    }
+                    p.cdepth[base + j] = p.cdepth[base + upj] + 1;
+                    p.cval[base + j] = val;
+                }
+            }
+            if (x < 0) {
+                sv[vs] = v;
+                sj[vs] = j;
+                ++vs;
+            }
+            ++j;
+        }
+        if (slot != slot_end) atomicExch(&p.flags[0], SCS_EINVAL);
+        // padding slot so adj_* share the offsets of leaf_taxon
+        p.c_adj_depth[slot_end - 1] = 0;
+        p.c_adj_val[slot_end - 1] = 0.0;
+    }
+    for (int32_t v = 0; v < k; ++v) mk[v] = 0;  // the marks are clean for the next split
+}
+
+}  // namespace
+
+extern "C" int scs_forest_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, const int64_t *node_off,
+                                 const int32_t *parent, const int32_t *taxon, const double *length,
+                                 const double *support, const double *weights, int64_t n_leaves,
+                                 scs_forest **out) {
+    SCS_REQUIRE(ctx && node_off && parent && taxon && length && support && weights && out,
+                "scs_forest_upload: null argument");
+    SCS_REQUIRE(n_taxa >= 1 && n_trees >= 1, "scs_forest_upload: need at least one taxon and one tree");
+    SCS_REQUIRE(node_off[0] == 0, "scs_forest_upload: node_off must start at 0");
+    for (int32_t t = 0; t < n_trees; ++t)
+        SCS_REQUIRE(node_off[t + 1] > node_off[t] && node_off[t + 1] - node_off[t] <= INT32_MAX / 4,
+                    "scs_forest_upload: tree %d has a bad node count", t);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t N = node_off[n_trees];
+    auto f = std::unique_ptr<scs_forest>(new scs_forest());
+    f->n_taxa = n_taxa;
+    f->n_trees = n_trees;
+    f->n_nodes = N;
+    f->region = std::make_shared<forest_region>();
+    f->region->ctx = ctx;
+    SCS_TRY(f->region->alloc((size_t)(n_trees + 1) * 8, (void **)&f->node_off));
+    SCS_TRY(f->region->alloc((size_t)N * 4, (void **)&f->parent));
+    SCS_TRY(f->region->alloc((size_t)N * 4, (void **)&f->taxon));
+    SCS_TRY(f->region->alloc((size_t)N * 8, (void **)&f->length));
+    SCS_TRY(f->region->alloc((size_t)N * 8, (void **)&f->support));
+    SCS_TRY(f->region->alloc((size_t)n_trees * 8, (void **)&f->weights));
+    hipStream_t s = ctx->stream;
+    SCS_HIP_CHECK(hipMemcpyAsync(f->node_off, node_off, (size_t)(n_trees + 1) * 8, hipMemcpyHostToDevice, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(f->parent, parent, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(f->taxon, taxon, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(f->length, length, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(f->support, support, (size_t)N * 8, hipMemcpyHostToDevice, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(f->weights, weights, (size_t)n_trees * 8, hipMemcpyHostToDevice, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));  // (the caller's arrays may go away)
+    SCS_REQUIRE(n_leaves >= n_trees && n_leaves <= N, "scs_forest_upload: bad leaf count");
+    f->n_leaves = n_leaves;  // (the number of nodes with taxon >= 0: sizes the children's arrays)
+    *out = f.release();
+    return SCS_OK;
+}
+
+extern "C" int scs_forest_free(scs_ctx *ctx, scs_forest *f) {
+    (void)ctx;
+    delete f;  // (the region goes with its last forest)
+    return SCS_OK;
+}
+
+extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of, const int32_t *new_id,
+                                int32_t n_parts, const int32_t *part_taxa, int32_t strategy,
+                                scs_forest **out_forests, scs_forest_info *info) {
+    SCS_REQUIRE(ctx && f && part_of && new_id && part_taxa && out_forests && info, "scs_forest_split: null argument");
+    SCS_REQUIRE(n_parts >= 1 && n_parts <= SPLIT_MAX_PARTS, "scs_forest_split: 1 .. %d parts (asked: %d)",
+                SPLIT_MAX_PARTS, n_parts);
+    SCS_REQUIRE(strategy >= 0 && strategy <= 3, "scs_forest_split: strategy must be 0 .. 3");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int M = f->n_trees;
+    const int64_t N = f->n_nodes, L = f->n_leaves;
+    for (int b = 0; b < n_parts; ++b) {
+        out_forests[b] = nullptr;
+        SCS_REQUIRE(part_taxa[b] >= 0 && part_taxa[b] <= f->n_taxa, "scs_forest_split: bad taxon count of part %d", b);
+    }
+
+    // scratch of this call (returned to the context's block cache at the end)
+    struct scratch_t {
+        scs_ctx *ctx;
+        std::vector<void *> blocks;
+        ~scratch_t() {
+            for (void *p : blocks) scs_block_release(ctx, p);
+        }
+        int alloc(size_t bytes, void **out) {
+            SCS_TRY(scs_block_alloc(ctx, bytes, out));
+            blocks.push_back(*out);
+            return SCS_OK;
+        }
+    } scratch{ctx, {}};
+    auto region = std::make_shared<forest_region>();
+    region->ctx = ctx;
+
+    split_params p;
+    memset(&p, 0, sizeof(p));
+    p.n_trees = M;
+    p.n_parts = n_parts;
+    p.strategy = strategy;
+    p.node_off = f->node_off;
+    p.parent = f->parent;
+    p.taxon = f->taxon;
+    p.length = f->length;
+    p.support = f->support;
+    p.weights = f->weights;
+    int32_t *d_part_of = nullptr, *d_new_id = nullptr;
+    SCS_TRY(scratch.alloc((size_t)f->n_taxa * 4, (void **)&d_part_of));
+    SCS_TRY(scratch.alloc((size_t)f->n_taxa * 4, (void **)&d_new_id));
+    SCS_HIP_CHECK(hipMemcpyAsync(d_part_of, part_of, (size_t)f->n_taxa * 4, hipMemcpyHostToDevice, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(d_new_id, new_id, (size_t)f->n_taxa * 4, hipMemcpyHostToDevice, s));
+    p.part_of = d_part_of;
+    p.new_id = d_new_id;
+    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.sub_end));
+    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_a));
+    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_b));
+    SCS_TRY(scratch.alloc((size_t)N, (void **)&p.mark));
+    SCS_HIP_CHECK(hipMemsetAsync(p.mark, 0, (size_t)N, s));
+    const size_t pm = (size_t)n_parts * M;
+    SCS_TRY(scratch.alloc(pm * 4, (void **)&p.leaves_cnt));
+    SCS_TRY(scratch.alloc(pm * 4, (void **)&p.nodes_cnt));
+    SCS_TRY(scratch.alloc(pm * 4, (void **)&p.tree_pos));
+    SCS_TRY(scratch.alloc(pm * 8, (void **)&p.node_start));
+    SCS_TRY(scratch.alloc(pm * 8, (void **)&p.leaf_start));
+    SCS_TRY(scratch.alloc((size_t)n_parts * 4 * 8, (void **)&p.totals));
+    SCS_TRY(scratch.alloc((size_t)(1 + SPLIT_MAX_PARTS) * 4, (void **)&p.flags));
+    {
+        int32_t h_flags[1 + SPLIT_MAX_PARTS];
+        h_flags[0] = 0;
+        for (int b = 0; b < SPLIT_MAX_PARTS; ++b) h_flags[1 + b] = 1;
+        // (pageable sources: the runtime stages them before the call returns)
+        SCS_HIP_CHECK(hipMemcpyAsync(p.flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, s));
+    }
+    // the children's arrays: together the parts of a tree hold its leaves once and at most
+    // leaves - 1 LCAs between them (an inner node of the parent may be kept by several parts)
+    const int64_t NC = std::max<int64_t>(2 * L, 2);
+    SCS_TRY(scratch.alloc((size_t)NC * 4, (void **)&p.cdepth));
+    SCS_TRY(scratch.alloc((size_t)NC * 8, (void **)&p.cval));
+    SCS_TRY(region->alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_node_off));
+    SCS_TRY(region->alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_tree_off));
+    SCS_TRY(region->alloc((size_t)NC * 4, (void **)&p.c_parent));
+    SCS_TRY(region->alloc((size_t)NC * 4, (void **)&p.c_taxon));
+    SCS_TRY(region->alloc((size_t)NC * 8, (void **)&p.c_length));
+    SCS_TRY(region->alloc((size_t)NC * 8, (void **)&p.c_support));
+    SCS_TRY(region->alloc(pm * 8, (void **)&p.c_weights));
+    SCS_TRY(region->alloc(pm * 4, (void **)&p.c_tree_index));
+    SCS_TRY(region->alloc((size_t)std::max<int64_t>(L, 1) * 4, (void **)&p.c_leaf_taxon));
+    SCS_TRY(region->alloc((size_t)std::max<int64_t>(L, 1) * 4, (void **)&p.c_adj_depth));
+    SCS_TRY(region->alloc((size_t)std::max<int64_t>(L, 1) * 8, (void **)&p.c_adj_val));
+    p.present_ld = f->n_taxa;
+    SCS_TRY(region->alloc((size_t)n_parts * f->n_taxa, (void **)&p.c_present));
+    SCS_HIP_CHECK(hipMemsetAsync(p.c_present, 0, (size_t)n_parts * f->n_taxa, s));
+
+    const unsigned grid = (unsigned)((M + SPLIT_THREADS - 1) / SPLIT_THREADS);
+    k_split_count<<<grid, SPLIT_THREADS, 0, s>>>(p);
+    k_split_scan<<<1, 1024, 0, s>>>(p);
+    k_split_fill<<<grid, SPLIT_THREADS, 0, s>>>(p);
+    SCS_HIP_CHECK(hipGetLastError());
+    int64_t h_tot[SPLIT_MAX_PARTS * 4];
+    int32_t h_flags[1 + SPLIT_MAX_PARTS];
+    SCS_HIP_CHECK(hipMemcpyAsync(h_tot, p.totals, (size_t)n_parts * 4 * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(h_flags, p.flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    if (h_flags[0] == -3) {
+        scs_set_error("scs_forest_split: an internal node without support under the bootstrap weighting");
+        return SCS_EUNSUP;
+    }
+    if (h_flags[0] != 0) {
+        scs_set_error("scs_forest_split: malformed tree arrays (not preorder, or inconsistent leaf counts)");
+        return SCS_EINVAL;
+    }
+    int64_t tree_base = 0, leaf_base = 0;
+    for (int b = 0; b < n_parts; ++b) {
+        const int64_t trees = h_tot[b * 4 + 0], nodes = h_tot[b * 4 + 1], leaves = h_tot[b * 4 + 2],
+                      node_base = h_tot[b * 4 + 3];
+        auto c = std::unique_ptr<scs_forest>(new scs_forest());
+        c->n_taxa = part_taxa[b];
+        c->n_trees = (int32_t)trees;
+        c->n_nodes = nodes;
+        c->n_leaves = leaves;
+        c->region = region;
+        c->node_off = p.c_node_off + (int64_t)b * (M + 1);
+        c->tree_off = p.c_tree_off + (int64_t)b * (M + 1);
+        c->parent = p.c_parent + node_base;
+        c->taxon = p.c_taxon + node_base;
+        c->length = p.c_length + node_base;
+        c->support = p.c_support + node_base;
+        c->weights = p.c_weights + tree_base;
+        c->tree_index = p.c_tree_index + tree_base;
+        c->leaf_taxon = p.c_leaf_taxon + leaf_base;
+        c->adj_depth = p.c_adj_depth + leaf_base;
+        c->adj_val = p.c_adj_val + leaf_base;
+        c->present = p.c_present + (int64_t)b * p.present_ld;
+        c->has_tables = true;
+        info[b].n_trees = (int32_t)trees;
+        info[b].monotone = h_flags[1 + b];
+        info[b].n_nodes = nodes;
+        info[b].n_leaves = leaves;
+        out_forests[b] = c.release();
+        tree_base += trees;
+        leaf_base += leaves;
+    }
+    return SCS_OK;
+}
+
+extern "C" int scs_forest_tables_download(scs_ctx *ctx, const scs_forest *f, int64_t *tree_off, int32_t *leaf_taxon,
+                                          int32_t *adj_depth, double *adj_val, int32_t *tree_index,
+                                          double *tree_w, uint8_t *present) {
+    SCS_REQUIRE(ctx && f, "scs_forest_tables_download: null argument");
+    SCS_REQUIRE(f->has_tables, "scs_forest_tables_download: only the children of scs_forest_split carry tables");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t m = (size_t)f->n_trees, l = (size_t)f->n_leaves;
+    if (tree_off) SCS_HIP_CHECK(hipMemcpyAsync(tree_off, f->tree_off, (m + 1) * 8, hipMemcpyDeviceToHost, s));
+    if (leaf_taxon && l) SCS_HIP_CHECK(hipMemcpyAsync(leaf_taxon, f->leaf_taxon, l * 4, hipMemcpyDeviceToHost, s));
+    if (adj_depth && l) SCS_HIP_CHECK(hipMemcpyAsync(adj_depth, f->adj_depth, l * 4, hipMemcpyDeviceToHost, s));
+    if (adj_val && l) SCS_HIP_CHECK(hipMemcpyAsync(adj_val, f->adj_val, l * 8, hipMemcpyDeviceToHost, s));
+    if (tree_index && m) SCS_HIP_CHECK(hipMemcpyAsync(tree_index, f->tree_index, m * 4, hipMemcpyDeviceToHost, s));
+    if (tree_w && m) SCS_HIP_CHECK(hipMemcpyAsync(tree_w, f->weights, m * 8, hipMemcpyDeviceToHost, s));
+    if (present && f->n_taxa) SCS_HIP_CHECK(hipMemcpyAsync(present, f->present, (size_t)f->n_taxa, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    return SCS_OK;
+}
+
+extern "C" int scs_forest_download(scs_ctx *ctx, const scs_forest *f, int32_t t_begin, int32_t t_end,
+                                   int64_t *node_off, int32_t *parent, int32_t *taxon, double *length,
+                                   double *support, double *weights) {
+    SCS_REQUIRE(ctx && f && node_off, "scs_forest_download: null argument");
+    SCS_REQUIRE(t_begin >= 0 && t_begin <= t_end && t_end <= f->n_trees, "scs_forest_download: bad tree range");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t m = (size_t)(t_end - t_begin);
+    SCS_HIP_CHECK(hipMemcpyAsync(node_off, f->node_off + t_begin, (m + 1) * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t lo = node_off[0], n = node_off[m] - lo;
+    if (parent && n) SCS_HIP_CHECK(hipMemcpyAsync(parent, f->parent + lo, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (taxon && n) SCS_HIP_CHECK(hipMemcpyAsync(taxon, f->taxon + lo, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    if (length && n) SCS_HIP_CHECK(hipMemcpyAsync(length, f->length + lo, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (support && n) SCS_HIP_CHECK(hipMemcpyAsync(support, f->support + lo, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (weights && m) SCS_HIP_CHECK(hipMemcpyAsync(weights, f->weights + t_begin, m * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t t = 0; t <= m; ++t) node_off[t] -= lo;  // (relative to the first downloaded tree)
+    return SCS_OK;
+}

@@ -501,6 +501,11 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
     """The recursion on flat tree arrays from its root node: ``_construct_node`` with, for a
     single-process run on the device path, a queue that lets the device work on nodes ahead of
     the walk (``ahead.Ahead``)."""
+    if bipartition is None and getattr(arrays, "resident_device", None) is None:
+        # the restriction step of the recursion runs on the device for forests big enough to be
+        # worth a launch (treearrays.ResidentArrays, scs_forest_split); the device is only
+        # created when such a split arrives (a run that never gets there touches none)
+        arrays.resident_device = (lambda: team.solo) if team is not None else default_device
     with _warm_allocator():
         return _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre)
 
@@ -672,7 +677,7 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
             continue
         children.append(["sub", component, None, None])
         to_split.append(np.asarray(component, dtype=np.int32))
-    subs = iter(arrays.split(to_split))
+    subs = iter(arrays.split(to_split, strategy=pcg_weighting))
     for child in children:
         if child[0] != "sub":
             continue

@@ -56,6 +56,8 @@ class TreeArrays:
     ids: np.ndarray | None = None
     _present: np.ndarray | None = None  # cached result of present_taxa (filled by split)
     _leaf_counts: np.ndarray | None = None
+    # the device the recursion may move this forest to (backend.Device; None: splits stay on the host)
+    resident_device: object | None = None
 
     @property
     def n_trees(self) -> int:
@@ -212,16 +214,23 @@ class TreeArrays:
                 raise ValueError(f"scs_host_restrict_fill: {_ERRORS.get(rc, rc)}")
         return out
 
-    def split(self, parts: Sequence[np.ndarray]) -> list["TreeArrays"]:
+    def split(self, parts: Sequence[np.ndarray], strategy: str | None = None) -> list["TreeArrays"]:
         """The forests induced on each of the disjoint taxon sets ``parts`` (sorted id arrays),
         all from ONE sweep of this forest (``scs_host_split_*``; reference: the loop over the
         parts at scs.py:139-155 with the restriction of :411-455).  Child ``c`` numbers its taxa
         ``0..len(parts[c])-1`` in the order of ``parts[c]``; its ``present_taxa`` and
-        ``leaf_counts`` come for free."""
+        ``leaf_counts`` come for free.
+
+        With a device attached (``resident_device``, set by the recursion) and a ``strategy`` the
+        forest goes to HBM once and the split -- and every later one below it -- runs there
+        (``ResidentArrays``, ``scs_forest_split``): the same child forests and tables, bit for bit."""
         lib = _load()
         n_parts = len(parts)
         if n_parts == 0:
             return []
+        if (self.resident_device is not None and strategy is not None and resident_split_wanted(self, n_parts)):
+            dev = self.resident_device() if callable(self.resident_device) else self.resident_device
+            return ResidentArrays.from_host(self, dev).split(parts, strategy)
         part_of = np.full(max(self.n_taxa, 1), -1, dtype=np.int32)
         new_id = np.zeros(max(self.n_taxa, 1), dtype=np.int32)
         parts = [np.asarray(p, dtype=np.int32) for p in parts]
@@ -266,6 +275,7 @@ class TreeArrays:
                     child.weights = self.weights[tree_index[:m]].copy()
                 child._present = np.flatnonzero(present[: len(ids)]).astype(np.int32)
                 child._leaf_counts = leaf_counts[:m]
+                child.resident_device = self.resident_device  # (a big child may move to the device later)
                 out.append(child)
         finally:
             lib.scs_host_split_end(plan)
@@ -335,3 +345,143 @@ class TreeArrays:
                 nodes[par].children.append(node)
                 node.parent = nodes[par]
         return nodes[0]
+
+
+# ---------------------------------------------------------------------------
+# forests resident in HBM (round 5): the recursion's restriction step on the device
+# ---------------------------------------------------------------------------
+def resident_split_wanted(forest, n_parts: int) -> bool:
+    """Whether a split of ``forest`` into ``n_parts`` runs on the device: at most 8 parts (one
+    mark bit per part), and enough tree nodes that three launches and two round trips are
+    cheaper than the host's sweep (SCS_DEVICE_SPLIT=0 switches the path off,
+    SCS_DEVICE_SPLIT_MIN_NODES moves the threshold)."""
+    import os
+
+    if not int(os.environ.get("SCS_DEVICE_SPLIT", "1") or 0):
+        return False
+    if n_parts > 8 or forest.n_trees == 0:
+        return False
+    n_nodes = forest.n_nodes if isinstance(forest, ResidentArrays) else len(forest.parent)
+    return n_nodes >= int(os.environ.get("SCS_DEVICE_SPLIT_MIN_NODES", "20000") or 0)
+
+
+class ResidentArrays:
+    """A forest whose node arrays live in HBM (``backend.DeviceForest``), with the interface the
+    recursion uses of ``TreeArrays``: ``n_trees``, ``name``, ``present_taxa``, ``flatten``,
+    ``split``, ``to_tree``.  A child of ``split`` arrives with its tables already flattened on
+    the device (for the weighting strategy the split was asked for) and downloaded; the node
+    arrays themselves never travel unless ``to_host`` is called (a split into more than eight
+    parts, a forest too small to be worth a launch, a single tree to graft)."""
+
+    def __init__(self, forest, n_taxa: int, weights: np.ndarray, taxa: list[str], ids: np.ndarray | None,
+                 strategy: str | None = None, tables=None) -> None:
+        self.forest = forest  # backend.DeviceForest
+        self.n_taxa = int(n_taxa)
+        self.weights = weights
+        self.taxa = taxa
+        self.ids = ids
+        self.strategy = strategy
+        self._tables = tables  # (tree_off, leaf_taxon, adj_depth, adj_val) of a split's child
+        self._present: np.ndarray | None = None
+        self.resident_device = forest.dev
+
+    # ---- TreeArrays' interface ------------------------------------------------
+    @property
+    def n_trees(self) -> int:
+        return self.forest.n_trees
+
+    @property
+    def n_nodes(self) -> int:
+        return self.forest.n_nodes
+
+    def name(self, i: int) -> str:
+        return self.taxa[int(i) if self.ids is None else int(self.ids[int(i)])]
+
+    @classmethod
+    def from_host(cls, arrays: "TreeArrays", dev) -> "ResidentArrays":
+        from spectralclustersupertree_amd.backend import DeviceForest
+
+        forest = DeviceForest.upload(
+            dev, max(arrays.n_taxa, 1), np.ascontiguousarray(arrays.node_off, dtype=np.int64),
+            np.ascontiguousarray(arrays.parent, dtype=np.int32), np.ascontiguousarray(arrays.taxon, dtype=np.int32),
+            np.ascontiguousarray(arrays.length, dtype=np.float64),
+            np.ascontiguousarray(arrays.support, dtype=np.float64),
+            np.ascontiguousarray(arrays.weights, dtype=np.float64), int(arrays.leaf_counts().sum()))
+        out = cls(forest, arrays.n_taxa, arrays.weights, arrays.taxa, arrays.ids)
+        out._present = arrays._present
+        return out
+
+    def to_host(self) -> "TreeArrays":
+        node_off, parent, taxon, length, support, weights = self.forest.download()
+        out = TreeArrays(n_taxa=self.n_taxa, node_off=node_off, parent=parent, taxon=taxon, length=length,
+                         support=support, weights=weights, taxa=self.taxa, ids=self.ids)
+        out._present = self._present
+        out.resident_device = self.resident_device
+        return out
+
+    def present_taxa(self) -> np.ndarray:
+        if self._present is None:
+            self._present = self.to_host().present_taxa()
+        return self._present
+
+    def leaf_counts(self) -> np.ndarray:
+        if self._tables is not None:
+            return np.diff(self._tables[0])
+        return self.to_host().leaf_counts()
+
+    def to_tree(self, t: int) -> TreeNode:
+        node_off, parent, taxon, length, support, weights = self.forest.download(t, t + 1)
+        one = TreeArrays(n_taxa=self.n_taxa, node_off=node_off, parent=parent, taxon=taxon, length=length,
+                         support=support, weights=weights, taxa=self.taxa, ids=self.ids)
+        return one.to_tree(0)
+
+    def flatten(self, strategy: str, local_ids: np.ndarray | None = None) -> TreeTables:
+        """The tables the split flattened on the device (same bits as ``TreeArrays.flatten``)."""
+        if strategy not in STRATEGIES:
+            msg = f"Invalid weighting strategy selected: '{strategy}'"
+            raise ValueError(msg)
+        if self._tables is None or strategy != self.strategy:
+            return self.to_host().flatten(strategy, local_ids)
+        tree_off, leaf_taxon, adj_depth, adj_val = self._tables
+        n_taxa = self.n_taxa
+        if local_ids is not None:
+            local_ids = np.asarray(local_ids, dtype=np.int32)
+            n_taxa = len(local_ids)
+            if n_taxa != self.n_taxa or not np.array_equal(local_ids, np.arange(n_taxa, dtype=np.int32)):
+                lut = np.zeros(max(self.n_taxa, 1), dtype=np.int32)  # id of this forest -> position in local_ids
+                lut[local_ids] = np.arange(n_taxa, dtype=np.int32)
+                leaf_taxon = lut[leaf_taxon]
+            taxa = [self.name(i) for i in local_ids]
+        else:
+            taxa = self.taxa if self.ids is None else [self.name(i) for i in range(n_taxa)]
+        monotone = (strategy in ("one", "depth", "branch") and bool(self.forest.monotone_flag)
+                    and bool(np.all(self.weights >= 0)))
+        return TreeTables(n_taxa=n_taxa, tree_off=tree_off, leaf_taxon=leaf_taxon, adj_depth=adj_depth,
+                          adj_val=adj_val, tree_w=self.weights.copy(), taxa=taxa, monotone=monotone)
+
+    def split(self, parts: Sequence[np.ndarray], strategy: str | None = None) -> list:
+        """``TreeArrays.split`` on the device (``scs_forest_split``; reference: scs.py:139-155 with
+        :411-455): children stay resident, their tables come back flattened for ``strategy``."""
+        n_parts = len(parts)
+        if n_parts == 0:
+            return []
+        if strategy is None or not resident_split_wanted(self, n_parts):
+            return self.to_host().split(parts)  # (host arrays carry the device on: a big grandchild may return)
+        if strategy not in STRATEGIES:
+            msg = f"Invalid weighting strategy selected: '{strategy}'"
+            raise ValueError(msg)
+        part_of = np.full(max(self.n_taxa, 1), -1, dtype=np.int32)
+        new_id = np.zeros(max(self.n_taxa, 1), dtype=np.int32)
+        parts = [np.ascontiguousarray(p, dtype=np.int32) for p in parts]
+        for c, ids in enumerate(parts):
+            part_of[ids] = c
+            new_id[ids] = np.arange(len(ids), dtype=np.int32)
+        kids = self.forest.split(part_of, new_id, [len(ids) for ids in parts], _STRATEGY_CODE[strategy])
+        out = []
+        for c, (ids, forest) in enumerate(zip(parts, kids)):
+            tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present = forest.tables()
+            child = ResidentArrays(forest, len(ids), tree_w, self.taxa, ids if self.ids is None else self.ids[ids],
+                                   strategy, (tree_off, leaf_taxon, adj_depth, adj_val))
+            child._present = np.flatnonzero(present[: len(ids)]).astype(np.int32)
+            out.append(child)
+        return out
