@@ -171,6 +171,13 @@ int scs_forest_tables_download(scs_ctx *ctx, const scs_forest *forest, int64_t *
                                int32_t *leaf_taxon, int32_t *adj_depth, double *adj_val,
                                int32_t *tree_index, double *tree_w, uint8_t *present);
 
+/* The same arrays WITHOUT a copy: scs_forest_split leaves the children's tables in page-locked
+ * host memory of the context (one device-to-host copy for all parts); the pointers stay valid
+ * until the forest is freed. */
+int scs_forest_tables_host(scs_ctx *ctx, const scs_forest *forest, const int64_t **tree_off,
+                           const int32_t **leaf_taxon, const int32_t **adj_depth, const double **adj_val,
+                           const int32_t **tree_index, const double **tree_w, const uint8_t **present);
+
 /* Node arrays of the trees [t_begin, t_end) to the host (node_off [t_end - t_begin + 1], made
  * relative to the first of them; the other pointers may be null). */
 int scs_forest_download(scs_ctx *ctx, const scs_forest *forest, int32_t t_begin, int32_t t_end,

@@ -225,20 +225,26 @@ class DeviceForest:
                              int(info[c].n_leaves), bool(info[c].monotone)) for c in range(n_parts)]
 
     def tables(self):
-        """``(tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present)`` of a child of ``split``."""
+        """``(tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present)`` of a child of
+        ``split``: read-only views of the page-locked host copy the split left (no further copy; the
+        views keep this forest -- and with it the block -- alive)."""
         m, l = self.n_trees, self.n_leaves
-        tree_off = np.zeros(m + 1, dtype=np.int64)
-        leaf_taxon = np.empty(l, dtype=np.int32)
-        adj_depth = np.empty(l, dtype=np.int32)
-        adj_val = np.empty(l, dtype=np.float64)
-        tree_index = np.empty(m, dtype=np.int32)
-        tree_w = np.empty(m, dtype=np.float64)
-        present = np.zeros(max(self.n_taxa, 1), dtype=np.uint8)
-        nv.check(self.dev._lib.scs_forest_tables_download(
-            self.dev._ctx, self._h, nv.lptr(tree_off), nv.iptr(leaf_taxon) if l else None,
-            nv.iptr(adj_depth) if l else None, nv.dptr(adj_val) if l else None, nv.iptr(tree_index) if m else None,
-            nv.dptr(tree_w) if m else None, present.ctypes.data))
-        return tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present
+        ptrs = [C.c_void_p() for _ in range(7)]
+        nv.check(self.dev._lib.scs_forest_tables_host(self.dev._ctx, self._h, *[C.byref(x) for x in ptrs]))
+
+        def view(ptr, dtype, count):
+            dt = np.dtype(dtype)
+            if count == 0:
+                return np.empty(0, dtype=dt)
+            buf = (C.c_char * (count * dt.itemsize)).from_address(ptr.value)
+            buf._scs_owner = self
+            a = np.frombuffer(buf, dtype=dt, count=count)
+            a.flags.writeable = False
+            return a
+
+        return (view(ptrs[0], np.int64, m + 1), view(ptrs[1], np.int32, l), view(ptrs[2], np.int32, l),
+                view(ptrs[3], np.float64, l), view(ptrs[4], np.int32, m), view(ptrs[5], np.float64, m),
+                view(ptrs[6], np.uint8, max(self.n_taxa, 0)))
 
     def download(self, t_begin: int = 0, t_end: int | None = None):
         """Node arrays of the trees ``[t_begin, t_end)``: ``(node_off, parent, taxon, length, support, weights)``."""

@@ -544,6 +544,48 @@ int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
     return SCS_OK;
 }
 
+int scs_pinned_get(scs_ctx *ctx, size_t bytes, void **out) {
+    if (bytes < 4096) bytes = 4096;
+    for (auto &b : ctx->pinned)
+        if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 65536) {
+            b.in_use = true;
+            *out = b.p;
+            return SCS_OK;
+        }
+    // (sizes in steps of 1/4 octave: the deep recursion asks for a slightly different size every time)
+    size_t cap = 4096;
+    while (cap < bytes) cap += cap / 4 >= 4096 ? cap / 4 : 4096;
+    void *p = nullptr;
+    hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        scs_set_error("cannot pin %zu bytes of host memory: %s", cap, hipGetErrorString(e));
+        return SCS_ENOMEM;
+    }
+    ctx->pinned.push_back({p, cap, true});
+    *out = p;
+    return SCS_OK;
+}
+
+void scs_pinned_release(scs_ctx *ctx, void *p) {
+    if (!p) return;
+    size_t free_bytes = 0;
+    for (auto &b : ctx->pinned) {
+        if (b.p == p) b.in_use = false;
+        if (!b.in_use) free_bytes += b.bytes;
+    }
+    while (free_bytes > SCS_PINNED_KEEP) {
+        size_t pick = ctx->pinned.size();
+        for (size_t i = 0; i < ctx->pinned.size(); ++i)
+            if (!ctx->pinned[i].in_use && (pick == ctx->pinned.size() || ctx->pinned[i].bytes > ctx->pinned[pick].bytes))
+                pick = i;
+        if (pick == ctx->pinned.size()) break;
+        free_bytes -= ctx->pinned[pick].bytes;
+        hipHostFree(ctx->pinned[pick].p);
+        ctx->pinned.erase(ctx->pinned.begin() + pick);
+    }
+}
+
 void scs_block_release(scs_ctx *ctx, void *p) {
     if (!p) return;
     size_t free_bytes = 0;
@@ -582,6 +624,9 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
         if (e) hipEventDestroy(e);
     if (ctx->w_cache) hipFree(ctx->w_cache);
     for (auto &b : ctx->blocks) hipFree(b.p);
+    // (a page-locked block still lent to a forest's host-side tables stays: arrays may still view it)
+    for (auto &b : ctx->pinned)
+        if (!b.in_use) hipHostFree(b.p);
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     for (auto &sl : ctx->small_slots) {
         if (sl.done) hipEventDestroy(sl.done);

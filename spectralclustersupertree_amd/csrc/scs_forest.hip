@@ -35,8 +35,10 @@ namespace {
 struct forest_region {
     scs_ctx *ctx = nullptr;
     std::vector<void *> blocks;
+    void *host_block = nullptr;  // page-locked copy of the children's tables (scs_pinned_get)
     ~forest_region() {
         for (void *p : blocks) scs_block_release(ctx, p);
+        if (host_block) scs_pinned_release(ctx, host_block);
     }
     int alloc(size_t bytes, void **out) {
         SCS_TRY(scs_block_alloc(ctx, bytes, out));
@@ -61,21 +63,33 @@ struct scs_forest {
     int32_t *leaf_taxon = nullptr, *adj_depth = nullptr, *tree_index = nullptr;
     double *adj_val = nullptr;
     unsigned char *present = nullptr;  // [n_taxa]
+    // ... and a copy of them in page-locked host memory (valid as long as the forest lives)
+    const int64_t *h_tree_off = nullptr;
+    const int32_t *h_leaf_taxon = nullptr, *h_adj_depth = nullptr, *h_tree_index = nullptr;
+    const double *h_adj_val = nullptr, *h_weights = nullptr;
+    const unsigned char *h_present = nullptr;
 };
 
 namespace {
 
 constexpr int SPLIT_MAX_PARTS = 8;
-constexpr int SPLIT_THREADS = 128;
+constexpr int SPLIT_THREADS = 64;   // trees per workgroup (one thread each)
+// A workgroup whose 64 trees hold at most this many nodes works on a copy of them in LDS (the
+// deep recursion: thousands of trees of a dozen nodes -- a thread's sweep is a chain of dependent
+// loads, 100 cycles each from LDS against 2 000 from memory: 446 -> ~100 us per split of 5 000
+// trees of 47 nodes); larger trees are walked in place.
+constexpr int SPLIT_CAP = 2304;
+constexpr size_t SPLIT_FILL_LDS = (size_t)SPLIT_CAP * (4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 1) + 64;
 
 struct split_params {
     int32_t n_trees, n_parts, strategy;
+    int32_t tpb;  // trees per workgroup (one thread each; 64 down to 8, so that their nodes fit SPLIT_CAP)
     const int64_t *node_off;
     const int32_t *parent, *taxon;
     const double *length, *support, *weights;
     const int32_t *part_of, *new_id;
-    // scratch, sized like the parent's node arrays
-    int32_t *sub_end, *stk_a, *stk_b, *cdepth;
+    // scratch, sized like the parent's node arrays (used by the workgroups that walk their trees in place)
+    int32_t *stk_a, *stk_b, *stk_c, *cdepth;
     unsigned char *mark;
     double *cval;
     // per (part, tree)
@@ -96,70 +110,88 @@ struct split_params {
 __global__ __launch_bounds__(SPLIT_THREADS) void k_split_count(split_params p) {
     __shared__ int32_t s_last[SPLIT_MAX_PARTS][SPLIT_THREADS];
     __shared__ int32_t s_cnt[SPLIT_MAX_PARTS][SPLIT_THREADS];
-    const int t = blockIdx.x * SPLIT_THREADS + threadIdx.x;
-    if (t >= p.n_trees) return;
+    __shared__ int32_t s_nodes[SPLIT_MAX_PARTS][SPLIT_THREADS];
+    __shared__ int32_t l_par[SPLIT_CAP], l_tax[SPLIT_CAP], l_st[SPLIT_CAP];
+    __shared__ unsigned char l_mk[SPLIT_CAP];
     const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * p.tpb;
+    const int t1 = min(p.n_trees, t0 + p.tpb);
+    const int t = t0 + tid;
     const int np = p.n_parts;
-    const int64_t off = p.node_off[t];
-    const int32_t k = (int32_t)(p.node_off[t + 1] - off);
-    const int32_t *par = p.parent + off, *tax = p.taxon + off;
-    int32_t *se = p.sub_end + off, *st = p.stk_a + off;
-    unsigned char *mk = p.mark + off;
-    for (int b = 0; b < np; ++b) {
-        s_last[b][tid] = 0;
-        s_cnt[b][tid] = 0;
-    }
-    for (int32_t i = 0; i < k; ++i) se[i] = i;
-    for (int32_t i = k - 1; i > 0; --i) {
-        const int32_t q = par[i];
-        if (q < 0 || q >= i) {  // not preorder
-            atomicExch(&p.flags[0], SCS_EINVAL);
-            return;
+    const int64_t n0 = p.node_off[t0], n1 = p.node_off[t1];
+    const bool stage = n1 - n0 <= SPLIT_CAP;
+    if (stage) {
+        for (int i = tid; i < (int)(n1 - n0); i += SPLIT_THREADS) {
+            l_par[i] = p.parent[n0 + i];
+            l_tax[i] = p.taxon[n0 + i];
+            l_mk[i] = 0;
         }
-        if (se[i] > se[q]) se[q] = se[i];
+        __syncthreads();
     }
-    int32_t sp = 0;
-    for (int32_t i = 0; i < k; ++i) {
-        while (sp > 0 && i > se[st[sp - 1]]) --sp;
-        const int32_t x = tax[i];
-        if (x < 0) {
-            st[sp++] = i;
-            continue;
+    if (t < t1) {
+        const int64_t off = p.node_off[t];
+        const int32_t k = (int32_t)(p.node_off[t + 1] - off);
+        const int32_t rel = (int32_t)(off - n0);
+        const int32_t *par = stage ? l_par + rel : p.parent + off;
+        const int32_t *tax = stage ? l_tax + rel : p.taxon + off;
+        int32_t *st = stage ? l_st + rel : p.stk_a + off;
+        unsigned char *mk = stage ? l_mk + rel : p.mark + off;
+        for (int b = 0; b < np; ++b) {
+            s_last[b][tid] = 0;
+            s_cnt[b][tid] = 0;
+            s_nodes[b][tid] = 0;
         }
-        const int32_t pc = p.part_of[x];
-        if (pc < 0) continue;
-        const int32_t xl = s_last[pc][tid] - 1;
-        if (xl >= 0) {
-            // deepest ancestor of i whose index is <= xl: the LCA of xl and i (st[0] = root <= xl)
-            int32_t lo = 0, hi = sp - 1;
-            while (lo < hi) {
-                const int32_t mid = (lo + hi + 1) >> 1;
-                if (st[mid] <= xl) lo = mid;
-                else hi = mid - 1;
+        int32_t sp = 0;
+        bool bad = false;
+        for (int32_t i = 0; i < k; ++i) {
+            const int32_t q = par[i];
+            if (i > 0 && (q < 0 || q >= i)) {  // not preorder
+                bad = true;
+                break;
             }
-            mk[st[lo]] |= (unsigned char)(1u << pc);
+            // the root path of i: the inner nodes still on the stack up to its parent
+            while (sp > 0 && st[sp - 1] != q) --sp;
+            const int32_t x = tax[i];
+            if (x < 0) {
+                st[sp++] = i;
+                continue;
+            }
+            const int32_t pc = p.part_of[x];
+            if (pc < 0) continue;
+            const unsigned char bit = (unsigned char)(1u << pc);
+            const int32_t xl = s_last[pc][tid] - 1;
+            if (xl >= 0 && sp > 0) {
+                // deepest ancestor of i whose index is <= xl: the LCA of xl and i (st[0] = root <= xl)
+                int32_t lo = 0, hi = sp - 1;
+                while (lo < hi) {
+                    const int32_t mid = (lo + hi + 1) >> 1;
+                    if (st[mid] <= xl) lo = mid;
+                    else hi = mid - 1;
+                }
+                const int32_t a = st[lo];
+                const unsigned char old = mk[a];
+                if (!(old & bit)) {
+                    mk[a] = old | bit;
+                    s_nodes[pc][tid] += 1;
+                }
+            }
+            mk[i] |= bit;
+            s_nodes[pc][tid] += 1;
+            s_last[pc][tid] = i + 1;
+            s_cnt[pc][tid] += 1;
         }
-        mk[i] |= (unsigned char)(1u << pc);
-        s_last[pc][tid] = i + 1;
-        s_cnt[pc][tid] += 1;
-    }
-    // nodes a part keeps (a part with fewer than two leaves is dropped: nothing counted)
-    int32_t nodes[SPLIT_MAX_PARTS];
-#pragma unroll
-    for (int b = 0; b < SPLIT_MAX_PARTS; ++b) nodes[b] = 0;
-    for (int32_t i = 0; i < k; ++i) {
-        const unsigned m = mk[i];
-#pragma unroll
-        for (int b = 0; b < SPLIT_MAX_PARTS; ++b) nodes[b] += (int32_t)((m >> b) & 1u);
-    }
-#pragma unroll
-    for (int b = 0; b < SPLIT_MAX_PARTS; ++b) {
-        if (b < np) {
+        if (bad) atomicExch(&p.flags[0], SCS_EINVAL);
+        // (a part with fewer than two leaves of this tree is dropped here: nothing counted)
+        for (int b = 0; b < np; ++b) {
             const int32_t c = s_cnt[b][tid];
-            const bool keep = c >= 2;
+            const bool keep = c >= 2 && !bad;
             p.leaves_cnt[(int64_t)b * p.n_trees + t] = keep ? c : 0;
-            p.nodes_cnt[(int64_t)b * p.n_trees + t] = keep ? nodes[b] : 0;
+            p.nodes_cnt[(int64_t)b * p.n_trees + t] = keep ? s_nodes[b][tid] : 0;
         }
+    }
+    if (stage) {
+        __syncthreads();
+        for (int i = tid; i < (int)(n1 - n0); i += SPLIT_THREADS) p.mark[n0 + i] = l_mk[i];
     }
 }
 
@@ -177,7 +209,7 @@ __global__ __launch_bounds__(1024) void k_split_scan(split_params p) {
     __syncthreads();
     for (int b = 0; b < p.n_parts; ++b) {
         const int32_t *lc = p.leaves_cnt + (int64_t)b * M, *nc = p.nodes_cnt + (int64_t)b * M;
-        const int t0 = tid * per, t1 = min(M, t0 + per);
+        const int t0 = min(M, tid * per), t1 = min(M, t0 + per);
         int64_t a = 0, n = 0, l = 0;
         for (int t = t0; t < t1; ++t) {
             a += lc[t] > 0;
@@ -235,47 +267,82 @@ __global__ __launch_bounds__(1024) void k_split_scan(split_params p) {
 }
 
 __global__ __launch_bounds__(SPLIT_THREADS) void k_split_fill(split_params p) {
-    const int t = blockIdx.x * SPLIT_THREADS + threadIdx.x;
-    if (t >= p.n_trees) return;
-    if (p.flags[0] != 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_fill[];
+    double *l_len = (double *)s_fill, *l_sup = l_len + SPLIT_CAP, *l_cv = l_sup + SPLIT_CAP;
+    int32_t *l_par = (int32_t *)(l_cv + SPLIT_CAP), *l_tax = l_par + SPLIT_CAP, *l_st = l_tax + SPLIT_CAP,
+            *l_sv = l_st + SPLIT_CAP, *l_sj = l_sv + SPLIT_CAP, *l_cd = l_sj + SPLIT_CAP;
+    unsigned char *l_mk = (unsigned char *)(l_cd + SPLIT_CAP);
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * p.tpb;
+    const int t1 = min(p.n_trees, t0 + p.tpb);
+    const int t = t0 + tid;
     const int np = p.n_parts;
     const int M = p.n_trees;
+    const int64_t n0 = p.node_off[t0], n1 = p.node_off[t1];
+    const bool stage = n1 - n0 <= SPLIT_CAP;
+    const bool failed = p.flags[0] != 0;  // (uniform: written by the count kernel only)
+    if (stage && !failed) {
+        for (int i = tid; i < (int)(n1 - n0); i += SPLIT_THREADS) {
+            l_par[i] = p.parent[n0 + i];
+            l_tax[i] = p.taxon[n0 + i];
+            l_len[i] = p.length[n0 + i];
+            l_sup[i] = p.support[n0 + i];
+            l_mk[i] = p.mark[n0 + i];
+        }
+        __syncthreads();
+    }
+    if (t >= t1 || failed) return;
     const int64_t off = p.node_off[t];
     const int32_t k = (int32_t)(p.node_off[t + 1] - off);
-    const int32_t *par = p.parent + off, *tax = p.taxon + off;
-    const double *len = p.length + off, *sup = p.support + off;
-    const int32_t *se = p.sub_end + off;
-    int32_t *sv = p.stk_a + off, *sj = p.stk_b + off;
-    unsigned char *mk = p.mark + off;
+    const int32_t rel = (int32_t)(off - n0);
+    const int32_t *par = stage ? l_par + rel : p.parent + off;
+    const int32_t *tax = stage ? l_tax + rel : p.taxon + off;
+    const double *len = stage ? l_len + rel : p.length + off;
+    const double *sup = stage ? l_sup + rel : p.support + off;
+    const unsigned char *mk = stage ? l_mk + rel : p.mark + off;
+    int32_t *st = stage ? l_st + rel : p.stk_a + off;
+    int32_t *sv = stage ? l_sv + rel : p.stk_b + off;
+    int32_t *sj = stage ? l_sj + rel : p.stk_c + off;
     const double wt = p.weights[t];
+    int64_t tree_base = 0;
     for (int b = 0; b < np; ++b) {
         const int32_t pos = p.tree_pos[(int64_t)b * M + t];
-        if (pos < 0) continue;
+        const int64_t trees_b = p.totals[b * 4 + 0];
+        if (pos < 0) {
+            tree_base += trees_b;
+            continue;
+        }
         const int64_t base = p.node_start[(int64_t)b * M + t];
         int64_t slot = p.leaf_start[(int64_t)b * M + t];
         const int64_t slot_end = slot + p.leaves_cnt[(int64_t)b * M + t];
-        const int64_t tbase = p.totals[b * 4 + 0];  // (unused: kept for symmetry)
-        (void)tbase;
-        // child arrays of this part
-        int64_t tree_base = 0;
-        for (int c = 0; c < b; ++c) tree_base += p.totals[c * 4 + 0];
+        // depth and value of the child's nodes by position (a tree's parts together hold at most k + 1 nodes)
+        int32_t *cd = stage ? l_cd + rel : p.cdepth + base;
+        double *cv = stage ? l_cv + rel : p.cval + base;
         p.c_weights[tree_base + pos] = wt;
         p.c_tree_index[tree_base + pos] = t;
+        tree_base += trees_b;
         unsigned char *present = p.c_present + (int64_t)b * p.present_ld;
-        int32_t vs = 0, j = 0;
+        int32_t sp = 0, vs = 0, j = 0;
         bool first_leaf = true;
         int32_t pend_depth = 0;
         double pend_val = 0.0;
         const unsigned bit = 1u << b;
         for (int32_t v = 0; v < k; ++v) {
-            if (!(mk[v] & bit)) continue;
-            while (vs > 0 && v > se[sv[vs - 1]]) --vs;
+            const int32_t q = par[v];
+            while (sp > 0 && st[sp - 1] != q) {
+                --sp;
+                if (vs > 0 && sv[vs - 1] == st[sp]) --vs;  // a kept ancestor leaves the path
+            }
+            const int32_t x = tax[v];
+            if (!(mk[v] & bit)) {
+                if (x < 0) st[sp++] = v;
+                continue;
+            }
             const int32_t upj = vs > 0 ? sj[vs - 1] : -1;
             const int32_t up = vs > 0 ? sv[vs - 1] : -1;
-            const int32_t x = tax[v];
             const int32_t ctx_ = x >= 0 ? p.new_id[x] : -1;
             double acc = len[v];
-            for (int32_t u = v == 0 ? -1 : par[v]; u >= 0 && u != up; u = par[u])
+            for (int32_t u = v == 0 ? -1 : q; u >= 0 && u != up; u = par[u])
                 if (!isnan(len[u]) && !isnan(acc)) acc = len[u] + acc;
             const double sp_ = sup[v];
             p.c_parent[base + j] = upj;
@@ -284,12 +351,12 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_fill(split_params p) {
             p.c_support[base + j] = sp_;
             // ---- the child's tables, as scs_host_flatten walks the child in preorder
             if (j == 0) {
-                p.cdepth[base] = 0;
-                p.cval[base] = 0.0;
+                cd[0] = 0;
+                cv[0] = 0.0;
             } else {
                 if (j != upj + 1) {  // not the first child: the next leaf's LCA with the previous one is upj
-                    pend_depth = p.cdepth[base + upj];
-                    pend_val = p.cval[base + upj];
+                    pend_depth = cd[upj];
+                    pend_val = cv[upj];
                 }
                 if (x >= 0) {
                     if (!first_leaf) {
@@ -301,7 +368,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_fill(split_params p) {
                     ++slot;
                     present[ctx_] = 1;
                 } else {
-                    const double pv = p.cval[base + upj];
+                    const double pv = cv[upj];
                     double val;
                     switch (p.strategy) {
                         case 0:
@@ -317,17 +384,18 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_fill(split_params p) {
                         default:
                             val = sp_;
                             if (isnan(val)) {
-                                // (every internal node of a restricted tree has two or more children)
+                                // (every inner node of a restricted tree has two or more children)
                                 atomicExch(&p.flags[0], -3);
                                 val = 0.0;
                             }
                             break;
                     }
-                    p.cdepth[base + j] = p.cdepth[base + upj] + 1;
-                    p.cval[base + j] = val;
+                    cd[j] = cd[upj] + 1;
+                    cv[j] = val;
                 }
             }
             if (x < 0) {
+                st[sp++] = v;
                 sv[vs] = v;
                 sj[vs] = j;
                 ++vs;
@@ -339,7 +407,6 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_fill(split_params p) {
         p.c_adj_depth[slot_end - 1] = 0;
         p.c_adj_val[slot_end - 1] = 0.0;
     }
-    for (int32_t v = 0; v < k; ++v) mk[v] = 0;  // the marks are clean for the next split
 }
 
 }  // namespace
@@ -399,10 +466,11 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int M = f->n_trees;
-    const int64_t N = f->n_nodes, L = f->n_leaves;
+    const int64_t N = f->n_nodes, L = std::max<int64_t>(f->n_leaves, 1);
+    const int32_t T = f->n_taxa;
     for (int b = 0; b < n_parts; ++b) {
         out_forests[b] = nullptr;
-        SCS_REQUIRE(part_taxa[b] >= 0 && part_taxa[b] <= f->n_taxa, "scs_forest_split: bad taxon count of part %d", b);
+        SCS_REQUIRE(part_taxa[b] >= 0 && part_taxa[b] <= T, "scs_forest_split: bad taxon count of part %d", b);
     }
 
     // scratch of this call (returned to the context's block cache at the end)
@@ -432,63 +500,87 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
     p.length = f->length;
     p.support = f->support;
     p.weights = f->weights;
-    int32_t *d_part_of = nullptr, *d_new_id = nullptr;
-    SCS_TRY(scratch.alloc((size_t)f->n_taxa * 4, (void **)&d_part_of));
-    SCS_TRY(scratch.alloc((size_t)f->n_taxa * 4, (void **)&d_new_id));
-    SCS_HIP_CHECK(hipMemcpyAsync(d_part_of, part_of, (size_t)f->n_taxa * 4, hipMemcpyHostToDevice, s));
-    SCS_HIP_CHECK(hipMemcpyAsync(d_new_id, new_id, (size_t)f->n_taxa * 4, hipMemcpyHostToDevice, s));
-    p.part_of = d_part_of;
-    p.new_id = d_new_id;
-    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.sub_end));
+    // ---- inputs: [flags (16 ints) | part_of | new_id] in ONE copy
+    const size_t in_ints = 16 + 2 * (size_t)T;
+    int32_t *d_in = nullptr;
+    SCS_TRY(scratch.alloc(in_ints * 4, (void **)&d_in));
+    {
+        std::vector<int32_t> h_in(in_ints, 0);
+        for (int b = 0; b < SPLIT_MAX_PARTS; ++b) h_in[1 + b] = 1;  // monotone until a negative length is met
+        memcpy(h_in.data() + 16, part_of, (size_t)T * 4);
+        memcpy(h_in.data() + 16 + T, new_id, (size_t)T * 4);
+        // (a pageable source is staged by the runtime before the call returns)
+        SCS_HIP_CHECK(hipMemcpyAsync(d_in, h_in.data(), in_ints * 4, hipMemcpyHostToDevice, s));
+    }
+    p.flags = d_in;
+    p.part_of = d_in + 16;
+    p.new_id = d_in + 16 + T;
+    // ---- scratch the size of the parent (only workgroups whose trees do not fit the LDS use it)
     SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_a));
     SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_b));
+    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_c));
     SCS_TRY(scratch.alloc((size_t)N, (void **)&p.mark));
     SCS_HIP_CHECK(hipMemsetAsync(p.mark, 0, (size_t)N, s));
     const size_t pm = (size_t)n_parts * M;
-    SCS_TRY(scratch.alloc(pm * 4, (void **)&p.leaves_cnt));
-    SCS_TRY(scratch.alloc(pm * 4, (void **)&p.nodes_cnt));
-    SCS_TRY(scratch.alloc(pm * 4, (void **)&p.tree_pos));
-    SCS_TRY(scratch.alloc(pm * 8, (void **)&p.node_start));
-    SCS_TRY(scratch.alloc(pm * 8, (void **)&p.leaf_start));
-    SCS_TRY(scratch.alloc((size_t)n_parts * 4 * 8, (void **)&p.totals));
-    SCS_TRY(scratch.alloc((size_t)(1 + SPLIT_MAX_PARTS) * 4, (void **)&p.flags));
     {
-        int32_t h_flags[1 + SPLIT_MAX_PARTS];
-        h_flags[0] = 0;
-        for (int b = 0; b < SPLIT_MAX_PARTS; ++b) h_flags[1 + b] = 1;
-        // (pageable sources: the runtime stages them before the call returns)
-        SCS_HIP_CHECK(hipMemcpyAsync(p.flags, h_flags, sizeof(h_flags), hipMemcpyHostToDevice, s));
+        // leaves_cnt | nodes_cnt | tree_pos (int32) then node_start | leaf_start (int64): one block
+        unsigned char *blk = nullptr;
+        SCS_TRY(scratch.alloc(pm * (3 * 4 + 2 * 8) + 64, (void **)&blk));
+        p.node_start = (int64_t *)blk;
+        p.leaf_start = p.node_start + pm;
+        p.leaves_cnt = (int32_t *)(p.leaf_start + pm);
+        p.nodes_cnt = p.leaves_cnt + pm;
+        p.tree_pos = p.nodes_cnt + pm;
     }
-    // the children's arrays: together the parts of a tree hold its leaves once and at most
+    // ---- the children's node arrays: together the parts of a tree hold its leaves once and at most
     // leaves - 1 LCAs between them (an inner node of the parent may be kept by several parts)
     const int64_t NC = std::max<int64_t>(2 * L, 2);
     SCS_TRY(scratch.alloc((size_t)NC * 4, (void **)&p.cdepth));
     SCS_TRY(scratch.alloc((size_t)NC * 8, (void **)&p.cval));
     SCS_TRY(region->alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_node_off));
-    SCS_TRY(region->alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_tree_off));
     SCS_TRY(region->alloc((size_t)NC * 4, (void **)&p.c_parent));
     SCS_TRY(region->alloc((size_t)NC * 4, (void **)&p.c_taxon));
     SCS_TRY(region->alloc((size_t)NC * 8, (void **)&p.c_length));
     SCS_TRY(region->alloc((size_t)NC * 8, (void **)&p.c_support));
-    SCS_TRY(region->alloc(pm * 8, (void **)&p.c_weights));
-    SCS_TRY(region->alloc(pm * 4, (void **)&p.c_tree_index));
-    SCS_TRY(region->alloc((size_t)std::max<int64_t>(L, 1) * 4, (void **)&p.c_leaf_taxon));
-    SCS_TRY(region->alloc((size_t)std::max<int64_t>(L, 1) * 4, (void **)&p.c_adj_depth));
-    SCS_TRY(region->alloc((size_t)std::max<int64_t>(L, 1) * 8, (void **)&p.c_adj_val));
-    p.present_ld = f->n_taxa;
-    SCS_TRY(region->alloc((size_t)n_parts * f->n_taxa, (void **)&p.c_present));
-    SCS_HIP_CHECK(hipMemsetAsync(p.c_present, 0, (size_t)n_parts * f->n_taxa, s));
+    // ---- everything the host wants back in ONE block (one copy to a page-locked twin of it):
+    //   totals [n_parts][4] i64 | tree_off [n_parts][M + 1] i64 | weights [n_parts M] f64 | adj_val [L] f64 |
+    //   tree_index [n_parts M] i32 | leaf_taxon [L] i32 | adj_depth [L] i32 | flags copy [16] i32 | present [n_parts][T] u8
+    const size_t o_tot = 0, o_toff = o_tot + (size_t)n_parts * 4 * 8, o_w = o_toff + (size_t)n_parts * (M + 1) * 8,
+                 o_aval = o_w + pm * 8, o_tidx = o_aval + (size_t)L * 8, o_ltax = o_tidx + pm * 4,
+                 o_adep = o_ltax + (size_t)L * 4, o_flags = o_adep + (size_t)L * 4, o_pres = o_flags + 64,
+                 out_bytes = (o_pres + (size_t)n_parts * T + 15) / 16 * 16;
+    unsigned char *d_out = nullptr;
+    SCS_TRY(region->alloc(out_bytes, (void **)&d_out));
+    p.totals = (int64_t *)(d_out + o_tot);
+    p.c_tree_off = (int64_t *)(d_out + o_toff);
+    p.c_weights = (double *)(d_out + o_w);
+    p.c_adj_val = (double *)(d_out + o_aval);
+    p.c_tree_index = (int32_t *)(d_out + o_tidx);
+    p.c_leaf_taxon = (int32_t *)(d_out + o_ltax);
+    p.c_adj_depth = (int32_t *)(d_out + o_adep);
+    p.c_present = d_out + o_pres;
+    p.present_ld = T;
+    SCS_HIP_CHECK(hipMemsetAsync(p.c_present, 0, (size_t)n_parts * T, s));
 
-    const unsigned grid = (unsigned)((M + SPLIT_THREADS - 1) / SPLIT_THREADS);
+    // trees per workgroup: as many as keep the workgroup's nodes inside the LDS copy
+    int tpb = SPLIT_THREADS;
+    while (tpb > 8 && (double)N / M * tpb > 0.85 * SPLIT_CAP) tpb >>= 1;
+    p.tpb = tpb;
+    const unsigned grid = (unsigned)((M + tpb - 1) / tpb);
+    SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_split_fill, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)SPLIT_FILL_LDS));
     k_split_count<<<grid, SPLIT_THREADS, 0, s>>>(p);
     k_split_scan<<<1, 1024, 0, s>>>(p);
-    k_split_fill<<<grid, SPLIT_THREADS, 0, s>>>(p);
+    k_split_fill<<<grid, SPLIT_THREADS, SPLIT_FILL_LDS, s>>>(p);
     SCS_HIP_CHECK(hipGetLastError());
-    int64_t h_tot[SPLIT_MAX_PARTS * 4];
-    int32_t h_flags[1 + SPLIT_MAX_PARTS];
-    SCS_HIP_CHECK(hipMemcpyAsync(h_tot, p.totals, (size_t)n_parts * 4 * 8, hipMemcpyDeviceToHost, s));
-    SCS_HIP_CHECK(hipMemcpyAsync(h_flags, p.flags, sizeof(h_flags), hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(d_out + o_flags, p.flags, 64, hipMemcpyDeviceToDevice, s));
+    unsigned char *h_out = nullptr;
+    SCS_TRY(scs_pinned_get(ctx, out_bytes, (void **)&h_out));
+    region->host_block = h_out;
+    SCS_HIP_CHECK(hipMemcpyAsync(h_out, d_out, out_bytes, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t *h_tot = (const int64_t *)(h_out + o_tot);
+    const int32_t *h_flags = (const int32_t *)(h_out + o_flags);
     if (h_flags[0] == -3) {
         scs_set_error("scs_forest_split: an internal node without support under the bootstrap weighting");
         return SCS_EUNSUP;
@@ -520,6 +612,13 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
         c->adj_val = p.c_adj_val + leaf_base;
         c->present = p.c_present + (int64_t)b * p.present_ld;
         c->has_tables = true;
+        c->h_tree_off = (const int64_t *)(h_out + o_toff) + (int64_t)b * (M + 1);
+        c->h_weights = (const double *)(h_out + o_w) + tree_base;
+        c->h_tree_index = (const int32_t *)(h_out + o_tidx) + tree_base;
+        c->h_leaf_taxon = (const int32_t *)(h_out + o_ltax) + leaf_base;
+        c->h_adj_depth = (const int32_t *)(h_out + o_adep) + leaf_base;
+        c->h_adj_val = (const double *)(h_out + o_aval) + leaf_base;
+        c->h_present = h_out + o_pres + (int64_t)b * T;
         info[b].n_trees = (int32_t)trees;
         info[b].monotone = h_flags[1 + b];
         info[b].n_nodes = nodes;
@@ -528,6 +627,23 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
         tree_base += trees;
         leaf_base += leaves;
     }
+    return SCS_OK;
+}
+
+extern "C" int scs_forest_tables_host(scs_ctx *ctx, const scs_forest *f, const int64_t **tree_off,
+                                      const int32_t **leaf_taxon, const int32_t **adj_depth,
+                                      const double **adj_val, const int32_t **tree_index,
+                                      const double **tree_w, const uint8_t **present) {
+    SCS_REQUIRE(ctx && f && tree_off && leaf_taxon && adj_depth && adj_val && tree_index && tree_w && present,
+                "scs_forest_tables_host: null argument");
+    SCS_REQUIRE(f->has_tables && f->h_tree_off, "scs_forest_tables_host: only the children of scs_forest_split carry tables");
+    *tree_off = f->h_tree_off;
+    *leaf_taxon = f->h_leaf_taxon;
+    *adj_depth = f->h_adj_depth;
+    *adj_val = f->h_adj_val;
+    *tree_index = f->h_tree_index;
+    *tree_w = f->h_weights;
+    *present = f->h_present;
     return SCS_OK;
 }
 

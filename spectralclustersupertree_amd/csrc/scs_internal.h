@@ -49,12 +49,16 @@ constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_
 // tables are 0.3 GB at 10 000 leaves and 0.6 GB from 50 000 on: kept -- a hipFree / hipMalloc pair of that
 // size cost 0.4 ms of every 21 ms step; the workspace of a memory-bound job, tens of GB, is not)
 constexpr size_t SCS_SCRATCH_KEEP = (size_t)1 << 30;
+constexpr size_t SCS_PINNED_KEEP = (size_t)2 << 30;  // free page-locked host blocks kept per context
 constexpr size_t SCS_BLOCK_KEEP = (size_t)32 << 30;  // free cached blocks kept per context (of 288 GB)
 
 struct scs_ctx;
 // cached device blocks of a context (scs_ctx.hip)
 int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out);
 void scs_block_release(scs_ctx *ctx, void *p);
+// cached page-locked host blocks of a context (scs_ctx.hip): the download side of scs_forest_split
+int scs_pinned_get(scs_ctx *ctx, size_t bytes, void **out);
+void scs_pinned_release(scs_ctx *ctx, void *p);
 
 // ---- communicator -----------------------------------------------------------
 struct scs_local_group;  // in-process barrier + exchange slots
@@ -115,6 +119,7 @@ struct scs_ctx {
         bool in_use;
     };
     std::vector<cached_block> blocks;
+    std::vector<cached_block> pinned;  // page-locked host blocks (scs_pinned_get), at most SCS_PINNED_KEEP free
     std::vector<hipEvent_t> event_pool;  // events of the timed SYMM launches, reused
     // staging of scs_small_solve (one pinned host block, one device block), grown on demand
     unsigned *h_flags = nullptr;  // 64 pinned bytes: results of device-side argument checks

@@ -362,7 +362,12 @@ def resident_split_wanted(forest, n_parts: int) -> bool:
     if n_parts > 8 or forest.n_trees == 0:
         return False
     n_nodes = forest.n_nodes if isinstance(forest, ResidentArrays) else len(forest.parent)
-    return n_nodes >= int(os.environ.get("SCS_DEVICE_SPLIT_MIN_NODES", "20000") or 0)
+    if n_nodes < int(os.environ.get("SCS_DEVICE_SPLIT_MIN_NODES", "20000") or 0):
+        return False
+    # one thread walks a tree: that pays while a workgroup's trees fit its LDS copy (up to ~280 nodes a
+    # tree); the host's sweep (3-4 ns per node on a many-core box) is faster on big trees (measured:
+    # tools/forest_split_bench.py, profiles/r05_forest_split.txt)
+    return n_nodes <= forest.n_trees * int(os.environ.get("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "280") or 0)
 
 
 class ResidentArrays:

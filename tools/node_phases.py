@@ -6,7 +6,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import numpy as np
 from spectralclustersupertree_amd import scs, synthetic, kmeans2, flatten as fl
-from spectralclustersupertree_amd.treearrays import TreeArrays
+from spectralclustersupertree_amd.treearrays import ResidentArrays, TreeArrays
 from spectralclustersupertree_amd.backend import Device
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
@@ -29,6 +29,9 @@ def timed(name, fn):
 TreeArrays.split = timed("split", TreeArrays.split)
 TreeArrays.flatten = timed("flatten", TreeArrays.flatten)
 TreeArrays.present_taxa = timed("present_taxa", TreeArrays.present_taxa)
+ResidentArrays.split = timed("split(device)", ResidentArrays.split)
+ResidentArrays.flatten = timed("flatten(device child)", ResidentArrays.flatten)
+ResidentArrays.from_host = timed("forest upload", ResidentArrays.from_host)
 fl.pcg_components = timed("pcg_components", fl.pcg_components)
 scs.prepare_node = timed("prepare_node", scs.prepare_node)
 Device.small_solve = timed("small_solve", Device.small_solve)
