@@ -57,6 +57,7 @@ struct scs_forest {
     int32_t *parent = nullptr, *taxon = nullptr;
     double *length = nullptr, *support = nullptr;
     double *weights = nullptr;  // [n_trees]
+    mutable int32_t *tree_id = nullptr;  // [n_nodes] tree of a node (made on first use by the node-parallel split)
     // children of a split also carry their flattened tables
     bool has_tables = false;
     int64_t *tree_off = nullptr;  // [n_trees + 1]
@@ -409,6 +410,363 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_fill(split_params p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Big trees: parallel WITHIN the tree (round 5).  One thread per tree leaves a forest of a few
+// thousand trees of 10^5 nodes each to a few dozen waves that walk them alone (8-15 ns per node,
+// slower than the host's team).  Every step of the restriction can be told per NODE instead:
+//   * the previous leaf of the same part (exclusive max-scan of "my index if I am a leaf of part b");
+//   * the LCA of two consecutive leaves x < y of a part = the first ancestor of y whose index is <= x
+//     (walk up from y: consecutive leaves meet low in the tree) -- it is marked, as are the leaves;
+//   * positions in the child = exclusive sum-scan of the marks; a kept node's parent in the child = its
+//     first marked ancestor, the merged length folded on the way up (the chains of spliced nodes
+//     are disjoint: linear work in all);
+//   * depth and strategy value of a kept inner node from ITS OWN root path in the child (collected
+//     walking up, summed top-down in the host's order of additions -- same bits; the paths of a
+//     balanced tree are a few dozen nodes; a path longer than PAR_PATH sends the call back to the
+//     one-thread-per-tree kernels);
+//   * a leaf's table entries from the walk to the LCA with its predecessor.
+// Launches over all nodes of the forest, coalesced where the tree allows; ~30 launches a split.
+constexpr int PAR_PATH = 192;
+
+enum { SCAN_SUM = 0, SCAN_MAX = 1 };
+
+template <int OP>
+__device__ __forceinline__ int32_t scan_op(int32_t a, int32_t b) {
+    return OP == SCAN_SUM ? a + b : (a > b ? a : b);
+}
+
+// out[i] = op over in(j), j < i (exclusive), i in [0, n]; in(n) is never read.  4096 items per workgroup.
+template <int OP, typename F>
+__global__ __launch_bounds__(256) void k_scan_local(F in, int32_t *__restrict__ out, int64_t n, int32_t ident,
+                                                     int32_t *__restrict__ block_sums) {
+    __shared__ int32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * 4096 + (int64_t)tid * 16;
+    int32_t v[16];
+    int32_t run = ident;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t i = base + k;
+        const int32_t x = i < n ? in(i) : ident;
+        v[k] = run;  // exclusive within the thread
+        run = scan_op<OP>(run, x);
+    }
+    // exclusive scan of the threads' totals within the wave
+    int32_t incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl = scan_op<OP>(o, incl);
+    }
+    int32_t excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = ident;
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int32_t wbase = ident;
+    for (int w = 0; w < wave; ++w) wbase = scan_op<OP>(wbase, s_w[w]);
+    const int32_t tbase = scan_op<OP>(wbase, excl);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t i = base + k;
+        if (i <= n) out[i] = scan_op<OP>(tbase, v[k]);
+    }
+    if (tid == 255) block_sums[blockIdx.x] = scan_op<OP>(wbase, incl);
+}
+
+template <int OP>
+__global__ __launch_bounds__(1024) void k_scan_blocks(int32_t *__restrict__ block_sums, int64_t n_blocks, int32_t ident) {
+    __shared__ int32_t s[1024];
+    __shared__ int32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = ident;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+        const int64_t i = b0 + tid;
+        const int32_t x = i < n_blocks ? block_sums[i] : ident;
+        s[tid] = x;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            int32_t o = ident;
+            if (tid >= d) o = s[tid - d];
+            __syncthreads();
+            s[tid] = scan_op<OP>(o, s[tid]);
+            __syncthreads();
+        }
+        const int32_t carry = s_carry;
+        const int32_t incl = s[tid];
+        if (i < n_blocks) block_sums[i] = scan_op<OP>(carry, tid > 0 ? s[tid - 1] : ident);  // exclusive
+        __syncthreads();
+        if (tid == 1023) s_carry = scan_op<OP>(carry, incl);
+        __syncthreads();
+    }
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_scan_add(int32_t *__restrict__ out, int64_t n, const int32_t *__restrict__ block_sums) {
+    const int64_t i0 = (int64_t)blockIdx.x * 4096;
+    const int32_t b = block_sums[blockIdx.x];
+    for (int k = threadIdx.x; k < 4096; k += 256) {
+        const int64_t i = i0 + k;
+        if (i <= n) out[i] = scan_op<OP>(b, out[i]);
+    }
+}
+
+template <int OP, typename F>
+static int scan_exclusive(F in, int32_t *out, int64_t n, int32_t ident, int32_t *block_sums, hipStream_t s) {
+    const int64_t nb = (n + 1 + 4095) / 4096;  // (entry n = the total)
+    k_scan_local<OP, F><<<(unsigned)nb, 256, 0, s>>>(in, out, n, ident, block_sums);
+    if (nb > 1) {
+        k_scan_blocks<OP><<<1, 1024, 0, s>>>(block_sums, nb, ident);
+        k_scan_add<OP><<<(unsigned)nb, 256, 0, s>>>(out, n, block_sums);
+    }
+    SCS_HIP_CHECK(hipGetLastError());
+    return SCS_OK;
+}
+
+struct par_params {
+    int32_t n_trees, n_parts, strategy, n_taxa;
+    int64_t n_nodes;
+    const int64_t *node_off;
+    const int32_t *parent, *taxon, *tree_id;
+    const double *length, *support, *weights;
+    const int32_t *part_of, *new_id;
+    signed char *pc;        // [N] part of a leaf, -1
+    int32_t *prev;          // [np][N + 1] previous leaf of the part (global index), -1
+    int32_t *rank;          // [np][N + 1] leaves of the part before this node, in kept trees only (after the second scan)
+    unsigned char *mark;    // [np][N]
+    int32_t *kpos;          // [np][N + 1] position in the child (all parts' children: per part from 0)
+    unsigned char *keep;    // [np][M]
+    int32_t *corig;         // [NC] original node of a child position (per part at node_base)
+    int32_t *cdepth;
+    double *cval;
+    // the same per-(part, tree) arrays and outputs as the serial path
+    int32_t *leaves_cnt, *nodes_cnt, *tree_pos;
+    int64_t *node_start, *leaf_start, *totals;
+    int64_t *c_node_off, *c_tree_off;
+    int32_t *c_parent, *c_taxon, *c_tree_index, *c_tree_id;
+    double *c_length, *c_support, *c_weights;
+    int32_t *c_leaf_taxon, *c_adj_depth;
+    double *c_adj_val;
+    unsigned char *c_present;
+    int32_t present_ld;
+    int32_t *flags;  // [0] error, [1 + b] monotone, [9] path overflow
+};
+
+struct f_key {
+    const signed char *pc;
+    int b;
+    __device__ int32_t operator()(int64_t i) const { return pc[i] == b ? (int32_t)i : -1; }
+};
+struct f_ind {
+    const signed char *pc;
+    int b;
+    __device__ int32_t operator()(int64_t i) const { return pc[i] == b ? 1 : 0; }
+};
+struct f_ind_kept {
+    const signed char *pc;
+    const unsigned char *keep;
+    const int32_t *tree_id;
+    int b;
+    __device__ int32_t operator()(int64_t i) const { return (pc[i] == b && keep[tree_id[i]]) ? 1 : 0; }
+};
+struct f_mark {
+    const unsigned char *mark;
+    __device__ int32_t operator()(int64_t i) const { return mark[i]; }
+};
+
+__global__ void k_par_tree_id(const int64_t *__restrict__ node_off, int32_t n_trees, int64_t n, int32_t *__restrict__ tree_id) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t lo = 0, hi = n_trees - 1;  // last t with node_off[t] <= i
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (node_off[mid] <= i) lo = mid;
+        else hi = mid - 1;
+    }
+    tree_id[i] = lo;
+}
+
+__global__ void k_par_pc(par_params p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_nodes) return;
+    const int32_t x = p.taxon[i];
+    p.pc[i] = x >= 0 ? (signed char)p.part_of[x] : (signed char)-1;
+    const int64_t t0 = p.node_off[p.tree_id[i]];
+    const int32_t q = p.parent[i];
+    if (i > t0 && (q < 0 || q >= i - t0)) atomicExch(&p.flags[0], SCS_EINVAL);  // not preorder
+}
+
+// per (part, tree): leaves of the part, kept or dropped
+__global__ void k_par_keep(par_params p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n_trees) return;
+    for (int b = 0; b < p.n_parts; ++b) {
+        const int32_t *r = p.rank + (int64_t)b * (p.n_nodes + 1);
+        const int32_t c = r[p.node_off[t + 1]] - r[p.node_off[t]];
+        p.keep[(int64_t)b * p.n_trees + t] = c >= 2;
+        p.leaves_cnt[(int64_t)b * p.n_trees + t] = c >= 2 ? c : 0;
+    }
+}
+
+// every leaf of a part marks itself and the LCA with the part's previous leaf in the tree
+__global__ void k_par_mark(par_params p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_nodes) return;
+    const int b = p.pc[i];
+    if (b < 0) return;
+    const int32_t t = p.tree_id[i];
+    if (!p.keep[(int64_t)b * p.n_trees + t]) return;
+    unsigned char *mk = p.mark + (int64_t)b * p.n_nodes;
+    mk[i] = 1;
+    const int64_t t0 = p.node_off[t];
+    const int64_t x = p.prev[(int64_t)b * (p.n_nodes + 1) + i];
+    if (x < t0) return;  // the part's first leaf in this tree
+    int64_t u = t0 + p.parent[i];
+    while (u > x) u = t0 + p.parent[u];
+    mk[u] = 1;
+}
+
+// per (part, tree): nodes of the child tree
+__global__ void k_par_nodes(par_params p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n_trees) return;
+    for (int b = 0; b < p.n_parts; ++b) {
+        const int32_t *kp = p.kpos + (int64_t)b * (p.n_nodes + 1);
+        p.nodes_cnt[(int64_t)b * p.n_trees + t] = kp[p.node_off[t + 1]] - kp[p.node_off[t]];
+    }
+}
+
+// every kept node: its parent in the child, the merged length, its place
+__global__ void k_par_nodes_fill(par_params p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_nodes) return;
+    const int32_t t = p.tree_id[i];
+    const int64_t t0 = p.node_off[t];
+    const int32_t x = p.taxon[i];
+    for (int b = 0; b < p.n_parts; ++b) {
+        const unsigned char *mk = p.mark + (int64_t)b * p.n_nodes;
+        if (!mk[i]) continue;
+        const int32_t *kp = p.kpos + (int64_t)b * (p.n_nodes + 1);
+        const int64_t node_base = p.totals[b * 4 + 3];
+        const int64_t j = node_base + kp[i];
+        double acc = p.length[i];
+        int64_t u = i == t0 ? -1 : t0 + p.parent[i];
+        while (u >= 0 && !mk[u]) {
+            const double lu = p.length[u];
+            if (!isnan(lu) && !isnan(acc)) acc = lu + acc;
+            u = u == t0 ? -1 : t0 + p.parent[u];
+        }
+        p.c_parent[j] = u < 0 ? -1 : kp[u] - kp[t0];
+        p.c_taxon[j] = x >= 0 ? p.new_id[x] : -1;
+        p.c_length[j] = acc;
+        p.c_support[j] = p.support[i];
+        p.c_tree_id[j] = p.tree_pos[(int64_t)b * p.n_trees + t];
+        p.corig[j] = (int32_t)(i - t0);
+        if (x >= 0) p.c_present[(int64_t)b * p.present_ld + p.new_id[x]] = 1;
+    }
+}
+
+// every kept inner node: depth and strategy value from its own root path in the child
+__global__ void k_par_values(par_params p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_nodes) return;
+    if (p.taxon[i] >= 0) return;
+    const int32_t t = p.tree_id[i];
+    const int64_t t0 = p.node_off[t];
+    for (int b = 0; b < p.n_parts; ++b) {
+        if (!p.mark[(int64_t)b * p.n_nodes + i]) continue;
+        const int32_t *kp = p.kpos + (int64_t)b * (p.n_nodes + 1);
+        const int64_t node_base = p.totals[b * 4 + 3];
+        const int64_t c0 = node_base + kp[t0];  // the child tree's root
+        const int64_t j = node_base + kp[i];
+        double path[PAR_PATH];
+        int d = 0;
+        bool overflow = false;
+        for (int64_t q = j; q != c0;) {
+            if (d == PAR_PATH) {
+                overflow = true;
+                break;
+            }
+            path[d++] = p.c_length[q];
+            q = c0 + p.c_parent[q];
+        }
+        if (overflow) {
+            atomicExch(&p.flags[9], 1);
+            continue;
+        }
+        double val = 0.0;
+        switch (p.strategy) {
+            case 0:
+                val = d > 0 ? 1.0 : 0.0;
+                break;
+            case 1:
+                for (int k = 0; k < d; ++k) val = val + 1.0;
+                break;
+            case 2:
+                for (int k = d - 1; k >= 0; --k) {
+                    const double l = path[k];
+                    val = val + (isnan(l) ? 1.0 : l);
+                    if (!isnan(l) && l < 0.0) p.flags[1 + b] = 0;
+                }
+                break;
+            default:
+                val = d > 0 ? p.c_support[j] : 0.0;
+                if (d > 0 && isnan(val)) {
+                    atomicExch(&p.flags[0], -3);
+                    val = 0.0;
+                }
+                break;
+        }
+        p.cdepth[j] = d;
+        p.cval[j] = val;
+    }
+}
+
+// every kept leaf: its slot, and the table entry between its predecessor and itself
+__global__ void k_par_tables(par_params p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_nodes) return;
+    const int b = p.pc[i];
+    if (b < 0) return;
+    const int32_t t = p.tree_id[i];
+    if (!p.keep[(int64_t)b * p.n_trees + t]) return;
+    const int64_t t0 = p.node_off[t], t1 = p.node_off[t + 1];
+    const int32_t *r = p.rank + (int64_t)b * (p.n_nodes + 1);
+    const int32_t *kp = p.kpos + (int64_t)b * (p.n_nodes + 1);
+    int64_t leaf_base = 0;
+    for (int c = 0; c < b; ++c) leaf_base += p.totals[c * 4 + 2];
+    const int64_t slot = leaf_base + r[i];
+    p.c_leaf_taxon[slot] = p.new_id[p.taxon[i]];
+    if (r[i] + 1 == r[t1]) {  // the tree's last leaf of the part: the padding entry
+        p.c_adj_depth[slot] = 0;
+        p.c_adj_val[slot] = 0.0;
+    }
+    const int64_t x = p.prev[(int64_t)b * (p.n_nodes + 1) + i];
+    if (x < t0) return;
+    const int64_t node_base = p.totals[b * 4 + 3];
+    const int64_t c0 = node_base + kp[t0];
+    int64_t q = c0 + p.c_parent[node_base + kp[i]];
+    while (p.corig[q] > (int32_t)(x - t0)) q = c0 + p.c_parent[q];
+    p.c_adj_depth[slot - 1] = p.cdepth[q];
+    p.c_adj_val[slot - 1] = p.cval[q];
+}
+
+// per (part, kept tree): weights and the index in the parent (offsets come from k_split_scan)
+__global__ void k_par_trees(par_params p) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.n_trees) return;
+    int64_t tree_base = 0;
+    for (int b = 0; b < p.n_parts; ++b) {
+        const int32_t pos = p.tree_pos[(int64_t)b * p.n_trees + t];
+        if (pos >= 0) {
+            p.c_weights[tree_base + pos] = p.weights[t];
+            p.c_tree_index[tree_base + pos] = t;
+        }
+        tree_base += p.totals[b * 4 + 0];
+    }
+}
+
 }  // namespace
 
 extern "C" int scs_forest_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, const int64_t *node_off,
@@ -456,9 +814,19 @@ extern "C" int scs_forest_free(scs_ctx *ctx, scs_forest *f) {
     return SCS_OK;
 }
 
+static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of, const int32_t *new_id,
+                        int32_t n_parts, const int32_t *part_taxa, int32_t strategy, scs_forest **out_forests,
+                        scs_forest_info *info, bool force_serial);
+
 extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of, const int32_t *new_id,
                                 int32_t n_parts, const int32_t *part_taxa, int32_t strategy,
                                 scs_forest **out_forests, scs_forest_info *info) {
+    return forest_split(ctx, f, part_of, new_id, n_parts, part_taxa, strategy, out_forests, info, false);
+}
+
+static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of, const int32_t *new_id,
+                        int32_t n_parts, const int32_t *part_taxa, int32_t strategy, scs_forest **out_forests,
+                        scs_forest_info *info, bool force_serial) {
     SCS_REQUIRE(ctx && f && part_of && new_id && part_taxa && out_forests && info, "scs_forest_split: null argument");
     SCS_REQUIRE(n_parts >= 1 && n_parts <= SPLIT_MAX_PARTS, "scs_forest_split: 1 .. %d parts (asked: %d)",
                 SPLIT_MAX_PARTS, n_parts);
@@ -515,12 +883,6 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
     p.flags = d_in;
     p.part_of = d_in + 16;
     p.new_id = d_in + 16 + T;
-    // ---- scratch the size of the parent (only workgroups whose trees do not fit the LDS use it)
-    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_a));
-    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_b));
-    SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_c));
-    SCS_TRY(scratch.alloc((size_t)N, (void **)&p.mark));
-    SCS_HIP_CHECK(hipMemsetAsync(p.mark, 0, (size_t)N, s));
     const size_t pm = (size_t)n_parts * M;
     {
         // leaves_cnt | nodes_cnt | tree_pos (int32) then node_start | leaf_start (int64): one block
@@ -562,17 +924,106 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
     p.present_ld = T;
     SCS_HIP_CHECK(hipMemsetAsync(p.c_present, 0, (size_t)n_parts * T, s));
 
-    // trees per workgroup: as many as keep the workgroup's nodes inside the LDS copy
-    int tpb = SPLIT_THREADS;
-    while (tpb > 8 && (double)N / M * tpb > 0.85 * SPLIT_CAP) tpb >>= 1;
-    p.tpb = tpb;
-    const unsigned grid = (unsigned)((M + tpb - 1) / tpb);
-    SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_split_fill, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)SPLIT_FILL_LDS));
-    k_split_count<<<grid, SPLIT_THREADS, 0, s>>>(p);
-    k_split_scan<<<1, 1024, 0, s>>>(p);
-    k_split_fill<<<grid, SPLIT_THREADS, SPLIT_FILL_LDS, s>>>(p);
-    SCS_HIP_CHECK(hipGetLastError());
+    // Big trees: every step per NODE (scans, walks); small ones: a thread per tree on an LDS copy.
+    const int par_min = getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES") ? atoi(getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES")) : 280;
+    const bool parallel = !force_serial && N < ((int64_t)1 << 31) - 8 && (double)N / M > (double)par_min;
+    int32_t *c_tree_id = nullptr;
+    SCS_TRY(region->alloc((size_t)NC * 4, (void **)&c_tree_id));
+    if (parallel) {
+        par_params q;
+        memset(&q, 0, sizeof(q));
+        q.n_trees = M;
+        q.n_parts = n_parts;
+        q.strategy = strategy;
+        q.n_taxa = T;
+        q.n_nodes = N;
+        q.node_off = f->node_off;
+        q.parent = f->parent;
+        q.taxon = f->taxon;
+        q.length = f->length;
+        q.support = f->support;
+        q.weights = f->weights;
+        q.part_of = p.part_of;
+        q.new_id = p.new_id;
+        q.flags = p.flags;
+        const unsigned gn = (unsigned)((N + 255) / 256), gm = (unsigned)((M + 255) / 256);
+        if (!f->tree_id) {
+            SCS_TRY(f->region->alloc((size_t)N * 4, (void **)&f->tree_id));
+            k_par_tree_id<<<gn, 256, 0, s>>>(f->node_off, M, N, f->tree_id);
+        }
+        q.tree_id = f->tree_id;
+        SCS_TRY(scratch.alloc((size_t)N, (void **)&q.pc));
+        SCS_TRY(scratch.alloc((size_t)n_parts * (N + 1) * 4, (void **)&q.prev));
+        SCS_TRY(scratch.alloc((size_t)n_parts * (N + 1) * 4, (void **)&q.rank));
+        SCS_TRY(scratch.alloc((size_t)n_parts * (N + 1) * 4, (void **)&q.kpos));
+        SCS_TRY(scratch.alloc((size_t)n_parts * N, (void **)&q.mark));
+        SCS_TRY(scratch.alloc((size_t)n_parts * M, (void **)&q.keep));
+        SCS_TRY(scratch.alloc((size_t)NC * 4, (void **)&q.corig));
+        int32_t *block_sums = nullptr;
+        SCS_TRY(scratch.alloc((size_t)((N + 1 + 4095) / 4096 + 1) * 4, (void **)&block_sums));
+        q.cdepth = p.cdepth;
+        q.cval = p.cval;
+        q.leaves_cnt = p.leaves_cnt;
+        q.nodes_cnt = p.nodes_cnt;
+        q.tree_pos = p.tree_pos;
+        q.node_start = p.node_start;
+        q.leaf_start = p.leaf_start;
+        q.totals = p.totals;
+        q.c_node_off = p.c_node_off;
+        q.c_tree_off = p.c_tree_off;
+        q.c_parent = p.c_parent;
+        q.c_taxon = p.c_taxon;
+        q.c_tree_index = p.c_tree_index;
+        q.c_tree_id = c_tree_id;
+        q.c_length = p.c_length;
+        q.c_support = p.c_support;
+        q.c_weights = p.c_weights;
+        q.c_leaf_taxon = p.c_leaf_taxon;
+        q.c_adj_depth = p.c_adj_depth;
+        q.c_adj_val = p.c_adj_val;
+        q.c_present = p.c_present;
+        q.present_ld = T;
+        k_par_pc<<<gn, 256, 0, s>>>(q);
+        for (int b = 0; b < n_parts; ++b) {
+            SCS_TRY((scan_exclusive<SCAN_MAX>(f_key{q.pc, b}, q.prev + (int64_t)b * (N + 1), N, -1, block_sums, s)));
+            SCS_TRY((scan_exclusive<SCAN_SUM>(f_ind{q.pc, b}, q.rank + (int64_t)b * (N + 1), N, 0, block_sums, s)));
+        }
+        k_par_keep<<<gm, 256, 0, s>>>(q);
+        for (int b = 0; b < n_parts; ++b)
+            SCS_TRY((scan_exclusive<SCAN_SUM>(f_ind_kept{q.pc, q.keep + (int64_t)b * M, q.tree_id, b},
+                                              q.rank + (int64_t)b * (N + 1), N, 0, block_sums, s)));
+        SCS_HIP_CHECK(hipMemsetAsync(q.mark, 0, (size_t)n_parts * N, s));
+        k_par_mark<<<gn, 256, 0, s>>>(q);
+        for (int b = 0; b < n_parts; ++b)
+            SCS_TRY((scan_exclusive<SCAN_SUM>(f_mark{q.mark + (int64_t)b * N}, q.kpos + (int64_t)b * (N + 1), N, 0,
+                                              block_sums, s)));
+        k_par_nodes<<<gm, 256, 0, s>>>(q);
+        p.tpb = SPLIT_THREADS;
+        k_split_scan<<<1, 1024, 0, s>>>(p);
+        k_par_nodes_fill<<<gn, 256, 0, s>>>(q);
+        k_par_values<<<gn, 256, 0, s>>>(q);
+        k_par_tables<<<gn, 256, 0, s>>>(q);
+        k_par_trees<<<gm, 256, 0, s>>>(q);
+        SCS_HIP_CHECK(hipGetLastError());
+    } else {
+        // scratch the size of the parent (only workgroups whose trees do not fit the LDS use it)
+        SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_a));
+        SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_b));
+        SCS_TRY(scratch.alloc((size_t)N * 4, (void **)&p.stk_c));
+        SCS_TRY(scratch.alloc((size_t)N, (void **)&p.mark));
+        SCS_HIP_CHECK(hipMemsetAsync(p.mark, 0, (size_t)N, s));
+        // trees per workgroup: as many as keep the workgroup's nodes inside the LDS copy
+        int tpb = SPLIT_THREADS;
+        while (tpb > 8 && (double)N / M * tpb > 0.85 * SPLIT_CAP) tpb >>= 1;
+        p.tpb = tpb;
+        const unsigned grid = (unsigned)((M + tpb - 1) / tpb);
+        SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_split_fill, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)SPLIT_FILL_LDS));
+        k_split_count<<<grid, SPLIT_THREADS, 0, s>>>(p);
+        k_split_scan<<<1, 1024, 0, s>>>(p);
+        k_split_fill<<<grid, SPLIT_THREADS, SPLIT_FILL_LDS, s>>>(p);
+        SCS_HIP_CHECK(hipGetLastError());
+    }
     SCS_HIP_CHECK(hipMemcpyAsync(d_out + o_flags, p.flags, 64, hipMemcpyDeviceToDevice, s));
     unsigned char *h_out = nullptr;
     SCS_TRY(scs_pinned_get(ctx, out_bytes, (void **)&h_out));
@@ -581,6 +1032,11 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
     SCS_HIP_CHECK(hipStreamSynchronize(s));
     const int64_t *h_tot = (const int64_t *)(h_out + o_tot);
     const int32_t *h_flags = (const int32_t *)(h_out + o_flags);
+    if (parallel && h_flags[9]) {
+        // a root path longer than PAR_PATH (a comb): the one-thread-per-tree kernels take this split
+        region.reset();
+        return forest_split(ctx, f, part_of, new_id, n_parts, part_taxa, strategy, out_forests, info, true);
+    }
     if (h_flags[0] == -3) {
         scs_set_error("scs_forest_split: an internal node without support under the bootstrap weighting");
         return SCS_EUNSUP;
@@ -612,6 +1068,7 @@ extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t
         c->adj_val = p.c_adj_val + leaf_base;
         c->present = p.c_present + (int64_t)b * p.present_ld;
         c->has_tables = true;
+        c->tree_id = parallel ? c_tree_id + node_base : nullptr;
         c->h_tree_off = (const int64_t *)(h_out + o_toff) + (int64_t)b * (M + 1);
         c->h_weights = (const double *)(h_out + o_w) + tree_base;
         c->h_tree_index = (const int32_t *)(h_out + o_tidx) + tree_base;

@@ -364,10 +364,10 @@ def resident_split_wanted(forest, n_parts: int) -> bool:
     n_nodes = forest.n_nodes if isinstance(forest, ResidentArrays) else len(forest.parent)
     if n_nodes < int(os.environ.get("SCS_DEVICE_SPLIT_MIN_NODES", "20000") or 0):
         return False
-    # one thread walks a tree: that pays while a workgroup's trees fit its LDS copy (up to ~280 nodes a
-    # tree); the host's sweep (3-4 ns per node on a many-core box) is faster on big trees (measured:
-    # tools/forest_split_bench.py, profiles/r05_forest_split.txt)
-    return n_nodes <= forest.n_trees * int(os.environ.get("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "280") or 0)
+    # (small trees: one thread per tree on an LDS copy; big ones: every step per node -- scs_forest.hip;
+    # SCS_DEVICE_SPLIT_MAX_TREE_NODES keeps forests of bigger trees on the host: measurements)
+    cap = int(os.environ.get("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "0") or 0)
+    return cap <= 0 or n_nodes <= forest.n_trees * cap
 
 
 class ResidentArrays:

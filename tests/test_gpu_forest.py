@@ -25,6 +25,15 @@ def dev():
     d.close()
 
 
+@pytest.fixture(autouse=True, params=["thread per tree", "per node"])
+def split_kernels(request, monkeypatch):
+    """Every test runs through both families of kernels: one thread per tree (small trees; staged in
+    LDS where a workgroup's trees fit) and the node-parallel one (big trees) -- forced here on
+    forests of any size; a comb deeper than its path buffer falls back to the first family."""
+    monkeypatch.setenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES", "1000000000" if request.param == "thread per tree" else "0")
+    return request.param
+
+
 def _same_bits(a: np.ndarray, b: np.ndarray) -> bool:
     return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
 
@@ -87,7 +96,6 @@ def test_device_split_matches_host_split_on_random_forests(dev, monkeypatch, see
     # multifurcations, unary chains, missing lengths, negative lengths (monotone flag), partial
     # coverage, taxa of no part, two to eight parts, two levels
     monkeypatch.setenv("SCS_DEVICE_SPLIT_MIN_NODES", "0")
-    monkeypatch.setenv("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "100000000")
     rng = random.Random(100 + seed)
     taxa, trees, weights = random_forest(seed, 60, 25, neg_len=0.1 if seed % 2 else 0.0)
     arrays = TreeArrays.from_trees(trees, weights, taxa)
@@ -97,7 +105,6 @@ def test_device_split_matches_host_split_on_random_forests(dev, monkeypatch, see
 
 def test_device_split_bootstrap_and_missing_support(dev, monkeypatch):
     monkeypatch.setenv("SCS_DEVICE_SPLIT_MIN_NODES", "0")
-    monkeypatch.setenv("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "100000000")
     rng = random.Random(7)
     taxa, trees, weights = random_forest(3, 50, 12, none_sup=0.0, unary=0.0)
     arrays = TreeArrays.from_trees(trees, weights, taxa)
@@ -113,7 +120,6 @@ def test_device_split_bootstrap_and_missing_support(dev, monkeypatch):
 def test_device_split_of_full_binary_forests_with_weights(dev, monkeypatch):
     # the benchmark's shape in small: every tree over all taxa, per-tree weights, a few levels deep
     monkeypatch.setenv("SCS_DEVICE_SPLIT_MIN_NODES", "0")
-    monkeypatch.setenv("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "100000000")
     arrays = synthetic.tree_arrays(5, 300, 40)
     arrays.weights[:] = np.random.RandomState(1).uniform(0.5, 2.0, arrays.n_trees)
     rng = random.Random(2)
@@ -124,7 +130,6 @@ def test_device_split_deep_caterpillars_and_single_leaf_parts(dev, monkeypatch):
     # a comb of 3 000 leaves (stack depth = tree height), a part that keeps ONE leaf of a tree
     # (dropped there), a part no tree keeps two leaves of (no trees at all)
     monkeypatch.setenv("SCS_DEVICE_SPLIT_MIN_NODES", "0")
-    monkeypatch.setenv("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "100000000")
     from spectralclustersupertree_amd.tree import TreeNode
 
     n = 3000
@@ -150,7 +155,6 @@ def test_whole_recursion_with_the_split_on_the_device(monkeypatch):
     for mode in ("0", "1"):
         monkeypatch.setenv("SCS_DEVICE_SPLIT", mode)
         monkeypatch.setenv("SCS_DEVICE_SPLIT_MIN_NODES", "0")
-        monkeypatch.setenv("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "100000000")
         rs = np.random.RandomState(5)
         tree = scs.construct_supertree(synthetic.tree_arrays(11, 700, 60), pcg_weighting="branch", random_state=rs)
         out[mode] = (tree.get_newick(), rs.randint(1 << 30))
