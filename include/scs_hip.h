@@ -353,6 +353,13 @@ int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
                           const int32_t *leaf_taxon, const int32_t *adj_depth, const double *adj_val,
                           const double *tree_w, const int32_t *group_start, int32_t want_w,
                           int32_t *ticket_out);
+/* scs_small_solve_begin for ONE node whose tables are resident -- a child of scs_forest_split
+ * (declared above): its leaf arrays are packed on the device, only the group boundaries and the
+ * renumbering travel.  relabel[x] (may be null: identity) = id of the forest's taxon x in the node's
+ * numbering (present taxa only, contraction groups consecutive); n_taxa = the node's taxon count. */
+int scs_small_solve_begin_forest(scs_ctx *ctx, const scs_forest *forest, const int32_t *relabel,
+                                 int32_t n_taxa, int32_t n_groups, const int32_t *group_start,
+                                 int32_t want_w, int32_t *ticket_out);
 int scs_small_solve_end(scs_ctx *ctx, int32_t ticket, double *maps_out, double *lambda_out,
                         double *w_out);
 

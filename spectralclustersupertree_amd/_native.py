@@ -152,6 +152,7 @@ SIGNATURES = {
     "scs_small_solve": (C.c_int, [_P, _I32, _IP, _IP, _IP, _IP, _IP, _IP, _DP, _DP, _IP, _DP, _DP, _DP]),
     "scs_small_solve_begin": (C.c_int, [_P, _I32, _IP, _IP, _IP, _IP, _IP, _IP, _DP, _DP, _IP, _I32,
                                         C.POINTER(C.c_int32)]),
+    "scs_small_solve_begin_forest": (C.c_int, [_P, _P, _IP, _I32, _I32, _IP, _I32, _P]),
     "scs_small_solve_end": (C.c_int, [_P, _I32, _DP, _DP, _DP]),
     "scs_debug_jacobi": (C.c_int, [_P, _DP, _I32, _DP, _DP]),
     "scs_debug_gram": (C.c_int, [_P, _DP, _DP, _I32, _I32, _I32, _I32, _DP]),

@@ -19,6 +19,12 @@ DEFAULT_TOL = 1e-13
 DEFAULT_MAX_ITER = 2000
 
 
+def _resident_solve() -> bool:
+    """SCS_RESIDENT_SOLVE=0 (diagnostic): small nodes pack their tables on the host even when the
+    tables are resident on the device."""
+    return bool(int(os.environ.get("SCS_RESIDENT_SOLVE", "1") or 0))
+
+
 class Device:
     """One libscs_hip context.  ``Device()`` = GPU 0, single rank."""
 
@@ -111,6 +117,20 @@ class Device:
         """The same, not waited for (``scs_small_solve_begin``): the returned ticket's
         ``result()`` is the list ``small_solve`` returns.  At least one node."""
         k = len(nodes)
+        if k == 1 and getattr(nodes[0][0], "resident", None) is not None and _resident_solve():
+            forest, relabel = nodes[0][0].resident
+            if forest.dev is self and forest._h:
+                # the node's tables are on this device already (a child of scs_forest_split): only the
+                # group boundaries and the renumbering travel (scs_small_solve_begin_forest)
+                tables, group_start = nodes[0]
+                gs = (np.arange(tables.n_taxa + 1, dtype=np.int32) if group_start is None
+                      else np.ascontiguousarray(group_start, dtype=np.int32))
+                rl = None if relabel is None else np.ascontiguousarray(relabel, dtype=np.int32)
+                ticket = C.c_int32(-1)
+                nv.check(self._lib.scs_small_solve_begin_forest(
+                    self._ctx, forest._h, nv.iptr(rl) if rl is not None else None, int(tables.n_taxa), len(gs) - 1,
+                    nv.iptr(gs), int(want_w), C.byref(ticket)))
+                return SmallTicket(self, ticket.value, np.asarray([len(gs) - 1], dtype=np.int32), want_w, list(nodes))
         n_taxa = np.empty(k, dtype=np.int32)
         n_trees = np.empty(k, dtype=np.int32)
         n_groups = np.empty(k, dtype=np.int32)

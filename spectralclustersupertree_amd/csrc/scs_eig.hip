@@ -2810,6 +2810,32 @@ __global__ __launch_bounds__(256) void k_small_finish_big(small_batch p) {
                                              : (tid < v ? s_norm[s_top[tid]] - 1.0 : 0.0);
 }
 
+// leaf arrays of ONE node straight from a forest's device tables into the batch's device block
+// (taxa renumbered through `relabel` when the node numbers them differently -- present taxa only,
+// contraction groups made consecutive), offsets narrowed to 32 bits
+__global__ void k_small_pack(const int64_t *__restrict__ tree_off64, const int32_t *__restrict__ leaf_taxon,
+                             const int32_t *__restrict__ adj_depth, const double *__restrict__ adj_val,
+                             const double *__restrict__ tree_w, const int32_t *__restrict__ relabel,
+                             int32_t n_trees, int64_t n_leaves, int32_t *__restrict__ to, int32_t *__restrict__ lt,
+                             int32_t *__restrict__ ad, double *__restrict__ av, double *__restrict__ tw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_leaves) {
+        const int32_t x = leaf_taxon[i];
+        lt[i] = relabel ? relabel[x] : x;
+        ad[i] = adj_depth[i];
+        av[i] = adj_val[i];
+    }
+    if (i <= n_trees) to[i] = (int32_t)tree_off64[i];
+    if (i < n_trees) tw[i] = tree_w[i];
+}
+
+static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
+                                  const int32_t *n_trees, const int32_t *n_groups,
+                                  const int32_t *tree_off, const int32_t *leaf_taxon,
+                                  const int32_t *adj_depth, const double *adj_val,
+                                  const double *tree_w, const int32_t *group_start, int32_t want_w,
+                                  int32_t *ticket_out, const scs_forest *src, const int32_t *relabel);
+
 extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
                                      const int32_t *n_trees, const int32_t *n_groups,
                                      const int32_t *tree_off, const int32_t *leaf_taxon,
@@ -2819,6 +2845,29 @@ extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_
     SCS_REQUIRE(ctx && n_taxa && n_trees && n_groups && tree_off && leaf_taxon && adj_depth &&
                     adj_val && tree_w && group_start && ticket_out,
                 "scs_small_solve: null argument");
+    return small_solve_begin_impl(ctx, n_nodes, n_taxa, n_trees, n_groups, tree_off, leaf_taxon, adj_depth, adj_val,
+                                  tree_w, group_start, want_w, ticket_out, nullptr, nullptr);
+}
+
+// ONE node whose tables are resident (a child of scs_forest_split): nothing but the group boundaries
+// and the renumbering travels; the leaf arrays are packed on the device (k_small_pack)
+extern "C" int scs_small_solve_begin_forest(scs_ctx *ctx, const scs_forest *forest, const int32_t *relabel,
+                                            int32_t n_taxa, int32_t n_groups, const int32_t *group_start,
+                                            int32_t want_w, int32_t *ticket_out) {
+    SCS_REQUIRE(ctx && forest && group_start && ticket_out, "scs_small_solve_begin_forest: null argument");
+    SCS_REQUIRE(forest->has_tables, "scs_small_solve_begin_forest: the forest carries no tables (not a child of scs_forest_split)");
+    SCS_REQUIRE(forest->n_leaves <= INT32_MAX, "scs_small_solve_begin_forest: too many leaves");
+    const int32_t n_trees = forest->n_trees;
+    return small_solve_begin_impl(ctx, 1, &n_taxa, &n_trees, &n_groups, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  group_start, want_w, ticket_out, forest, relabel);
+}
+
+static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
+                                  const int32_t *n_trees, const int32_t *n_groups,
+                                  const int32_t *tree_off, const int32_t *leaf_taxon,
+                                  const int32_t *adj_depth, const double *adj_val,
+                                  const double *tree_w, const int32_t *group_start, int32_t want_w,
+                                  int32_t *ticket_out, const scs_forest *src, const int32_t *relabel) {
     const bool w_out = want_w != 0;
     SCS_REQUIRE(n_nodes >= 1, "scs_small_solve: need at least one node");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
@@ -2837,17 +2886,19 @@ extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_
         SCS_REQUIRE(n_groups[k] >= 2 && n_groups[k] <= n_taxa[k], "scs_small_solve: node %d: bad group count %d",
                     k, n_groups[k]);
         SCS_REQUIRE(n_trees[k] >= 1, "scs_small_solve: node %d has no tree", k);
-        const int32_t *to = tree_off + toff_at;
-        SCS_REQUIRE(to[0] == 0, "scs_small_solve: node %d: tree_off must start at 0", k);
-        for (int t = 0; t < n_trees[k]; ++t)
-            SCS_REQUIRE(to[t + 1] >= to[t] && to[t + 1] - to[t] <= n_taxa[k],
-                        "scs_small_solve: node %d tree %d: bad leaf range", k, t);
+        const int32_t *to = src ? nullptr : tree_off + toff_at;
+        if (!src) {
+            SCS_REQUIRE(to[0] == 0, "scs_small_solve: node %d: tree_off must start at 0", k);
+            for (int t = 0; t < n_trees[k]; ++t)
+                SCS_REQUIRE(to[t + 1] >= to[t] && to[t + 1] - to[t] <= n_taxa[k],
+                            "scs_small_solve: node %d tree %d: bad leaf range", k, t);
+        }
         const int32_t *gs = group_start + vertex_ptr[k] + k;
         SCS_REQUIRE(gs[0] == 0 && gs[n_groups[k]] == n_taxa[k], "scs_small_solve: node %d: group_start must span the taxa", k);
         for (int g = 0; g < n_groups[k]; ++g)
             SCS_REQUIRE(gs[g] < gs[g + 1], "scs_small_solve: node %d: empty group %d", k, g);
         tree_ptr[k + 1] = tree_ptr[k] + n_trees[k];
-        leaf_ptr[k + 1] = leaf_ptr[k] + to[n_trees[k]];
+        leaf_ptr[k + 1] = leaf_ptr[k] + (src ? src->n_leaves : (int64_t)to[n_trees[k]]);
         vertex_ptr[k + 1] = vertex_ptr[k] + n_groups[k];
         w_ptr[k + 1] = w_ptr[k] + (int64_t)n_groups[k] * n_groups[k];
         toff_at += n_trees[k] + 1;
@@ -2899,6 +2950,9 @@ extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_
     const size_t o_ad = at; at += up8((size_t)n_leaf * 4);
     const size_t o_av = at; at += (size_t)n_leaf * 8;
     const size_t o_tw = at; at += (size_t)n_tree * 8;
+    // (a resident node: the leaf arrays above are filled on the device; only the header travels --
+    // up to o_to -- and the renumbering behind it)
+    const size_t o_rl = at; if (src && relabel) at += up8((size_t)src->n_taxa * 4);
     const size_t in_bytes = at;
     const size_t o_maps = at; at += (size_t)vertex_ptr[K] * 16;
     const size_t o_lam = at; at += (size_t)K * 24;
@@ -2955,13 +3009,30 @@ extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_
     memcpy(h + o_i1, item_t1.data(), n_items * 4);
     memcpy(h + o_sn, sum_node.data(), n_sums * 4);
     memcpy(h + o_s0, sum_e0.data(), n_sums * 4);
-    memcpy(h + o_to, tree_off, (size_t)n_toff * 4);
     memcpy(h + o_gs, group_start, (size_t)n_gs * 4);
-    memcpy(h + o_lt, leaf_taxon, (size_t)n_leaf * 4);
-    memcpy(h + o_ad, adj_depth, (size_t)n_leaf * 4);
-    memcpy(h + o_av, adj_val, (size_t)n_leaf * 8);
-    memcpy(h + o_tw, tree_w, (size_t)n_tree * 8);
-    SCS_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    if (!src) {
+        memcpy(h + o_to, tree_off, (size_t)n_toff * 4);
+        memcpy(h + o_lt, leaf_taxon, (size_t)n_leaf * 4);
+        memcpy(h + o_ad, adj_depth, (size_t)n_leaf * 4);
+        memcpy(h + o_av, adj_val, (size_t)n_leaf * 8);
+        memcpy(h + o_tw, tree_w, (size_t)n_tree * 8);
+        SCS_HIP_CHECK(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, s));
+    } else {
+        // header and group boundaries (two small pieces around the leaf arrays), the renumbering
+        SCS_HIP_CHECK(hipMemcpyAsync(d, h, o_to, hipMemcpyHostToDevice, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(d + o_gs, h + o_gs, up8((size_t)n_gs * 4), hipMemcpyHostToDevice, s));
+        const int32_t *d_rl = nullptr;
+        if (relabel) {
+            memcpy(h + o_rl, relabel, (size_t)src->n_taxa * 4);
+            SCS_HIP_CHECK(hipMemcpyAsync(d + o_rl, h + o_rl, (size_t)src->n_taxa * 4, hipMemcpyHostToDevice, s));
+            d_rl = (const int32_t *)(d + o_rl);
+        }
+        const int64_t work = std::max<int64_t>(n_leaf, n_tree + 1);
+        k_small_pack<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(
+            src->tree_off, src->leaf_taxon, src->adj_depth, src->adj_val, src->weights, d_rl, (int32_t)n_tree, n_leaf,
+            (int32_t *)(d + o_to), (int32_t *)(d + o_lt), (int32_t *)(d + o_ad), (double *)(d + o_av),
+            (double *)(d + o_tw));
+    }
     small_batch sb;
     sb.n_taxa = (const int32_t *)(d + o_nt);
     sb.n_trees = (const int32_t *)(d + o_nm);

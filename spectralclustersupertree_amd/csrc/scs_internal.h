@@ -184,6 +184,47 @@ struct scs_graph {
     double dd_norm = 0.0;  // ||sqrt(deg)||_2 with isolated rows counted as 1
 };
 
+// ---- source forests in HBM (scs_forest.hip; scs_eig.hip packs a small node's tables from one) ----
+#include <memory>
+// device arrays a split leaves behind for ALL children: one allocation each, children are slices
+struct forest_region {
+    scs_ctx *ctx = nullptr;
+    std::vector<void *> blocks;
+    void *host_block = nullptr;  // page-locked copy of the children's tables (scs_pinned_get)
+    ~forest_region() {
+        for (void *p : blocks) scs_block_release(ctx, p);
+        if (host_block) scs_pinned_release(ctx, host_block);
+    }
+    int alloc(size_t bytes, void **out) {
+        SCS_TRY(scs_block_alloc(ctx, bytes, out));
+        blocks.push_back(*out);
+        return SCS_OK;
+    }
+};
+
+struct scs_forest {
+    int32_t n_taxa = 0, n_trees = 0;
+    int64_t n_nodes = 0, n_leaves = 0;
+    std::shared_ptr<forest_region> region;  // (owner of every pointer below)
+    int64_t *node_off = nullptr;            // [n_trees + 1], relative to this forest's arrays
+    int32_t *parent = nullptr, *taxon = nullptr;
+    double *length = nullptr, *support = nullptr;
+    double *weights = nullptr;  // [n_trees]
+    mutable int32_t *tree_id = nullptr;  // [n_nodes] tree of a node (made on first use by the node-parallel split)
+    // children of a split also carry their flattened tables
+    bool has_tables = false;
+    int64_t *tree_off = nullptr;  // [n_trees + 1]
+    int32_t *leaf_taxon = nullptr, *adj_depth = nullptr, *tree_index = nullptr;
+    double *adj_val = nullptr;
+    unsigned char *present = nullptr;  // [n_taxa]
+    // ... and a copy of them in page-locked host memory (valid as long as the forest lives)
+    const int64_t *h_tree_off = nullptr;
+    const int32_t *h_leaf_taxon = nullptr, *h_adj_depth = nullptr, *h_tree_index = nullptr;
+    const double *h_adj_val = nullptr, *h_weights = nullptr;
+    const unsigned char *h_present = nullptr;
+};
+
+
 // build.hip
 int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g);
 // row splits of every rank (contiguous, ordered by rank): collective, world + 1 entries

@@ -47,6 +47,11 @@ class TreeTables:
     # tree (`one`, `depth`, `branch` without negative internal lengths): lets the device take
     # its cheaper monotone kernel (same bits).  False is always safe.
     monotone: bool = False
+    # (forest, relabel) when these tables are also RESIDENT on the device: `forest` a
+    # backend.DeviceForest (a child of scs_forest_split) whose tables equal these except that its
+    # leaf_taxon[p] maps to ours through relabel (int32 array over the forest's taxa, or None =
+    # identity).  Lets a small node's solve pack its leaf arrays on the device (Device.small_solve_begin).
+    resident: object | None = None
 
     @property
     def n_trees(self) -> int:

@@ -135,6 +135,10 @@ def relabel_for_contraction(tables: fl.TreeTables, groups: np.ndarray):
         taxa=None,
         monotone=tables.monotone,
     )
+    res = getattr(tables, "resident", None)
+    if res is not None:  # the device copy follows: forest id -> node id -> contracted numbering
+        forest, lut = res
+        relabelled.resident = (forest, new_of_old if lut is None else new_of_old[lut].astype(np.int32))
     return relabelled, order.astype(np.int32), group_start
 
 

@@ -449,6 +449,7 @@ class ResidentArrays:
             return self.to_host().flatten(strategy, local_ids)
         tree_off, leaf_taxon, adj_depth, adj_val = self._tables
         n_taxa = self.n_taxa
+        relabel = None
         if local_ids is not None:
             local_ids = np.asarray(local_ids, dtype=np.int32)
             n_taxa = len(local_ids)
@@ -456,13 +457,15 @@ class ResidentArrays:
                 lut = np.zeros(max(self.n_taxa, 1), dtype=np.int32)  # id of this forest -> position in local_ids
                 lut[local_ids] = np.arange(n_taxa, dtype=np.int32)
                 leaf_taxon = lut[leaf_taxon]
+                relabel = lut
             taxa = [self.name(i) for i in local_ids]
         else:
             taxa = self.taxa if self.ids is None else [self.name(i) for i in range(n_taxa)]
         monotone = (strategy in ("one", "depth", "branch") and bool(self.forest.monotone_flag)
                     and bool(np.all(self.weights >= 0)))
         return TreeTables(n_taxa=n_taxa, tree_off=tree_off, leaf_taxon=leaf_taxon, adj_depth=adj_depth,
-                          adj_val=adj_val, tree_w=self.weights.copy(), taxa=taxa, monotone=monotone)
+                          adj_val=adj_val, tree_w=self.weights.copy(), taxa=taxa, monotone=monotone,
+                          resident=(self.forest, relabel))
 
     def split(self, parts: Sequence[np.ndarray], strategy: str | None = None) -> list:
         """``TreeArrays.split`` on the device (``scs_forest_split``; reference: scs.py:139-155 with

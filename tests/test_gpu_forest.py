@@ -160,3 +160,32 @@ def test_whole_recursion_with_the_split_on_the_device(monkeypatch):
         out[mode] = (tree.get_newick(), rs.randint(1 << 30))
     assert out["0"] == out["1"]
     assert arrays.n_trees == 60
+
+
+def test_small_solve_from_resident_tables_equals_the_host_packed_one(dev, monkeypatch):
+    # a child of the device split is solved straight from its device tables (k_small_pack: present-taxon
+    # and contraction renumbering applied on the device) -- W, eigenvalues and embedding bit for bit
+    # those of the batch packed on the host; few trees: taxa contract, some are absent
+    from spectralclustersupertree_amd import scs
+
+    monkeypatch.setenv("SCS_DEVICE_SPLIT_MIN_NODES", "0")
+    rng = random.Random(12)
+    for seed, n, m in ((3, 90, 6), (4, 160, 40), (5, 40, 3)):
+        taxa, trees, weights = random_forest(seed, n, m, none_sup=0.0, unary=0.05)
+        arrays = TreeArrays.from_trees(trees, weights, taxa)
+        res = ResidentArrays.from_host(arrays, dev)
+        for child in res.split(random_parts(rng, n, 2, 0.05), "branch"):
+            if child.n_trees < 1 or len(child.present_taxa()) < 3:
+                continue
+            tables = child.flatten("branch", local_ids=child.present_taxa())
+            assert tables.resident is not None and tables.resident[0] is child.forest
+            work, perm, group_start, n_groups = scs.prepare_node(tables, True)
+            if n_groups < 2 or work.n_taxa > dev.SMALL_MAX_TAXA:
+                continue
+            assert work.resident is not None
+            got = {}
+            for mode in ("1", "0"):
+                monkeypatch.setenv("SCS_RESIDENT_SOLVE", mode)
+                got[mode] = dev.small_solve([(work, group_start)], want_w=True)[0]
+            for a, b in zip(got["1"], got["0"]):
+                assert np.array_equal(a, b)
