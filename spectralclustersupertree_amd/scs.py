@@ -522,13 +522,15 @@ class _warm_allocator:
     """glibc's mmap threshold raised for the duration of a recursion (``scs_host_malloc_tune``,
     csrc/scs_host.c: the node arrays of every split then come from the warm heap instead of fresh
     pages); counted, so that recursions on several threads (in-process teams) share it.
-    ``SCS_MALLOC_TUNE=0`` leaves the allocator alone."""
+    OPT-IN since round 5 (``SCS_MALLOC_TUNE=1``): the forests of the recursion live on the device
+    now (``treearrays.ResidentArrays``) and the host no longer allocates node arrays by the
+    thousand, so a library call leaves the process-wide allocator settings alone by default."""
 
     def __enter__(self):
         import os
 
         global _allocator_users
-        self.active = bool(int(os.environ.get("SCS_MALLOC_TUNE", "1") or 0))
+        self.active = bool(int(os.environ.get("SCS_MALLOC_TUNE", "0") or 0))
         if not self.active:
             return self
         from spectralclustersupertree_amd import _hostlib
