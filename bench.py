@@ -444,7 +444,8 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         report["stages"]["multi_rank_mode"] = mode
     # HBM traffic from the committed PMC passes of this workload, if any
     try:
-        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(name, [])
+        pmc_key = name if name != "custom" else f"custom_{n}_{m}_{strategy}"
+        pmc = json.loads((ROOT / "profiles" / "pmc_traffic.json").read_text()).get(pmc_key, [])
         for roof in (roof_symm, roof_acc):
             short = roof["kernel"].split("<")[0].split(" ")[0]
             for entry in pmc if isinstance(pmc, list) else [pmc]:

@@ -23,6 +23,17 @@ echo "SQ passes done"
 SCS_ACC_STAMP=1 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-parity > /dev/null 2> $out/stamps.txt || true
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo "default bench done"
+# configs[3] on one device and configs[2]'s shape under `bootstrap` (k_accumulate_gen): kernel times and traffic
+c3="--workload cfg3 --steps 1 --warmup 1 --no-cpu-baseline --no-extra --no-parity"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg3 -- python3 bench.py $c3 > $out/bench_cfg3_under_rocprof.json 2> $out/kt_cfg3.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_cfg3 -- python3 bench.py $c3 > /dev/null 2> $out/fetch_cfg3.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write_cfg3 -- python3 bench.py $c3 > /dev/null 2> $out/write_cfg3.err
+echo "cfg3 passes done"
+bs="--workload custom --taxa 10000 --trees 500 --strategy bootstrap --steps 2 --warmup 0 --no-cpu-baseline --no-extra --no-parity"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_boot -- python3 bench.py $bs > $out/bench_boot_under_rocprof.json 2> $out/kt_boot.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_boot -- python3 bench.py $bs > /dev/null 2> $out/fetch_boot.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write_boot -- python3 bench.py $bs > /dev/null 2> $out/write_boot.err
+echo "bootstrap passes done"
 python3 bench.py --workload cfg4 --steps 1 --no-extra --no-cpu-baseline > $out/bench_cfg4.json 2> $out/bench_cfg4.err || true
 echo "cfg4 done"
 python3 tools/summarize_counters.py $out > $out/counters_summary.txt || true

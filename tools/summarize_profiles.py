@@ -44,9 +44,9 @@ bench = json.load(open(raw / "bench_under_rocprof.json"))
 default = json.load(open(raw / "bench_default.json"))
 
 
-def pmc(kind):
+def pmc(kind, needle="k_accumulate"):
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-    f = newest(f"{kind}/*/*counter_collection.csv", "k_accumulate")
+    f = newest(f"{kind}/*/*counter_collection.csv", needle)
     for r in csv.DictReader(open(f)):
         a = acc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]]
         a[0] += 1
@@ -83,7 +83,7 @@ lines = [f"# Round-{tag[1:]} profile: `python3 bench.py --steps 5 --no-cpu-basel
          f"seeds, planted input and the configs[1]/configs[3] reference passes), `{tag}_accumulate_phase_stamps.txt`, "
          f"`{tag}_accumulate_sq_counters_*.txt` (SQ counters of the accumulate kernel: round-1 structure, with the hand-scheduled "
          f"cell loop, final structure), `{tag}_bench_cfg4_single_gpu.json` (configs[4] on ONE device).", "",
-         "## Kernel time (6 passes of the hot path: 1 warm-up + 5 timed)", "",
+         "## Kernel time (11 passes of the hot path: 1 warm-up + 5 timed by the protocol + 5 on HBM-resident tables)", "",
          "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
 for r in rows[:16]:
     lines.append(f"| `{r['Name'].split('(')[0]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | "
@@ -178,5 +178,46 @@ pj = {"_comment": "HBM-side bytes per launch from committed rocprofv3 PMC passes
           {"kernel": ACC, "fetch_raw": round(afr), "fetch_corrected": round(acorr), "write": round(awr),
            "traffic": round(acorr + awr), "source": f"profiles/{tag}_bench_cfg2_summary.md (fetches are 8-byte gathers: "
                                                      "uncalibrated width, quoted raw)"}]}
+
+
+def extra_rows(suffix, label, bench_file, kernels):
+    """PMC rows + kernel stats of another workload's passes (kt_<suffix>, fetch_<suffix>, write_<suffix>)."""
+    try:
+        f2, w2 = pmc(f"fetch_{suffix}"), pmc(f"write_{suffix}")
+        st2 = newest(f"kt_{suffix}/*/*kernel_stats.csv", "k_symm")
+        shutil.copy(st2, out / f"{tag}_bench_{label}_kernel_stats.csv")
+        if (raw / bench_file).exists():
+            shutil.copy(raw / bench_file, out / f"{tag}_bench_{label}_under_rocprof.json")
+        rows2 = []
+        for needle in kernels:
+            k = next((k for k in f2 if needle in k), None)
+            if k is None:
+                continue
+            frr = f2[k]["FETCH_SIZE"][1] / f2[k]["FETCH_SIZE"][0] * 1024
+            wrr = w2[k]["WRITE_SIZE"][1] / w2[k]["WRITE_SIZE"][0] * 1024
+            cor = frr * 2 if "k_symm" in k else frr
+            rows2.append({"kernel": k.replace("void ", "").split("<")[0].split("(")[0], "launches_profiled": f2[k]["FETCH_SIZE"][0],
+                          "fetch_raw": round(frr), "fetch_corrected": round(cor), "write": round(wrr),
+                          "traffic": round(cor + wrr),
+                          "source": f"profiles/{tag}_bench_{label}_kernel_stats.csv + PMC passes of tools/collect_profiles.sh"
+                                    + ("" if "k_symm" in k else " (8-byte gathers: uncalibrated width, quoted raw)")})
+        return rows2
+    except (FileNotFoundError, KeyError, StopIteration, ZeroDivisionError) as e:
+        print(f"(no {label} rows: {e})")
+        return []
+
+
+cfg3_rows = extra_rows("cfg3", "cfg3", "bench_cfg3_under_rocprof.json", ["k_symm_tri", "k_accumulate_spec", "k_accumulate_mono"])
+if cfg3_rows:
+    pj["cfg3"] = cfg3_rows
+boot_rows = extra_rows("boot", "cfg2_bootstrap", "bench_boot_under_rocprof.json", ["k_accumulate_gen", "k_symm_tri"])
+if boot_rows:
+    pj["custom_10000_500_bootstrap"] = boot_rows
 (out / "pmc_traffic.json").write_text(json.dumps(pj, indent=1))
+with open(out / f"{tag}_bench_cfg2_summary.md", "a") as fh:
+    fh.write("\n## HBM-side traffic of the other workloads (same PMC recipe; bench.py quotes them as roofline.traffic)\n\n")
+    for key in ("cfg3", "custom_10000_500_bootstrap"):
+        for r in pj.get(key, []):
+            fh.write(f"* {key} `{r['kernel']}`: fetch {r['fetch_raw']:,} raw / {r['fetch_corrected']:,} corrected, write {r['write']:,} "
+                     f"-> {r['traffic']:,} bytes per launch ({r['launches_profiled']} launches profiled)\n")
 print("\n".join(lines[:60]))
