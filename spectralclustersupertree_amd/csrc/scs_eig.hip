@@ -1449,6 +1449,23 @@ __global__ __launch_bounds__(256) void k_panel_tf_solve(double *q, const double 
     }
 }
 
+// Pass 2 of the orthonormalisation of R folded into the Gram kernel (scs_panel.h, round 5): the
+// small solve on pass 1's Gram partials in front, then R and S R transformed on the way to Q^T S Q.
+template <int B, int FINISH>
+__global__ __launch_bounds__(256) void k_panel_gram_tf_solve(double *q, double *aq, const double *__restrict__ u,
+                                                              const double *__restrict__ part_in, int nparts_in,
+                                                              int *mask_r, const double *__restrict__ theta_g, int n,
+                                                              const double *__restrict__ ypart, int nseg,
+                                                              const double *__restrict__ dinv,
+                                                              double *__restrict__ partial, int64_t chunk = 0,
+                                                              const int32_t *__restrict__ splits = nullptr) {
+    __shared__ double coef_s[PANEL_COEF_ROWS<B> * B];
+    const bool lead = blockIdx.x == 0;
+    small_orth_body(part_in, nparts_in, B, 0.0, coef_s, lead ? mask_r : nullptr, theta_g, nullptr, -1.0);
+    __syncthreads();
+    panel_gram_tf_body<B, FINISH>(q, aq, u, coef_s, n, ypart, nseg, dinv, partial, chunk, splits);
+}
+
 // c = first b columns of the 3b x 3b identity, d = 0: the Rayleigh-Ritz coefficients that
 // leave X alone and clear the search directions (first iteration, and after a refresh)
 __global__ void k_unit_coeffs(double *__restrict__ c, double *__restrict__ d, int b) {
@@ -1500,7 +1517,13 @@ struct solver {
     hipStream_t s = nullptr;
     int n = 0, b = 0, rows = 0, world = 1;
     bool use_mfma = true;
-    dbuf q, aq, z, ypart, yloc, yfull, recv, u, part, part2, small, splits_d;
+    dbuf q, aq, z, ypart, yloc, yfull, recv, u, part, part2, part3, small, splits_d;
+    // round 5: the second orthonormalisation pass of R rides the Gram kernel behind the SYMM stream
+    // (k_panel_gram_tf_solve; SCS_FOLD_PASS2=0 keeps it as a launch of its own in front of the stream)
+    bool fold_pass2 = false;
+    const double *fold_u = nullptr;
+    int *fold_mask_r = nullptr;
+    const double *fold_theta = nullptr;
     size_t ypart_cap = 0;
     int64_t chunk = 0;
     int gram_blocks = 0;
@@ -1810,6 +1833,16 @@ struct solver {
                           const int *maskp_in, int *mask_r, int *maskp_out, double drop_tol,
                           double *report, double seq) {
         const int nb = panel_blocks16();
+        if (fold_pass2) {
+            // round 5: pass 1 writes Z; pass 2 rides the Gram kernel behind the SYMM stream (fused_back)
+            k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part3.d(), nparts_in, solve, theta,
+                                                   maskp_in, mask_r, maskp_out, drop_tol, n, part.d());
+            k_panel_tf_solve<B, true, true><<<nb, 256, 0, s>>>(q.d(), uvec, part.d(), nb, drop_tol, mask_r,
+                                                               theta, report, seq, n, part2.d(), g->d_dinv,
+                                                               z.d(), ldz);
+            SCS_HIP_CHECK(hipGetLastError());
+            return SCS_OK;
+        }
         k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part2.d(), nparts_in, solve, theta,
                                                maskp_in, mask_r, maskp_out, drop_tol, n, part.d());
         k_panel_tf_solve<B, true, false><<<nb, 256, 0, s>>>(q.d(), uvec, part.d(), nb, drop_tol, mask_r,
@@ -1841,7 +1874,8 @@ struct solver {
             ev.push_back(e0);
             ev.push_back(e1);
         }
-        const int nb = panel_blocks4();
+        const int nb = fold_pass2 ? panel_blocks16() : panel_blocks4();
+        const int nb16 = panel_blocks16();  // partials of pass 1's Gram products (k_panel_tf_solve)
         *nparts = nb;
         if (part_mode) {
             // the gathered partial products (world x V x b, unscaled) are added in rank order and
@@ -1850,14 +1884,22 @@ struct solver {
             SCS_TRY(launch_symm(z.d(), nullptr));
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
-            k_gram_qaq<B, 3><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, pout);
+            if (fold_pass2)
+                k_panel_gram_tf_solve<B, 3><<<nb, 256, 0, s>>>(q.d(), aq.d(), fold_u, part2.d(), nb16, fold_mask_r,
+                                                               fold_theta, n, recv.d(), world, g->d_dinv, pout);
+            else
+                k_gram_qaq<B, 3><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, pout);
         } else if (world == 1) {
             if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
             SCS_TRY(launch_symm(z.d(), nullptr));
             if (timed) SCS_HIP_CHECK(hipEventRecord(e1, s));
             ++n_apply;
-            k_gram_qaq<B, 1><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
-                                                   g->d_dinv, pout);
+            if (fold_pass2)
+                k_panel_gram_tf_solve<B, 1><<<nb, 256, 0, s>>>(q.d(), aq.d(), fold_u, part2.d(), nb16, fold_mask_r,
+                                                               fold_theta, n, ypart.d(), last_nseg, g->d_dinv, pout);
+            else
+                k_gram_qaq<B, 1><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
+                                                       g->d_dinv, pout);
         } else {
             if (timed) SCS_HIP_CHECK(hipEventRecord(e0, s));
             SCS_TRY(launch_symm(z.d(), yloc.d()));
@@ -1865,8 +1907,13 @@ struct solver {
             ++n_apply;
             SCS_TRY(gather(yloc.d(), recv.d(), (size_t)chunk));
             // (the gathered slices go straight into AQ's R slot inside the Gram kernel)
-            k_gram_qaq<B, 2><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, pout,
-                                                (int64_t)chunk, (const int32_t *)splits_d.p);
+            if (fold_pass2)
+                k_panel_gram_tf_solve<B, 2><<<nb, 256, 0, s>>>(q.d(), aq.d(), fold_u, part2.d(), nb16, fold_mask_r,
+                                                               fold_theta, n, recv.d(), world, g->d_dinv, pout,
+                                                               (int64_t)chunk, (const int32_t *)splits_d.p);
+            else
+                k_gram_qaq<B, 2><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, recv.d(), world, g->d_dinv, pout,
+                                                    (int64_t)chunk, (const int32_t *)splits_d.p);
         }
         time_ag = false;
         SCS_HIP_CHECK(hipGetLastError());
@@ -2073,6 +2120,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_TRY(sv.u.alloc((size_t)n * 8));
     SCS_TRY(sv.part.alloc((size_t)1024 * q3 * q3 * 8));
     SCS_TRY(sv.part2.alloc((size_t)1024 * q3 * q3 * 8));
+    SCS_TRY(sv.part3.alloc((size_t)1024 * q3 * q3 * 8));
     SCS_TRY(sv.small.alloc((size_t)SM_TOTAL * 8));
     if (sv.world > 1 && !sv.part_mode) {
         SCS_TRY(sv.yfull.alloc((size_t)n * b * 8));
@@ -2171,6 +2219,11 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     const double *uvec = constrained ? sv.u.d() : nullptr;
     // SCS_SPLIT_SMALL=1: the small solves as one-workgroup kernels of their own (the round-3 loop)
     const bool split_small = getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"));
+    sv.fold_pass2 = fused && !split_small && !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
+    sv.fold_u = uvec;
+    sv.fold_mask_r = MASK + 2 * b;
+    sv.fold_theta = TH;
+    double *qaq_out = sv.fold_pass2 ? sv.part3.d() : sv.part2.d();
     int rr_solve = 0, rr_parts = 0, mpar = 0;
     int *maskp[2] = {MASK + b, MASK + 32};
 
@@ -2187,11 +2240,11 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 if (b == 4) {
                     SCS_TRY(sv.fused_front_solve<4>(uvec, rr_parts, rr_solve, TH, maskp[mpar], MASK + 2 * b,
                                                     maskp[mpar ^ 1], drop_tol, ctx->d_report, seq));
-                    SCS_TRY(sv.fused_back<4>(&nparts, sv.part2.d()));
+                    SCS_TRY(sv.fused_back<4>(&nparts, qaq_out));
                 } else {
                     SCS_TRY(sv.fused_front_solve<8>(uvec, rr_parts, rr_solve, TH, maskp[mpar], MASK + 2 * b,
                                                     maskp[mpar ^ 1], drop_tol, ctx->d_report, seq));
-                    SCS_TRY(sv.fused_back<8>(&nparts, sv.part2.d()));
+                    SCS_TRY(sv.fused_back<8>(&nparts, qaq_out));
                 }
                 rr_parts = nparts;
                 rr_solve = 1;

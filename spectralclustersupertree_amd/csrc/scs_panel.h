@@ -334,3 +334,147 @@ __global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, 
                 }
     }
 }
+
+// ---------------------------------------------------------------------------
+// Round 5: the SECOND orthonormalisation pass of R folded into the Gram kernel.
+// The iteration used to be  rr -> tf (pass 1) -> tf (pass 2, writes Z) -> SYMM -> finish -> gram.
+// Pass 2 only removes the rounding left by pass 1 (its transform is the identity to ~1e-16), and
+// it is linear: R2 = [X P R1 u] K  implies  S R2 = [SX SP SR1 u] K  (S u = u).  So pass 1 writes Z,
+// the operator is applied to R1, and THIS kernel -- which combines the SYMM partials into S R1 and
+// forms Q^T (S Q) anyway -- applies K to both R1 and S R1 on the way, for its rows, before the Gram
+// products: one tall launch and one small solve fewer on the critical path of every iteration.
+// `coefm`: PANEL_COEF_ROWS<B> x B, rows [x | p | r | u | pad] (small_orth_body's output).
+// Tiles of 16 rows per wave as panel_rr_body: the transform's accumulator layout is the Gram
+// product's operand layout, and the new R columns land where the Gram product wants them
+// (columns 2B .. 3B-1 of the panel) because the coefficient columns are shifted there.
+// ---------------------------------------------------------------------------
+template <int B, int FINISH>
+__device__ __forceinline__ void panel_gram_tf_body(double *q, double *aq, const double *__restrict__ u,
+                                                   const double *coefm, int n,
+                                                   const double *__restrict__ ypart, int nseg,
+                                                   const double *__restrict__ dinv,
+                                                   double *__restrict__ partial, int64_t chunk,
+                                                   const int32_t *__restrict__ splits) {
+    static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
+    constexpr int LD = 3 * B;
+    constexpr int KC = PANEL_COEF_ROWS<B> / 4;
+    constexpr int NT = (LD + 15) / 16;     // 16-column tiles of the panels
+    constexpr int RT = (2 * B) / 16;       // tile that holds the R columns (B = 4: tile 0; B = 8: tile 1)
+    constexpr int RC0 = 2 * B - 16 * RT;   // first R column inside that tile
+    __shared__ double red[4][NT * NT][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    const int n_groups = (n + 15) / 16;
+    panel_v4d acc[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (panel_v4d){0.0, 0.0, 0.0, 0.0};
+    // B operand of the transform: coefficient rows 4k + kk, output column cc of tile RT = R column cc - RC0
+    double coef[KC];
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        coef[k] = (cc >= RC0 && cc < RC0 + B) ? coefm[(4 * k + kk) * B + (cc - RC0)] : 0.0;
+    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+        const int base = grp * 16;
+        const int ra = base + cc;  // row of this lane's A operand
+        // ---- operands of the two transforms: [x p r u] rows of Q, [Sx Sp Sr u] rows of SQ
+        double q_op[KC], a_op[KC];
+#pragma unroll
+        for (int k = 0; k < KC - 1; ++k) {
+            const int col = 4 * k + kk;
+            q_op[k] = ra < n ? q[(int64_t)ra * LD + col] : 0.0;
+            double v = 0.0;
+            if (ra < n) {
+                if (col < 2 * B || FINISH == 0) {
+                    v = aq[(int64_t)ra * LD + col];
+                } else if (FINISH == 1) {
+                    const int64_t idx = (int64_t)ra * B + (col - 2 * B);
+                    double part[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) part[g] = g < nseg ? ypart[(int64_t)g * n * B + idx] : 0.0;
+                    v = dinv[ra] * (((part[0] + part[1]) + part[2]) + part[3]);
+                } else if (FINISH == 2) {
+                    int r = 0;
+                    while (r + 1 < nseg && ra >= splits[r + 1]) ++r;
+                    v = ypart[(int64_t)r * chunk + (int64_t)(ra - splits[r]) * B + (col - 2 * B)];
+                } else {
+                    const int64_t idx = (int64_t)ra * B + (col - 2 * B);
+                    double sum = 0.0;
+                    for (int g = 0; g < nseg; ++g) sum += ypart[(int64_t)g * n * B + idx];
+                    v = dinv[ra] * sum;
+                }
+            }
+            a_op[k] = v;
+        }
+        {
+            const double uu = (kk == 0 && u && ra < n) ? u[ra] : 0.0;
+            q_op[KC - 1] = uu;
+            a_op[KC - 1] = uu;  // S u = u
+        }
+        // ---- the x, p columns in the Gram product's layout (read before the stores below)
+        double xq[NT][4], xa[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = base + kk + 4 * r, col = t * 16 + cc;
+                const bool live = row < n && col < 2 * B;
+                xq[t][r] = live ? q[(int64_t)row * LD + col] : 0.0;
+                xa[t][r] = live ? aq[(int64_t)row * LD + col] : 0.0;
+            }
+        panel_v4d dr = {0.0, 0.0, 0.0, 0.0}, da = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            dr = __builtin_amdgcn_mfma_f64_16x16x4f64(q_op[k], coef[k], dr, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[k], coef[k], da, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = base + kk + 4 * r;
+            const bool rcol = cc >= RC0 && cc < RC0 + B;
+            if (row < n && rcol) {
+                q[(int64_t)row * LD + 2 * B + (cc - RC0)] = dr[r];
+                aq[(int64_t)row * LD + 2 * B + (cc - RC0)] = da[r];
+            }
+            // tile RT of the panels: x / p columns from memory, R columns from the transform
+            double fq[NT], fa[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fq[t] = xq[t][r];
+                fa[t] = xa[t][r];
+            }
+            if (rcol) {
+                fq[RT] = row < n ? dr[r] : 0.0;
+                fa[RT] = row < n ? da[r] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fq[i], fa[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][i * NT + j][r][lane] = acc[i][j][r];
+    __syncthreads();
+    if (wave == 0) {
+        double *out = partial + (int64_t)blockIdx.x * LD * LD;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = i * NT + j;
+                    const double sres = ((red[0][t][r][lane] + red[1][t][r][lane]) + red[2][t][r][lane]) +
+                                        red[3][t][r][lane];
+                    const int orow = i * 16 + kk + 4 * r, ocol = j * 16 + cc;
+                    if (orow < LD && ocol < LD) out[orow * LD + ocol] = sres;
+                }
+    }
+}

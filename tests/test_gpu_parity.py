@@ -320,13 +320,23 @@ def test_small_solves_in_front_of_the_tall_kernels_change_no_bit(dev, n, block, 
     dtab = dev.upload(tables)
     g = dtab.build()
     monkeypatch.delenv("SCS_SPLIT_SMALL", raising=False)
+    monkeypatch.setenv("SCS_FOLD_PASS2", "0")  # (round 5's default folds pass 2 into the Gram kernel: below)
     maps_a, stats_a = g.fiedler(None, block=block)
     monkeypatch.setenv("SCS_SPLIT_SMALL", "1")
     maps_b, stats_b = g.fiedler(None, block=block)
+    # round 5: the second orthonormalisation pass of R applied behind the SYMM stream, inside the Gram
+    # kernel (to R and S R alike: it is linear) -- another sequence of roundings, the same eigenvector
+    monkeypatch.delenv("SCS_SPLIT_SMALL")
+    monkeypatch.delenv("SCS_FOLD_PASS2")
+    maps_c, stats_c = g.fiedler(None, block=block)
     g.free()
     dtab.free()
     assert stats_a["iterations"] == stats_b["iterations"] > 3
     assert np.array_equal(maps_a, maps_b)
+    assert stats_c["converged"] == 1 and abs(stats_c["iterations"] - stats_a["iterations"]) <= 3
+    assert abs(stats_c["lambda"][1] - stats_a["lambda"][1]) <= 1e-13
+    scale = float(np.max(np.abs(maps_a[:, 1])))
+    assert float(np.max(np.abs(maps_c[:, 1] - maps_a[:, 1]))) <= 1e-10 * scale
 
 
 @pytest.mark.parametrize("n", [3, 4, 8, 33, 64, 65, 80, 96])
