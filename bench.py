@@ -60,6 +60,10 @@ WORKLOADS = {
     "cfg2": (10000, 500, "branch", False, 2),
     "cfg3": (50000, 2000, "branch", False, 3),
     "cfg4": (100000, 5000, "branch", True, 4),
+    # partial-coverage forests (not BASELINE.json configs; the reference's own fixtures are of this kind --
+    # scs.py:644-658 does one update per pair of leaves OF A TREE): a sixth field = leaves per tree
+    "sparse10": (10000, 500, "branch", False, -2, 1000),   # every tree holds 10 % of the taxa: the dense walk
+    "sparse05": (20000, 2000, "branch", False, -3, 100),   # 0.5 %: every tile walks its own list of trees
 }
 
 
@@ -108,19 +112,23 @@ def make_input(name, args, seed, planted):
     """Synthetic tables in page-locked host memory (the upload inside a step is then a DMA)."""
     from spectralclustersupertree_amd import synthetic
 
+    lpt = None
     if name == "custom":
         n, m, strategy, rw, cfg_idx = args.taxa, args.trees, args.strategy, False, -1
     else:
-        n, m, strategy, rw, cfg_idx = WORKLOADS[name]
+        n, m, strategy, rw, cfg_idx, *rest = WORKLOADS[name]
+        lpt = rest[0] if rest else None
     t0 = time.perf_counter()
     spr = int(np.ceil(0.02 * n)) if planted else None
     try:
-        tables = synthetic.make_tables(seed, n, m, strategy, random_weights=rw, planted_spr=spr, pinned=True)
+        tables = synthetic.make_tables(seed, n, m, strategy, leaves_per_tree=lpt, random_weights=rw, planted_spr=spr,
+                                       pinned=True)
         tables.pinned = True
     except (RuntimeError, OSError):
         # no HIP device to pin memory on (the CPU-only control-flow tests): pageable arrays
-        tables = synthetic.make_tables(seed, n, m, strategy, random_weights=rw, planted_spr=spr)
+        tables = synthetic.make_tables(seed, n, m, strategy, leaves_per_tree=lpt, random_weights=rw, planted_spr=spr)
         tables.pinned = False
+    tables.leaves_per_tree = lpt
     return tables, (n, m, strategy, rw, cfg_idx), time.perf_counter() - t0
 
 
@@ -356,6 +364,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         "launches_per_step": main_launch["launches_per_step"] if main_launch else n_batches,
         "launches": launches,
         "device_ms_per_step": round(acc_ms, 3),
+        "tile_list_batches": int(bstats.get("listed_batches", 0)),
         "cell_trees_per_step": bstats["cell_trees"],
         "cell_trees_per_s": round(cell_rate_k, 0),
         "cell_trees_per_s_all_launches": round(cell_rate, 0),
@@ -383,7 +392,9 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
                 + ("planted trees (model tree + ceil(0.02 N) SPR moves)" if planted
                    else "random-join rooted trees")
                 + f", pcg_weighting='{strategy}'" + (", per-tree weights" if rw else "")
-                if cfg_idx >= 0 else f"custom: {n} taxa / {m} trees / {strategy}"
+                if cfg_idx >= 0 else
+                (f"partial coverage: {n} taxa / {m} trees of {tables.leaves_per_tree} leaves each / {strategy}"
+                 if getattr(tables, "leaves_per_tree", None) else f"custom: {n} taxa / {m} trees / {strategy}")
             ),
             "n_taxa": n,
             "n_trees": m,

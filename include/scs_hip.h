@@ -89,6 +89,8 @@ typedef struct scs_build_stats {
                                       afterwards (k_sum_tree_tiles) -- same bits as the walk */
     int32_t spec_trees;            /* trees the spec_batches walked (the rest: 4-wave kernels)       */
     double spec_ms;                /* device time of the k_accumulate_spec launches (of accumulate_ms) */
+    int32_t listed_batches;        /* batches walked through per-tile tree lists (partial-coverage forests) */
+    int32_t reserved;
 } scs_build_stats;
 
 /* ABI version of this header: 101.  100 -> 101: scs_build_stats is 8 bytes longer

@@ -103,6 +103,8 @@ class BuildStats(C.Structure):
         ("tree_parallel_batches", C.c_int32),
         ("spec_trees", C.c_int32),
         ("spec_ms", C.c_double),
+        ("listed_batches", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

@@ -566,6 +566,41 @@ int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int3
     return SCS_OK;
 }
 
+// ---- partial-coverage forests (round 5): which trees touch a tile at all
+// The reference does one update per PAIR OF LEAVES of a tree (scs.py:644-658); the tile kernels walk
+// every tree of a batch in every tile, adding +0.0 where a tree holds no row of the tile's row block or
+// no column of its column group.  With trees that cover a few per cent of the taxa most (tile, tree)
+// steps are such no-ops: every tile gets the list of the trees that do touch it, in tree order
+// (k_accumulate_mono<.., .., true> walks the list; skipping an addend of +0.0 changes no bit).
+// pcol[cg][t] = 1 when tree t0 + t holds a column of column group cg
+__global__ __launch_bounds__(64) void k_col_presence(const int32_t *__restrict__ pos, int64_t npad, int n,
+                                                      int cols_per_group, int n_batch,
+                                                      unsigned char *__restrict__ pcol) {
+    const int cg = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    bool any = false;
+    for (int c = cg * cols_per_group + lane; c < min(n, (cg + 1) * cols_per_group); c += 64)
+        any = any || pos[(int64_t)t * npad + c] >= 0;
+    if (__ballot(any) != 0 && lane == 0) pcol[(int64_t)cg * n_batch + t] = 1;
+    if (__ballot(any) == 0 && lane == 0) pcol[(int64_t)cg * n_batch + t] = 0;
+}
+
+// one thread per tile: the batch's trees with a present row in the tile's row block (the record's
+// count) and a present column in its column group
+__global__ void k_tile_lists(const int2 *__restrict__ tiles, int n_tiles, const unsigned char *__restrict__ rec,
+                             int rec_bytes, int cnt_off, int n_batch, const unsigned char *__restrict__ pcol,
+                             int32_t *__restrict__ lists, int32_t *__restrict__ list_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_tiles) return;
+    const int2 tile = tiles[i];
+    const unsigned char *rb = rec + (int64_t)tile.x * n_batch * rec_bytes + cnt_off;
+    const unsigned char *pc = pcol + (int64_t)tile.y * n_batch;
+    int32_t *out = lists + (int64_t)i * n_batch;
+    int c = 0;
+    for (int t = 0; t < n_batch; ++t)
+        if (pc[t] && *(const int *)(rb + (int64_t)t * rec_bytes) > 0) out[c++] = t;
+    list_cnt[i] = c;
+}
+
 extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_begin,
                              int32_t row_end, int32_t flags, scs_graph **out,
                              scs_build_stats *stats) {
@@ -733,11 +768,20 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // up to 24 tiles the tree-parallel build below is faster still when the trees are many.)
     // (diagnostic switches are read on every call: tests and A/B tools set them in-process)
     const size_t wide_min_tiles = getenv("SCS_WIDE_MIN_TILES") ? (size_t)atoi(getenv("SCS_WIDE_MIN_TILES")) : 13;
-    int wide_mode = (monotone && !scatter && !tree_par && tiles.size() >= wide_min_tiles) ? 3 : 0;
+    // Partial-coverage forests: when an average tree holds less than 1 / 64 of a tile's 64 + 256 rows
+    // and columns' worth of the taxa -- less than about 1.5 % of them -- most (tile, tree) steps add
+    // +0.0 everywhere; every tile then walks its own list of trees (k_tile_lists; the 4-wave kernel:
+    // its step is the cheapest to skip).  SCS_TILE_LISTS=0 / 1 force either way.
+    bool listed = monotone && !scatter && !tiles.empty() && tb->n_trees > 0 &&
+                  (double)tb->n_leaves / ((double)tb->n_trees * std::max(n, 1)) < 1.0 / 64.0;
+    if (const char *e = getenv("SCS_TILE_LISTS")) listed = monotone && !scatter && !tiles.empty() && atoi(e) != 0;
+    if (listed) tree_par = false;
+    int wide_mode = (monotone && !scatter && !tree_par && !listed && tiles.size() >= wide_min_tiles) ? 3 : 0;
     bool wide_forced = false;  // an explicit SCS_WIDE=1 also lifts the trees-per-batch gate below
     if (const char *e = getenv("SCS_WIDE")) {
         wide_mode = (monotone && !scatter && !tiles.empty() && atoi(e)) ? 3 : 0;
         wide_forced = wide_mode != 0;
+        if (wide_mode) listed = false;
     }
     // the producer / consumer kernel needs more dynamic LDS than every device offers
     if (wide_mode && ctx->max_lds_bytes < (int)spec_layout::LDS_BYTES) {
@@ -861,6 +905,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     float spec_ms = 0.f;
     bool single_batch_spec = false;
     pooled_buf d_pos(ctx, 1), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5), d_cells(ctx, 6);
+    dev_buf d_pcol, d_lists, d_list_cnt;  // (partial-coverage forests: per-tile tree lists)
+    int listed_batches = 0;
     for (int bi = 0; bi < n_batches; ++bi) {
         const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
         const int nb = t1 - t0;
@@ -969,6 +1015,8 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.tile_out = shared ? (double *)d_tile_out.p : nullptr;
             mp.stamps = nullptr;
             mp.split_tiles = 0;
+            mp.lists = nullptr;
+            mp.list_cnt = nullptr;
             const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
             if (wide_b) {
                 wide_params wp;
@@ -1039,6 +1087,22 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 k_accumulate_mono<true, false><<<nt * (unsigned)nb, MONO_TCW, 0, s>>>(ap);
                 k_sum_tree_tiles<true, mono_params><<<nt * SCS_TR, MONO_TCW, 0, s>>>(mp, (const double *)d_cells.p,
                                                                                     (int)nt);
+            } else if (nt && listed) {
+                // every tile's own list of the batch's trees (those that touch it), then the walk over it
+                SCS_TRY(d_pcol.alloc((size_t)n_cgroups * nb));
+                SCS_TRY(d_lists.alloc((size_t)nt * nb * 4));
+                SCS_TRY(d_list_cnt.alloc((size_t)nt * 4));
+                k_col_presence<<<dim3((unsigned)n_cgroups, (unsigned)nb), 64, 0, s>>>(
+                    (const int32_t *)d_pos.p, npad, n, cols_per_tile, nb, (unsigned char *)d_pcol.p);
+                k_tile_lists<<<(nt + 255) / 256, 256, 0, s>>>((const int2 *)d_tiles.p, (int)nt,
+                                                             (const unsigned char *)d_rec.p, R3_BYTES, R3_CNT, nb,
+                                                             (const unsigned char *)d_pcol.p, (int32_t *)d_lists.p,
+                                                             (int32_t *)d_list_cnt.p);
+                mp.lists = (const int32_t *)d_lists.p;
+                mp.list_cnt = (const int32_t *)d_list_cnt.p;
+                if (sym) k_accumulate_mono<true, false, true><<<nt, MONO_TCW, 0, s>>>(mp);
+                else k_accumulate_mono<false, false, true><<<nt, MONO_TCW, 0, s>>>(mp);
+                ++listed_batches;
             } else if (nt) {
                 if (sym) k_accumulate_mono<true, false><<<nt, MONO_TCW, 0, s>>>(mp);
                 else k_accumulate_mono<false, false><<<nt, MONO_TCW, 0, s>>>(mp);
@@ -1183,6 +1247,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         stats->spec_batches = spec_batches;
         stats->tree_parallel_batches = tree_par ? n_batches : 0;
         stats->spec_trees = spec_trees;
+        stats->listed_batches = listed_batches;
         stats->spec_ms = spec_ms;
         stats->cell_trees = (double)tiles.size() * SCS_TR * cols_per_tile * (double)M;
         stats->prep_ms = prep_ms;

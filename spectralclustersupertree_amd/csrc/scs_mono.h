@@ -182,6 +182,11 @@ struct mono_params {
     int split_tiles;             // > 0: tree-parallel build of a small node (k_sum_tree_tiles): the
                                  // grid is split_tiles x n_batch, workgroup x takes tile x % split_tiles
                                  // of tree x / split_tiles ALONE and leaves its cells in tile_out slot x
+    // partial-coverage forests (round 5, k_accumulate_mono<.., .., true>): tile i walks only the
+    // trees lists[i * n_batch + 0 .. list_cnt[i]) -- those with a present row in its row block AND a
+    // present column in its column group, in tree order (the others would add +0.0 to every cell)
+    const int32_t *lists;
+    const int32_t *list_cnt;
 };
 
 // ---- end of a tile (shared by the monotone and the general tile kernel): write the sums once,
@@ -249,7 +254,7 @@ __device__ __forceinline__ void tile_store(const P &p, double (&acc)[SCS_TR], co
     }
 }
 
-template <bool SYM, bool STAMPED>
+template <bool SYM, bool STAMPED, bool LISTED = false>
 __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mono_params p) {
     __shared__ __attribute__((aligned(16))) double s_dv[DT_DOUBLES];
     __shared__ __attribute__((aligned(16))) unsigned char s_rec[2][R3_BYTES];
@@ -280,8 +285,14 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
     const int col = tile.y * MONO_TCW + tid;
     const int nt = p.n_batch;
     // the trees this workgroup walks: all of the batch, or (tree-parallel build) one
-    const int tl0 = split > 0 ? (int)blockIdx.x / split : 0;
-    const int tl1 = split > 0 ? tl0 + 1 : nt;
+    // (LISTED: positions in the tile's own list of trees; every use of a tree index below goes
+    // through T(k), the parity of the record / table buffers follows k)
+    typedef const __attribute__((address_space(4))) int32_t *clist;
+    const clist lst = LISTED ? (clist)(size_t)(p.lists + (int64_t)blockIdx.x * nt) : nullptr;
+    const int nl = LISTED ? __builtin_amdgcn_readfirstlane(p.list_cnt[blockIdx.x]) : nt;
+    auto T = [&](int k) -> int { return LISTED ? lst[min(k, max(nl - 1, 0))] : k; };
+    const int tl0 = LISTED ? 0 : (split > 0 ? (int)blockIdx.x / split : 0);
+    const int tl1 = LISTED ? nl : (split > 0 ? tl0 + 1 : nt);
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     // a column that is one of the tile's own rows (tiles on the diagonal): its cells are the
     // row-row table itself, no search or range-minimum needed; W[c][c] stays 0
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
     // search tree tl's record (in s_rec[tl & 1]) for the column's position `cpos`, decide
     // which neighbour carries the larger LCA value and ISSUE the two loads of that ONE
     // range-minimum query; then request the position of the column in the next tree
-    auto column_issue = [&](int tl, int cpos) {
+    auto column_issue = [&](int tl, int cpos, int t_next) {
         const unsigned char *rb = s_rec[tl & 1];
         const int *s_spos = (const int *)(rb + R3_SPOS);
         const int *s_arg = (const int *)(rb + R3_ARGPOS);
@@ -367,8 +378,7 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         // (a tree's table is < 4 GiB: 32-bit byte offsets from a scalar base)
         qx = *(const double *)(st + (unsigned)o[0] * 8u);
         qy = *(const double *)(st + (unsigned)o[1] * 8u);
-        cpos_next = __builtin_amdgcn_raw_buffer_load_b32(
-            r_pos, col4, min(tl + 1, nt - 1) * (int)p.npad * 4, 0);
+        cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, t_next * (int)p.npad * 4, 0);
     };
 
     // expand tree tl's row-row value table into s_dv.  In rank space entry (a, b), a < b, is
@@ -410,12 +420,16 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
 
     // ---- prologue: the records of the first two trees, the column's position in the first one;
     // then its column step
-    issue_record(tl0, tl0 & 1);
-    issue_record(min(tl0 + 1, nt - 1), (tl0 + 1) & 1);
-    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, tl0 * (int)p.npad * 4, 0);
+    if (LISTED && nl == 0) {  // (uniform: no tree of the batch touches this tile)
+        tile_store<SYM>(p, acc, tile, row0, col, self, tid, lane, wave, s_dv);
+        return;
+    }
+    issue_record(T(tl0), tl0 & 1);
+    issue_record(T(min(tl0 + 1, nl - 1)), (tl0 + 1) & 1);
+    cpos_next = __builtin_amdgcn_raw_buffer_load_b32(r_pos, col4, T(tl0) * (int)p.npad * 4, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    column_issue(tl0, cpos_next);  // 3 operations in flight: 2 table loads + the next position
+    column_issue(tl0, cpos_next, T(min(tl0 + 1, nl - 1)));  // 3 operations in flight: 2 table loads + the next position
     if (STAMPED) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 
     // Order inside a step (tree tl).  The compiler cannot tell an LDS-DMA in flight from the
@@ -447,13 +461,13 @@ __global__ __launch_bounds__(MONO_TCW, MONO_TCW / 256) void k_accumulate_mono(mo
         stamp(2);
         // (the last step searches its own tree again, result unused: keeps the step free of
         // branches the compiler would have to merge wait states over)
-        column_issue(min(tl + 1, nt - 1), cpos_next);  // 3 operations
+        column_issue(min(tl + 1, nl - 1), cpos_next, T(min(tl + 2, nl - 1)));  // 3 operations
         stamp(3);
         expand(tl);
         stamp(4);
         SCS_BARE_BARRIER();  // B: the table is complete; the record of tree tl is free
         stamp(5);
-        issue_record(min(tl + 2, nt - 1), tl & 1);
+        issue_record(T(min(tl + 2, nl - 1)), tl & 1);
         {
             double tmp[SCS_CELLS_DEPTH];
             const unsigned addr =

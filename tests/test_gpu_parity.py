@@ -720,6 +720,49 @@ def test_small_node_that_fails_is_solved_again_on_the_general_path(dev, monkeypa
         assert np.max(np.abs(g[0][:, 1] - w[0][:, 1])) <= 1e-10 * np.max(np.abs(w[0][:, 1]))
 
 
+@pytest.mark.parametrize("strategy", ["one", "depth", "branch"])
+def test_partial_coverage_forests_walk_per_tile_tree_lists(dev, monkeypatch, strategy):
+    # trees that hold well under 1 / 64 of the taxa: every tile walks only the trees that touch it
+    # (k_tile_lists + k_accumulate_mono<.., .., true>) -- the skipped steps would add +0.0: same bits.
+    # Taxa no tree holds, tiles no tree touches, several tree batches (the sums travel through W),
+    # row ranges of a row-partitioned rank; then the same through the switch on a denser forest.
+    monkeypatch.delenv("SCS_TILE_LISTS", raising=False)
+    tables = synthetic.make_tables(41, 3000, 300, strategy, leaves_per_tree=20, random_weights=True)
+    assert tables.monotone
+    w_ref, _ = to.pcg_dense(tables)
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    assert g.build_stats["listed_batches"] == g.build_stats["n_batches"] >= 1 and g.build_stats["spec_batches"] == 0
+    assert np.array_equal(g.download(), w_ref)
+    g.free()
+    for rb, re_ in ((0, 1000), (1024, 3000), (64, 65)):
+        g = dtab.build(rb, re_)
+        assert g.build_stats["listed_batches"] >= 1
+        assert np.array_equal(g.download(), w_ref[rb:re_])
+        g.free()
+    dtab.free()
+    monkeypatch.setenv("SCS_WS_LIMIT_MB", "1")
+    small = Device(0)
+    try:
+        dtab = small.upload(tables)
+        g = dtab.build()
+        assert g.build_stats["n_batches"] > 1 and g.build_stats["listed_batches"] == g.build_stats["n_batches"]
+        assert np.array_equal(g.download(), w_ref)
+        g.free()
+        dtab.free()
+    finally:
+        small.close()
+    monkeypatch.delenv("SCS_WS_LIMIT_MB")
+    monkeypatch.setenv("SCS_TILE_LISTS", "1")
+    tables = synthetic.make_tables(42, 900, 40, strategy, leaves_per_tree=300)
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    assert g.build_stats["listed_batches"] >= 1
+    assert np.array_equal(g.download(), to.pcg_dense(tables)[0])
+    g.free()
+    dtab.free()
+
+
 def test_rccl_world_of_one(dev):
     # exercises the RCCL binding (dlopen, unique id, comm init, all-gather) on one GPU
     uid = Device.unique_id()
