@@ -702,6 +702,8 @@ int scs_tables_finish(scs_ctx *ctx, const scs_tables *t) {
     }
     t->late_ev.clear();
     t->late_start.clear();
+    // (the range checks of the late chunks run behind their events on the copy stream)
+    if (e == hipSuccess && ctx->copy_stream) e = hipStreamSynchronize(ctx->copy_stream);
     unsigned bad = 0;
     if (e == hipSuccess) e = hipMemcpy(&bad, t->d_flags, 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) {
@@ -833,11 +835,12 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
             e = hipMemcpyAsync(t->d_leaf_taxon + p0, leaf_taxon + p0, (size_t)cnt * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipMemcpyAsync(t->d_adj_depth + p0, adj_depth + p0, (size_t)cnt * 4, hipMemcpyHostToDevice, cs);
             if (e == hipSuccess) e = hipMemcpyAsync(t->d_adj_val + p0, adj_val + p0, (size_t)cnt * 8, hipMemcpyHostToDevice, cs);
-            if (e == hipSuccess) {
-                const int grid = (int)std::min<int64_t>((cnt + 255) / 256 + 1, 4096);
-                k_validate_tables<<<grid, 256, 0, cs>>>(t->d_leaf_taxon + p0, t->d_adj_depth + p0, cnt, n_taxa, d_flags);
-                e = hipGetLastError();
-            }
+            // the chunk's event fires when its BYTES have arrived; the range check follows it on the copy
+            // stream and is waited for by scs_tables_finish only.  (Round 5: with the check in front of the
+            // event a build whose tile kernel fills every CU -- one twelve-wave workgroup each, all vector
+            // registers taken, milliseconds per workgroup -- kept the check, and with it the next tree
+            // batch, waiting for a free slot: 210 ms of a configs[4] step.  The build's own kernels guard
+            // against ids out of range; the verdict is collected at the end of the build as before.)
             hipEvent_t ev = nullptr;
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
             if (e == hipSuccess) e = hipEventRecord(ev, cs);
@@ -846,6 +849,11 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
                 t->late_ev.push_back(ev);
             } else if (ev) {
                 hipEventDestroy(ev);
+            }
+            if (e == hipSuccess) {
+                const int grid = (int)std::min<int64_t>((cnt + 255) / 256 + 1, 4096);
+                k_validate_tables<<<grid, 256, 0, cs>>>(t->d_leaf_taxon + p0, t->d_adj_depth + p0, cnt, n_taxa, d_flags);
+                e = hipGetLastError();
             }
         }
     }
