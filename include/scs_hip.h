@@ -186,6 +186,14 @@ int scs_forest_download(scs_ctx *ctx, const scs_forest *forest, int32_t t_begin,
                         int64_t *node_off, int32_t *parent, int32_t *taxon, double *length,
                         double *support, double *weights);
 
+/* The tables of a child of scs_forest_split as an scs_tables handle (what scs_tables_upload makes from
+ * host arrays) WITHOUT leaving the device: relabel[x] (may be null: identity) = id of the forest's taxon
+ * x in the node's numbering, n_taxa = the node's taxon count.  For scs_pcg_build of the recursion's
+ * larger nodes; free with scs_tables_free.  `ctx` may be another context on the same GPU than the one
+ * the forest was split on (the look-ahead worker's). */
+int scs_tables_from_forest(scs_ctx *ctx, const scs_forest *forest, const int32_t *relabel, int32_t n_taxa,
+                           scs_tables **out);
+
 /* ---- tables ------------------------------------------------------------ */
 
 /* Page-locked host memory (hipHostMalloc) for callers that want scs_tables_upload to run at

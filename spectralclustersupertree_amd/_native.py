@@ -138,6 +138,7 @@ SIGNATURES = {
     "scs_forest_split": (C.c_int, [_P, _P, _IP, _IP, _I32, _IP, _I32, _P, _P]),
     "scs_forest_tables_download": (C.c_int, [_P, _P, _LP, _IP, _IP, _DP, _IP, _DP, _P]),
     "scs_forest_tables_host": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "scs_tables_from_forest": (C.c_int, [_P, _P, _IP, _I32, _PP]),
     "scs_forest_download": (C.c_int, [_P, _P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP]),
     "scs_host_alloc": (C.c_int, [C.c_size_t, _PP]),
     "scs_host_free": (C.c_int, [_P]),

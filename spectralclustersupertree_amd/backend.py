@@ -86,6 +86,14 @@ class Device:
     def upload(self, tables: TreeTables) -> "DeviceTables":
         tables.validate(ranges=False)  # (ranges: checked by a kernel on the uploaded copy)
         handle = C.c_void_p()
+        res = getattr(tables, "resident", None)
+        if res is not None and _resident_solve() and res[0].dev.index == self.index and res[0]._h:
+            # the tables are on this device already (a child of scs_forest_split): device-to-device
+            forest, relabel = res
+            rl = None if relabel is None else np.ascontiguousarray(relabel, dtype=np.int32)
+            nv.check(self._lib.scs_tables_from_forest(self._ctx, forest._h, nv.iptr(rl) if rl is not None else None,
+                                                      int(tables.n_taxa), C.byref(handle)))
+            return DeviceTables(self, handle, tables.n_taxa, tables.n_trees, bool(tables.monotone))
         rc = self._lib.scs_tables_upload(
             self._ctx, tables.n_taxa, tables.n_trees, nv.lptr(tables.tree_off),
             nv.iptr(tables.leaf_taxon), nv.iptr(tables.adj_depth), nv.dptr(tables.adj_val),

@@ -741,6 +741,79 @@ extern "C" int scs_tables_free(scs_ctx *ctx, scs_tables *t) {
     return SCS_OK;
 }
 
+// leaf_taxon of a resident forest's tables through the node's renumbering (null: identity)
+__global__ void k_relabel_taxa(const int32_t *__restrict__ src, const int32_t *__restrict__ relabel, int64_t n,
+                               int32_t *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = relabel ? relabel[src[i]] : src[i];
+}
+
+// scs_tables of a node whose tables are already on the device: a child of scs_forest_split.  Device-to-
+// device copies and the taxon renumbering (present taxa only, contraction groups consecutive) instead of
+// the host -> HBM copy of scs_tables_upload; nothing to range-check (the split produced the ids and the
+// map comes from the same host code that would have renumbered the host arrays).
+extern "C" int scs_tables_from_forest(scs_ctx *ctx, const scs_forest *f, const int32_t *relabel, int32_t n_taxa,
+                                      scs_tables **out) {
+    SCS_REQUIRE(ctx && f && out, "scs_tables_from_forest: null argument");
+    SCS_REQUIRE(f->has_tables && f->h_tree_off, "scs_tables_from_forest: the forest carries no tables (not a child of scs_forest_split)");
+    SCS_REQUIRE(n_taxa >= 1 && f->n_trees >= 1, "scs_tables_from_forest: need >= 1 taxon and >= 1 tree");
+    const int32_t n_trees = f->n_trees;
+    const int64_t L = f->n_leaves;
+    int64_t max_leaves = 0;
+    for (int32_t t = 0; t < n_trees; ++t) max_leaves = std::max(max_leaves, f->h_tree_off[t + 1] - f->h_tree_off[t]);
+    SCS_REQUIRE(max_leaves <= n_taxa, "scs_tables_from_forest: a tree has more leaves (%lld) than the node has taxa (%d)",
+                (long long)max_leaves, n_taxa);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_off = 0;
+    const size_t o_tax = o_off + up256(((size_t)n_trees + 1) * 8);
+    const size_t o_dep = o_tax + up256((size_t)L * 4);
+    const size_t o_val = o_dep + up256((size_t)L * 4);
+    const size_t o_w = o_val + up256((size_t)L * 8);
+    const size_t o_flag = o_w + up256((size_t)n_trees * 8);
+    const size_t o_rl = o_flag + 256;
+    void *block = nullptr;
+    SCS_TRY(scs_block_alloc(ctx, o_rl + (relabel ? up256((size_t)f->n_taxa * 4) : 0), &block));
+    auto *t = new scs_tables();
+    t->n_taxa = n_taxa;
+    t->n_trees = n_trees;
+    t->n_leaves = L;
+    t->max_leaves = (int32_t)max_leaves;
+    t->h_tree_off.assign(f->h_tree_off, f->h_tree_off + n_trees + 1);
+    t->d_block = block;
+    char *base = (char *)block;
+    t->d_tree_off = (int64_t *)(base + o_off);
+    t->d_leaf_taxon = (int32_t *)(base + o_tax);
+    t->d_adj_depth = (int32_t *)(base + o_dep);
+    t->d_adj_val = (double *)(base + o_val);
+    t->d_tree_w = (double *)(base + o_w);
+    t->d_flags = (unsigned *)(base + o_flag);
+    hipStream_t s = ctx->stream;
+    hipError_t e = hipMemsetAsync(t->d_flags, 0, 4, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_tree_off, f->tree_off, ((size_t)n_trees + 1) * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_depth, f->adj_depth, (size_t)L * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_val, f->adj_val, (size_t)L * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_tree_w, f->weights, (size_t)n_trees * 8, hipMemcpyDeviceToDevice, s);
+    const int32_t *d_rl = nullptr;
+    if (e == hipSuccess && relabel) {
+        // (a pageable source: staged by the runtime before the call returns)
+        e = hipMemcpyAsync(base + o_rl, relabel, (size_t)f->n_taxa * 4, hipMemcpyHostToDevice, s);
+        d_rl = (const int32_t *)(base + o_rl);
+    }
+    if (e == hipSuccess && L) {
+        k_relabel_taxa<<<(unsigned)((L + 255) / 256), 256, 0, s>>>(f->leaf_taxon, d_rl, L, t->d_leaf_taxon);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // (the forest may be freed by the caller right away)
+    if (e != hipSuccess) {
+        scs_tables_free(ctx, t);
+        scs_set_error("scs_tables_from_forest failed: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? SCS_ENOMEM : SCS_EHIP;
+    }
+    *out = t;
+    return SCS_OK;
+}
+
 extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
                                  const int64_t *tree_off, const int32_t *leaf_taxon,
                                  const int32_t *adj_depth, const double *adj_val,

@@ -58,7 +58,11 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ 
                                                      const double *__restrict__ zt, int64_t ldz,
                                                      const int2 *__restrict__ tiles,
                                                      double *__restrict__ pdir,
-                                                     double *__restrict__ ptr_) {
+                                                     double *__restrict__ ptr_,
+                                                     int64_t panel_stride = 0) {
+    // panel_stride > 0 (tools/symm_tri_bench.hip only: a measurement of what a tile-major storage of W
+    // would buy): column panel J of TW columns is stored on its own, row-major with leading dimension
+    // TW, at w + J * panel_stride -- a tile is then one contiguous piece of memory
     static_assert(B == 4 || B == 8, "block widths 4 and 8");
     constexpr int TW = CT * 128;
     constexpr int NG = 32 / RPW;  // groups of RPW rows per wave: 32 rows
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ 
     auto row_ptr = [&](int g, int i) {
         int r = r_wave + g * RPW + i;
         r = r < n ? r : n - 1;  // clamped rows meet z = 0 (transposed) and are not stored (direct)
+        if (panel_stride) return (const char *)(w + (int64_t)tile.y * panel_stride + (int64_t)r * TW) + lane * 16;
         return (const char *)(w + (int64_t)r * ld + cb) + lane * 16;
     };
     // D pipeline stages: the loads of D - 1 groups are in flight while one is used

@@ -189,3 +189,34 @@ def test_small_solve_from_resident_tables_equals_the_host_packed_one(dev, monkey
                 got[mode] = dev.small_solve([(work, group_start)], want_w=True)[0]
             for a, b in zip(got["1"], got["0"]):
                 assert np.array_equal(a, b)
+
+
+def test_tables_of_a_larger_node_straight_from_the_resident_forest(dev, monkeypatch):
+    # scs_tables_from_forest: device-to-device copies + the renumbering kernel instead of the host -> HBM
+    # upload; the graph built from them is the one built from the uploaded host tables, bit for bit --
+    # also from a second context on the same GPU (the look-ahead worker's)
+    from spectralclustersupertree_amd import scs
+
+    monkeypatch.setenv("SCS_DEVICE_SPLIT_MIN_NODES", "0")
+    rng = random.Random(3)
+    taxa, trees, weights = random_forest(8, 400, 30, none_sup=0.0, unary=0.05)
+    arrays = TreeArrays.from_trees(trees, weights, taxa)
+    res = ResidentArrays.from_host(arrays, dev)
+    other = Device(0)
+    try:
+        for child in res.split(random_parts(rng, 400, 2, 0.05), "branch"):
+            tables = child.flatten("branch", local_ids=child.present_taxa())
+            work, perm, group_start, n_groups = scs.prepare_node(tables, True)
+            assert work.resident is not None
+            got = {}
+            for mode, d in (("1", dev), ("0", dev), ("1", other)):
+                monkeypatch.setenv("SCS_RESIDENT_SOLVE", mode)
+                dtab = d.upload(work)
+                g = dtab.build()
+                got[(mode, d is dev)] = g.download()
+                g.free()
+                dtab.free()
+            assert np.array_equal(got[("1", True)], got[("0", True)])
+            assert np.array_equal(got[("1", False)], got[("0", True)])
+    finally:
+        other.close()
