@@ -384,6 +384,97 @@ static void run_lv(int nt, int blocks) {
     hipFree(d_cyc);
 }
 
+// ---- L32 (round 5): the product's loop with HALF a row block per wave -- 32 accumulators (64 registers)
+// instead of 64, so that four or five waves fit a SIMD where three do now; two waves share a column's
+// (table row, own value) pair.  WAVES waves per workgroup (all consumers), WGS workgroups per CU.
+template <int WAVES, int V, int LDV, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_probe_l32(int nt, double *out, unsigned long long *cyc) {
+    extern __shared__ __attribute__((aligned(16))) double s_tb[];  // [2][64 * LDV]
+    constexpr int TBV = 64 * LDV;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int e = tid; e < 2 * TBV; e += WAVES * 64) {
+        const int r = (e % TBV) / LDV, i = (e % TBV) % LDV;
+        s_tb[e] = i < 64 ? table_value(r, i) : 0.0;
+    }
+    __syncthreads();
+    double acc[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+    const double vn = 1e300;
+    const int half = wave & 1, cgrp = wave >> 1;
+    unsigned long long t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int t = 0; t < nt; ++t) {
+        const int nb = pick_row(cgrp * 64 + lane, t);
+        const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)&s_tb[(t & 1) * TBV + nb * LDV + half * 32];
+        double *o = s_tb + ((t + 1) & 1) * TBV;
+#pragma unroll
+        for (int j = 0; j < (64 + WAVES - 1) / WAVES; ++j) {
+            const int b = (wave * ((64 + WAVES - 1) / WAVES) + j) & 63;
+            o[lane * LDV + b] = table_value(lane, b);
+            o[b * LDV + lane] = table_value(b, lane);
+        }
+        double tmp[16];
+        if constexpr (V == 6) PROBE_L_ASM_V6(acc, tmp, addr, vn);
+        else PROBE_L_ASM_V7(acc, tmp, addr, vn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    unsigned long long t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += acc[i];
+    out[(size_t)blockIdx.x * WAVES * 64 + tid] = s;
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int WAVES, int V, int LDV, int MINW>
+static void run_l32(int nt, int blocks) {
+    double *d_out;
+    unsigned long long *d_cyc;
+    const size_t n_out = (size_t)blocks * WAVES * 64;
+    CK(hipMalloc(&d_out, n_out * 8));
+    CK(hipMalloc(&d_cyc, blocks * 8));
+    const size_t lds = 2 * 64 * LDV * 8 + 5504;
+    CK(hipFuncSetAttribute((const void *)k_probe_l32<WAVES, V, LDV, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    k_probe_l32<WAVES, V, LDV, MINW><<<blocks, WAVES * 64, lds>>>(nt, d_out, d_cyc);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    k_probe_l32<WAVES, V, LDV, MINW><<<blocks, WAVES * 64, lds>>>(nt, d_out, d_cyc);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<unsigned long long> cyc(blocks);
+    std::vector<double> out(n_out);
+    CK(hipMemcpy(cyc.data(), d_cyc, blocks * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(out.data(), d_out, n_out * 8, hipMemcpyDeviceToHost));
+    size_t bad = 0;
+    for (int w = 0; w < WAVES; ++w)
+        for (int l = 0; l < 64; ++l) {
+            double acc[32];
+            for (int i = 0; i < 32; ++i) acc[i] = 0.0;
+            for (int t = 0; t < nt; ++t)
+                for (int i = 0; i < 32; ++i) acc[i] += host_table_l(host_row_l((w >> 1) * 64 + l, t), (w & 1) * 32 + i);
+            double s = 0.0;
+            for (int i = 0; i < 32; ++i) s += acc[i];
+            if (out[w * 64 + l] != s) ++bad;
+        }
+    double mean = 0;
+    for (auto v : cyc) mean += (double)v;
+    mean /= blocks;
+    const double cells = (double)blocks * WAVES * 64 * 32 * nt;
+    printf("L32 V%d waves/WG %2d (%d WG/CU asked)  row stride %d  WGs %5d  trees %4d: %8.3f ms  %.3e cell-trees/s  s_memtime ticks per step %.0f  check: %zu of %d sums wrong\n",
+           V, WAVES, MINW, LDV, blocks, nt, ms, cells / (ms * 1e-3), mean / nt, bad, WAVES * 64);
+    hipFree(d_out);
+    hipFree(d_cyc);
+}
+
 static double host_table(int r, int i) { return 1.0 + (double)((r * 64 + i) % 977) * 0.03125; }
 static int host_row(int c, int t) { return (c * 7 + t * 13 + (c >> 3)) & 63; }
 
@@ -477,6 +568,12 @@ int main(int argc, char **argv) {
     run_l<4, 2>(nt, 256 * 3 * 4);
     run_l<12, 2>(nt, 256 * 4);
     run_l<8, 2>(nt, 256 * 6);
+    run_l32<16, 6, 65, 1>(nt, 256 * 6);
+    run_l32<16, 7, 66, 1>(nt, 256 * 6);
+    run_l32<8, 6, 65, 2>(nt, 256 * 12);
+    run_l32<8, 7, 66, 2>(nt, 256 * 12);
+    run_l32<10, 6, 65, 2>(nt, 256 * 12);
+    run_l32<12, 6, 65, 1>(nt, 256 * 8);
     run_lv<8, 0, 65>(nt, 256 * 6);
     run_lv<8, 1, 65>(nt, 256 * 6);
     run_lv<8, 2, 66>(nt, 256 * 6);

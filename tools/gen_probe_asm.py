@@ -186,7 +186,7 @@ def probe_h(name="PROBE_H_ASM", depth=8, group=8, weave=True, nops=0, mode="onof
 
 
 
-def probe_l(name, b128=False, wait_every=1, depth=8, tbase=8):
+def probe_l(name, b128=False, wait_every=1, depth=8, tbase=8, rows=64):
     """Variants of the product's column-lane cell loop (SCS_CELLS_ASM) with FEWER INSTRUCTIONS per
     cell -- round 5's probe found the tile kernels bound by instruction issue (about one instruction
     of any kind per four cycles and SIMD), not by the LDS: `wait_every` cells share one counted
@@ -215,7 +215,7 @@ def probe_l(name, b128=False, wait_every=1, depth=8, tbase=8):
     for k in range(0, depth, per):
         read(k, k)
     group = max(wait_every, per)
-    for i0 in range(0, 64, group):
+    for i0 in range(0, rows, group):
         # the last read this group needs
         last = (i0 + group - 1) % depth
         consume(last - (last % per))
@@ -223,9 +223,9 @@ def probe_l(name, b128=False, wait_every=1, depth=8, tbase=8):
             k = i % depth
             L.append(f"v_min_f64 {t(k)}, {t(k)}, %[vn]")
             L.append(f"v_add_f64 %[a{i}], %[a{i}], {t(k)}")
-            if i % per == per - 1 and i + depth - (per - 1) < 64:
+            if i % per == per - 1 and i + depth - (per - 1) < rows:
                 read(k - (per - 1), i + depth - (per - 1))
-    outs = ("," + BS).join(f'          [a{i}] "+v"(ACC[{i}])' for i in range(64))
+    outs = ("," + BS).join(f'          [a{i}] "+v"(ACC[{i}])' for i in range(rows))
     tmps = ("," + BS).join(f'          "=&{{v[{tbase + 2 * k}:{tbase + 2 * k + 1}]}}"(TMP[{k}])' for k in range(depth))
     return f"""#define {name}(ACC, TMP, ADDR, VN) \\
     asm volatile( \\
@@ -245,6 +245,8 @@ L_VARIANTS = [
     dict(b128=True, wait_every=4),
     dict(b128=True, wait_every=8, depth=16),
     dict(b128=False, wait_every=8, depth=16),
+    dict(b128=False, wait_every=1, rows=32),   # V6: half a row block per wave (32 accumulators: more waves per SIMD)
+    dict(b128=True, wait_every=2, rows=32),    # V7
 ]
 
 H_VARIANTS = [  # (profiles/r05_cells_probe_rank_halved.txt was collected over several such lists)
