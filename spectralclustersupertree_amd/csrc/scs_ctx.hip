@@ -614,6 +614,10 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     }
     scs_comm_destroy(&ctx->comm);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->small_stream) {
+        hipStreamSynchronize(ctx->small_stream);
+        hipStreamDestroy(ctx->small_stream);
+    }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->h_report) hipHostFree(ctx->h_report);
     for (auto &sl : ctx->scratch)
@@ -632,6 +636,7 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
         if (sl.done) hipEventDestroy(sl.done);
         if (sl.dev) hipFree(sl.dev);
         if (sl.host) hipHostFree(sl.host);
+        if (sl.scratch) hipFree(sl.scratch);
     }
     ctx->small_slots.clear();
     if (ctx->h_flags) hipHostFree(ctx->h_flags);

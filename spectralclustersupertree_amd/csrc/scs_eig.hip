@@ -2924,7 +2924,11 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     const bool w_out = want_w != 0;
     SCS_REQUIRE(n_nodes >= 1, "scs_small_solve: need at least one node");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    // (a stream of its own: scs_internal.h; SCS_SMALL_STREAM=0 keeps the batch on the main stream)
+    const bool own_stream = !(getenv("SCS_SMALL_STREAM") && !atoi(getenv("SCS_SMALL_STREAM")));
+    if (own_stream && !ctx->small_stream)
+        SCS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->small_stream, hipStreamNonBlocking));
+    hipStream_t s = own_stream ? ctx->small_stream : ctx->stream;
     const int K = n_nodes;
     // ---- layout of the one staging block: [pointers | tree_off | group_start | leaf arrays |
     // tree_w], 8-byte aligned pieces
@@ -3044,9 +3048,16 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     if (!slot.done) SCS_HIP_CHECK(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
     // device scratch: the addends (trees x cells per node) and the uncontracted weights
     t_ctx = ctx;
-    dbuf d_add, d_w0;
-    SCS_TRY(d_add.alloc((size_t)std::max<int64_t>(add_ptr[K], 1) * 8));
-    SCS_TRY(d_w0.alloc((size_t)std::max<int64_t>(w0_ptr[K], 1) * 8));
+    const size_t add_bytes = ((size_t)std::max<int64_t>(add_ptr[K], 1) * 8 + 255) / 256 * 256;
+    const size_t w0_bytes = (size_t)std::max<int64_t>(w0_ptr[K], 1) * 8;
+    if (slot.scratch_cap < add_bytes + w0_bytes) {
+        if (slot.scratch) hipFree(slot.scratch);
+        slot.scratch = nullptr;
+        slot.scratch_cap = 0;
+        const size_t cap = std::max<size_t>((add_bytes + w0_bytes) * 3 / 2, (size_t)1 << 20);
+        SCS_HIP_CHECK(hipMalloc((void **)&slot.scratch, cap));
+        slot.scratch_cap = cap;
+    }
     unsigned char *h = slot.host, *d = slot.dev;
     memcpy(h + o_nt, n_taxa, (size_t)K * 4);
     memcpy(h + o_nm, n_trees, (size_t)K * 4);
@@ -3110,8 +3121,8 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     sb.maps = (double *)(d + o_maps);
     sb.lambda = (double *)(d + o_lam);
     sb.w_out = w_out ? (double *)(d + o_w) : nullptr;
-    sb.addends = d_add.d();
-    sb.w0 = d_w0.d();
+    sb.addends = (double *)slot.scratch;
+    sb.w0 = (double *)(slot.scratch + add_bytes);
     k_small_addends<<<(unsigned)n_items, 256, 0, s>>>(sb);
     k_small_sum<<<(unsigned)n_sums, 256, 0, s>>>(sb);
     k_small_finish<<<K, 256, 0, s>>>(sb);

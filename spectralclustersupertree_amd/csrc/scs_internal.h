@@ -133,8 +133,16 @@ struct scs_ctx {
         hipEvent_t done = nullptr;
         bool busy = false;
         size_t o_maps = 0, maps_bytes = 0, o_lam = 0, lam_bytes = 0, o_w = 0, w_bytes = 0;
+        // the batch's device scratch (addends, uncontracted weights): owned by the slot until the
+        // ticket is ended -- the batch runs on small_stream, beside whatever the main stream does
+        unsigned char *scratch = nullptr;
+        size_t scratch_cap = 0;
     };
     std::vector<small_slot> small_slots;
+    // Round 5: begun small solves run on a stream of their own.  The walk of the recursion needs the
+    // split of the node it stands on at once, while a right sibling's solve -- begun earlier, wanted
+    // later -- may still be running: on one stream the split queued behind it.
+    hipStream_t small_stream = nullptr;
 };
 
 struct scs_tables {

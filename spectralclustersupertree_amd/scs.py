@@ -493,6 +493,15 @@ def _induce(names: set[str], trees, weights):
     return out_trees, out_weights
 
 
+def _begin_small() -> bool:
+    """Small children's solves are BEGUN (``scs_small_solve_begin``, a ticket) as soon as their tables are
+    there and ended at the visit -- with or without the look-ahead worker (round 5: the tickets never
+    needed it).  SCS_BEGIN_SMALL=0 (diagnostic): one waited-for batch per node when no worker runs."""
+    import os
+
+    return bool(int(os.environ.get("SCS_BEGIN_SMALL", "1") or 0))
+
+
 def _ahead_enabled() -> bool:
     """SCS_AHEAD=0 (diagnostic) keeps all device work on the walk's own thread, node by node."""
     import os
@@ -765,7 +774,7 @@ def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahea
             continue
         if tables.n_taxa <= Device.SMALL_MAX_TAXA:
             work, perm, group_start, n_groups = prepare_node(tables, contract_edges)
-            if ahead is not None:
+            if ahead is not None or _begin_small():
                 # begun at once, not waited for: the next child is flattened meanwhile, and a right
                 # sibling's embedding is long there when the walk arrives
                 if small_dev is None:
