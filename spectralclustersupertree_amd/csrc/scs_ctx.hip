@@ -508,6 +508,7 @@ extern "C" int scs_ctx_create_local(int device, int rank, scs_local_group *group
 }
 
 int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
+    std::lock_guard<std::mutex> lock(ctx->cache_mu);
     if (bytes < 256) bytes = 256;
     for (auto &b : ctx->blocks)
         if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096) {
@@ -545,6 +546,7 @@ int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
 }
 
 int scs_pinned_get(scs_ctx *ctx, size_t bytes, void **out) {
+    std::lock_guard<std::mutex> lock(ctx->cache_mu);
     if (bytes < 4096) bytes = 4096;
     for (auto &b : ctx->pinned)
         if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 65536) {
@@ -569,6 +571,7 @@ int scs_pinned_get(scs_ctx *ctx, size_t bytes, void **out) {
 
 void scs_pinned_release(scs_ctx *ctx, void *p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(ctx->cache_mu);
     size_t free_bytes = 0;
     for (auto &b : ctx->pinned) {
         if (b.p == p) b.in_use = false;
@@ -588,6 +591,7 @@ void scs_pinned_release(scs_ctx *ctx, void *p) {
 
 void scs_block_release(scs_ctx *ctx, void *p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(ctx->cache_mu);
     size_t free_bytes = 0;
     for (auto &b : ctx->blocks) {
         if (b.p == p) b.in_use = false;

@@ -886,8 +886,8 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
     const int par_min = getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES") ? atoi(getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES")) : 32;
     const bool parallel = !force_serial && N < ((int64_t)1 << 31) - 8 && (double)N / M > (double)par_min;
     int32_t *c_tree_id = nullptr;
-    SCS_TRY(region->alloc((size_t)NC * 4, (void **)&c_tree_id));
     if (parallel) {
+        SCS_TRY(region->alloc((size_t)NC * 4, (void **)&c_tree_id));
         par_params q;
         memset(&q, 0, sizeof(q));
         q.n_trees = M;

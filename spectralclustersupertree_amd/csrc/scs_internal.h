@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -118,6 +119,9 @@ struct scs_ctx {
         size_t bytes;
         bool in_use;
     };
+    // (the two caches below are locked: a forest's last reference may be dropped -- and its blocks handed
+    // back -- by another host thread than the one working on this context, e.g. the look-ahead worker)
+    std::mutex cache_mu;
     std::vector<cached_block> blocks;
     std::vector<cached_block> pinned;  // page-locked host blocks (scs_pinned_get), at most SCS_PINNED_KEEP free
     std::vector<hipEvent_t> event_pool;  // events of the timed SYMM launches, reused
