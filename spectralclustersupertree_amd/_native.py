@@ -31,6 +31,7 @@ class ScsError(RuntimeError):
 
 
 EINVAL = -1  # SCS_EINVAL
+ENOMEM = -3  # SCS_ENOMEM
 ENOCONV = -5  # SCS_ENOCONV: scs_fiedler stopped above tol (maps and stats are still filled)
 EUNSUP = -6  # SCS_EUNSUP
 

@@ -229,8 +229,16 @@ class TreeArrays:
         if n_parts == 0:
             return []
         if (self.resident_device is not None and strategy is not None and resident_split_wanted(self, n_parts)):
+            from spectralclustersupertree_amd import _native as nv
+
             dev = self.resident_device() if callable(self.resident_device) else self.resident_device
-            return ResidentArrays.from_host(self, dev).split(parts, strategy)
+            try:
+                return ResidentArrays.from_host(self, dev).split(parts, strategy)
+            except nv.ScsError as exc:
+                if exc.code != nv.ENOMEM:
+                    raise
+                # not enough device memory for the forest and its children beside what the solves hold:
+                # this split runs on the host (the children carry the device on and may move later)
         part_of = np.full(max(self.n_taxa, 1), -1, dtype=np.int32)
         new_id = np.zeros(max(self.n_taxa, 1), dtype=np.int32)
         parts = [np.asarray(p, dtype=np.int32) for p in parts]
@@ -484,7 +492,14 @@ class ResidentArrays:
         for c, ids in enumerate(parts):
             part_of[ids] = c
             new_id[ids] = np.arange(len(ids), dtype=np.int32)
-        kids = self.forest.split(part_of, new_id, [len(ids) for ids in parts], _STRATEGY_CODE[strategy])
+        from spectralclustersupertree_amd import _native as nv
+
+        try:
+            kids = self.forest.split(part_of, new_id, [len(ids) for ids in parts], _STRATEGY_CODE[strategy])
+        except nv.ScsError as exc:
+            if exc.code != nv.ENOMEM:
+                raise
+            return self.to_host().split(parts)  # (out of device memory: this split on the host)
         out = []
         for c, (ids, forest) in enumerate(zip(parts, kids)):
             tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present = forest.tables()
