@@ -340,6 +340,21 @@ struct jacobi_lds {
     double red[256];
     double w[MAXS];
     int perm[MAXS];
+    __device__ double *rot_log() { return &e[16][0]; }  // jacobi_eig_waves' log of a sweep's rotations
+};
+
+// The same for ONE size M in {4, 8}: 2 KB instead of 80 -- a kernel whose LDS also holds another role's
+// tiles (k_symm_tri_tf) runs its small solve on this one (jacobi_eig_waves is written against either)
+template <int M>
+struct jacobi_small_lds {
+    alignas(16) double a[M][M];
+    alignas(16) double e[M][M];
+    alignas(16) double cs[M / 2][2];
+    alignas(16) double rlog[2 * (M - 1) * (M / 2) * 2];
+    double w[M];
+    int pq[1][2];
+    int perm[M];
+    __device__ double *rot_log() { return rlog; }
 };
 
 // On entry s.a holds the symmetric matrix (n x n).  On exit s.w holds the
@@ -618,14 +633,14 @@ constexpr int jw_next_pos(int i, int m) {
     return i == 2 ? 1 : i - 2;
 }
 
-template <int M>
-__device__ void jacobi_eig_waves(jacobi_lds &s) {
+template <int M, typename L>
+__device__ void jacobi_eig_waves(L &s) {
     constexpr int H = M / 2, NB = H * H, SPS = M - 1;
     static_assert(M % 2 == 0 && NB <= 64 && M <= 16, "one wave holds the blocks");
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     double *fa = &s.a[0][0];                 // [NB][4]: 2 x 2 blocks, row-major inside a block
-    double *rlog = &s.e[16][0];              // [2][SPS][H][2]: (c, s) of a sweep's rotations
+    double *rlog = s.rot_log();              // [2][SPS][H][2]: (c, s) of a sweep's rotations
     volatile int *flag = &s.pq[0][0];        // [2]: wave 0's verdict before sweep k, at k & 1
     const int kr = lane / H, kc = lane - kr * H;
     const bool blk = wave == 0 && lane < NB;
@@ -891,10 +906,9 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
 // order with all 256 threads of the workgroup: eight interleaved slices of the partials are
 // summed with the loads of a slice in flight together, then the slices are combined.
 // out(e, value) is called by one thread per output; ends with a workgroup barrier.
-template <typename F>
+template <int TL, typename F>
 __device__ __forceinline__ void sum_partials(const double *__restrict__ partial, int nparts,
-                                             int nout, double (*tmp)[3 * MAXB * 3 * MAXB / 4],
-                                             F out) {
+                                             int nout, double (*tmp)[TL], F out) {
     // tmp: [8][>= nout] doubles of LDS
     // (up to five outputs per thread at a time, sixteen loads of each in flight before the first
     // add: the kernel is one workgroup, nothing else hides the latency of a load, and the
@@ -1300,20 +1314,40 @@ __global__ __launch_bounds__(256) void k_small_rr(const double *__restrict__ tm,
 // report (mapped host memory, may be null): [0, b) squared residual norms diag(G),
 // [16, 16 + b] the current Ritz values, [40] the caller's sequence number, written last.
 // (coef may live in LDS, mask may be null: k_panel_tf_solve runs this in front of its panel pass)
-__device__ __forceinline__ void small_orth_body(const double *__restrict__ partial, int nparts, int b,
-                                double drop_tol, double *coef, int *mask,
-                                const double *__restrict__ theta, double *report, double seq) {
-    __shared__ jacobi_lds s;
-    __shared__ double cxp[16][8], gm[9][8], mm[8][8], tt[8][8], dsc[8];
+// (the working set is a template parameter: the general one below, or the compact one of a single block
+// width -- same arithmetic, same bits)
+struct orth_lds {
+    jacobi_lds s;
+    double cxp[16][8], gm[9][8], mm[8][8], tt[8][8], dsc[8];
+    double tmp[8][3 * MAXB * 3 * MAXB / 4];
+    __device__ void eig(int b) { jacobi_eig(s, b); }
+};
+template <int B>
+struct orth_small_lds {
+    jacobi_small_lds<B> s;
+    double cxp[2 * B][B], gm[B + 1][B], mm[B][B], tt[B][B], dsc[B];
+    double tmp[8][3 * B * B + B];
+    double coef[PANEL_COEF_ROWS<B> * B];
+    panel_red_t red;
+    __device__ void eig(int) { jacobi_eig_waves<B>(s); }
+};
+
+template <typename ST>
+__device__ __forceinline__ void small_orth_core(ST &L, const double *__restrict__ partial, int nparts, int b,
+                                                double drop_tol, double *coef, int *mask,
+                                                const double *__restrict__ theta, double *report, double seq) {
+    auto &s = L.s;
+    auto &cxp = L.cxp;
+    auto &gm = L.gm;
+    auto &mm = L.mm;
+    auto &tt = L.tt;
+    auto &dsc = L.dsc;
     const int tid = threadIdx.x;
     const int nxp = 2 * b * b, nout = 3 * b * b + b;
-    {
-        __shared__ double tmp[8][3 * MAXB * 3 * MAXB / 4];
-        sum_partials(partial, nparts, nout, tmp, [&](int e, double v) {
-            if (e < nxp) cxp[e / b][e % b] = v;
-            else gm[(e - nxp) / b][(e - nxp) % b] = v;
-        });
-    }
+    sum_partials(partial, nparts, nout, L.tmp, [&](int e, double v) {
+        if (e < nxp) cxp[e / b][e % b] = v;
+        else gm[(e - nxp) / b][(e - nxp) % b] = v;
+    });
     if (report) {
         // hand the norms to the host through mapped memory: data, system-scope fence, then the
         // sequence number the host is polling for (no stream event: recording one costs the
@@ -1350,7 +1384,7 @@ __device__ __forceinline__ void small_orth_body(const double *__restrict__ parti
         s.a[i][j] = 0.5 * (mm[i][j] + mm[j][i]) * dsc[i] * dsc[j];
     }
     __syncthreads();
-    jacobi_eig(s, b);
+    L.eig(b);
     const double wmax = s.w[0];
     for (int e = tid; e < b * b; e += 256) {
         const int i = e / b, c = e - i * b;
@@ -1372,6 +1406,13 @@ __device__ __forceinline__ void small_orth_body(const double *__restrict__ parti
         }
         coef[e] = v;
     }
+}
+
+__device__ __forceinline__ void small_orth_body(const double *__restrict__ partial, int nparts, int b,
+                                                double drop_tol, double *coef, int *mask,
+                                                const double *__restrict__ theta, double *report, double seq) {
+    __shared__ orth_lds L;
+    small_orth_core(L, partial, nparts, b, drop_tol, coef, mask, theta, report, seq);
 }
 
 __global__ __launch_bounds__(256) void k_small_orth(const double *__restrict__ partial,
@@ -1401,7 +1442,9 @@ __global__ __launch_bounds__(256) void k_panel_rr_solve(double *q, double *aq,
                                                          const int *__restrict__ maskp_in,
                                                          const int *__restrict__ mask_r,
                                                          int *maskp_out, double drop_tol, int n,
-                                                         double *__restrict__ partial) {
+                                                         double *__restrict__ partial,
+                                                         const double *__restrict__ dinv = nullptr,
+                                                         double *__restrict__ zt = nullptr, int64_t ldz = 0) {
     __shared__ double c_s[3 * B * B], d_s[3 * B * B], th_s[B + 4];
     __shared__ int live_s[3 * B], mp_s[B];
     const int tid = threadIdx.x;
@@ -1423,7 +1466,7 @@ __global__ __launch_bounds__(256) void k_panel_rr_solve(double *q, double *aq,
         if (solve && tid <= B) theta_g[tid] = th_s[tid];
         if (tid < B) maskp_out[tid] = mp_s[tid];
     }
-    panel_rr_body<B>(q, aq, u, c_s, d_s, th_s, n, partial);
+    panel_rr_body<B>(q, aq, u, c_s, d_s, th_s, n, partial, dinv, zt, ldz);
 }
 
 template <int B, bool GRAM, bool WRITE_Z>
@@ -1458,12 +1501,66 @@ __global__ __launch_bounds__(256) void k_panel_gram_tf_solve(double *q, double *
                                                               const double *__restrict__ ypart, int nseg,
                                                               const double *__restrict__ dinv,
                                                               double *__restrict__ partial, int64_t chunk = 0,
-                                                              const int32_t *__restrict__ splits = nullptr) {
-    __shared__ double coef_s[PANEL_COEF_ROWS<B> * B];
+                                                              const int32_t *__restrict__ splits = nullptr,
+                                                              const double *__restrict__ coef1 = nullptr) {
+    constexpr int NC = PANEL_COEF_ROWS<B> * B;
+    __shared__ double coef_s[NC], coefa_s[NC];
     const bool lead = blockIdx.x == 0;
     small_orth_body(part_in, nparts_in, B, 0.0, coef_s, lead ? mask_r : nullptr, theta_g, nullptr, -1.0);
     __syncthreads();
-    panel_gram_tf_body<B, FINISH>(q, aq, u, coef_s, n, ypart, nseg, dinv, partial, chunk, splits);
+    // coef1 (overlapped loop, k_symm_tri_tf): the operator was applied to the RAW residual block R~, and
+    // pass 1 made R1 = R~ T1 + [x p u] K1 beside it.  With pass 2's R2 = R1 T2 + [x p u] K2:
+    //   S R2 = (S R~) T1 T2 + S [x p u] (K1 T2 + K2)
+    for (int e = threadIdx.x; e < NC; e += 256) {
+        const int k = e / B, c = e - k * B;
+        double v = coef_s[e];
+        if (coef1) {
+            if (k >= 2 * B && k < 3 * B) v = 0.0;
+            for (int i = 0; i < B; ++i) v += coef1[k * B + i] * coef_s[(2 * B + i) * B + c];
+        }
+        coefa_s[e] = v;
+    }
+    __syncthreads();
+    panel_gram_tf_body<B, FINISH>(q, aq, u, coef_s, coefa_s, n, ypart, nseg, dinv, partial, chunk, splits);
+}
+
+// Pass 1 of that orthonormalisation INSIDE the SYMM launch (round 5): the first n_tf workgroups run it
+// (small solve on the compact LDS layout, then their share of the rows) while the others stream W against
+// the raw residual block.  The two roles share the workgroup's LDS; nothing passes between them inside
+// the launch.  Workgroup 0 publishes pass 1's coefficients for the Gram kernel (above).
+template <int B, int CT, int RPW, int D>
+__global__ __launch_bounds__(256, 2) void k_symm_tri_tf(const double *__restrict__ w, int64_t ld, int n,
+                                                        const double *__restrict__ zt, int64_t ldz,
+                                                        const int2 *__restrict__ tiles,
+                                                        double *__restrict__ pdir, double *__restrict__ ptr_,
+                                                        int n_tf, double *q, const double *__restrict__ u,
+                                                        const double *__restrict__ part_in, int nparts_in,
+                                                        double drop_tol, int *mask_r,
+                                                        const double *__restrict__ theta_g, double *report,
+                                                        double seq, double *__restrict__ partial,
+                                                        double *__restrict__ coef_out) {
+    union lds_t {
+        symm_tri_lds<B, CT> symm;
+        orth_small_lds<B> tf;
+    };
+    __shared__ lds_t lds;
+    const int bid = blockIdx.x;
+    if (bid >= n_tf) {
+        symm_tri_body<B, CT, RPW, D>(w, ld, n, zt, ldz, tiles[bid - n_tf], pdir, ptr_, 0, lds.symm);
+        return;
+    }
+    const bool lead = bid == 0;
+    small_orth_core(lds.tf, part_in, nparts_in, B, drop_tol, lds.tf.coef, lead ? mask_r : nullptr, theta_g,
+                    lead ? report : nullptr, -1.0);
+    __syncthreads();
+    if (lead)
+        for (int e = threadIdx.x; e < PANEL_COEF_ROWS<B> * B; e += 256) coef_out[e] = lds.tf.coef[e];
+    panel_tf_body<B, true, false>(q, u, lds.tf.coef, n, partial, nullptr, nullptr, 0, bid, n_tf, &lds.tf.red);
+    if (lead && report) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) ((volatile double *)report)[40] = seq;
+    }
 }
 
 // c = first b columns of the 3b x 3b identity, d = 0: the Rayleigh-Ritz coefficients that
@@ -1521,6 +1618,15 @@ struct solver {
     // round 5: the second orthonormalisation pass of R rides the Gram kernel behind the SYMM stream
     // (k_panel_gram_tf_solve; SCS_FOLD_PASS2=0 keeps it as a launch of its own in front of the stream)
     bool fold_pass2 = false;
+    // ... and the first pass rides the SYMM launch itself (k_symm_tri_tf: one device, symmetric schedule;
+    // SCS_OVERLAP_PASS1=0 keeps it in front)
+    bool overlap_pass1 = false;
+    struct {
+        bool armed = false;
+        double drop_tol = 0.0, seq = 0.0;
+        double *report = nullptr;
+    } tf1;
+    dbuf coef1;
     const double *fold_u = nullptr;
     int *fold_mask_r = nullptr;
     const double *fold_theta = nullptr;
@@ -1597,9 +1703,17 @@ struct solver {
         // its own row blocks
         const double *w_eff = g->d_w - (int64_t)g->row_begin * g->ld - g->col0;
         double *ptr_eff = tri_ptr.d() - (int64_t)tri_rb_lo * n * b;
+        // (tf1.armed: pass 1 of R's orthonormalisation in the first workgroups of the launch)
+        const int n_tf = panel_blocks16();
 #define TRI(B_, CT_, RPW_, D_)                                                                       \
-    k_symm_tri<B_, CT_, RPW_, D_><<<tri_ntiles, 256, 0, s>>>(w_eff, g->ld, n, zin, ldz,              \
-                                                             tile_list, tri_pdir.d(), ptr_eff)
+    if (tf1.armed)                                                                                   \
+        k_symm_tri_tf<B_, CT_, RPW_, D_><<<tri_ntiles + n_tf, 256, 0, s>>>(                          \
+            w_eff, g->ld, n, zin, ldz, tile_list, tri_pdir.d(), ptr_eff, n_tf, q.d(), fold_u,        \
+            part.d(), n_tf, tf1.drop_tol, fold_mask_r, fold_theta, tf1.report, tf1.seq, part2.d(),   \
+            coef1.d());                                                                              \
+    else                                                                                             \
+        k_symm_tri<B_, CT_, RPW_, D_><<<tri_ntiles, 256, 0, s>>>(w_eff, g->ld, n, zin, ldz,          \
+                                                                 tile_list, tri_pdir.d(), ptr_eff)
         const int2 *tile_list = (const int2 *)tri_tiles.p + (tri_backwards ? tri_ntiles : 0);
         static const bool no_flip = getenv("SCS_TRI_NO_FLIP") && atoi(getenv("SCS_TRI_NO_FLIP"));
         tri_backwards = !no_flip && !tri_backwards;
@@ -1613,6 +1727,7 @@ struct solver {
         }
 #undef TRI
         SCS_HIP_CHECK(hipGetLastError());
+        tf1.armed = false;
         if (part_mode) {
             // this rank's partial product, unscaled, all V rows: gathered and added by the caller
             k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), ptr_eff, n, b, tw, tri_nct,
@@ -1833,6 +1948,19 @@ struct solver {
                           const int *maskp_in, int *mask_r, int *maskp_out, double drop_tol,
                           double *report, double seq) {
         const int nb = panel_blocks16();
+        if (overlap_pass1) {
+            // the Rayleigh-Ritz kernel hands the SYMM the scaled RAW residual block; pass 1 is armed for
+            // the SYMM launch of fused_back
+            k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part3.d(), nparts_in, solve, theta,
+                                                   maskp_in, mask_r, maskp_out, drop_tol, n, part.d(),
+                                                   g->d_dinv, z.d(), ldz);
+            SCS_HIP_CHECK(hipGetLastError());
+            tf1.armed = true;
+            tf1.drop_tol = drop_tol;
+            tf1.report = report;
+            tf1.seq = seq;
+            return SCS_OK;
+        }
         if (fold_pass2) {
             // round 5: pass 1 writes Z; pass 2 rides the Gram kernel behind the SYMM stream (fused_back)
             k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part3.d(), nparts_in, solve, theta,
@@ -1896,7 +2024,8 @@ struct solver {
             ++n_apply;
             if (fold_pass2)
                 k_panel_gram_tf_solve<B, 1><<<nb, 256, 0, s>>>(q.d(), aq.d(), fold_u, part2.d(), nb16, fold_mask_r,
-                                                               fold_theta, n, ypart.d(), last_nseg, g->d_dinv, pout);
+                                                               fold_theta, n, ypart.d(), last_nseg, g->d_dinv, pout,
+                                                               0, nullptr, overlap_pass1 ? coef1.d() : nullptr);
             else
                 k_gram_qaq<B, 1><<<nb, 256, 0, s>>>(q.d(), aq.d(), n, ypart.d(), last_nseg,
                                                        g->d_dinv, pout);
@@ -2220,6 +2349,9 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // SCS_SPLIT_SMALL=1: the small solves as one-workgroup kernels of their own (the round-3 loop)
     const bool split_small = getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"));
     sv.fold_pass2 = fused && !split_small && !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
+    sv.overlap_pass1 = sv.fold_pass2 && sv.tri && !sv.part_mode && sv.world == 1 &&
+                       !(getenv("SCS_OVERLAP_PASS1") && !atoi(getenv("SCS_OVERLAP_PASS1")));
+    if (sv.overlap_pass1) SCS_TRY(sv.coef1.alloc((size_t)(3 * 8 + 4) * 8 * 8));
     sv.fold_u = uvec;
     sv.fold_mask_r = MASK + 2 * b;
     sv.fold_theta = TH;

@@ -55,11 +55,17 @@ struct panel_out {
 template <int B>
 constexpr int PANEL_COEF_ROWS = 3 * B + 4;
 
+typedef double panel_red_t[4][2][4][64];
+
 template <int B>
 __device__ __forceinline__ void panel_store_partials(panel_v4d g1, panel_v4d g2,
-                                                     double *__restrict__ partial) {
+                                                     double *__restrict__ partial, int bid = -1,
+                                                     panel_red_t *red_ext = nullptr) {
     // cross-wave sum in fixed order through LDS, then one partial per workgroup
-    __shared__ double red[4][2][4][64];
+    // (red_ext: the caller's LDS -- a kernel that shares its LDS between two roles, scs_eig.hip)
+    __shared__ panel_red_t red_own;
+    panel_red_t &red = red_ext ? *red_ext : red_own;
+    if (bid < 0) bid = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = lane >> 4, cc = lane & 15;
 #pragma unroll
@@ -69,7 +75,7 @@ __device__ __forceinline__ void panel_store_partials(panel_v4d g1, panel_v4d g2,
     }
     __syncthreads();
     if (wave == 0) {
-        double *out = partial + (int64_t)blockIdx.x * panel_out<B>::TOTAL;
+        double *out = partial + (int64_t)bid * panel_out<B>::TOTAL;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = kk + 4 * r;  // output row
@@ -90,7 +96,9 @@ __device__ __forceinline__ void panel_store_partials(panel_v4d g1, panel_v4d g2,
 template <int B>
 __device__ __forceinline__ void panel_rr_body(double *q, double *aq, const double *__restrict__ u,
                                               const double *c, const double *d, const double *theta,
-                                              int n, double *__restrict__ partial) {
+                                              int n, double *__restrict__ partial,
+                                              const double *__restrict__ dinv = nullptr,
+                                              double *__restrict__ zt = nullptr, int64_t ldz = 0) {
     static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
     constexpr int LD = 3 * B;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -137,7 +145,11 @@ __device__ __forceinline__ void panel_rr_body(double *q, double *aq, const doubl
                 q[(int64_t)row * LD + cc] = dq[r];
                 aq[(int64_t)row * LD + cc] = da[r];
             }
-            if (live && cc < B) q[(int64_t)row * LD + 2 * B + cc] = res;
+            if (live && cc < B) {
+                q[(int64_t)row * LD + 2 * B + cc] = res;
+                // (round 5, overlapped loop: the operator is applied to the RAW residual block)
+                if (zt) zt[(int64_t)cc * ldz + row] = dinv[row] * res;
+            }
             g1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dq[r], res, g1, 0, 0, 0);
             g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ru, res, g2, 0, 0, 0);
         }
@@ -162,10 +174,15 @@ __device__ __forceinline__ void panel_tf_body(double *q, const double *__restric
                                               const double *coefm, int n,
                                               double *__restrict__ partial,
                                               const double *__restrict__ dinv,
-                                              double *__restrict__ zt, int64_t ldz) {
+                                              double *__restrict__ zt, int64_t ldz, int bid = -1,
+                                              int nblk = -1, panel_red_t *red_ext = nullptr) {
     static_assert(B == 4 || B == 8, "fused panel kernels take block widths 4 and 8");
     constexpr int LD = 3 * B;
     constexpr int KC = PANEL_COEF_ROWS<B> / 4;
+    if (bid < 0) {
+        bid = blockIdx.x;
+        nblk = gridDim.x;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = lane >> 4, cc = lane & 15;
     const int n_groups = (n + 15) / 16;
@@ -173,7 +190,7 @@ __device__ __forceinline__ void panel_tf_body(double *q, const double *__restric
     double coef[KC];
 #pragma unroll
     for (int k = 0; k < KC; ++k) coef[k] = cc < B ? coefm[(4 * k + kk) * B + cc] : 0.0;
-    for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
+    for (int grp = bid * 4 + wave; grp < n_groups; grp += nblk * 4) {
         const int base = grp * 16;
         const int ra = base + cc;
         double a_op[KC];
@@ -214,7 +231,7 @@ __device__ __forceinline__ void panel_tf_body(double *q, const double *__restric
             }
         }
     }
-    if (GRAM) panel_store_partials<B>(g1, g2, partial);
+    if (GRAM) panel_store_partials<B>(g1, g2, partial, bid, red_ext);
 }
 
 template <int B, bool GRAM, bool WRITE_Z>
@@ -350,7 +367,7 @@ __global__ __launch_bounds__(256) void k_gram_qaq(const double *__restrict__ q, 
 // ---------------------------------------------------------------------------
 template <int B, int FINISH>
 __device__ __forceinline__ void panel_gram_tf_body(double *q, double *aq, const double *__restrict__ u,
-                                                   const double *coefm, int n,
+                                                   const double *coefm, const double *coefam, int n,
                                                    const double *__restrict__ ypart, int nseg,
                                                    const double *__restrict__ dinv,
                                                    double *__restrict__ partial, int64_t chunk,
@@ -371,10 +388,15 @@ __device__ __forceinline__ void panel_gram_tf_body(double *q, double *aq, const 
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (panel_v4d){0.0, 0.0, 0.0, 0.0};
     // B operand of the transform: coefficient rows 4k + kk, output column cc of tile RT = R column cc - RC0
-    double coef[KC];
+    // (coefam: the coefficients for the S Q side when they differ -- the overlapped loop applied the
+    // operator to the raw residual block, so S R2 comes from [SX SP S R~ u] through both passes' transforms)
+    double coef[KC], coefa[KC];
 #pragma unroll
-    for (int k = 0; k < KC; ++k)
-        coef[k] = (cc >= RC0 && cc < RC0 + B) ? coefm[(4 * k + kk) * B + (cc - RC0)] : 0.0;
+    for (int k = 0; k < KC; ++k) {
+        const bool rc = cc >= RC0 && cc < RC0 + B;
+        coef[k] = rc ? coefm[(4 * k + kk) * B + (cc - RC0)] : 0.0;
+        coefa[k] = rc ? coefam[(4 * k + kk) * B + (cc - RC0)] : 0.0;
+    }
     for (int grp = blockIdx.x * 4 + wave; grp < n_groups; grp += gridDim.x * 4) {
         const int base = grp * 16;
         const int ra = base + cc;  // row of this lane's A operand
@@ -427,7 +449,7 @@ __device__ __forceinline__ void panel_gram_tf_body(double *q, double *aq, const 
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             dr = __builtin_amdgcn_mfma_f64_16x16x4f64(q_op[k], coef[k], dr, 0, 0, 0);
-            da = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[k], coef[k], da, 0, 0, 0);
+            da = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[k], coefa[k], da, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

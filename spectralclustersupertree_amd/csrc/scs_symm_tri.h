@@ -53,13 +53,20 @@ __device__ __forceinline__ void tri_halving_reduce(double (&v)[NV], int lane) {
     }
 }
 
+// LDS of one workgroup of the symmetric SYMM: B x (2 TW + 128) doubles
+template <int B, int CT>
+struct symm_tri_lds {
+    static constexpr int TW = CT * 128;
+    alignas(16) double zc[B][TW];
+    alignas(16) double zr[B][TRI_TH];
+    alignas(16) double red[B][TW];
+};
+
 template <int B, int CT, int RPW, int D>
-__global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ w, int64_t ld, int n,
-                                                     const double *__restrict__ zt, int64_t ldz,
-                                                     const int2 *__restrict__ tiles,
-                                                     double *__restrict__ pdir,
-                                                     double *__restrict__ ptr_,
-                                                     int64_t panel_stride = 0) {
+__device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int64_t ld, int n,
+                                              const double *__restrict__ zt, int64_t ldz, const int2 tile,
+                                              double *__restrict__ pdir, double *__restrict__ ptr_,
+                                              int64_t panel_stride, symm_tri_lds<B, CT> &lds) {
     // panel_stride > 0 (tools/symm_tri_bench.hip only: a measurement of what a tile-major storage of W
     // would buy): column panel J of TW columns is stored on its own, row-major with leading dimension
     // TW, at w + J * panel_stride -- a tile is then one contiguous piece of memory
@@ -68,13 +75,12 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ 
     constexpr int NG = 32 / RPW;  // groups of RPW rows per wave: 32 rows
     constexpr int NV = RPW * B;
     static_assert(NV == 8 || NV == 16 || NV == 32, "partial sums per group");
-    __shared__ __attribute__((aligned(16))) double zc[B][TW];
-    __shared__ __attribute__((aligned(16))) double zr[B][TRI_TH];
-    __shared__ __attribute__((aligned(16))) double red[B][TW];
+    double (&zc)[B][TW] = lds.zc;
+    double (&zr)[B][TRI_TH] = lds.zr;
+    double (&red)[B][TW] = lds.red;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int2 tile = tiles[blockIdx.x];
     const int rb = tile.x * TRI_TH, cb = tile.y * TW;
     const bool diag = tile.y == rb / TW;  // uniform over the workgroup
 
@@ -187,6 +193,17 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ 
             if (cb + c < n) ptr_[((int64_t)tile.x * n + cb + c) * B + k] = red[k][c];
         }
     }
+}
+
+template <int B, int CT, int RPW, int D>
+__global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ w, int64_t ld, int n,
+                                                     const double *__restrict__ zt, int64_t ldz,
+                                                     const int2 *__restrict__ tiles,
+                                                     double *__restrict__ pdir,
+                                                     double *__restrict__ ptr_,
+                                                     int64_t panel_stride = 0) {
+    __shared__ symm_tri_lds<B, CT> lds;
+    symm_tri_body<B, CT, RPW, D>(w, ld, n, zt, ldz, tiles[blockIdx.x], pdir, ptr_, panel_stride, lds);
 }
 
 // y[r][:] = scale(r) * ( sum_J pdir[J][r][:] + sum_I ptr[I][r][:] ), J from the diagonal tile
