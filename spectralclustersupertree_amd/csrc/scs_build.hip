@@ -520,6 +520,11 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
     }
     // (the two V-vectors come from the context's block cache: a hipFree each cost every step of the
     // benchmark and every node of a recursion a device-wide synchronisation)
+    if (ctx && g->deg_stage) {
+        // (an error between the two halves of scs_graph_prepare_degrees: the copy may still be running)
+        hipStreamSynchronize(ctx->stream);
+        scs_pinned_release(ctx, g->deg_stage);
+    }
     if (ctx) {
         if (g->d_deg) scs_block_release(ctx, g->d_deg);
         if (g->d_dinv) scs_block_release(ctx, g->d_dinv);
@@ -1354,8 +1359,11 @@ extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t
 
 // degrees of ALL vertices on every rank (local rows computed here, the rest
 // gathered), plus 1/sqrt(d)
-int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
-    if (g->have_deg) return SCS_OK;
+// The degrees in two halves: `begin` enqueues the kernels and the copy of the degrees into page-locked
+// staging, `finish` waits and takes the host-side sums.  scs_fiedler puts its allocations and memsets
+// between the two (the host works while k_degrees streams W); everything else calls both at once.
+int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g) {
+    if (g->have_deg || g->deg_stage) return SCS_OK;
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int n = g->n;
@@ -1387,19 +1395,31 @@ int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
         SCS_HIP_CHECK(hipStreamSynchronize(s));  // send / recv go out of scope
     }
     k_dinv<<<(n + 255) / 256, 256, 0, s>>>(g->d_deg, n, g->d_dinv);
-    std::vector<double> deg((size_t)n);
-    SCS_HIP_CHECK(hipMemcpyAsync(deg.data(), g->d_deg, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    SCS_HIP_CHECK(hipGetLastError());
+    SCS_TRY(scs_pinned_get(ctx, (size_t)n * 8, &g->deg_stage));
+    SCS_HIP_CHECK(hipMemcpyAsync(g->deg_stage, g->d_deg, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    return SCS_OK;
+}
+
+int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g) {
+    if (g->have_deg) return SCS_OK;
+    SCS_TRY(scs_graph_prepare_degrees_begin(ctx, g));
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    const double *deg = (const double *)g->deg_stage;
     int iso = 0;
     double nrm2 = 0.0;
-    for (int i = 0; i < n; ++i) {
-        if (deg[i] == 0.0) {
-            ++iso;
-            nrm2 += 1.0;
-        } else {
-            nrm2 += deg[i];
+    if (e == hipSuccess)
+        for (int i = 0; i < g->n; ++i) {
+            if (deg[i] == 0.0) {
+                ++iso;
+                nrm2 += 1.0;
+            } else {
+                nrm2 += deg[i];
+            }
         }
-    }
+    scs_pinned_release(ctx, g->deg_stage);
+    g->deg_stage = nullptr;
+    SCS_HIP_CHECK(e);
     g->n_isolated = iso;
     g->dd_norm = sqrt(nrm2);
     g->have_deg = true;

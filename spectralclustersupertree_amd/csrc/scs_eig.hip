@@ -2180,7 +2180,10 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     hipEvent_t ev_a = ctx->solve_events[0], ev_b = ctx->solve_events[1];
     SCS_HIP_CHECK(hipEventRecord(ev_a, s));
 
-    SCS_TRY(scs_graph_prepare_degrees(ctx, g));
+    // (the iterative path below allocates and clears its buffers while k_degrees streams W, and only then
+    // waits for the degrees)
+    SCS_TRY(scs_graph_prepare_degrees_begin(ctx, g));
+    if (n <= DENSE2_MAX) SCS_TRY(scs_graph_prepare_degrees(ctx, g));
 
     // 65 .. 96 vertices on one rank: the one-sided dense solve.  Its time grows with n^2 (n - 1
     // steps per sweep, each rewriting two columns per pair): measured 1.9 ms at 80 vertices
@@ -2207,8 +2210,6 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         return SCS_OK;
     }
 
-    const bool constrained = g->n_isolated == 0;
-    const int want = constrained ? 1 : 2;
     // default width: 4 while the panel kernels and the 3b x 3b Rayleigh-Ritz solve weigh
     // against the SYMM stream, 8 once streaming W dominates (measured crossover ~ 16k)
     int b = block ? block : (n >= 16384 ? 8 : 4);
@@ -2222,7 +2223,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 pick = a;
                 break;
             }
-        b = std::max(pick, want);
+        b = pick;  // (>= 4: more than the one or two pairs wanted)
     }
     const int q3 = 3 * b;
 
@@ -2272,6 +2273,10 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     double *TH = sv.small_at(SM_THETA), *RN = sv.small_at(SM_RN);
     int *MASK = (int *)sv.small_at(SM_MASK);
     const double drop_tol = 1e-13;
+
+    SCS_TRY(scs_graph_prepare_degrees(ctx, g));  // (begun at the top: the degrees are needed from here on)
+    const bool constrained = g->n_isolated == 0;
+    const int want = constrained ? 1 : 2;
 
     // constraint vector
     dbuf x0d;
@@ -2507,8 +2512,17 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_TRY(maps_d.alloc((size_t)n * 2 * 8));
     k_extract_maps<<<(n + 255) / 256, 256, 0, s>>>(Q, q3, n, g->d_dinv, 1.0 / g->dd_norm, constrained ? 1 : 0,
                                                   maps_d.d());
-    std::vector<double> cols((size_t)n * 2);
-    SCS_HIP_CHECK(hipMemcpyAsync(cols.data(), maps_d.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost, s));
+    // (page-locked staging: a pageable destination goes through the runtime's own bounce buffers)
+    struct pinned_buf {
+        scs_ctx *ctx;
+        void *p = nullptr;
+        ~pinned_buf() {
+            if (p) scs_pinned_release(ctx, p);
+        }
+    } cols_h{ctx};
+    SCS_TRY(scs_pinned_get(ctx, (size_t)n * 2 * 8, &cols_h.p));
+    const double *cols = (const double *)cols_h.p;
+    SCS_HIP_CHECK(hipMemcpyAsync(cols_h.p, maps_d.p, (size_t)n * 2 * 8, hipMemcpyDeviceToHost, s));
     // (fused loop: TH already holds the next iteration's Ritz values; h_th has X's)
     if (!fused)
         SCS_HIP_CHECK(hipMemcpyAsync(h_th.data(), TH, (size_t)(b + 1) * 8, hipMemcpyDeviceToHost, s));

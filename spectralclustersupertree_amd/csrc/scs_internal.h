@@ -190,6 +190,7 @@ struct scs_graph {
     size_t w_bytes = 0;     // size of the d_w allocation (may exceed the need: reused buffer)
     // degree data for all V vertices (filled lazily by scs_graph_prepare_degrees)
     bool have_deg = false;
+    void *deg_stage = nullptr;  // page-locked copy in flight (scs_graph_prepare_degrees_begin)
     double *d_deg = nullptr;   // [V] row sums
     double *d_dinv = nullptr;  // [V] 1/sqrt(deg) (1 where deg == 0)
     int32_t n_isolated = 0;
@@ -239,6 +240,7 @@ struct scs_forest {
 
 // build.hip
 int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g);
+int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g);
 // row splits of every rank (contiguous, ordered by rank): collective, world + 1 entries
 int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int32_t n,
                           std::vector<int32_t> &splits);

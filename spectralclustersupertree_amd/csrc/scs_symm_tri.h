@@ -53,25 +53,47 @@ __device__ __forceinline__ void tri_halving_reduce(double (&v)[NV], int lane) {
     }
 }
 
-// LDS of one workgroup of the symmetric SYMM: B x (2 TW + 128) doubles
-template <int B, int CT>
+// A lane's 16-byte piece of a row of W: two doubles, or four floats of the single-precision image W32
+// (round 5: the operator applied to the search directions inside the LOBPCG loop; scs_eig.hip)
+template <typename WT>
+struct tri_piece;
+template <>
+struct tri_piece<double> {
+    static constexpr int N = 2;
+    double2 v;
+    __device__ __forceinline__ double at(int j) const { return j == 0 ? v.x : v.y; }
+};
+template <>
+struct tri_piece<float> {
+    static constexpr int N = 4;
+    float4 v;
+    __device__ __forceinline__ double at(int j) const {
+        return (double)(j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w);
+    }
+};
+
+// LDS of one workgroup of the symmetric SYMM: B x (2 TW + 128) doubles (TW = CT sub-chunks of 64 pieces)
+template <int B, int CT, typename WT = double>
 struct symm_tri_lds {
-    static constexpr int TW = CT * 128;
+    static constexpr int TW = CT * 64 * tri_piece<WT>::N;
     alignas(16) double zc[B][TW];
     alignas(16) double zr[B][TRI_TH];
     alignas(16) double red[B][TW];
 };
 
-template <int B, int CT, int RPW, int D>
-__device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int64_t ld, int n,
+template <int B, int CT, int RPW, int D, typename WT = double>
+__device__ __forceinline__ void symm_tri_body(const WT *__restrict__ w, int64_t ld, int n,
                                               const double *__restrict__ zt, int64_t ldz, const int2 tile,
                                               double *__restrict__ pdir, double *__restrict__ ptr_,
-                                              int64_t panel_stride, symm_tri_lds<B, CT> &lds) {
+                                              int64_t panel_stride, symm_tri_lds<B, CT, WT> &lds) {
     // panel_stride > 0 (tools/symm_tri_bench.hip only: a measurement of what a tile-major storage of W
     // would buy): column panel J of TW columns is stored on its own, row-major with leading dimension
     // TW, at w + J * panel_stride -- a tile is then one contiguous piece of memory
     static_assert(B == 4 || B == 8, "block widths 4 and 8");
-    constexpr int TW = CT * 128;
+    typedef tri_piece<WT> piece;
+    constexpr int PN = piece::N;       // columns per lane and sub-chunk
+    constexpr int SUB = 64 * PN;       // columns per sub-chunk (1 KB of a row)
+    constexpr int TW = CT * SUB;
     constexpr int NG = 32 / RPW;  // groups of RPW rows per wave: 32 rows
     constexpr int NV = RPW * B;
     static_assert(NV == 8 || NV == 16 || NV == 32, "partial sums per group");
@@ -102,19 +124,21 @@ __device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int6
         return (const char *)(w + (int64_t)r * ld + cb) + lane * 16;
     };
     // D pipeline stages: the loads of D - 1 groups are in flight while one is used
-    double2 a[D][RPW][CT];
+    piece a[D][RPW][CT];
 #pragma unroll
     for (int g = 0; g < D - 1; ++g)
 #pragma unroll
         for (int i = 0; i < RPW; ++i)
 #pragma unroll
-            for (int s = 0; s < CT; ++s) a[g][i][s] = *(const double2 *)(row_ptr(g, i) + s * 1024);
+            for (int s = 0; s < CT; ++s) a[g][i][s].v = *(const decltype(piece::v) *)(row_ptr(g, i) + s * 1024);
 
-    double acct[CT][2][B];
+    double acct[CT][PN][B];
 #pragma unroll
     for (int s = 0; s < CT; ++s)
 #pragma unroll
-        for (int k = 0; k < B; ++k) acct[s][0][k] = acct[s][1][k] = 0.0;
+        for (int j = 0; j < PN; ++j)
+#pragma unroll
+            for (int k = 0; k < B; ++k) acct[s][j][k] = 0.0;
     __syncthreads();
 
 #pragma unroll
@@ -125,7 +149,7 @@ __device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int6
             for (int i = 0; i < RPW; ++i)
 #pragma unroll
                 for (int s = 0; s < CT; ++s)
-                    a[(g + D - 1) % D][i][s] = *(const double2 *)(row_ptr(g + D - 1, i) + s * 1024);
+                    a[(g + D - 1) % D][i][s].v = *(const decltype(piece::v) *)(row_ptr(g + D - 1, i) + s * 1024);
         }
         double acc[NV];
 #pragma unroll
@@ -135,12 +159,17 @@ __device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int6
 #pragma unroll
             for (int k = 0; k < B; ++k) {
                 // (loop-invariant over the unrolled groups: the compiler keeps these in registers)
-                const double2 zz = *(const double2 *)&zc[k][s * 128 + 2 * lane];
+                double zz[PN];
 #pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    acc[i * B + k] = fma(a[cur][i][s].x, zz.x, acc[i * B + k]);
-                    acc[i * B + k] = fma(a[cur][i][s].y, zz.y, acc[i * B + k]);
+                for (int j = 0; j < PN; j += 2) {
+                    const double2 t = *(const double2 *)&zc[k][s * SUB + PN * lane + j];
+                    zz[j] = t.x;
+                    zz[j + 1] = t.y;
                 }
+#pragma unroll
+                for (int i = 0; i < RPW; ++i)
+#pragma unroll
+                    for (int j = 0; j < PN; ++j) acc[i * B + k] = fma(a[cur][i][s].at(j), zz[j], acc[i * B + k]);
             }
         }
         if (!diag) {
@@ -151,10 +180,9 @@ __device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int6
                 for (int k = 0; k < B; ++k) {
                     const double zz = zr[k][rl];  // one address for the whole wave: broadcast
 #pragma unroll
-                    for (int s = 0; s < CT; ++s) {
-                        acct[s][0][k] = fma(a[cur][i][s].x, zz, acct[s][0][k]);
-                        acct[s][1][k] = fma(a[cur][i][s].y, zz, acct[s][1][k]);
-                    }
+                    for (int s = 0; s < CT; ++s)
+#pragma unroll
+                        for (int j = 0; j < PN; ++j) acct[s][j][k] = fma(a[cur][i][s].at(j), zz, acct[s][j][k]);
                 }
             }
         }
@@ -175,16 +203,18 @@ __device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int6
 #pragma unroll
                 for (int s = 0; s < CT; ++s)
 #pragma unroll
-                    for (int k = 0; k < B; ++k) {
-                        double2 *slot = (double2 *)&red[k][s * 128 + 2 * lane];
-                        double2 v = make_double2(acct[s][0][k], acct[s][1][k]);
-                        if (turn > 0) {
-                            const double2 old = *slot;
-                            v.x = old.x + v.x;
-                            v.y = old.y + v.y;
+                    for (int k = 0; k < B; ++k)
+#pragma unroll
+                        for (int j = 0; j < PN; j += 2) {
+                            double2 *slot = (double2 *)&red[k][s * SUB + PN * lane + j];
+                            double2 v = make_double2(acct[s][j][k], acct[s][j + 1][k]);
+                            if (turn > 0) {
+                                const double2 old = *slot;
+                                v.x = old.x + v.x;
+                                v.y = old.y + v.y;
+                            }
+                            *slot = v;
                         }
-                        *slot = v;
-                    }
             }
             __syncthreads();
         }
@@ -195,15 +225,15 @@ __device__ __forceinline__ void symm_tri_body(const double *__restrict__ w, int6
     }
 }
 
-template <int B, int CT, int RPW, int D>
-__global__ __launch_bounds__(256, 2) void k_symm_tri(const double *__restrict__ w, int64_t ld, int n,
+template <int B, int CT, int RPW, int D, typename WT = double>
+__global__ __launch_bounds__(256, 2) void k_symm_tri(const WT *__restrict__ w, int64_t ld, int n,
                                                      const double *__restrict__ zt, int64_t ldz,
                                                      const int2 *__restrict__ tiles,
                                                      double *__restrict__ pdir,
                                                      double *__restrict__ ptr_,
                                                      int64_t panel_stride = 0) {
-    __shared__ symm_tri_lds<B, CT> lds;
-    symm_tri_body<B, CT, RPW, D>(w, ld, n, zt, ldz, tiles[blockIdx.x], pdir, ptr_, panel_stride, lds);
+    __shared__ symm_tri_lds<B, CT, WT> lds;
+    symm_tri_body<B, CT, RPW, D, WT>(w, ld, n, zt, ldz, tiles[blockIdx.x], pdir, ptr_, panel_stride, lds);
 }
 
 // y[r][:] = scale(r) * ( sum_J pdir[J][r][:] + sum_I ptr[I][r][:] ), J from the diagonal tile

@@ -21,19 +21,19 @@
         }                                                                                 \
     } while (0)
 
-template <int B, int CT, int RPW, int D>
-static void run(const char *what, const double *w, int64_t ld, int n, int64_t panel_stride, const double *z, int64_t ldz,
+template <int B, int CT, int RPW, int D, typename WT = double>
+static void run(const char *what, const WT *w, int64_t ld, int n, int64_t panel_stride, const double *z, int64_t ldz,
                 const int2 *tiles, int n_tiles, double *pdir, double *ptr) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) k_symm_tri<B, CT, RPW, D><<<n_tiles, 256>>>(w, ld, n, z, ldz, tiles, pdir, ptr, panel_stride);
+    for (int i = 0; i < 2; ++i) k_symm_tri<B, CT, RPW, D, WT><<<n_tiles, 256>>>(w, ld, n, z, ldz, tiles, pdir, ptr, panel_stride);
     CK(hipDeviceSynchronize());
     float tot = 0, best = 1e30f;
     const int reps = 10;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0));
-        k_symm_tri<B, CT, RPW, D><<<n_tiles, 256>>>(w, ld, n, z, ldz, tiles, pdir, ptr, panel_stride);
+        k_symm_tri<B, CT, RPW, D, WT><<<n_tiles, 256>>>(w, ld, n, z, ldz, tiles, pdir, ptr, panel_stride);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         float ms;
@@ -41,7 +41,7 @@ static void run(const char *what, const double *w, int64_t ld, int n, int64_t pa
         tot += ms;
         best = ms < best ? ms : best;
     }
-    const double bytes = 8.0 * (double)n_tiles * TRI_TH * (CT * 128);
+    const double bytes = 1024.0 * CT * (double)n_tiles * TRI_TH;
     printf("k_symm_tri<%d, %d, %d, %d> %-28s n %6d: avg %8.3f ms (%6.0f GB/s)  best %8.3f ms (%6.0f GB/s)\n", B, CT, RPW, D, what,
            n, tot / reps, bytes / (tot / reps) / 1e6, best, bytes / best / 1e6);
 }
@@ -73,6 +73,11 @@ int main(int argc, char **argv) {
         run<8, 2, 2, 4>("column panels (tile-major)", w, ld, n, panel_stride, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
         run<4, 2, 4, 3>("row-major (ld)", w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
         run<4, 2, 4, 3>("column panels (tile-major)", w, ld, n, panel_stride, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
+        // round 5, mixed precision: the single-precision image of W (same tiles: 128 x 256, 1 KB row pieces)
+        run<4, 1, 4, 3, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
+        run<4, 1, 4, 4, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
+        run<8, 1, 2, 4, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
+        run<8, 1, 2, 6, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
     }
     return 0;
 }
