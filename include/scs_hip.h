@@ -63,6 +63,11 @@ typedef struct scs_stats {
                                 * (timed every 4th, scaled to all n_allgather)            */
     double allgather_bytes;  /* bytes ONE all-gather delivers to this rank (world x chunk x 8) */
     int32_t n_allgather;     /* all-gathers enqueued by the solve                      */
+    int32_t n_apply32;       /* of n_apply: launches that streamed the single-precision image of W
+                              * (mixed-precision loop; apply_ms_total covers the OTHER launches)   */
+    double apply32_ms_total; /* SYMM kernel time of those launches (timed sample scaled to all)   */
+    double apply32_bytes;    /* algorithmic HBM bytes of ONE such launch                          */
+    int32_t lowp_renewals;   /* times S X and S P were renewed through W inside the loop          */
     int32_t reserved;
 } scs_stats;
 
@@ -93,7 +98,8 @@ typedef struct scs_build_stats {
     int32_t reserved;
 } scs_build_stats;
 
-/* ABI version of this header: 101.  100 -> 101: scs_build_stats is 8 bytes longer
+/* ABI version of this header: 102.  101 -> 102: scs_stats is 24 bytes longer (n_apply32 in the old
+ * `reserved` slot, apply32_ms_total, apply32_bytes, lowp_renewals).  100 -> 101: scs_build_stats is 8 bytes longer
  * (tree_parallel_batches; the old `reserved` slot became spec_batches) and again by spec_trees /
  * spec_ms; scs_forest_* added.  Callers compare it with the value they were compiled against before passing
  * structs (the Python binding refuses a library of another version at load). */

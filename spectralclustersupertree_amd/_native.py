@@ -63,6 +63,10 @@ class Stats(C.Structure):
         ("allgather_ms_total", C.c_double),
         ("allgather_bytes", C.c_double),
         ("n_allgather", C.c_int32),
+        ("n_apply32", C.c_int32),
+        ("apply32_ms_total", C.c_double),
+        ("apply32_bytes", C.c_double),
+        ("lowp_renewals", C.c_int32),
         ("reserved", C.c_int32),
     ]
 
@@ -120,7 +124,7 @@ _I32 = C.c_int32
 # per argument (``data_as``) costs more than the call itself for the tiny nodes of a deep recursion;
 # dptr / iptr / lptr below check the dtype instead
 _DP = _IP = _LP = C.c_void_p
-ABI_VERSION = 101  # scs_version() of the header these bindings were written against
+ABI_VERSION = 102  # scs_version() of the header these bindings were written against
 
 SIGNATURES = {
     "scs_version": (C.c_int, []),

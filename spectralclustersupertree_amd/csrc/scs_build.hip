@@ -291,20 +291,30 @@ __global__ void k_contract(const double *__restrict__ w, int64_t ld, int old_row
 // ---------------------------------------------------------------------------
 // degrees: one wave per row
 // ---------------------------------------------------------------------------
+// IMG (round 5): the pass also leaves the single-precision image W32 of what the symmetric SYMM streams
+// -- a row from the first column of its 256-column diagonal tile to the end of the padding -- for the
+// eigen-solver's operator applications to its search directions (scs_eig.hip); same leading dimension.
+template <bool IMG>
 __global__ __launch_bounds__(256) void k_degrees(const double *__restrict__ w, int64_t ld, int n,
                                                   int rows, int row_begin,
-                                                  double *__restrict__ deg_full) {
+                                                  double *__restrict__ deg_full,
+                                                  float *__restrict__ w32 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const double *row = w + (int64_t)r * ld;
     double s0 = 0.0, s1 = 0.0;
     const int n2 = n & ~1;
+    const int c0 = (row_begin + r) / 256 * 256;
+    float *row32 = IMG ? w32 + (int64_t)r * ld : nullptr;
     for (int j = lane * 2; j < n2; j += 128) {
         const double2 v = *(const double2 *)(row + j);
         s0 += v.x;
         s1 += v.y;
+        if (IMG && j >= c0) *(float2 *)(row32 + j) = make_float2((float)v.x, (float)v.y);
     }
+    if (IMG)  // the last column of an odd n and the padding (zeros)
+        for (int j = n2 + lane; j < ld; j += 64) row32[j] = (float)row[j];
     if ((n & 1) && lane == 0) s0 += row[n - 1];
     double s = s0 + s1;
 #pragma unroll
@@ -526,9 +536,11 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
         scs_pinned_release(ctx, g->deg_stage);
     }
     if (ctx) {
+        if (g->d_w32) scs_block_release(ctx, g->d_w32);
         if (g->d_deg) scs_block_release(ctx, g->d_deg);
         if (g->d_dinv) scs_block_release(ctx, g->d_dinv);
     } else {
+        hipFree(g->d_w32);
         hipFree(g->d_deg);
         hipFree(g->d_dinv);
     }
@@ -1362,7 +1374,7 @@ extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t
 // The degrees in two halves: `begin` enqueues the kernels and the copy of the degrees into page-locked
 // staging, `finish` waits and takes the host-side sums.  scs_fiedler puts its allocations and memsets
 // between the two (the host works while k_degrees streams W); everything else calls both at once.
-int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g) {
+int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
     if (g->have_deg || g->deg_stage) return SCS_OK;
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1371,8 +1383,12 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g) {
     if (!g->d_deg) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_deg));
     if (!g->d_dinv) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_dinv));
     const int world = ctx->comm.world;
-    if (world == 1 && !g->upper) {
-        k_degrees<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg);
+    if (world == 1 && !g->upper && want_w32 && g->row_begin == 0 && rows == n) {
+        if (!g->d_w32) SCS_TRY(scs_block_alloc(ctx, (size_t)rows * g->ld * 4, (void **)&g->d_w32));
+        k_degrees<true><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg, g->d_w32);
+        g->have_w32 = true;
+    } else if (world == 1 && !g->upper) {
+        k_degrees<false><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg);
     } else {
         // every rank contributes a V-long vector that is zero outside its rows
         dev_buf send, recv;
@@ -1385,8 +1401,8 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g) {
             k_degrees_upper_cols<<<(n - g->col0 + 255) / 256, 256, 0, s>>>(
                 g->d_w, g->ld, n, g->row_begin, g->row_end, g->col0, (double *)send.p);
         } else
-        k_degrees<<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin,
-                                                 (double *)send.p);
+        k_degrees<false><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin,
+                                                        (double *)send.p);
         SCS_TRY(scs_comm_allgather_f64(&ctx->comm, (const double *)send.p, (double *)recv.p,
                                        (size_t)n, s));
         // every index is non-zero in its owner's slice only: the sum in rank order is exact

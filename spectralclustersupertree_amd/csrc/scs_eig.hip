@@ -1203,9 +1203,15 @@ __device__ void rr_directions_wave(const jacobi_lds &s, int nq, double drop_tol,
 //   nparts > 0: tm holds nparts per-workgroup partials of T (k_gram_qaq), summed here in
 //   fixed order.
 // (mask, c, d, theta, mask_p may live in LDS: k_panel_rr_solve runs this in front of its panel pass)
+// exact_from >= 0 (mixed-precision loop): only the products S Q_i of the columns i < exact_from (the X
+// block) are exact -- S R came through the single-precision image of W, and S P is a combination that
+// contains it.  Of the two entries of a pair (i < exact_from <= j) only the one with the exact product,
+// Q_j^T (S Q_i), is used: the other carries the image's rounding as an ABSOLUTE error, on an entry (the
+// coupling of X to a search direction) that is as small as the residual itself.  Pairs of two search
+// directions keep the mean: their entries are O(||S||).
 __device__ __forceinline__ void small_rr_body(const double *__restrict__ tm, int nparts, int nq, int b,
                               const int *mask, double *c, double *d, double *theta, int *mask_p,
-                              double drop_tol) {
+                              double drop_tol, int exact_from = -1) {
     __shared__ jacobi_lds s;
     __shared__ double cc[3 * MAXB][MAXB];
     __shared__ double dd[3 * MAXB][MAXB];
@@ -1221,6 +1227,8 @@ __device__ __forceinline__ void small_rr_body(const double *__restrict__ tm, int
         const int i = e / nq, j = e - i * nq;
         double v = nparts > 0 ? 0.5 * (s.e[i][j] + s.e[j][i])
                               : 0.5 * (tm[i * nq + j] + tm[j * nq + i]);
+        if (exact_from >= 0 && nparts > 0 && (i < exact_from) != (j < exact_from))
+            v = i < j ? s.e[j][i] : s.e[i][j];
         const bool live = mask[i] && mask[j];
         if (!live) v = (i == j) ? -1e30 : 0.0;  // dead directions can never be selected
         s.a[i][j] = v;
@@ -1444,14 +1452,15 @@ __global__ __launch_bounds__(256) void k_panel_rr_solve(double *q, double *aq,
                                                          int *maskp_out, double drop_tol, int n,
                                                          double *__restrict__ partial,
                                                          const double *__restrict__ dinv = nullptr,
-                                                         double *__restrict__ zt = nullptr, int64_t ldz = 0) {
+                                                         double *__restrict__ zt = nullptr, int64_t ldz = 0,
+                                                         int exact_from = -1) {
     __shared__ double c_s[3 * B * B], d_s[3 * B * B], th_s[B + 4];
     __shared__ int live_s[3 * B], mp_s[B];
     const int tid = threadIdx.x;
     if (solve) {
         if (tid < 3 * B) live_s[tid] = tid < B ? 1 : (tid < 2 * B ? maskp_in[tid - B] : mask_r[tid - 2 * B]);
         __syncthreads();
-        small_rr_body(tm, nparts_in, 3 * B, B, live_s, c_s, d_s, th_s, mp_s, drop_tol);
+        small_rr_body(tm, nparts_in, 3 * B, B, live_s, c_s, d_s, th_s, mp_s, drop_tol, exact_from);
     } else {
         // first iteration, and after a refresh: X stays, no search directions
         for (int e = tid; e < 3 * B * B; e += 256) {
@@ -1528,8 +1537,8 @@ __global__ __launch_bounds__(256) void k_panel_gram_tf_solve(double *q, double *
 // (small solve on the compact LDS layout, then their share of the rows) while the others stream W against
 // the raw residual block.  The two roles share the workgroup's LDS; nothing passes between them inside
 // the launch.  Workgroup 0 publishes pass 1's coefficients for the Gram kernel (above).
-template <int B, int CT, int RPW, int D>
-__global__ __launch_bounds__(256, 2) void k_symm_tri_tf(const double *__restrict__ w, int64_t ld, int n,
+template <int B, int CT, int RPW, int D, typename WT = double>
+__global__ __launch_bounds__(256, 2) void k_symm_tri_tf(const WT *__restrict__ w, int64_t ld, int n,
                                                         const double *__restrict__ zt, int64_t ldz,
                                                         const int2 *__restrict__ tiles,
                                                         double *__restrict__ pdir, double *__restrict__ ptr_,
@@ -1540,13 +1549,13 @@ __global__ __launch_bounds__(256, 2) void k_symm_tri_tf(const double *__restrict
                                                         double seq, double *__restrict__ partial,
                                                         double *__restrict__ coef_out) {
     union lds_t {
-        symm_tri_lds<B, CT> symm;
+        symm_tri_lds<B, CT, WT> symm;
         orth_small_lds<B> tf;
     };
     __shared__ lds_t lds;
     const int bid = blockIdx.x;
     if (bid >= n_tf) {
-        symm_tri_body<B, CT, RPW, D>(w, ld, n, zt, ldz, tiles[bid - n_tf], pdir, ptr_, 0, lds.symm);
+        symm_tri_body<B, CT, RPW, D, WT>(w, ld, n, zt, ldz, tiles[bid - n_tf], pdir, ptr_, 0, lds.symm);
         return;
     }
     const bool lead = bid == 0;
@@ -1627,6 +1636,13 @@ struct solver {
         double *report = nullptr;
     } tf1;
     dbuf coef1;
+    // round 5, mixed precision: while use32 is set the symmetric SYMM streams the single-precision image
+    // of W (g->d_w32, half the bytes; products and sums stay in double precision) -- the operator applied
+    // to SEARCH DIRECTIONS only; S X and S P are renewed through W itself (scs_fiedler)
+    bool use32 = false;
+    bool gram_from32 = false;  // the Gram partials waiting for the next Rayleigh-Ritz solve hold image products
+    int n_apply32 = 0;
+    std::vector<char> ev32;  // per timed launch in `ev`: streamed the image
     const double *fold_u = nullptr;
     int *fold_mask_r = nullptr;
     const double *fold_theta = nullptr;
@@ -1705,19 +1721,24 @@ struct solver {
         double *ptr_eff = tri_ptr.d() - (int64_t)tri_rb_lo * n * b;
         // (tf1.armed: pass 1 of R's orthonormalisation in the first workgroups of the launch)
         const int n_tf = panel_blocks16();
-#define TRI(B_, CT_, RPW_, D_)                                                                       \
+#define TRI_T(B_, CT_, RPW_, D_, WT_, W_)                                                            \
     if (tf1.armed)                                                                                   \
-        k_symm_tri_tf<B_, CT_, RPW_, D_><<<tri_ntiles + n_tf, 256, 0, s>>>(                          \
-            w_eff, g->ld, n, zin, ldz, tile_list, tri_pdir.d(), ptr_eff, n_tf, q.d(), fold_u,        \
+        k_symm_tri_tf<B_, CT_, RPW_, D_, WT_><<<tri_ntiles + n_tf, 256, 0, s>>>(                     \
+            W_, g->ld, n, zin, ldz, tile_list, tri_pdir.d(), ptr_eff, n_tf, q.d(), fold_u,           \
             part.d(), n_tf, tf1.drop_tol, fold_mask_r, fold_theta, tf1.report, tf1.seq, part2.d(),   \
             coef1.d());                                                                              \
     else                                                                                             \
-        k_symm_tri<B_, CT_, RPW_, D_><<<tri_ntiles, 256, 0, s>>>(w_eff, g->ld, n, zin, ldz,          \
-                                                                 tile_list, tri_pdir.d(), ptr_eff)
+        k_symm_tri<B_, CT_, RPW_, D_, WT_><<<tri_ntiles, 256, 0, s>>>(W_, g->ld, n, zin, ldz,        \
+                                                                      tile_list, tri_pdir.d(), ptr_eff)
+#define TRI(B_, CT_, RPW_, D_) TRI_T(B_, CT_, RPW_, D_, double, w_eff)
         const int2 *tile_list = (const int2 *)tri_tiles.p + (tri_backwards ? tri_ntiles : 0);
         static const bool no_flip = getenv("SCS_TRI_NO_FLIP") && atoi(getenv("SCS_TRI_NO_FLIP"));
         tri_backwards = !no_flip && !tri_backwards;
-        if (b == 4) {
+        if (use32) {
+            // (b = 4, 256-column tiles: the image's piece of a row is 1 KB where W's is 2 KB)
+            TRI_T(4, 1, 4, 3, float, g->d_w32);
+            ++n_apply32;
+        } else if (b == 4) {
             if (tri_ct == 4) TRI(4, 4, 2, 3);
             else if (tri_ct == 1) TRI(4, 1, 4, 4);
             else TRI(4, 2, 4, 3);
@@ -1726,6 +1747,7 @@ struct solver {
             else TRI(8, 2, 2, 4);
         }
 #undef TRI
+#undef TRI_T
         SCS_HIP_CHECK(hipGetLastError());
         tf1.armed = false;
         if (part_mode) {
@@ -1868,6 +1890,7 @@ struct solver {
         SCS_TRY(new_event(&e1));
         ev.push_back(e0);
         ev.push_back(e1);
+        ev32.push_back(use32 ? 1 : 0);
         SCS_HIP_CHECK(hipEventRecord(e0, s));
         SCS_TRY(launch_symm(z.d(), yloc.d()));
         SCS_HIP_CHECK(hipEventRecord(e1, s));
@@ -1953,7 +1976,7 @@ struct solver {
             // the SYMM launch of fused_back
             k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part3.d(), nparts_in, solve, theta,
                                                    maskp_in, mask_r, maskp_out, drop_tol, n, part.d(),
-                                                   g->d_dinv, z.d(), ldz);
+                                                   g->d_dinv, z.d(), ldz, gram_from32 ? B : -1);
             SCS_HIP_CHECK(hipGetLastError());
             tf1.armed = true;
             tf1.drop_tol = drop_tol;
@@ -1964,7 +1987,8 @@ struct solver {
         if (fold_pass2) {
             // round 5: pass 1 writes Z; pass 2 rides the Gram kernel behind the SYMM stream (fused_back)
             k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part3.d(), nparts_in, solve, theta,
-                                                   maskp_in, mask_r, maskp_out, drop_tol, n, part.d());
+                                                   maskp_in, mask_r, maskp_out, drop_tol, n, part.d(), nullptr,
+                                                   nullptr, 0, gram_from32 ? B : -1);
             k_panel_tf_solve<B, true, true><<<nb, 256, 0, s>>>(q.d(), uvec, part.d(), nb, drop_tol, mask_r,
                                                                theta, report, seq, n, part2.d(), g->d_dinv,
                                                                z.d(), ldz);
@@ -1972,7 +1996,8 @@ struct solver {
             return SCS_OK;
         }
         k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part2.d(), nparts_in, solve, theta,
-                                               maskp_in, mask_r, maskp_out, drop_tol, n, part.d());
+                                               maskp_in, mask_r, maskp_out, drop_tol, n, part.d(), nullptr,
+                                               nullptr, 0, gram_from32 ? B : -1);
         k_panel_tf_solve<B, true, false><<<nb, 256, 0, s>>>(q.d(), uvec, part.d(), nb, drop_tol, mask_r,
                                                             theta, report, seq, n, part2.d(), nullptr,
                                                             nullptr, 0);
@@ -2001,7 +2026,9 @@ struct solver {
             SCS_TRY(new_event(&e1));
             ev.push_back(e0);
             ev.push_back(e1);
+            ev32.push_back(use32 ? 1 : 0);
         }
+        gram_from32 = use32;
         const int nb = fold_pass2 ? panel_blocks16() : panel_blocks4();
         const int nb16 = panel_blocks16();  // partials of pass 1's Gram products (k_panel_tf_solve)
         *nparts = nb;
@@ -2180,9 +2207,6 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     hipEvent_t ev_a = ctx->solve_events[0], ev_b = ctx->solve_events[1];
     SCS_HIP_CHECK(hipEventRecord(ev_a, s));
 
-    // (the iterative path below allocates and clears its buffers while k_degrees streams W, and only then
-    // waits for the degrees)
-    SCS_TRY(scs_graph_prepare_degrees_begin(ctx, g));
     if (n <= DENSE2_MAX) SCS_TRY(scs_graph_prepare_degrees(ctx, g));
 
     // 65 .. 96 vertices on one rank: the one-sided dense solve.  Its time grows with n^2 (n - 1
@@ -2226,6 +2250,28 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         b = pick;  // (>= 4: more than the one or two pairs wanted)
     }
     const int q3 = 3 * b;
+
+    // ---- mixed precision (round 5; SCS_LOWP=0 off, 1, 2 = default).  The loop applies the operator to
+    // its SEARCH DIRECTIONS only (S X and S P are carried by linear updates), and a search direction does
+    // not need S to sixteen digits: with the symmetric schedule at width 4 the SYMM streams a single-
+    // precision image of W -- half the bytes, products and sums still in double precision -- that the
+    // degree pass writes on its way through W.  What the image's rounding leaves in S X and S P is removed
+    // by renewing both through W itself once the residual is below SCS_LOWP_TOL (two applications); mode 1
+    // then goes on in double precision, mode 2 stays with the image.  The confirmation at the end always
+    // applies W, and a solve it sends back into the loop continues without the image.
+    const int lowp_mode = getenv("SCS_LOWP") ? atoi(getenv("SCS_LOWP")) : 2;
+    const double lowp_tol = getenv("SCS_LOWP_TOL") ? atof(getenv("SCS_LOWP_TOL")) : 1e-8;
+    // (only the default loop hands its Rayleigh-Ritz solve the one-sided entries: small_rr_body)
+    const bool loop_fused = !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP"))) &&
+                            !(getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"))) &&
+                            !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
+    const bool want32 = lowp_mode > 0 && b == 4 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
+                        g->row_begin == 0 && g->row_end == n && (!g->have_deg || g->have_w32) &&
+                        !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
+                        !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
+    // (the iterative path allocates and clears its buffers while k_degrees streams W, and only then waits
+    // for the degrees)
+    SCS_TRY(scs_graph_prepare_degrees_begin(ctx, g, want32));
 
     solver sv;
     sv.ctx = ctx;
@@ -2275,6 +2321,8 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     const double drop_tol = 1e-13;
 
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));  // (begun at the top: the degrees are needed from here on)
+    sv.use32 = want32 && sv.tri && sv.tri_ct == 2 && g->have_w32;
+    int lowp_state = sv.use32 ? 1 : 0;  // 1: the image in use, S X / S P not yet renewed; 2: renewed
     const bool constrained = g->n_isolated == 0;
     const int want = constrained ? 1 : 2;
 
@@ -2451,7 +2499,19 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         } else if (++since_best >= 12 && worst < 1e-9) {
             stop = true;  // stagnated at the floating-point floor
         }
+        if (!stop && lowp_state == 1 && worst <= lowp_tol) {
+            // S X and S P anew through W itself, behind the iteration already enqueued (its Gram matrix,
+            // formed with the old products, steers one more Rayleigh-Ritz step: coefficients only)
+            sv.use32 = false;
+            SCS_TRY(sv.apply(Q, 0, AQ, 0));
+            SCS_TRY(sv.apply(Q, b, AQ, b));
+            lowp_state = 2;
+            sv.use32 = lowp_mode >= 2;
+            ++st->lowp_renewals;
+        }
         if (stop) {
+            sv.use32 = false;  // the confirmation, and whatever follows it, through W
+            lowp_state = 0;
             // confirm against a freshly applied operator (AX drifts by linear updates)
             if (refreshes < 3) {
                 ++refreshes;
@@ -2547,6 +2607,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     st->block = b;
     st->iterations = iter;
     st->n_apply = sv.n_apply;
+    st->n_apply32 = sv.n_apply32;
     st->converged = converged ? 1 : 0;
     st->used_constraint = constrained ? 1 : 0;
     st->resid[0] = final_res[0];
@@ -2554,20 +2615,29 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     float ms = 0.f;
     hipEventElapsedTime(&ms, ev_a, ev_b);
     st->solve_ms = ms;
-    double tot = 0.0, mn = 1e300;
-    int n_timed = 0;
+    double tot = 0.0, mn = 1e300, tot32 = 0.0;
+    int n_timed = 0, n_timed32 = 0;
     for (size_t i = 0; i + 1 < sv.ev.size(); i += 2) {
         float t = 0.f;
         if (hipEventElapsedTime(&t, sv.ev[i], sv.ev[i + 1]) == hipSuccess) {
+            if (i / 2 < sv.ev32.size() && sv.ev32[i / 2]) {
+                tot32 += t;
+                ++n_timed32;
+                continue;
+            }
             tot += t;
             mn = std::min(mn, (double)t);
             ++n_timed;
         }
     }
-    // the fused loop times every fourth launch: scale the sample to all launches
-    if (n_timed > 0) tot *= (double)sv.n_apply / n_timed;
+    // the fused loop times every fourth launch: scale the sample to all launches (of its kind: the
+    // launches that streamed the single-precision image are reported on their own)
+    if (n_timed > 0) tot *= (double)(sv.n_apply - sv.n_apply32) / n_timed;
+    if (n_timed32 > 0) tot32 *= (double)sv.n_apply32 / n_timed32;
     st->apply_ms_total = tot;
-    st->apply_ms_min = sv.n_apply ? mn : 0.0;
+    st->apply32_ms_total = tot32;
+    st->apply32_bytes = sv.n_apply32 ? 0.5 * sv.w_bytes_per_apply + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b : 0.0;
+    st->apply_ms_min = n_timed ? mn : 0.0;
     // W bytes one application streams (all of this rank's rows, or the upper tiles of the
     // symmetric schedule) + the block in and out
     st->apply_bytes = sv.w_bytes_per_apply + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;

@@ -191,6 +191,10 @@ struct scs_graph {
     // degree data for all V vertices (filled lazily by scs_graph_prepare_degrees)
     bool have_deg = false;
     void *deg_stage = nullptr;  // page-locked copy in flight (scs_graph_prepare_degrees_begin)
+    // single-precision image of the tiles the symmetric SYMM streams (written beside the degrees when the
+    // eigen-solver asks for it: mixed-precision LOBPCG, scs_eig.hip); leading dimension ld
+    float *d_w32 = nullptr;
+    bool have_w32 = false;
     double *d_deg = nullptr;   // [V] row sums
     double *d_dinv = nullptr;  // [V] 1/sqrt(deg) (1 where deg == 0)
     int32_t n_isolated = 0;
@@ -240,7 +244,7 @@ struct scs_forest {
 
 // build.hip
 int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g);
-int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g);
+int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32 = false);
 // row splits of every rank (contiguous, ordered by rank): collective, world + 1 entries
 int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int32_t n,
                           std::vector<int32_t> &splits);
