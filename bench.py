@@ -250,7 +250,7 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         protocol_step()
 
     acc = {"apply_ms": 0.0, "n_apply": 0, "iters": 0, "build_ms": 0.0, "acc_ms": 0.0, "prep_ms": 0.0,
-           "solve_ms": 0.0, "exch_ms": 0.0, "spec_ms": 0.0, "ag_ms": 0.0, "n_ag": 0}
+           "solve_ms": 0.0, "exch_ms": 0.0, "spec_ms": 0.0, "ag_ms": 0.0, "n_ag": 0, "apply32_ms": 0.0, "n_apply32": 0}
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -260,6 +260,8 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         kept, maps, stats, bstats = protocol_step(keep=(world > 1 and i == steps - 1))
         acc["apply_ms"] += stats["apply_ms_total"]
         acc["n_apply"] += stats["n_apply"]
+        acc["apply32_ms"] += stats.get("apply32_ms_total", 0.0)
+        acc["n_apply32"] += stats.get("n_apply32", 0)
         acc["iters"] += stats["iterations"]
         acc["build_ms"] += bstats["total_ms"]
         acc["acc_ms"] += bstats["accumulate_ms"]
@@ -278,20 +280,27 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
     maps, stats, bstats = last
     steps = max(steps, 1)
     sec_per_step = elapsed / steps
-    apply_avg_ms = acc["apply_ms"] / max(acc["n_apply"], 1)
+    # (mixed-precision loop: the launches that streamed the single-precision image of W are timed and
+    # priced on their own -- half the bytes; apply_ms_total covers the double-precision launches)
+    n_apply64 = acc["n_apply"] - acc["n_apply32"]
+    apply_avg_ms = acc["apply_ms"] / max(n_apply64, 1)
+    apply32_avg_ms = acc["apply32_ms"] / max(acc["n_apply32"], 1)
+    apply32_bytes = stats.get("apply32_bytes", 0.0)
     symm_gbs = stats["apply_bytes"] / (apply_avg_ms * 1e-3) / 1e9 if apply_avg_ms > 0 else 0.0
     acc_ms = acc["acc_ms"] / steps
     n_batches = max(int(bstats["n_batches"]), 1)
     cell_rate = bstats["cell_trees"] / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
     build_bytes = bstats["bytes_w"] + bstats["bytes_tables"]
     build_gbs = build_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-    symm_ms_step = acc["apply_ms"] / steps
-    n_apply_step = acc["n_apply"] / steps
+    symm_ms_step = (acc["apply_ms"] + acc["apply32_ms"]) / steps
+    n_apply_step = n_apply64 / steps
+    n_apply32_step = acc["n_apply32"] / steps
     # B_C = n_apply (W bytes of one apply + 16 V b) + n_iter 72 V b with the W
     # bytes the SELECTED kernel must stream -- 4 V^2 (upper tiles) when the symmetric SYMM ran,
     # 8 rows V otherwise: stats["apply_bytes"] is exactly that; B_A = bytes_w + tables
     symm_tri = mode == "upper" or stats["apply_bytes"] < 6.0 * (re_ - rb) * n
-    b_c = n_apply_step * stats["apply_bytes"] + (acc["iters"] / steps) * 72.0 * n * stats["block"]
+    b_c = (n_apply_step * stats["apply_bytes"] + n_apply32_step * apply32_bytes +
+           (acc["iters"] / steps) * 72.0 * n * stats["block"])
     path_gbs = (build_bytes + b_c) / sec_per_step / 1e9
 
     roof_symm = {
@@ -308,8 +317,18 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         "bytes_per_launch": stats["apply_bytes"],
         "avg_launch_ms": round(apply_avg_ms, 5),
         "launches_per_step": n_apply_step,
-        "device_ms_per_step": round(symm_ms_step, 3),
+        "device_ms_per_step": round(acc["apply_ms"] / steps, 3),
     }
+    if acc["n_apply32"]:
+        g32 = apply32_bytes / (apply32_avg_ms * 1e-3) / 1e9 if apply32_avg_ms > 0 else 0.0
+        roof_symm["image_launches"] = {
+            "kernel": (f"k_symm_tri_tf<{stats['block']}, float> (the same tiles from the single-precision image of W: "
+                       "2 V^2 bytes; products and sums in double precision -- the operator on the loop's search directions)"),
+            "bytes_per_launch": apply32_bytes, "avg_launch_ms": round(apply32_avg_ms, 5),
+            "launches_per_step": n_apply32_step, "achieved": round(g32, 1), "unit": "GB/s",
+            "frac": round(g32 / HBM_PEAK_GBS, 4), "device_ms_per_step": round(acc["apply32_ms"] / steps, 3),
+            "renewals_of_SX_SP_through_W_per_solve": stats.get("lowp_renewals", 0),
+        }
     # the PCG accumulation does 0.5 V^2 M cell-tree evaluations (one ds_read_b64, one v_min_f64,
     # one v_add_f64 each) against 8 V^2 bytes written once: its HBM fraction is tiny by
     # construction and is reported as is, next to the fractions of the units that do bound it

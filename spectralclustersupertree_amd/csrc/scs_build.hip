@@ -1375,15 +1375,18 @@ extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t
 // staging, `finish` waits and takes the host-side sums.  scs_fiedler puts its allocations and memsets
 // between the two (the host works while k_degrees streams W); everything else calls both at once.
 int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
-    if (g->have_deg || g->deg_stage) return SCS_OK;
-    SCS_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    if (g->deg_stage) return SCS_OK;
     const int n = g->n;
     const int rows = g->row_end - g->row_begin;
+    const bool need_img = want_w32 && !g->have_w32 && ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && rows == n;
+    if (g->have_deg && !need_img) return SCS_OK;
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
     if (!g->d_deg) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_deg));
     if (!g->d_dinv) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_dinv));
     const int world = ctx->comm.world;
-    if (world == 1 && !g->upper && want_w32 && g->row_begin == 0 && rows == n) {
+    if (need_img) {
+        // (a graph whose degrees are known already gets them again, bit for bit, beside the image)
         if (!g->d_w32) SCS_TRY(scs_block_alloc(ctx, (size_t)rows * g->ld * 4, (void **)&g->d_w32));
         k_degrees<true><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg, g->d_w32);
         g->have_w32 = true;
@@ -1409,6 +1412,10 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
         k_combine_degrees<<<(n + 255) / 256, 256, 0, s>>>((const double *)recv.p, world, n, g->d_deg);
         SCS_HIP_CHECK(hipGetLastError());
         SCS_HIP_CHECK(hipStreamSynchronize(s));  // send / recv go out of scope
+    }
+    if (g->have_deg) {
+        SCS_HIP_CHECK(hipGetLastError());
+        return SCS_OK;
     }
     k_dinv<<<(n + 255) / 256, 256, 0, s>>>(g->d_deg, n, g->d_dinv);
     SCS_HIP_CHECK(hipGetLastError());

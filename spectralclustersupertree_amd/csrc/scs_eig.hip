@@ -1207,8 +1207,11 @@ __device__ void rr_directions_wave(const jacobi_lds &s, int nq, double drop_tol,
 // block) are exact -- S R came through the single-precision image of W, and S P is a combination that
 // contains it.  Of the two entries of a pair (i < exact_from <= j) only the one with the exact product,
 // Q_j^T (S Q_i), is used: the other carries the image's rounding as an ABSOLUTE error, on an entry (the
-// coupling of X to a search direction) that is as small as the residual itself.  Pairs of two search
-// directions keep the mean: their entries are O(||S||).
+// coupling of X to a search direction) that is as small as the residual itself.  Inside the X block the
+// entry with the product of the LOWER column is used likewise: the columns behind the wanted one take
+// long steps along image products, their S X drifts by more, and the mean would rotate that drift into
+// the wanted column (measured: a floor of 1.4e-13 ... 3e-13 under the residual of column 0).  Pairs of
+// two search directions keep the mean: their entries are O(||S||).
 __device__ __forceinline__ void small_rr_body(const double *__restrict__ tm, int nparts, int nq, int b,
                               const int *mask, double *c, double *d, double *theta, int *mask_p,
                               double drop_tol, int exact_from = -1) {
@@ -1227,7 +1230,7 @@ __device__ __forceinline__ void small_rr_body(const double *__restrict__ tm, int
         const int i = e / nq, j = e - i * nq;
         double v = nparts > 0 ? 0.5 * (s.e[i][j] + s.e[j][i])
                               : 0.5 * (tm[i * nq + j] + tm[j * nq + i]);
-        if (exact_from >= 0 && nparts > 0 && (i < exact_from) != (j < exact_from))
+        if (exact_from >= 0 && nparts > 0 && i != j && (i < exact_from || j < exact_from))
             v = i < j ? s.e[j][i] : s.e[i][j];
         const bool live = mask[i] && mask[j];
         if (!live) v = (i == j) ? -1e30 : 0.0;  // dead directions can never be selected
@@ -2256,17 +2259,19 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // not need S to sixteen digits: with the symmetric schedule at width 4 the SYMM streams a single-
     // precision image of W -- half the bytes, products and sums still in double precision -- that the
     // degree pass writes on its way through W.  What the image's rounding leaves in S X and S P is removed
-    // by renewing both through W itself once the residual is below SCS_LOWP_TOL (two applications); mode 1
-    // then goes on in double precision, mode 2 stays with the image.  The confirmation at the end always
-    // applies W, and a solve it sends back into the loop continues without the image.
+    // by renewing both through W itself (two applications) when the residual passes SCS_LOWP_TOL and again at
+    // SCS_LOWP_TOL2; mode 1 goes on in double precision after the first renewal, mode 2 stays with the
+    // image.  The confirmation at the end always applies W, and a solve it sends back into the loop
+    // continues without the image.
     const int lowp_mode = getenv("SCS_LOWP") ? atoi(getenv("SCS_LOWP")) : 2;
     const double lowp_tol = getenv("SCS_LOWP_TOL") ? atof(getenv("SCS_LOWP_TOL")) : 1e-8;
+    const double lowp_tol2 = getenv("SCS_LOWP_TOL2") ? atof(getenv("SCS_LOWP_TOL2")) : 1e-11;
     // (only the default loop hands its Rayleigh-Ritz solve the one-sided entries: small_rr_body)
     const bool loop_fused = !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP"))) &&
                             !(getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"))) &&
                             !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
     const bool want32 = lowp_mode > 0 && b == 4 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
-                        g->row_begin == 0 && g->row_end == n && (!g->have_deg || g->have_w32) &&
+                        g->row_begin == 0 && g->row_end == n &&
                         !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
                         !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
     // (the iterative path allocates and clears its buffers while k_degrees streams W, and only then waits
@@ -2322,7 +2327,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));  // (begun at the top: the degrees are needed from here on)
     sv.use32 = want32 && sv.tri && sv.tri_ct == 2 && g->have_w32;
-    int lowp_state = sv.use32 ? 1 : 0;  // 1: the image in use, S X / S P not yet renewed; 2: renewed
+    int lowp_state = sv.use32 ? 1 : 0;  // image in use: 1 + the renewals of S X / S P made so far; 0: off
     const bool constrained = g->n_isolated == 0;
     const int want = constrained ? 1 : 2;
 
@@ -2499,13 +2504,22 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         } else if (++since_best >= 12 && worst < 1e-9) {
             stop = true;  // stagnated at the floating-point floor
         }
-        if (!stop && lowp_state == 1 && worst <= lowp_tol) {
+        if (!stop && lowp_state > 0 && since_best >= 8) {
+            // the image's rounding has become the floor (a loop that has not halved its residual in eight
+            // iterations): on through the confirmation below -- X renewed through W, search directions
+            // restarted, the rest of the solve in double precision
+            stop = true;
+        }
+        if (!stop && lowp_state > 0 && lowp_state <= 2 && worst <= (lowp_state == 1 ? lowp_tol : lowp_tol2)) {
             // S X and S P anew through W itself, behind the iteration already enqueued (its Gram matrix,
-            // formed with the old products, steers one more Rayleigh-Ritz step: coefficients only)
+            // formed with the old products, steers one more Rayleigh-Ritz step: coefficients only).
+            // What the image adds to S X afterwards is its rounding (~1e-10 ||S||) times the steps still
+            // to be taken, which are of the size of the residual over the spectral gap: a first renewal
+            // clears what the long early steps left, a second one leaves a floor far below the tolerance.
             sv.use32 = false;
             SCS_TRY(sv.apply(Q, 0, AQ, 0));
             SCS_TRY(sv.apply(Q, b, AQ, b));
-            lowp_state = 2;
+            lowp_state = lowp_mode >= 2 ? lowp_state + 1 : 0;
             sv.use32 = lowp_mode >= 2;
             ++st->lowp_renewals;
         }

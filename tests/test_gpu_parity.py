@@ -346,6 +346,39 @@ def test_small_solves_in_front_of_the_tall_kernels_change_no_bit(dev, n, block, 
         assert np.array_equal(maps_c, maps_d)  # no symmetric schedule, nothing to ride on
 
 
+@pytest.mark.parametrize(("n", "m", "weights", "planted"), [(4096, 12, True, False), (5200, 40, False, False),
+                                                               (6000, 6, True, True), (8192, 25, True, False)])
+def test_mixed_precision_loop_reaches_the_same_pair(dev, monkeypatch, n, m, weights, planted):
+    # round 5: at 4 096 <= V < 16 384 the loop's SYMM streams a single-precision image of W (search
+    # directions only; S X / S P renewed through W, the confirmation through W) -- the same eigenpair to the
+    # same tolerance as the all-double loop (SCS_LOWP=0) and as the mode that leaves the image after the
+    # renewal (SCS_LOWP=1); the residual both report is the one measured through W itself
+    tables = synthetic.make_tables(n + 7, n, m, "branch", random_weights=weights,
+                                   planted_spr=int(np.ceil(0.02 * n)) if planted else None)
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    out = {}
+    for mode in ("0", "2", "1"):
+        monkeypatch.setenv("SCS_LOWP", mode)
+        out[mode] = g.fiedler(None, block=4)
+    # (the same graph again: the image is already there, the degrees are not computed a second time)
+    monkeypatch.setenv("SCS_LOWP", "2")
+    again = g.fiedler(None, block=4)
+    g.free()
+    dtab.free()
+    maps0, st0 = out["0"]
+    assert st0["n_apply32"] == 0 and st0["converged"] == 1
+    scale = float(np.max(np.abs(maps0[:, 1])))
+    for mode in ("2", "1"):
+        maps, st = out[mode]
+        assert st["converged"] == 1 and st["n_apply32"] > 0 and st["lowp_renewals"] <= 2, st
+        assert abs(st["lambda"][1] - st0["lambda"][1]) <= 1e-13
+        assert float(np.max(np.abs(maps[:, 1] - maps0[:, 1]))) <= 1e-9 * scale
+        assert st["iterations"] <= st0["iterations"] + 6, (st, st0)
+    assert out["2"][1]["n_apply32"] >= out["1"][1]["n_apply32"]
+    assert np.array_equal(again[0], out["2"][0])
+
+
 @pytest.mark.parametrize("n", [3, 4, 8, 33, 64, 65, 80, 96])
 def test_fiedler_small_dense_path(dev, n):
     # generic (random tree weights, branch lengths) so that no eigenvalue is repeated
