@@ -1378,16 +1378,21 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
     if (g->deg_stage) return SCS_OK;
     const int n = g->n;
     const int rows = g->row_end - g->row_begin;
-    const bool need_img = want_w32 && !g->have_w32 && ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && rows == n;
+    bool need_img = want_w32 && !g->have_w32 && ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && rows == n;
     if (g->have_deg && !need_img) return SCS_OK;
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
+    // (no room for the image: the solve goes without it)
+    if (need_img && !g->d_w32 && scs_block_alloc(ctx, (size_t)rows * g->ld * 4, (void **)&g->d_w32) != SCS_OK) {
+        g->d_w32 = nullptr;
+        need_img = false;
+        if (g->have_deg) return SCS_OK;
+    }
     if (!g->d_deg) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_deg));
     if (!g->d_dinv) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_dinv));
     const int world = ctx->comm.world;
     if (need_img) {
         // (a graph whose degrees are known already gets them again, bit for bit, beside the image)
-        if (!g->d_w32) SCS_TRY(scs_block_alloc(ctx, (size_t)rows * g->ld * 4, (void **)&g->d_w32));
         k_degrees<true><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg, g->d_w32);
         g->have_w32 = true;
     } else if (world == 1 && !g->upper) {

@@ -2237,9 +2237,32 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         return SCS_OK;
     }
 
+    // ---- mixed precision (round 5; SCS_LOWP=0 off, 1, 2 = default).  The loop applies the operator to
+    // its SEARCH DIRECTIONS only (S X and S P are carried by linear updates), and a search direction does
+    // not need S to sixteen digits: with the symmetric schedule at width 4 the SYMM streams a single-
+    // precision image of W -- half the bytes, products and sums still in double precision -- that the
+    // degree pass writes on its way through W.  What the image's rounding leaves in S X and S P is removed
+    // by renewing both through W itself (two applications) when the residual passes SCS_LOWP_TOL (1e-8), and
+    // once more should it stop halving; mode 1 goes on in double precision after the first renewal, mode 2
+    // stays with the image.  The confirmation at the end always applies W, and a solve it sends back into the loop
+    // continues without the image.
+    const int lowp_mode = getenv("SCS_LOWP") ? atoi(getenv("SCS_LOWP")) : 2;
+    const double lowp_tol = getenv("SCS_LOWP_TOL") ? atof(getenv("SCS_LOWP_TOL")) : 1e-8;
+    const double lowp_tol2 = getenv("SCS_LOWP_TOL2") ? atof(getenv("SCS_LOWP_TOL2")) : 0.0;
+    // (only the default loop hands its Rayleigh-Ritz solve the one-sided entries: small_rr_body)
+    const bool loop_fused = !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP"))) &&
+                            !(getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"))) &&
+                            !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
+    const bool image_ok = lowp_mode > 0 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
+                          g->row_begin == 0 && g->row_end == n &&
+                        !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
+                        !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
     // default width: 4 while the panel kernels and the 3b x 3b Rayleigh-Ritz solve weigh
-    // against the SYMM stream, 8 once streaming W dominates (measured crossover ~ 16k)
-    int b = block ? block : (n >= 16384 ? 8 : 4);
+    // against the SYMM stream, 8 once streaming W dominates (measured crossover ~ 16k) -- unless the
+    // loop can stream the single-precision image, which exists at width 4: half the bytes an
+    // application outweigh the iterations width 8 saves (configs[3], 50 000 vertices: 48 iterations and
+    // 78 ms against 35 and 101)
+    int b = block ? block : ((n >= 16384 && !image_ok) ? 8 : 4);
     if (g->upper && b > 8) b = 8;  // the symmetric SYMM kernel comes in widths 4 and 8
     {
         const int allowed[] = {16, 12, 8, 4};
@@ -2254,26 +2277,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     }
     const int q3 = 3 * b;
 
-    // ---- mixed precision (round 5; SCS_LOWP=0 off, 1, 2 = default).  The loop applies the operator to
-    // its SEARCH DIRECTIONS only (S X and S P are carried by linear updates), and a search direction does
-    // not need S to sixteen digits: with the symmetric schedule at width 4 the SYMM streams a single-
-    // precision image of W -- half the bytes, products and sums still in double precision -- that the
-    // degree pass writes on its way through W.  What the image's rounding leaves in S X and S P is removed
-    // by renewing both through W itself (two applications) when the residual passes SCS_LOWP_TOL and again at
-    // SCS_LOWP_TOL2; mode 1 goes on in double precision after the first renewal, mode 2 stays with the
-    // image.  The confirmation at the end always applies W, and a solve it sends back into the loop
-    // continues without the image.
-    const int lowp_mode = getenv("SCS_LOWP") ? atoi(getenv("SCS_LOWP")) : 2;
-    const double lowp_tol = getenv("SCS_LOWP_TOL") ? atof(getenv("SCS_LOWP_TOL")) : 1e-8;
-    const double lowp_tol2 = getenv("SCS_LOWP_TOL2") ? atof(getenv("SCS_LOWP_TOL2")) : 1e-11;
-    // (only the default loop hands its Rayleigh-Ritz solve the one-sided entries: small_rr_body)
-    const bool loop_fused = !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP"))) &&
-                            !(getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"))) &&
-                            !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
-    const bool want32 = lowp_mode > 0 && b == 4 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
-                        g->row_begin == 0 && g->row_end == n &&
-                        !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
-                        !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
+    const bool want32 = image_ok && b == 4;
     // (the iterative path allocates and clears its buffers while k_degrees streams W, and only then waits
     // for the degrees)
     SCS_TRY(scs_graph_prepare_degrees_begin(ctx, g, want32));
@@ -2510,12 +2514,14 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             // restarted, the rest of the solve in double precision
             stop = true;
         }
-        if (!stop && lowp_state > 0 && lowp_state <= 2 && worst <= (lowp_state == 1 ? lowp_tol : lowp_tol2)) {
+        if (!stop && ((lowp_state == 1 && worst <= lowp_tol) ||
+                      (lowp_state == 2 && (worst <= lowp_tol2 || (since_best >= 4 && worst < lowp_tol))))) {
             // S X and S P anew through W itself, behind the iteration already enqueued (its Gram matrix,
             // formed with the old products, steers one more Rayleigh-Ritz step: coefficients only).
             // What the image adds to S X afterwards is its rounding (~1e-10 ||S||) times the steps still
-            // to be taken, which are of the size of the residual over the spectral gap: a first renewal
-            // clears what the long early steps left, a second one leaves a floor far below the tolerance.
+            // to be taken, which are of the size of the residual over the spectral gap: one renewal clears
+            // what the long early steps left (measured: without it 15 more iterations); a second one is
+            // made when the residual stops halving (four iterations) or passes SCS_LOWP_TOL2 (default: off).
             sv.use32 = false;
             SCS_TRY(sv.apply(Q, 0, AQ, 0));
             SCS_TRY(sv.apply(Q, b, AQ, b));

@@ -147,9 +147,11 @@ def _large_config_properties(dev, n, m, random_weights, n_rows, blocks, second_s
         maps, stats = graph.fiedler(v0)
         maps2 = stats2 = None
         if second_solve:
-            # an independent solve: another start vector, the other block width (the default is
-            # 8 at this size) -- another Krylov sequence altogether
-            maps2, stats2 = graph.fiedler(np.random.RandomState(1).uniform(-1, 1, n), block=4)
+            # an independent solve: another start vector, the other block width -- another Krylov
+            # sequence altogether, and (round 5) the other arithmetic: the default on one device is
+            # width 4 with the loop's SYMM streaming the single-precision image of W; width 8
+            # streams W itself throughout
+            maps2, stats2 = graph.fiedler(np.random.RandomState(1).uniform(-1, 1, n), block=8)
     finally:
         graph.free()
         dtab.free()
@@ -182,13 +184,14 @@ def _large_config_properties(dev, n, m, random_weights, n_rows, blocks, second_s
         # the gap (1e-11 / 2.6e-5): two solves that share nothing but the matrix and agree to
         # 1e-11 on the unit-norm scale put the entries where the 1e-10 bar asks (the measured
         # distance to scikit-learn's own solve, 3.7e-12, is profiles/r03_config3_vs_sklearn_final.json)
-        assert stats2["converged"] == 1 and stats2["block"] == 4 and stats["block"] != 4, (stats, stats2)
+        assert stats2["converged"] == 1 and stats2["block"] == 8 and stats["block"] == 4, (stats, stats2)
+        assert stats["n_apply32"] > 0 and stats2["n_apply32"] == 0, (stats, stats2)
         x2 = maps2[:, 1] * dd
         x2 /= float(np.linalg.norm(x2))
         agree_unit = float(np.max(np.abs(x - x2)))
         agree_maps = float(np.max(np.abs(maps[:, 1] - maps2[:, 1])))
         print(f"CFG n={n} two independent solves: b={stats['block']} {stats['iterations']} it, "
-              f"b=4 {stats2['iterations']} it, max |dx| unit-norm {agree_unit:.3e}, embedding {agree_maps:.3e}, "
+              f"b={stats2['block']} {stats2['iterations']} it, max |dx| unit-norm {agree_unit:.3e}, embedding {agree_maps:.3e}, "
               f"|dlambda2| {abs(stats['lambda'][1] - stats2['lambda'][1]):.2e}")
         assert agree_unit <= 1e-11
         assert agree_maps <= 1e-11

@@ -67,6 +67,14 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&ptr, (size_t)n_rb * n * 8 * 8));
     CK(hipMalloc(&d_tiles, tiles.size() * sizeof(int2)));
     CK(hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
+    std::vector<int2> tiles512;
+    const int n_ct512 = (n + 511) / 512;
+    for (int i = 0; i < n_rb; ++i)
+        for (int j = i * TRI_TH / 512; j < n_ct512; ++j) tiles512.push_back(make_int2(i, j));
+    int2 *d_tiles512;
+    const int n_tiles512 = (int)tiles512.size();
+    CK(hipMalloc(&d_tiles512, tiles512.size() * sizeof(int2)));
+    CK(hipMemcpy(d_tiles512, tiles512.data(), tiles512.size() * sizeof(int2), hipMemcpyHostToDevice));
     printf("%zu upper tiles of 128 x 256, %.2f GB streamed per application\n", tiles.size(), 8.0 * tiles.size() * TRI_TH * tw / 1e9);
     for (int rep = 0; rep < 2; ++rep) {
         run<8, 2, 2, 4>("row-major (ld)", w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
@@ -77,7 +85,10 @@ int main(int argc, char **argv) {
         run<4, 1, 4, 3, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
         run<4, 1, 4, 4, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
         run<8, 1, 2, 4, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
-        run<8, 1, 2, 6, float>("W32 row-major (ld)", (const float *)w, ld, n, 0, z, ld, d_tiles, (int)tiles.size(), pdir, ptr);
+        // 512-column tiles of the image (2 KB row pieces): every second tile of the 256-column list
+        run<4, 2, 4, 2, float>("W32, 128 x 512 tiles", (const float *)w, ld, n, 0, z, ld, d_tiles512, n_tiles512, pdir, ptr);
+        run<4, 2, 2, 3, float>("W32, 128 x 512 tiles", (const float *)w, ld, n, 0, z, ld, d_tiles512, n_tiles512, pdir, ptr);
+        run<4, 2, 2, 4, float>("W32, 128 x 512 tiles", (const float *)w, ld, n, 0, z, ld, d_tiles512, n_tiles512, pdir, ptr);
     }
     return 0;
 }
