@@ -484,11 +484,17 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
         ctx->w_cache_bytes = 0;
     } else {
         hipError_t e = hipMalloc((void **)&g->d_w, bytes);
-        if (e != hipSuccess && ctx->w_cache) {  // make room and try once more
+        if (e != hipSuccess && (ctx->w_cache || ctx->w32_cache)) {  // make room and try once more
             (void)hipGetLastError();
-            hipFree(ctx->w_cache);
+            if (ctx->w_cache) hipFree(ctx->w_cache);
             ctx->w_cache = nullptr;
             ctx->w_cache_bytes = 0;
+            {
+                std::lock_guard<std::mutex> lock(ctx->cache_mu);
+                if (ctx->w32_cache) hipFree(ctx->w32_cache);
+                ctx->w32_cache = nullptr;
+                ctx->w32_cache_bytes = 0;
+            }
             e = hipMalloc((void **)&g->d_w, bytes);
         }
         if (e != hipSuccess) {
@@ -536,7 +542,19 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
         scs_pinned_release(ctx, g->deg_stage);
     }
     if (ctx) {
-        if (g->d_w32) scs_block_release(ctx, g->d_w32);
+        if (g->d_w32) {
+            std::lock_guard<std::mutex> lock(ctx->cache_mu);
+            if (getenv("SCS_TRACE_SOLVES") && atoi(getenv("SCS_TRACE_SOLVES")) && ctx->w32_cache)
+                fprintf(stderr, "[image] hipFree of %.2f GB\n",
+                        std::min(g->w32_bytes, ctx->w32_cache_bytes) / 1073741824.0);
+            if (!ctx->w32_cache || g->w32_bytes > ctx->w32_cache_bytes) {
+                if (ctx->w32_cache) hipFree(ctx->w32_cache);
+                ctx->w32_cache = g->d_w32;
+                ctx->w32_cache_bytes = g->w32_bytes;
+            } else {
+                hipFree(g->d_w32);
+            }
+        }
         if (g->d_deg) scs_block_release(ctx, g->d_deg);
         if (g->d_dinv) scs_block_release(ctx, g->d_dinv);
     } else {
@@ -1383,11 +1401,25 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     // (no room for the image: the solve goes without it)
-    if (need_img && !g->d_w32 && scs_block_alloc(ctx, (size_t)rows * g->ld * 4, (void **)&g->d_w32) != SCS_OK) {
-        g->d_w32 = nullptr;
-        need_img = false;
-        if (g->have_deg) return SCS_OK;
+    if (need_img && !g->d_w32) {
+        const size_t need = (size_t)rows * g->ld * 4;
+        std::lock_guard<std::mutex> lock(ctx->cache_mu);
+        if (ctx->w32_cache && ctx->w32_cache_bytes >= need) {
+            g->d_w32 = ctx->w32_cache;
+            g->w32_bytes = ctx->w32_cache_bytes;
+            ctx->w32_cache = nullptr;
+            ctx->w32_cache_bytes = 0;
+        } else if (hipMalloc((void **)&g->d_w32, need) == hipSuccess) {
+            g->w32_bytes = need;
+            if (getenv("SCS_TRACE_SOLVES") && atoi(getenv("SCS_TRACE_SOLVES")))
+                fprintf(stderr, "[image] hipMalloc of %.2f GB\n", need / 1073741824.0);
+        } else {
+            (void)hipGetLastError();
+            g->d_w32 = nullptr;
+            need_img = false;
+        }
     }
+    if (!need_img && g->have_deg) return SCS_OK;
     if (!g->d_deg) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_deg));
     if (!g->d_dinv) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_dinv));
     const int world = ctx->comm.world;

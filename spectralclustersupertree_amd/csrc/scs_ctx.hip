@@ -535,6 +535,11 @@ int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
             ctx->w_cache = nullptr;
             ctx->w_cache_bytes = 0;
         }
+        if (ctx->w32_cache) {
+            hipFree(ctx->w32_cache);
+            ctx->w32_cache = nullptr;
+            ctx->w32_cache_bytes = 0;
+        }
         e = hipMalloc(&p, bytes);
         if (e != hipSuccess) {
             scs_set_error("cannot allocate %zu bytes of device memory: %s", bytes, hipGetErrorString(e));
@@ -632,6 +637,7 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     for (auto &e : ctx->solve_events)
         if (e) hipEventDestroy(e);
     if (ctx->w_cache) hipFree(ctx->w_cache);
+    if (ctx->w32_cache) hipFree(ctx->w32_cache);
     for (auto &b : ctx->blocks) hipFree(b.p);
     // (a page-locked block still lent to a forest's host-side tables stays: arrays may still view it)
     for (auto &b : ctx->pinned)

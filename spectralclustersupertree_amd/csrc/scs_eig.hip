@@ -2209,6 +2209,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         if (!e) SCS_HIP_CHECK(hipEventCreate(&e));
     hipEvent_t ev_a = ctx->solve_events[0], ev_b = ctx->solve_events[1];
     SCS_HIP_CHECK(hipEventRecord(ev_a, s));
+    const auto t_entry = std::chrono::steady_clock::now();
 
     if (n <= DENSE2_MAX) SCS_TRY(scs_graph_prepare_degrees(ctx, g));
 
@@ -2253,7 +2254,11 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     const bool loop_fused = !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP"))) &&
                             !(getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"))) &&
                             !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
+    // (an image above SCS_LOWP_MAX_BYTES, default 16 GiB -- about 65 000 vertices -- is not made: what it
+    // saves a solve of that size, some 80 ms, is less than what an allocation of tens of GB can cost)
+    const double lowp_max_bytes = getenv("SCS_LOWP_MAX_BYTES") ? atof(getenv("SCS_LOWP_MAX_BYTES")) : 16.0 * (1u << 30);
     const bool image_ok = lowp_mode > 0 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
+                          (g->have_w32 || 4.0 * (double)n * (double)g->ld <= lowp_max_bytes) &&
                           g->row_begin == 0 && g->row_end == n &&
                         !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
                         !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
@@ -2677,6 +2682,12 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         // bytes one all-gather delivers to this rank: `world` chunks of `chunk` doubles
         st->allgather_bytes = sv.world > 1 ? 8.0 * (double)sv.chunk * sv.world : 0.0;
     }
+    if (n >= 4096 && getenv("SCS_TRACE_SOLVES") && atoi(getenv("SCS_TRACE_SOLVES")))
+        fprintf(stderr, "[solve] V %d block %d iterations %d applies %d image %d renewals %d refreshes %d solve_ms %.3f "
+                        "wall_ms %.3f residual %.3e gap %.3e\n", n, b, iter, sv.n_apply, sv.n_apply32, st->lowp_renewals,
+                refreshes, st->solve_ms,
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(),
+                std::max(final_res[0], final_res[1]), st->lambda[1] - st->lambda_next);
     if (!converged) {
         // maps_out and stats are filled: the caller decides whether the block is usable
         scs_set_error("scs_fiedler: residual %.3e above tol %.3e after %d iterations (V = %d, block %d)",

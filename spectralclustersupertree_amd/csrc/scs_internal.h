@@ -110,6 +110,12 @@ struct scs_ctx {
     // matrix; the recursion makes thousands of small ones).  One buffer at most.
     double *w_cache = nullptr;
     size_t w_cache_bytes = 0;
+    // the single-precision image of the graph freed last (mixed-precision loop, scs_eig.hip): any later
+    // image that fits takes it over; the larger of two is kept.  Large hipMalloc / hipFree pairs are not
+    // free on this runtime (tools/malloc_time.py: a free returns in 0.4 ms and a LATER hipMalloc of tens
+    // of GB pays 2 - 6 s for it now and then), so the image does not go through the block cache.
+    float *w32_cache = nullptr;
+    size_t w32_cache_bytes = 0;
     // device blocks of the solver, kept between calls (scs_fiedler needs a dozen buffers per
     // call; the recursion calls it thousands of times): a block is handed out again when it is
     // large enough and at most twice the request.  Free blocks beyond SCS_BLOCK_KEEP bytes in
@@ -194,6 +200,7 @@ struct scs_graph {
     // single-precision image of the tiles the symmetric SYMM streams (written beside the degrees when the
     // eigen-solver asks for it: mixed-precision LOBPCG, scs_eig.hip); leading dimension ld
     float *d_w32 = nullptr;
+    size_t w32_bytes = 0;  // size of that allocation (may exceed the need: reused buffer)
     bool have_w32 = false;
     double *d_deg = nullptr;   // [V] row sums
     double *d_dinv = nullptr;  // [V] 1/sqrt(deg) (1 where deg == 0)
