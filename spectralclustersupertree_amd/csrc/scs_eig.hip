@@ -1976,10 +1976,15 @@ struct solver {
         const int nb = panel_blocks16();
         if (overlap_pass1) {
             // the Rayleigh-Ritz kernel hands the SYMM the scaled RAW residual block; pass 1 is armed for
-            // the SYMM launch of fused_back
+            // the SYMM launch of fused_back.  (One-sided Gram entries, exact_from = B, in this loop always:
+            // S R is composed from S applied to the raw block and the products of what pass 1 projects out,
+            // a difference of terms up to 1e6 times its size when a column's residual lies almost inside
+            // [X P] -- its rounding is then what the image's is, small_rr_body.  Found by
+            // tools/fuzz_mixed_precision.py: with the mean of both entries the all-double loop left a
+            // converged column's noise grow until the block blew up, graphs with isolated vertices.)
             k_panel_rr_solve<B><<<nb, 256, 0, s>>>(q.d(), aq.d(), uvec, part3.d(), nparts_in, solve, theta,
                                                    maskp_in, mask_r, maskp_out, drop_tol, n, part.d(),
-                                                   g->d_dinv, z.d(), ldz, gram_from32 ? B : -1);
+                                                   g->d_dinv, z.d(), ldz, B);
             SCS_HIP_CHECK(hipGetLastError());
             tf1.armed = true;
             tf1.drop_tol = drop_tol;
@@ -2512,6 +2517,10 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             since_best = 0;
         } else if (++since_best >= 12 && worst < 1e-9) {
             stop = true;  // stagnated at the floating-point floor
+        } else if (best_res < 1e-6 && worst > 100.0 * best_res) {
+            // moving away from where it had been: the confirmation renews S X through W and restarts the
+            // search directions (no loop this solver runs should come here; a guard, not a path)
+            stop = true;
         }
         if (!stop && lowp_state > 0 && since_best >= 8) {
             // the image's rounding has become the floor (a loop that has not halved its residual in eight
