@@ -379,6 +379,32 @@ def test_mixed_precision_loop_reaches_the_same_pair(dev, monkeypatch, n, m, weig
     assert np.array_equal(again[0], out["2"][0])
 
 
+@pytest.mark.parametrize(("seed", "n", "m", "strategy"), [(11, 4501, 3, "branch"), (12, 6564, 3, "depth"),
+                                                          (13, 5446, 6, "depth")])
+def test_symmetric_schedule_with_isolated_vertices_converges(dev, monkeypatch, seed, n, m, strategy):
+    # partial coverage by a few trees: taxa of degree 0, both leading pairs iterated, and the trivial one
+    # converges to rounding level long before the other -- the loop with pass 1 inside the SYMM launch then
+    # composes S R from terms far larger than R itself; with the mean of both Gram entries it let that
+    # column's noise grow until the block blew up (round 5, found by tools/fuzz_mixed_precision.py: 2 000
+    # iterations, lambda 1e145).  All-double and image loop alike: a few dozen iterations, the same pair.
+    tables = synthetic.make_tables(seed, n, m, strategy, leaves_per_tree=int(0.6 * n))
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    out = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("SCS_LOWP", mode)
+        out[mode] = g.fiedler(None)
+    g.free()
+    dtab.free()
+    (m0, s0), (m2, s2) = out["0"], out["2"]
+    assert s0["used_constraint"] == 0
+    for st in (s0, s2):
+        assert st["converged"] == 1 and st["iterations"] < 150, st
+    assert abs(s0["lambda"][1] - s2["lambda"][1]) <= 1e-13
+    if abs(s0["lambda"][1] - s0["lambda_next"]) > 1e-6:
+        assert float(np.max(np.abs(m0[:, 1] - m2[:, 1]))) <= 1e-9 * float(np.max(np.abs(m0[:, 1])))
+
+
 @pytest.mark.parametrize("n", [3, 4, 8, 33, 64, 65, 80, 96])
 def test_fiedler_small_dense_path(dev, n):
     # generic (random tree weights, branch lengths) so that no eigenvalue is repeated
