@@ -330,6 +330,14 @@ int scs_graph_free(scs_ctx *ctx, scs_graph *graph);
 int scs_fiedler(scs_ctx *ctx, scs_graph *graph, const double *x_init, double tol,
                 int32_t max_iter, int32_t block, double *maps_out, scs_stats *stats);
 
+/* A MEASURED COMPARISON, not the product path: a graph WITHOUT its matrix.  scs_fiedler on
+ * it applies W straight from the flattened tables (per tree one sweep from the left and one from the right
+ * over the leaves, a stack of (depth, value, sum) per sweep; trees added in order) -- scs_pcg_build is not run
+ * at all.  One device, more than 128 taxa, block widths 4 and 8 (max_block: the widest the graph's buffers are
+ * made for); the tables must outlive the graph; no contraction, no download.  Results agree with the dense
+ * path to rounding, not bit for bit.  Free with scs_graph_free. */
+int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tables, int32_t max_block, scs_graph **out);
+
 /* ---- batched small nodes ----------------------------------------------- */
 
 /* Deep recursion levels (reference: scs.py:110-134 at depth): K

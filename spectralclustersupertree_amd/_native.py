@@ -151,6 +151,7 @@ SIGNATURES = {
     "scs_tables_free": (C.c_int, [_P, _P]),
     "scs_pcg_build": (C.c_int, [_P, _P, _I32, _I32, _I32, _PP, C.POINTER(BuildStats)]),
     "scs_graph_contract": (C.c_int, [_P, _P, _IP, _I32, _PP]),
+    "scs_graph_matrix_free": (C.c_int, [_P, _P, _I32, _PP]),
     "scs_graph_shape": (C.c_int, [_P, _IP, _IP, _IP]),
     "scs_graph_download": (C.c_int, [_P, _P, _DP]),
     "scs_graph_download_rows": (C.c_int, [_P, _P, _I32, _I32, _DP]),

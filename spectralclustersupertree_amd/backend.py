@@ -433,6 +433,15 @@ class DeviceTables:
         return graph
 
 
+    def matrix_free_graph(self, max_block: int = 8) -> "DeviceGraph":
+        """A graph WITHOUT its matrix (``scs_graph_matrix_free``): ``fiedler`` on it applies W straight
+        from these tables -- a measured comparison (``tools/matrix_free_compare.py``), not the product
+        path; the tables must outlive the graph; no ``download`` / ``contract``."""
+        handle = C.c_void_p()
+        nv.check(self.dev._lib.scs_graph_matrix_free(self.dev._ctx, self._h, int(max_block), C.byref(handle)))
+        return DeviceGraph(self.dev, handle, {})
+
+
 class DeviceGraph:
     def __init__(self, dev: Device, handle, build_stats: dict | None = None) -> None:
         self.dev, self._h = dev, handle

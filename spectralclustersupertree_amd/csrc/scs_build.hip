@@ -521,6 +521,10 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
 extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
     if (!g) return SCS_OK;
     if (ctx) hipSetDevice(ctx->device);
+    if (g->mf) {
+        if (ctx) hipStreamSynchronize(ctx->stream);
+        scs_matfree_release(g);
+    }
     if (ctx && g->d_w) {
         // keep the larger of the two buffers for the next graph; the kernels that used this
         // one are ordered before any later use by the context's stream
@@ -1299,6 +1303,10 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
 extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *group_start,
                                   int32_t n_groups, scs_graph **out) {
     SCS_REQUIRE(ctx && g && group_start && out, "scs_graph_contract: null argument");
+    if (g->mf) {
+        scs_set_error("scs_graph_contract: a matrix-free graph has no matrix to contract");
+        return SCS_EUNSUP;
+    }
     if (g->upper) {
         scs_set_error("scs_graph_contract: an SCS_BUILD_UPPER graph holds no whole rows; build it "
                       "row-partitioned (SCS_BUILD_SHARED) when the node contracts");
@@ -1350,6 +1358,7 @@ extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t
 
 extern "C" int scs_graph_download(scs_ctx *ctx, const scs_graph *g, double *out) {
     SCS_REQUIRE(ctx && g && out, "scs_graph_download: null argument");
+    SCS_REQUIRE(!g->mf, "scs_graph_download: a matrix-free graph has no matrix");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const size_t rows = (size_t)(g->row_end - g->row_begin);
@@ -1362,6 +1371,7 @@ extern "C" int scs_graph_download(scs_ctx *ctx, const scs_graph *g, double *out)
 extern "C" int scs_graph_download_rows(scs_ctx *ctx, const scs_graph *g, int32_t first,
                                        int32_t count, double *out) {
     SCS_REQUIRE(ctx && g && out, "scs_graph_download_rows: null argument");
+    SCS_REQUIRE(!g->mf, "scs_graph_download_rows: a matrix-free graph has no matrix");
     SCS_REQUIRE(count >= 1 && first >= g->row_begin && first + count <= g->row_end,
                 "scs_graph_download_rows: rows [%d, %d) outside this rank's block [%d, %d)", first,
                 first + count, g->row_begin, g->row_end);
@@ -1396,6 +1406,19 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
     if (g->deg_stage) return SCS_OK;
     const int n = g->n;
     const int rows = g->row_end - g->row_begin;
+    if (g->mf && !g->have_deg) {
+        // matrix-free graph: the degrees are W applied to the vector of ones
+        SCS_HIP_CHECK(hipSetDevice(ctx->device));
+        hipStream_t s = ctx->stream;
+        if (!g->d_deg) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_deg));
+        if (!g->d_dinv) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_dinv));
+        SCS_TRY(scs_matfree_apply(ctx, g, nullptr, 0, 4, nullptr, s));  // (null operand: ones; column 0 -> d_deg)
+        k_dinv<<<(n + 255) / 256, 256, 0, s>>>(g->d_deg, n, g->d_dinv);
+        SCS_HIP_CHECK(hipGetLastError());
+        SCS_TRY(scs_pinned_get(ctx, (size_t)n * 8, &g->deg_stage));
+        SCS_HIP_CHECK(hipMemcpyAsync(g->deg_stage, g->d_deg, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+        return SCS_OK;
+    }
     bool need_img = want_w32 && !g->have_w32 && ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && rows == n;
     if (g->have_deg && !need_img) return SCS_OK;
     SCS_HIP_CHECK(hipSetDevice(ctx->device));

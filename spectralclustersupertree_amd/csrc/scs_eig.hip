@@ -17,6 +17,7 @@
 
 #include "scs_internal.h"
 #include "scs_symm.h"
+#include "scs_matfree.h"
 #include "scs_symm_tri.h"
 
 #include <sched.h>
@@ -1594,6 +1595,175 @@ __global__ void k_dense_s(const double *__restrict__ w, int64_t ld, int n,
 }
 
 // ---------------------------------------------------------------------------
+// matrix-free graphs (scs_matfree.h): creation, the operator, release
+// ---------------------------------------------------------------------------
+void scs_matfree_release(scs_graph *g) {
+    mf_data *m = g->mf;
+    if (!m) return;
+    hipFree(m->d_stack_off);
+    hipFree(m->st_val);
+    hipFree(m->st_sum);
+    hipFree(m->st_dep);
+    hipFree(m->sm_val);
+    hipFree(m->sm_sum);
+    hipFree(m->sm_dep);
+    hipFree(m->cy_pa);
+    hipFree(m->cy_ps);
+    hipFree(m->cy_dep);
+    hipFree(m->sm_cnt);
+    hipFree(m->sm_root);
+    hipFree(m->cy_cnt);
+    hipFree(m->x);
+    hipFree(m->y);
+    hipFree(m->slabs);
+    delete m;
+    g->mf = nullptr;
+}
+
+extern "C" int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tb, int32_t max_block, scs_graph **out) {
+    SCS_REQUIRE(ctx && tb && out, "scs_graph_matrix_free: null argument");
+    SCS_REQUIRE(max_block == 4 || max_block == 8, "scs_graph_matrix_free: widest block 4 or 8 (asked: %d)", max_block);
+    SCS_REQUIRE(ctx->comm.world == 1, "scs_graph_matrix_free: one device only (a measured comparison, DESIGN.md)");
+    SCS_REQUIRE(tb->n_taxa > DENSE2_MAX, "scs_graph_matrix_free: more than %d taxa (the dense small paths need W)", DENSE2_MAX);
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    SCS_TRY(scs_tables_finish(ctx, tb));
+    hipStream_t s = ctx->stream;
+    const int n = tb->n_taxa, M = tb->n_trees;
+    auto *g = new scs_graph();
+    g->n = n;
+    g->row_begin = 0;
+    g->row_end = n;
+    g->ld = scs_round_up(n, SCS_LD_ALIGN);
+    g->mf = new mf_data();
+    mf_data *m = g->mf;
+    m->tb = tb;
+    m->b_cap = max_block;
+    auto fail = [&](int rc) {
+        scs_matfree_release(g);
+        delete g;
+        return rc;
+    };
+    // strips: a tree's stack never holds more entries than its deepest separator
+    int32_t *d_maxd = nullptr;
+    if (hipMalloc((void **)&d_maxd, (size_t)M * 4) != hipSuccess) return fail(SCS_ENOMEM);
+    hipMemsetAsync(d_maxd, 0, (size_t)M * 4, s);
+    k_mf_maxdepth<<<(unsigned)(((tb->n_leaves + 63) / 64 + 255) / 256), 256, 0, s>>>(tb->d_tree_off, M, tb->d_adj_depth,
+                                                                                     tb->n_leaves, d_maxd);
+    std::vector<int32_t> maxd((size_t)M);
+    hipError_t e = hipMemcpyAsync(maxd.data(), d_maxd, (size_t)M * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    hipFree(d_maxd);
+    if (e != hipSuccess) {
+        scs_set_error("scs_graph_matrix_free: %s", hipGetErrorString(e));
+        return fail(SCS_EHIP);
+    }
+    std::vector<int64_t> soff((size_t)M + 1, 0);
+    for (int t = 0; t < M; ++t) soff[t + 1] = soff[t] + maxd[t] + 1;
+    m->stack_total = soff[M];
+    // chunks per direction: pieces of a few hundred leaves, at most 16 (SCS_MF_CHUNKS overrides)
+    m->chunks = std::max(1, std::min(16, tb->max_leaves / 256));
+    if (getenv("SCS_MF_CHUNKS")) m->chunks = std::max(1, std::min(64, atoi(getenv("SCS_MF_CHUNKS"))));
+    const size_t strips = (size_t)2 * max_block * (size_t)m->chunks * (size_t)m->stack_total;
+    const size_t slots = (size_t)2 * max_block * (size_t)m->chunks * (size_t)M;
+    const size_t slab_bytes = (size_t)2 * M * (size_t)n * max_block * 8;
+    if (hipMalloc((void **)&m->d_stack_off, (size_t)(M + 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->st_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->st_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->st_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&m->sm_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->sm_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->sm_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&m->cy_pa, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->cy_ps, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&m->cy_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&m->sm_cnt, slots * 4) != hipSuccess ||
+        hipMalloc((void **)&m->sm_root, slots * 4) != hipSuccess ||
+        hipMalloc((void **)&m->cy_cnt, slots * 4) != hipSuccess ||
+        hipMalloc((void **)&m->x, (size_t)n * max_block * 8) != hipSuccess ||
+        hipMalloc((void **)&m->y, (size_t)n * max_block * 8) != hipSuccess ||
+        hipMalloc((void **)&m->slabs, slab_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        scs_set_error("scs_graph_matrix_free: cannot allocate %.1f GB of slabs", slab_bytes / 1073741824.0);
+        return fail(SCS_ENOMEM);
+    }
+    e = hipMemcpyAsync(m->d_stack_off, soff.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(m->slabs, 0, slab_bytes, s);  // taxa a tree does not hold stay zero
+    if (e == hipSuccess) e = hipStreamSynchronize(s);                      // (`soff` goes out of scope)
+    if (e != hipSuccess) {
+        scs_set_error("scs_graph_matrix_free: %s", hipGetErrorString(e));
+        return fail(SCS_EHIP);
+    }
+    *out = g;
+    return SCS_OK;
+}
+
+// zt == null: the vector of ones (the degrees: column 0 of the result goes to g->d_deg)
+int scs_matfree_apply(scs_ctx *ctx, scs_graph *g, const double *zt, int64_t ldz, int b, double *y_out,
+                      hipStream_t s) {
+    mf_data *m = g->mf;
+    SCS_REQUIRE(m && (b == 4 || b == 8) && b <= m->b_cap, "matrix-free apply: block width %d (graph made for %d)", b,
+                m ? m->b_cap : 0);
+    const scs_tables *tb = m->tb;
+    const int n = g->n, M = tb->n_trees;
+    const int64_t nb = (int64_t)n * b;
+    if (m->slabs_b != b) {
+        // another width lays the slabs out differently: entries of taxa a tree does not hold must be zero
+        SCS_HIP_CHECK(hipMemsetAsync(m->slabs, 0, (size_t)2 * M * (size_t)n * b * 8, s));
+        m->slabs_b = b;
+    }
+    if (zt) {
+        if (b == 4) k_mf_operand<4><<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(zt, ldz, n, m->x);
+        else k_mf_operand<8><<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(zt, ldz, n, m->x);
+    } else {
+        k_mf_fill<<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(m->x, nb, 1.0);
+    }
+    mf_params a;
+    a.tree_off = tb->d_tree_off;
+    a.leaf_taxon = tb->d_leaf_taxon;
+    a.adj_depth = tb->d_adj_depth;
+    a.adj_val = tb->d_adj_val;
+    a.tree_w = tb->d_tree_w;
+    a.stack_off = m->d_stack_off;
+    a.n_trees = M;
+    a.n_taxa = n;
+    a.stack_total = m->stack_total;
+    a.st_val = m->st_val;
+    a.st_sum = m->st_sum;
+    a.st_dep = m->st_dep;
+    a.x = m->x;
+    a.y_slabs = m->slabs;
+    a.chunks = m->chunks;
+    a.sm_dep = m->sm_dep;
+    a.sm_val = m->sm_val;
+    a.sm_sum = m->sm_sum;
+    a.cy_dep = m->cy_dep;
+    a.cy_pa = m->cy_pa;
+    a.cy_ps = m->cy_ps;
+    a.sm_cnt = m->sm_cnt;
+    a.sm_root = m->sm_root;
+    a.cy_cnt = m->cy_cnt;
+    const int64_t units = (int64_t)M * 2 * b;
+    const int64_t threads = units * m->chunks;
+    double *y = y_out ? y_out : m->y;
+    // (strips are laid out for the graph's widest block; a narrower one uses a prefix of the units)
+    if (b == 4) {
+        k_mf_chunk<4, false><<<(unsigned)((threads + 63) / 64), 64, 0, s>>>(a);
+        k_mf_carry<4><<<(unsigned)((units + 63) / 64), 64, 0, s>>>(a);
+        k_mf_chunk<4, true><<<(unsigned)((threads + 63) / 64), 64, 0, s>>>(a);
+        k_mf_reduce<4><<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(m->slabs, M, n, y);
+    } else {
+        k_mf_chunk<8, false><<<(unsigned)((threads + 63) / 64), 64, 0, s>>>(a);
+        k_mf_carry<8><<<(unsigned)((units + 63) / 64), 64, 0, s>>>(a);
+        k_mf_chunk<8, true><<<(unsigned)((threads + 63) / 64), 64, 0, s>>>(a);
+        k_mf_reduce<8><<<(unsigned)((nb + 255) / 256), 256, 0, s>>>(m->slabs, M, n, y);
+    }
+    if (!zt) k_mf_column0<<<(n + 255) / 256, 256, 0, s>>>(y, n, b, g->d_deg);
+    SCS_HIP_CHECK(hipGetLastError());
+    ++m->n_apply;
+    return SCS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
 namespace {
@@ -1778,6 +1948,16 @@ struct solver {
     // yout (rows x b) = dinv (.) (W_local * Z), Z given k-major in zin (b x ld);
     // yout == null leaves the column segments in ypart for the caller to combine
     int launch_symm(const double *zin, double *yout) {
+        if (g->mf) {
+            // matrix-free graph: one unscaled segment into ypart, as k_symm leaves its column segments
+            SCS_TRY(scs_matfree_apply(ctx, g, zin, ldz, b, ypart.d(), s));
+            last_nseg = 1;
+            if (yout)
+                k_symm_finish<<<(rows * b + 255) / 256, 256, 0, s>>>(ypart.d(), 1, rows, b, g->d_dinv,
+                                                                     g->row_begin, yout);
+            SCS_HIP_CHECK(hipGetLastError());
+            return SCS_OK;
+        }
         if (tri) return launch_symm_tri(zin, yout);
         const int64_t ld = g->ld;
         int rpw = 4, sdepth = 2;
@@ -1827,6 +2007,9 @@ struct solver {
         SCS_TRY(z.alloc((size_t)b * ldz * 8));
         SCS_HIP_CHECK(hipMemsetAsync(z.p, 0, (size_t)b * ldz * 8, s));
         w_bytes_per_apply = 8.0 * rows * (double)n;
+        if (g->mf)  // both sweeps read the leaf arrays (16 bytes a leaf); the slabs are written and read once
+            w_bytes_per_apply = 2.0 * 16.0 * (double)g->mf->tb->n_leaves +
+                                2.0 * 2.0 * 8.0 * (double)g->mf->tb->n_trees * (double)n * b;
         if (g->upper) {
             // the job's upper triangle, this rank's row blocks: TW = 256 (the diagonal tile of a
             // row block then starts where the build's stored cells of those rows start)
@@ -1861,7 +2044,7 @@ struct solver {
         // diagonal need streaming (small matrices keep k_symm, whose column segments fill the
         // chip better).  SCS_NO_TRI=1 keeps the full stream.
         static const bool no_tri = getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"));
-        tri = !no_tri && world == 1 && rows == n && g->row_begin == 0 && n >= 4096 && (b == 4 || b == 8);
+        tri = !g->mf && !no_tri && world == 1 && rows == n && g->row_begin == 0 && n >= 4096 && (b == 4 || b == 8);
         if (tri) {
             if (getenv("SCS_TRI_CT")) tri_ct = atoi(getenv("SCS_TRI_CT"));
             const int tw = tri_ct * 128;
@@ -2262,7 +2445,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // (an image above SCS_LOWP_MAX_BYTES, default 16 GiB -- about 65 000 vertices -- is not made: what it
     // saves a solve of that size, some 80 ms, is less than what an allocation of tens of GB can cost)
     const double lowp_max_bytes = getenv("SCS_LOWP_MAX_BYTES") ? atof(getenv("SCS_LOWP_MAX_BYTES")) : 16.0 * (1u << 30);
-    const bool image_ok = lowp_mode > 0 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
+    const bool image_ok = !g->mf && lowp_mode > 0 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
                           (g->have_w32 || 4.0 * (double)n * (double)g->ld <= lowp_max_bytes) &&
                           g->row_begin == 0 && g->row_end == n &&
                         !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
@@ -2274,6 +2457,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // 78 ms against 35 and 101)
     int b = block ? block : ((n >= 16384 && !image_ok) ? 8 : 4);
     if (g->upper && b > 8) b = 8;  // the symmetric SYMM kernel comes in widths 4 and 8
+    if (g->mf) b = std::min(b <= 4 ? 4 : 8, g->mf->b_cap);  // (the sweep kernel likewise)
     {
         const int allowed[] = {16, 12, 8, 4};
         const int cap = (n - 2) / 3;  // 3b basis vectors + the constraint must fit in V

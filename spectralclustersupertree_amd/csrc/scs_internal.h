@@ -182,7 +182,27 @@ int scs_tables_wait(scs_ctx *ctx, const scs_tables *t, int32_t t_end, hipStream_
 // wait (on the host) for everything still on its way; SCS_EINVAL when its range check failed
 int scs_tables_finish(scs_ctx *ctx, const scs_tables *t);
 
+// A graph WITHOUT its matrix (scs_graph_matrix_free, scs_matfree.h: the measured comparison of round 5):
+// the operator is applied from the tables; everything here is plain device memory owned by the graph.
+struct mf_data {
+    const scs_tables *tb = nullptr;  // borrowed: must outlive the graph
+    int64_t *d_stack_off = nullptr;
+    int64_t stack_total = 0;
+    int b_cap = 0;                   // widest block the buffers below are sized for
+    int chunks = 1;                  // pieces a tree's leaves are cut into per direction (scs_matfree.h)
+    double *st_val = nullptr, *st_sum = nullptr;
+    int32_t *st_dep = nullptr;
+    double *sm_val = nullptr, *sm_sum = nullptr, *cy_pa = nullptr, *cy_ps = nullptr;
+    int32_t *sm_dep = nullptr, *cy_dep = nullptr, *sm_cnt = nullptr, *sm_root = nullptr, *cy_cnt = nullptr;
+    double *x = nullptr;             // [n][b_cap] operand, row-major
+    double *y = nullptr;             // [n][b_cap] result, row-major
+    double *slabs = nullptr;         // [2][n_trees][n][b_cap]
+    int slabs_b = 0;                 // block width the slabs were last written with (absent taxa stay zero)
+    int64_t n_apply = 0;
+};
+
 struct scs_graph {
+    mf_data *mf = nullptr;  // non-null: no d_w; see above
     int32_t n = 0;          // V: number of vertices (columns)
     int32_t row_begin = 0;  // first row owned by this rank
     int32_t row_end = 0;
@@ -252,6 +272,10 @@ struct scs_forest {
 // build.hip
 int scs_graph_prepare_degrees(scs_ctx *ctx, scs_graph *g);
 int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32 = false);
+// scs_eig.hip: y (row-major n x b, unscaled) = W x for a matrix-free graph; zt k-major (b x ldz)
+int scs_matfree_apply(scs_ctx *ctx, scs_graph *g, const double *zt, int64_t ldz, int b, double *y_out,
+                      hipStream_t stream);
+void scs_matfree_release(scs_graph *g);
 // row splits of every rank (contiguous, ordered by rank): collective, world + 1 entries
 int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int32_t n,
                           std::vector<int32_t> &splits);
