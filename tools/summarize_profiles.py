@@ -62,15 +62,30 @@ def key_of(acc, needle):
     return next(k for k in acc if needle in k)
 
 
-k_symm = key_of(fetch, "k_symm")
+def symm_key(acc, image):
+    """the SYMM kernel that streams W (double) or its single-precision image (float) among the profiled names"""
+    for k in acc:
+        if ("k_symm_tri<" in k or "k_symm_tri_tf<" in k or "k_symm<" in k) and (("float" in k) == image):
+            return k
+    return None
+
+
+k_symm = symm_key(fetch, False) or key_of(fetch, "k_symm")
+k_img = symm_key(fetch, True)
 roofs = {r["kernel"].split(" ")[0].split("<")[0]: r for r in (bench["roofline"], bench["roofline_other"])}
+for r in list(roofs.values()):  # the SYMM entry carries the launches of the other arithmetic inside it
+    for nest in ("double_precision_launches", "image_launches"):
+        if r.get(nest):
+            roofs[r[nest]["kernel"].split(" ")[0].split("<")[0]] = r[nest]
 # the tile kernel that walked the long tree batches (round 4: k_accumulate_spec up to 20 000 leaves)
 ACC = next(k for k in roofs if k.startswith("k_accumulate"))
 k_acc = key_of(fetch, ACC)
-symm_alg = next(v for k, v in roofs.items() if k.startswith("k_symm"))["bytes_per_launch"]
+symm_alg = roofs["k_symm_tri" if "k_symm_tri" in roofs else next(k for k in roofs if k.startswith("k_symm"))]["bytes_per_launch"]
 acc_alg = roofs[ACC]["bytes_per_launch"]
 alg = {k_symm: (symm_alg, "bytes of W tiles streamed + block in/out"),
-       "k_degrees": (8.0 * n * n, "8 V^2"),
+       **({k_img: (roofs["k_symm_tri_tf"]["bytes_per_launch"], "bytes of the single-precision image's tiles + block in/out")}
+          if k_img and "k_symm_tri_tf" in roofs else {}),
+       key_of(fetch, "k_degrees"): (8.0 * n * n, "8 V^2 read (+ 2 V^2 written when the pass leaves the single-precision image)"),
        k_acc: (acc_alg, "per tree batch: W tile sums written once + tables read once")}
 
 lines = [f"# Round-{tag[1:]} profile: `python3 bench.py --steps 5 --no-cpu-baseline --no-extra --no-parity` "
@@ -108,7 +123,7 @@ traffic = {}
 for k, (ab, note) in alg.items():
     fr = fetch[k]["FETCH_SIZE"][1] / fetch[k]["FETCH_SIZE"][0] * 1024
     wr = write[k]["WRITE_SIZE"][1] / write[k]["WRITE_SIZE"][0] * 1024
-    corr = fr * 2 if ("k_symm" in k or k == "k_degrees") else fr
+    corr = fr * 2 if ("k_symm" in k or "k_degrees" in k) else fr
     lines.append(f"| `{k}` | {fetch[k]['FETCH_SIZE'][0]} | {fr:,.0f} | {corr:,.0f} | {wr:,.0f} | {ab:,.0f} ({note}) |")
     traffic[k] = (fr, corr, wr)
 fr, corr, wr = traffic[k_symm]
@@ -173,8 +188,12 @@ pj = {"_comment": "HBM-side bytes per launch from committed rocprofv3 PMC passes
                   "for wide coalesced reads where that applies, + WRITE_SIZE), keyed by workload name; bench.py quotes the "
                   "matching entry as roofline.traffic",
       "cfg2": [
-          {"kernel": k_symm.replace("void ", "").split("<")[0], "fetch_raw": round(fr), "fetch_corrected": round(corr),
+          {"kernel": "k_symm_tri" if "k_symm_tri" in k_symm else k_symm.replace("void ", "").split("<")[0], "fetch_raw": round(fr), "fetch_corrected": round(corr),
            "write": round(wr), "traffic": round(corr + wr), "source": f"profiles/{tag}_bench_cfg2_summary.md"},
+          *([{"kernel": "k_symm_tri_tf", "fetch_raw": round(traffic[k_img][0]), "fetch_corrected": round(traffic[k_img][1]),
+              "write": round(traffic[k_img][2]), "traffic": round(traffic[k_img][1] + traffic[k_img][2]),
+              "source": f"profiles/{tag}_bench_cfg2_summary.md (the launches that stream the single-precision image)"}]
+            if k_img in traffic else []),
           {"kernel": ACC, "fetch_raw": round(afr), "fetch_corrected": round(acorr), "write": round(awr),
            "traffic": round(acorr + awr), "source": f"profiles/{tag}_bench_cfg2_summary.md (fetches are 8-byte gathers: "
                                                      "uncalibrated width, quoted raw)"}]}
@@ -190,13 +209,18 @@ def extra_rows(suffix, label, bench_file, kernels):
             shutil.copy(raw / bench_file, out / f"{tag}_bench_{label}_under_rocprof.json")
         rows2 = []
         for needle in kernels:
-            k = next((k for k in f2 if needle in k), None)
+            if needle == "k_symm_tri":
+                k = symm_key(f2, False)
+            elif needle == "k_symm_tri_tf":
+                k = symm_key(f2, True)
+            else:
+                k = next((k for k in f2 if needle in k), None)
             if k is None:
                 continue
             frr = f2[k]["FETCH_SIZE"][1] / f2[k]["FETCH_SIZE"][0] * 1024
             wrr = w2[k]["WRITE_SIZE"][1] / w2[k]["WRITE_SIZE"][0] * 1024
             cor = frr * 2 if "k_symm" in k else frr
-            rows2.append({"kernel": k.replace("void ", "").split("<")[0].split("(")[0], "launches_profiled": f2[k]["FETCH_SIZE"][0],
+            rows2.append({"kernel": needle if needle.startswith("k_symm_tri") else k.replace("void ", "").split("<")[0].split("(")[0], "launches_profiled": f2[k]["FETCH_SIZE"][0],
                           "fetch_raw": round(frr), "fetch_corrected": round(cor), "write": round(wrr),
                           "traffic": round(cor + wrr),
                           "source": f"profiles/{tag}_bench_{label}_kernel_stats.csv + PMC passes of tools/collect_profiles.sh"
@@ -207,7 +231,7 @@ def extra_rows(suffix, label, bench_file, kernels):
         return []
 
 
-cfg3_rows = extra_rows("cfg3", "cfg3", "bench_cfg3_under_rocprof.json", ["k_symm_tri", "k_accumulate_spec", "k_accumulate_mono"])
+cfg3_rows = extra_rows("cfg3", "cfg3", "bench_cfg3_under_rocprof.json", ["k_symm_tri", "k_symm_tri_tf", "k_accumulate_spec", "k_accumulate_mono"])
 if cfg3_rows:
     pj["cfg3"] = cfg3_rows
 boot_rows = extra_rows("boot", "cfg2_bootstrap", "bench_boot_under_rocprof.json", ["k_accumulate_gen", "k_symm_tri"])
