@@ -2706,13 +2706,15 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             // search directions (no loop this solver runs should come here; a guard, not a path)
             stop = true;
         }
-        if (!stop && lowp_state > 0 && since_best >= 8) {
-            // the image's rounding has become the floor (a loop that has not halved its residual in eight
-            // iterations): on through the confirmation below -- X renewed through W, search directions
-            // restarted, the rest of the solve in double precision
+        if (!stop && lowp_state >= 2 && since_best >= 8) {
+            // the image's rounding has become the floor (a loop that, S X and S P renewed, has not halved its
+            // residual in eight iterations): on through the confirmation below -- X renewed through W, search
+            // directions restarted, the rest of the solve in double precision.  (Only after the first
+            // renewal: LOBPCG has plateaus of its own -- ten iterations at 4e-5 on the `bootstrap` workload --
+            // and up there the image's rounding is five orders of magnitude below the residual.)
             stop = true;
         }
-        if (!stop && ((lowp_state == 1 && worst <= lowp_tol) ||
+        if (!stop && ((lowp_state == 1 && (worst <= lowp_tol || (since_best >= 8 && worst < 1e-6))) ||
                       (lowp_state == 2 && (worst <= lowp_tol2 || (since_best >= 4 && worst < lowp_tol))))) {
             // S X and S P anew through W itself, behind the iteration already enqueued (its Gram matrix,
             // formed with the old products, steers one more Rayleigh-Ritz step: coefficients only).

@@ -64,10 +64,10 @@ def key_of(acc, needle):
 
 def symm_key(acc, image):
     """the SYMM kernel that streams W (double) or its single-precision image (float) among the profiled names"""
-    for k in acc:
-        if ("k_symm_tri<" in k or "k_symm_tri_tf<" in k or "k_symm<" in k) and (("float" in k) == image):
-            return k
-    return None
+    found = [k for k in acc
+             if ("k_symm_tri<" in k or "k_symm_tri_tf<" in k or "k_symm<" in k) and (("float" in k) == image)]
+    # (the loop's launches -- k_symm_tri_tf -- outnumber the few of the plain kernel: take the kind profiled most)
+    return max(found, key=lambda k: acc[k]["FETCH_SIZE" if "FETCH_SIZE" in acc[k] else "WRITE_SIZE"][0]) if found else None
 
 
 k_symm = symm_key(fetch, False) or key_of(fetch, "k_symm")
