@@ -69,6 +69,8 @@ typedef struct scs_stats {
     double apply32_bytes;    /* algorithmic HBM bytes of ONE such launch                          */
     int32_t lowp_renewals;   /* times S X and S P were renewed through W inside the loop          */
     int32_t reserved;
+    double event_pair_ms;    /* an EMPTY event pair on the solve's stream: what the pair around a timed
+                              * launch adds to apply_ms_* (a profiler's kernel time is about that much less) */
 } scs_stats;
 
 /* Per-call report of scs_pcg_build. */
@@ -98,8 +100,8 @@ typedef struct scs_build_stats {
     int32_t reserved;
 } scs_build_stats;
 
-/* ABI version of this header: 102.  101 -> 102: scs_stats is 24 bytes longer (n_apply32 in the old
- * `reserved` slot, apply32_ms_total, apply32_bytes, lowp_renewals).  100 -> 101: scs_build_stats is 8 bytes longer
+/* ABI version of this header: 103.  102 -> 103: scs_stats ends with event_pair_ms.  101 -> 102: scs_stats is
+ * 24 bytes longer (n_apply32 in the old `reserved` slot, apply32_ms_total, apply32_bytes, lowp_renewals).  100 -> 101: scs_build_stats is 8 bytes longer
  * (tree_parallel_batches; the old `reserved` slot became spec_batches) and again by spec_trees /
  * spec_ms; scs_forest_* added.  Callers compare it with the value they were compiled against before passing
  * structs (the Python binding refuses a library of another version at load). */

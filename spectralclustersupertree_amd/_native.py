@@ -68,6 +68,7 @@ class Stats(C.Structure):
         ("apply32_bytes", C.c_double),
         ("lowp_renewals", C.c_int32),
         ("reserved", C.c_int32),
+        ("event_pair_ms", C.c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -124,7 +125,7 @@ _I32 = C.c_int32
 # per argument (``data_as``) costs more than the call itself for the tiny nodes of a deep recursion;
 # dptr / iptr / lptr below check the dtype instead
 _DP = _IP = _LP = C.c_void_p
-ABI_VERSION = 102  # scs_version() of the header these bindings were written against
+ABI_VERSION = 103  # scs_version() of the header these bindings were written against
 
 SIGNATURES = {
     "scs_version": (C.c_int, []),

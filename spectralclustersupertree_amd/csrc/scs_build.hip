@@ -292,7 +292,7 @@ __global__ void k_contract(const double *__restrict__ w, int64_t ld, int old_row
 // degrees: one wave per row
 // ---------------------------------------------------------------------------
 // IMG (round 5): the pass also leaves the single-precision image W32 of what the symmetric SYMM streams
-// -- a row from the first column of its 256-column diagonal tile to the end of the padding -- for the
+// -- a row from the first column of its 512-column diagonal tile to the end of the padding -- for the
 // eigen-solver's operator applications to its search directions (scs_eig.hip); same leading dimension.
 template <bool IMG>
 __global__ __launch_bounds__(256) void k_degrees(const double *__restrict__ w, int64_t ld, int n,
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_degrees(const double *__restrict__ w, i
     const double *row = w + (int64_t)r * ld;
     double s0 = 0.0, s1 = 0.0;
     const int n2 = n & ~1;
-    const int c0 = (row_begin + r) / 256 * 256;
+    const int c0 = (row_begin + r) / 512 * 512;  // (the image is streamed in 128 x 512 tiles)
     float *row32 = IMG ? w32 + (int64_t)r * ld : nullptr;
     for (int j = lane * 2; j < n2; j += 128) {
         const double2 v = *(const double2 *)(row + j);

@@ -33,7 +33,8 @@ void scs_set_error(const char *fmt, ...) {
 extern "C" const char *scs_last_error(void) { return g_last_error.c_str(); }
 // 101 (round 5): scs_build_stats grew by tree_parallel_batches / spec_batches (round 4), scs_tables_split added
 // 102 (round 5): scs_stats grew by the mixed-precision loop's fields
-extern "C" int scs_version(void) { return 102; }
+// 103: ... and by event_pair_ms
+extern "C" int scs_version(void) { return 103; }
 
 extern "C" int scs_device_count(void) {
     int n = 0;

@@ -1826,6 +1826,7 @@ struct solver {
     // timing of SYMM launches
     std::vector<hipEvent_t> ev;
     std::vector<hipEvent_t> ev_ag;  // pairs around the timed all-gathers (multi-rank solves)
+    hipEvent_t ev_cal[2] = {nullptr, nullptr};  // an empty pair (calibration)
     bool time_ag = false;           // set by fused_back for the launches it times
     int n_allgather = 0;
     int n_apply = 0;
@@ -1834,7 +1835,11 @@ struct solver {
         if (ctx) {
             ctx->event_pool.insert(ctx->event_pool.end(), ev.begin(), ev.end());
             ctx->event_pool.insert(ctx->event_pool.end(), ev_ag.begin(), ev_ag.end());
+            for (auto e : ev_cal)
+                if (e) ctx->event_pool.push_back(e);
         } else {
+            for (auto e : ev_cal)
+                if (e) hipEventDestroy(e);
             for (auto e : ev) hipEventDestroy(e);
             for (auto e : ev_ag) hipEventDestroy(e);
         }
@@ -1882,6 +1887,10 @@ struct solver {
     // its own slabs of the partial sums: the order of the tiles does not touch the result.
     bool tri_backwards = false;
     dbuf tri_tiles, tri_pdir, tri_ptr, ysend;
+    // the image is streamed in 128 x 512 tiles (2 KB pieces of a row, as W's 256 doubles): its own tile list,
+    // stored behind W's in tri_tiles; the partial-sum slabs are W's (fewer column tiles: a prefix)
+    int tri32_nct = 0, tri32_ntiles = 0;
+    double w32_bytes_per_apply = 0.0;
     int64_t ldz = 0;                 // leading dimension of the k-major operand z
     double w_bytes_per_apply = 0.0;  // bytes of W one application streams
 
@@ -1894,22 +1903,23 @@ struct solver {
         double *ptr_eff = tri_ptr.d() - (int64_t)tri_rb_lo * n * b;
         // (tf1.armed: pass 1 of R's orthonormalisation in the first workgroups of the launch)
         const int n_tf = panel_blocks16();
+        const int ntiles = use32 ? tri32_ntiles : tri_ntiles;
 #define TRI_T(B_, CT_, RPW_, D_, WT_, W_)                                                            \
     if (tf1.armed)                                                                                   \
-        k_symm_tri_tf<B_, CT_, RPW_, D_, WT_><<<tri_ntiles + n_tf, 256, 0, s>>>(                     \
+        k_symm_tri_tf<B_, CT_, RPW_, D_, WT_><<<ntiles + n_tf, 256, 0, s>>>(                         \
             W_, g->ld, n, zin, ldz, tile_list, tri_pdir.d(), ptr_eff, n_tf, q.d(), fold_u,           \
             part.d(), n_tf, tf1.drop_tol, fold_mask_r, fold_theta, tf1.report, tf1.seq, part2.d(),   \
             coef1.d());                                                                              \
     else                                                                                             \
-        k_symm_tri<B_, CT_, RPW_, D_, WT_><<<tri_ntiles, 256, 0, s>>>(W_, g->ld, n, zin, ldz,        \
+        k_symm_tri<B_, CT_, RPW_, D_, WT_><<<ntiles, 256, 0, s>>>(W_, g->ld, n, zin, ldz,            \
                                                                       tile_list, tri_pdir.d(), ptr_eff)
 #define TRI(B_, CT_, RPW_, D_) TRI_T(B_, CT_, RPW_, D_, double, w_eff)
-        const int2 *tile_list = (const int2 *)tri_tiles.p + (tri_backwards ? tri_ntiles : 0);
+        const int2 *tile_list = (const int2 *)tri_tiles.p + (use32 ? 2 * tri_ntiles : 0) + (tri_backwards ? ntiles : 0);
         static const bool no_flip = getenv("SCS_TRI_NO_FLIP") && atoi(getenv("SCS_TRI_NO_FLIP"));
         tri_backwards = !no_flip && !tri_backwards;
         if (use32) {
-            // (b = 4, 256-column tiles: the image's piece of a row is 1 KB where W's is 2 KB)
-            TRI_T(4, 1, 4, 3, float, g->d_w32);
+            // (b = 4, 128 x 512 tiles: 8 % faster than 256-column ones, tools/symm_tri_bench.hip)
+            TRI_T(4, 2, 2, 3, float, g->d_w32);
             ++n_apply32;
         } else if (b == 4) {
             if (tri_ct == 4) TRI(4, 4, 2, 3);
@@ -1923,6 +1933,7 @@ struct solver {
 #undef TRI_T
         SCS_HIP_CHECK(hipGetLastError());
         tf1.armed = false;
+        const bool img_tiles = use32;
         if (part_mode) {
             // this rank's partial product, unscaled, all V rows: gathered and added by the caller
             k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), ptr_eff, n, b, tw, tri_nct,
@@ -1937,7 +1948,8 @@ struct solver {
             return SCS_OK;
         }
         // one segment: scaled into yout, or unscaled into ypart for k_gram_qaq to fold in
-        k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), tri_ptr.d(), n, b, tw, tri_nct,
+        k_symm_tri_finish<<<(4 * n * b + 255) / 256, 256, 0, s>>>(tri_pdir.d(), tri_ptr.d(), n, b, img_tiles ? 512 : tw,
+                                                              img_tiles ? tri32_nct : tri_nct,
                                                               yout ? g->d_dinv : nullptr,
                                                               yout ? yout : ypart.d());
         SCS_HIP_CHECK(hipGetLastError());
@@ -2055,11 +2067,22 @@ struct solver {
                 for (int j = i * TRI_TH / tw; j < tri_nct; ++j) tiles.push_back(make_int2(i, j));
             tri_ntiles = (int)tiles.size();
             tiles.insert(tiles.end(), tiles.rbegin(), tiles.rend());  // and backwards
+            {
+                // the image's 128 x 512 tiles, behind W's list
+                std::vector<int2> t32;
+                tri32_nct = (n + 511) / 512;
+                for (int i = 0; i < n_rb; ++i)
+                    for (int j = i * TRI_TH / 512; j < tri32_nct; ++j) t32.push_back(make_int2(i, j));
+                tri32_ntiles = (int)t32.size();
+                tiles.insert(tiles.end(), t32.begin(), t32.end());
+                tiles.insert(tiles.end(), t32.rbegin(), t32.rend());
+                w32_bytes_per_apply = 4.0 * (double)tri32_ntiles * TRI_TH * 512;
+            }
             SCS_TRY(tri_tiles.alloc(tiles.size() * sizeof(int2)));
             SCS_HIP_CHECK(hipMemcpyAsync(tri_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                          hipMemcpyHostToDevice, s));
             SCS_HIP_CHECK(hipStreamSynchronize(s));  // `tiles` goes out of scope
-            SCS_TRY(tri_pdir.alloc((size_t)tri_nct * n * b * 8));
+            SCS_TRY(tri_pdir.alloc((size_t)std::max(tri_nct, tri32_nct) * n * b * 8));
             SCS_TRY(tri_ptr.alloc((size_t)n_rb * n * b * 8));
             w_bytes_per_apply = 8.0 * (double)tri_ntiles * TRI_TH * tw;
         }
@@ -2787,6 +2810,16 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         SCS_HIP_CHECK(hipGetLastError());
     }
 
+    // what an event pair around a launch adds to the launch's own time on this stream (the pair's two records
+    // back to back, the stream busy with the solve's last kernels): reported beside the timed launches
+    hipEvent_t ev_c0 = nullptr, ev_c1 = nullptr;
+    if (sv.new_event(&ev_c0) == SCS_OK && sv.new_event(&ev_c1) == SCS_OK) {
+        sv.ev_cal[0] = ev_c0;
+        sv.ev_cal[1] = ev_c1;
+        hipEventRecord(ev_c0, s);
+        hipEventRecord(ev_c1, s);
+    }
+
     // ---- results: the two wanted columns, scaled, from the device (not the whole panel)
     dbuf maps_d;
     SCS_TRY(maps_d.alloc((size_t)n * 2 * 8));
@@ -2856,8 +2889,12 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     if (n_timed32 > 0) tot32 *= (double)sv.n_apply32 / n_timed32;
     st->apply_ms_total = tot;
     st->apply32_ms_total = tot32;
-    st->apply32_bytes = sv.n_apply32 ? 0.5 * sv.w_bytes_per_apply + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b : 0.0;
+    st->apply32_bytes = sv.n_apply32 ? sv.w32_bytes_per_apply + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b : 0.0;
     st->apply_ms_min = n_timed ? mn : 0.0;
+    {
+        float t = 0.f;
+        st->event_pair_ms = (sv.ev_cal[1] && hipEventElapsedTime(&t, sv.ev_cal[0], sv.ev_cal[1]) == hipSuccess) ? t : 0.0;
+    }
     // W bytes one application streams (all of this rank's rows, or the upper tiles of the
     // symmetric schedule) + the block in and out
     st->apply_bytes = sv.w_bytes_per_apply + 8.0 * (double)n * b + 8.0 * (double)sv.rows * b;

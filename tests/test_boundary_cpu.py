@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # sizes the header implies (int32 fields then doubles, natural alignment)
     # (+ allgather_ms_total, allgather_bytes, n_allgather, n_apply32; + apply32_ms_total, apply32_bytes, lowp_renewals, reserved)
-    assert nv.C.sizeof(nv.Stats) == 6 * 4 + 9 * 8 + 2 * 8 + 2 * 4 + 2 * 8 + 2 * 4
+    assert nv.C.sizeof(nv.Stats) == 6 * 4 + 9 * 8 + 2 * 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8  # (+ event_pair_ms)
     assert nv.C.sizeof(nv.BuildStats) == 8 * 4 + 8 * 8 + 2 * 4 + 8 + 2 * 4  # (+ tree_parallel_batches, spec_trees, spec_ms, listed_batches, reserved)
 
 
