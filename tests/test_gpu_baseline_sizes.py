@@ -148,10 +148,11 @@ def _large_config_properties(dev, n, m, random_weights, n_rows, blocks, second_s
         maps2 = stats2 = None
         if second_solve:
             # an independent solve: another start vector, the other block width -- another Krylov
-            # sequence altogether, and (round 5) the other arithmetic: the default on one device is
-            # width 4 with the loop's SYMM streaming the single-precision image of W; width 8
-            # streams W itself throughout
-            maps2, stats2 = graph.fiedler(np.random.RandomState(1).uniform(-1, 1, n), block=8)
+            # sequence altogether, and (round 5, where the image is made: up to 16 GiB, configs[3]) the
+            # other arithmetic: the default on one device is then width 4 with the loop's SYMM streaming
+            # the single-precision image of W; width 8 streams W itself throughout
+            maps2, stats2 = graph.fiedler(np.random.RandomState(1).uniform(-1, 1, n),
+                                          block=8 if stats["block"] == 4 else 4)
     finally:
         graph.free()
         dtab.free()
@@ -184,8 +185,8 @@ def _large_config_properties(dev, n, m, random_weights, n_rows, blocks, second_s
         # the gap (1e-11 / 2.6e-5): two solves that share nothing but the matrix and agree to
         # 1e-11 on the unit-norm scale put the entries where the 1e-10 bar asks (the measured
         # distance to scikit-learn's own solve, 3.7e-12, is profiles/r03_config3_vs_sklearn_final.json)
-        assert stats2["converged"] == 1 and stats2["block"] == 8 and stats["block"] == 4, (stats, stats2)
-        assert stats["n_apply32"] > 0 and stats2["n_apply32"] == 0, (stats, stats2)
+        assert stats2["converged"] == 1 and {stats["block"], stats2["block"]} == {4, 8}, (stats, stats2)
+        assert (stats["n_apply32"] > 0) == (n <= 60000) and stats2["n_apply32"] == 0, (stats, stats2)
         x2 = maps2[:, 1] * dd
         x2 /= float(np.linalg.norm(x2))
         agree_unit = float(np.max(np.abs(x - x2)))
