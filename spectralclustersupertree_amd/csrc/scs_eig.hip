@@ -1887,6 +1887,7 @@ struct solver {
     // its own slabs of the partial sums: the order of the tiles does not touch the result.
     bool tri_backwards = false;
     dbuf tri_tiles, tri_pdir, tri_ptr, ysend;
+    std::vector<int2> tiles_host;  // source of the asynchronous upload of the tile lists: lives as long as the solve
     // the image is streamed in 128 x 512 tiles (2 KB pieces of a row, as W's 256 doubles): its own tile list,
     // stored behind W's in tri_tiles; the partial-sum slabs are W's (fewer column tiles: a prefix)
     int tri32_nct = 0, tri32_ntiles = 0;
@@ -2062,7 +2063,8 @@ struct solver {
             const int tw = tri_ct * 128;
             const int n_rb = (n + TRI_TH - 1) / TRI_TH;
             tri_nct = (n + tw - 1) / tw;
-            std::vector<int2> tiles;
+            std::vector<int2> &tiles = tiles_host;
+            tiles.clear();
             for (int i = 0; i < n_rb; ++i)
                 for (int j = i * TRI_TH / tw; j < tri_nct; ++j) tiles.push_back(make_int2(i, j));
             tri_ntiles = (int)tiles.size();
@@ -2079,9 +2081,9 @@ struct solver {
                 w32_bytes_per_apply = 4.0 * (double)tri32_ntiles * TRI_TH * 512;
             }
             SCS_TRY(tri_tiles.alloc(tiles.size() * sizeof(int2)));
+            // (no wait here: the degree pass is still streaming W, and the list's source outlives the solve)
             SCS_HIP_CHECK(hipMemcpyAsync(tri_tiles.p, tiles.data(), tiles.size() * sizeof(int2),
                                          hipMemcpyHostToDevice, s));
-            SCS_HIP_CHECK(hipStreamSynchronize(s));  // `tiles` goes out of scope
             SCS_TRY(tri_pdir.alloc((size_t)std::max(tri_nct, tri32_nct) * n * b * 8));
             SCS_TRY(tri_ptr.alloc((size_t)n_rb * n * b * 8));
             w_bytes_per_apply = 8.0 * (double)tri_ntiles * TRI_TH * tw;
