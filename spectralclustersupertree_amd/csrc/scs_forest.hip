@@ -156,45 +156,77 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_count(split_params p) {
 
 // one workgroup of 1024: per part, exclusive scans over the trees
 __global__ __launch_bounds__(1024) void k_split_scan(split_params p) {
-    __shared__ int64_t s_a[1024], s_b[1024], s_c[1024];
-    __shared__ int64_t s_node_base, s_leaf_base;
-    const int tid = threadIdx.x;
+    // (round 5, late: wave-level scans -- shuffles inside the sixteen waves, their totals scanned by the
+    // first wave, two barriers in all -- instead of a ten-step Hillis-Steele scan per part with two barriers a
+    // step: 28 -> 9 us a call, and a recursion makes tens of thousands of them)
+    __shared__ int64_t s_tot[SPLIT_MAX_PARTS][16][3];   // per part, per wave: trees, nodes, leaves
+    __shared__ int64_t s_pre[SPLIT_MAX_PARTS][16][3];   // exclusive over the waves
+    __shared__ int64_t s_base[SPLIT_MAX_PARTS + 1][2];  // node / leaf base of a part (sum over the parts before)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = p.n_trees;
     const int per = (M + 1023) / 1024;
-    if (tid == 0) {
-        s_node_base = 0;
-        s_leaf_base = 0;
-    }
-    __syncthreads();
-    for (int b = 0; b < p.n_parts; ++b) {
+    const int t0 = min(M, tid * per), t1 = min(M, t0 + per);
+    int64_t own[SPLIT_MAX_PARTS][3], inc[SPLIT_MAX_PARTS][3];
+#pragma unroll
+    for (int b = 0; b < SPLIT_MAX_PARTS; ++b) {
+        if (b >= p.n_parts) break;
         const int32_t *lc = p.leaves_cnt + (int64_t)b * M, *nc = p.nodes_cnt + (int64_t)b * M;
-        const int t0 = min(M, tid * per), t1 = min(M, t0 + per);
         int64_t a = 0, n = 0, l = 0;
         for (int t = t0; t < t1; ++t) {
             a += lc[t] > 0;
             n += nc[t];
             l += lc[t];
         }
-        s_a[tid] = a;
-        s_b[tid] = n;
-        s_c[tid] = l;
-        __syncthreads();
-        // inclusive scan of the 1024 partial sums (Hillis-Steele)
-        for (int d = 1; d < 1024; d <<= 1) {
-            int64_t xa = 0, xb = 0, xc = 0;
-            if (tid >= d) {
-                xa = s_a[tid - d];
-                xb = s_b[tid - d];
-                xc = s_c[tid - d];
+        own[b][0] = a;
+        own[b][1] = n;
+        own[b][2] = l;
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            int64_t x = own[b][v];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int64_t y = __shfl_up(x, d, 64);
+                if (lane >= d) x += y;
             }
-            __syncthreads();
-            s_a[tid] += xa;
-            s_b[tid] += xb;
-            s_c[tid] += xc;
-            __syncthreads();
+            inc[b][v] = x;
+            if (lane == 63) s_tot[b][wave][v] = x;
         }
-        const int64_t node_base = s_node_base, leaf_base = s_leaf_base;
-        int64_t ea = s_a[tid] - a, eb = s_b[tid] - n, ec = s_c[tid] - l;  // exclusive
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // lanes 0 .. 15 hold a wave's totals: exclusive scan over the waves, per part and value
+        for (int b = 0; b < p.n_parts; ++b)
+            for (int v = 0; v < 3; ++v) {
+                const int64_t mine = lane < 16 ? s_tot[b][lane][v] : 0;
+                int64_t x = mine;
+#pragma unroll
+                for (int d = 1; d < 16; d <<= 1) {
+                    const int64_t y = __shfl_up(x, d, 64);
+                    if (lane >= d) x += y;
+                }
+                if (lane < 16) s_pre[b][lane][v] = x - mine;
+                if (lane == 15) s_tot[b][0][v] = x;  // the part's total, parked in slot 0
+            }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int64_t nb = 0, lb = 0;
+        for (int b = 0; b < p.n_parts; ++b) {
+            s_base[b][0] = nb;
+            s_base[b][1] = lb;
+            nb += s_tot[b][0][1];
+            lb += s_tot[b][0][2];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < SPLIT_MAX_PARTS; ++b) {
+        if (b >= p.n_parts) break;
+        const int32_t *lc = p.leaves_cnt + (int64_t)b * M, *nc = p.nodes_cnt + (int64_t)b * M;
+        const int64_t node_base = s_base[b][0], leaf_base = s_base[b][1];
+        int64_t ea = s_pre[b][wave][0] + inc[b][0] - own[b][0];  // exclusive
+        int64_t eb = s_pre[b][wave][1] + inc[b][1] - own[b][1];
+        int64_t ec = s_pre[b][wave][2] + inc[b][2] - own[b][2];
         int64_t *cno = p.c_node_off + (int64_t)b * (M + 1), *cto = p.c_tree_off + (int64_t)b * (M + 1);
         for (int t = t0; t < t1; ++t) {
             const bool keep = lc[t] > 0;
@@ -209,19 +241,15 @@ __global__ __launch_bounds__(1024) void k_split_scan(split_params p) {
             eb += nc[t];
             ec += lc[t];
         }
-        __syncthreads();
         if (tid == 1023) {
-            const int64_t trees = s_a[1023], nodes = s_b[1023], leaves = s_c[1023];
+            const int64_t trees = s_tot[b][0][0], nodes = s_tot[b][0][1], leaves = s_tot[b][0][2];
             p.totals[b * 4 + 0] = trees;
             p.totals[b * 4 + 1] = nodes;
             p.totals[b * 4 + 2] = leaves;
             p.totals[b * 4 + 3] = node_base;
             cno[trees] = nodes;
             cto[trees] = leaves;
-            s_node_base = node_base + nodes;
-            s_leaf_base = leaf_base + leaves;
         }
-        __syncthreads();
     }
 }
 
