@@ -423,10 +423,15 @@ __device__ __forceinline__ int32_t scan_op(int32_t a, int32_t b) {
 }
 
 // out[i] = op over in(j), j < i (exclusive), i in [0, n]; in(n) is never read.  4096 items per workgroup.
+// (round 5, late: all parts of a split in ONE launch -- blockIdx.y is the part; `in0.with(part)` is the part's
+// input, out and block_sums advance by a stride per part: a split of two parts made 24 scan launches, now 12)
 template <int OP, typename F>
-__global__ __launch_bounds__(256) void k_scan_local(F in, int32_t *__restrict__ out, int64_t n, int32_t ident,
-                                                     int32_t *__restrict__ block_sums) {
+__global__ __launch_bounds__(256) void k_scan_local(F in0, int32_t *__restrict__ out, int64_t out_stride, int64_t n,
+                                                     int32_t ident, int32_t *__restrict__ block_sums, int64_t nb) {
     __shared__ int32_t s_w[4];
+    const F in = in0.with((int)blockIdx.y);
+    out += (int64_t)blockIdx.y * out_stride;
+    block_sums += (int64_t)blockIdx.y * nb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * 4096 + (int64_t)tid * 16;
     int32_t v[16];
@@ -460,36 +465,43 @@ __global__ __launch_bounds__(256) void k_scan_local(F in, int32_t *__restrict__ 
     if (tid == 255) block_sums[blockIdx.x] = scan_op<OP>(wbase, incl);
 }
 
+// exclusive scan of a part's block sums in place (one workgroup per part): shuffles inside the sixteen
+// waves, their totals scanned by every thread from LDS -- two barriers per 1 024 blocks
 template <int OP>
 __global__ __launch_bounds__(1024) void k_scan_blocks(int32_t *__restrict__ block_sums, int64_t n_blocks, int32_t ident) {
-    __shared__ int32_t s[1024];
+    __shared__ int32_t s_w[16];
     __shared__ int32_t s_carry;
-    const int tid = threadIdx.x;
+    block_sums += (int64_t)blockIdx.x * n_blocks;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = ident;
     __syncthreads();
     for (int64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
         const int64_t i = b0 + tid;
         const int32_t x = i < n_blocks ? block_sums[i] : ident;
-        s[tid] = x;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            int32_t o = ident;
-            if (tid >= d) o = s[tid - d];
-            __syncthreads();
-            s[tid] = scan_op<OP>(o, s[tid]);
-            __syncthreads();
+        int32_t incl = x;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl = scan_op<OP>(o, incl);
         }
-        const int32_t carry = s_carry;
-        const int32_t incl = s[tid];
-        if (i < n_blocks) block_sums[i] = scan_op<OP>(carry, tid > 0 ? s[tid - 1] : ident);  // exclusive
+        int32_t excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = ident;
+        if (lane == 63) s_w[wave] = incl;
         __syncthreads();
-        if (tid == 1023) s_carry = scan_op<OP>(carry, incl);
+        int32_t wbase = s_carry;
+        for (int w = 0; w < wave; ++w) wbase = scan_op<OP>(wbase, s_w[w]);
+        if (i < n_blocks) block_sums[i] = scan_op<OP>(wbase, excl);
+        __syncthreads();
+        if (tid == 1023) s_carry = scan_op<OP>(wbase, incl);
         __syncthreads();
     }
 }
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_scan_add(int32_t *__restrict__ out, int64_t n, const int32_t *__restrict__ block_sums) {
+__global__ __launch_bounds__(256) void k_scan_add(int32_t *__restrict__ out, int64_t out_stride, int64_t n,
+                                                   const int32_t *__restrict__ block_sums, int64_t nb) {
+    out += (int64_t)blockIdx.y * out_stride;
+    block_sums += (int64_t)blockIdx.y * nb;
     const int64_t i0 = (int64_t)blockIdx.x * 4096;
     const int32_t b = block_sums[blockIdx.x];
     for (int k = threadIdx.x; k < 4096; k += 256) {
@@ -498,13 +510,15 @@ __global__ __launch_bounds__(256) void k_scan_add(int32_t *__restrict__ out, int
     }
 }
 
+// out[part][i], i in [0, n]: the exclusive scan of in.with(part) for every part (block_sums: n_parts x nb ints)
 template <int OP, typename F>
-static int scan_exclusive(F in, int32_t *out, int64_t n, int32_t ident, int32_t *block_sums, hipStream_t s) {
+static int scan_exclusive(F in, int32_t *out, int64_t out_stride, int n_parts, int64_t n, int32_t ident,
+                          int32_t *block_sums, hipStream_t s) {
     const int64_t nb = (n + 1 + 4095) / 4096;  // (entry n = the total)
-    k_scan_local<OP, F><<<(unsigned)nb, 256, 0, s>>>(in, out, n, ident, block_sums);
+    k_scan_local<OP, F><<<dim3((unsigned)nb, (unsigned)n_parts), 256, 0, s>>>(in, out, out_stride, n, ident, block_sums, nb);
     if (nb > 1) {
-        k_scan_blocks<OP><<<1, 1024, 0, s>>>(block_sums, nb, ident);
-        k_scan_add<OP><<<(unsigned)nb, 256, 0, s>>>(out, n, block_sums);
+        k_scan_blocks<OP><<<(unsigned)n_parts, 1024, 0, s>>>(block_sums, nb, ident);
+        k_scan_add<OP><<<dim3((unsigned)nb, (unsigned)n_parts), 256, 0, s>>>(out, out_stride, n, block_sums, nb);
     }
     SCS_HIP_CHECK(hipGetLastError());
     return SCS_OK;
@@ -542,22 +556,28 @@ struct par_params {
 struct f_key {
     const signed char *pc;
     int b;
+    __device__ f_key with(int part) const { return f_key{pc, part}; }
     __device__ int32_t operator()(int64_t i) const { return pc[i] == b ? (int32_t)i : -1; }
 };
 struct f_ind {
     const signed char *pc;
     int b;
+    __device__ f_ind with(int part) const { return f_ind{pc, part}; }
     __device__ int32_t operator()(int64_t i) const { return pc[i] == b ? 1 : 0; }
 };
 struct f_ind_kept {
     const signed char *pc;
-    const unsigned char *keep;
+    const unsigned char *keep;  // [parts][n_trees]
     const int32_t *tree_id;
+    int64_t n_trees;
     int b;
+    __device__ f_ind_kept with(int part) const { return f_ind_kept{pc, keep + part * n_trees, tree_id, n_trees, part}; }
     __device__ int32_t operator()(int64_t i) const { return (pc[i] == b && keep[tree_id[i]]) ? 1 : 0; }
 };
 struct f_mark {
-    const unsigned char *mark;
+    const unsigned char *mark;  // [parts][n_nodes]
+    int64_t n_nodes;
+    __device__ f_mark with(int part) const { return f_mark{mark + part * n_nodes, n_nodes}; }
     __device__ int32_t operator()(int64_t i) const { return mark[i]; }
 };
 
@@ -946,7 +966,7 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         SCS_TRY(scratch.alloc((size_t)n_parts * M, (void **)&q.keep));
         SCS_TRY(scratch.alloc((size_t)NC * 4, (void **)&q.corig));
         int32_t *block_sums = nullptr;
-        SCS_TRY(scratch.alloc((size_t)((N + 1 + 4095) / 4096 + 1) * 4, (void **)&block_sums));
+        SCS_TRY(scratch.alloc((size_t)((N + 1 + 4095) / 4096 + 1) * 4 * SPLIT_MAX_PARTS, (void **)&block_sums));
         q.cdepth = p.cdepth;
         q.cval = p.cval;
         q.leaves_cnt = p.leaves_cnt;
@@ -970,19 +990,14 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         q.c_present = p.c_present;
         q.present_ld = T;
         k_par_pc<<<gn, 256, 0, s>>>(q);
-        for (int b = 0; b < n_parts; ++b) {
-            SCS_TRY((scan_exclusive<SCAN_MAX>(f_key{q.pc, b}, q.prev + (int64_t)b * (N + 1), N, -1, block_sums, s)));
-            SCS_TRY((scan_exclusive<SCAN_SUM>(f_ind{q.pc, b}, q.rank + (int64_t)b * (N + 1), N, 0, block_sums, s)));
-        }
+        SCS_TRY((scan_exclusive<SCAN_MAX>(f_key{q.pc, 0}, q.prev, N + 1, n_parts, N, -1, block_sums, s)));
+        SCS_TRY((scan_exclusive<SCAN_SUM>(f_ind{q.pc, 0}, q.rank, N + 1, n_parts, N, 0, block_sums, s)));
         k_par_keep<<<gm, 256, 0, s>>>(q);
-        for (int b = 0; b < n_parts; ++b)
-            SCS_TRY((scan_exclusive<SCAN_SUM>(f_ind_kept{q.pc, q.keep + (int64_t)b * M, q.tree_id, b},
-                                              q.rank + (int64_t)b * (N + 1), N, 0, block_sums, s)));
+        SCS_TRY((scan_exclusive<SCAN_SUM>(f_ind_kept{q.pc, q.keep, q.tree_id, M, 0}, q.rank, N + 1, n_parts, N, 0,
+                                          block_sums, s)));
         SCS_HIP_CHECK(hipMemsetAsync(q.mark, 0, (size_t)n_parts * N, s));
         k_par_mark<<<gn, 256, 0, s>>>(q);
-        for (int b = 0; b < n_parts; ++b)
-            SCS_TRY((scan_exclusive<SCAN_SUM>(f_mark{q.mark + (int64_t)b * N}, q.kpos + (int64_t)b * (N + 1), N, 0,
-                                              block_sums, s)));
+        SCS_TRY((scan_exclusive<SCAN_SUM>(f_mark{q.mark, N}, q.kpos, N + 1, n_parts, N, 0, block_sums, s)));
         k_par_nodes<<<gm, 256, 0, s>>>(q);
         p.tpb = SPLIT_THREADS;
         k_split_scan<<<1, 1024, 0, s>>>(p);
