@@ -510,13 +510,38 @@ __global__ __launch_bounds__(256) void k_scan_add(int32_t *__restrict__ out, int
     }
 }
 
+// k_scan_blocks and k_scan_add in one launch while the blocks are few: every workgroup reduces the raw sums of the
+// blocks in front of it itself (integers under + or max: any order gives the same value) and adds the result
+template <int OP>
+__global__ __launch_bounds__(256) void k_scan_add_raw(int32_t *__restrict__ out, int64_t out_stride, int64_t n,
+                                                       const int32_t *__restrict__ block_sums, int64_t nb, int32_t ident) {
+    __shared__ int32_t s_w[4];
+    out += (int64_t)blockIdx.y * out_stride;
+    block_sums += (int64_t)blockIdx.y * nb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t acc = ident;
+    for (int64_t j = tid; j < (int64_t)blockIdx.x; j += 256) acc = scan_op<OP>(acc, block_sums[j]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc = scan_op<OP>(acc, __shfl_xor(acc, d, 64));
+    if (lane == 0) s_w[wave] = acc;
+    __syncthreads();
+    const int32_t b = scan_op<OP>(scan_op<OP>(s_w[0], s_w[1]), scan_op<OP>(s_w[2], s_w[3]));
+    const int64_t i0 = (int64_t)blockIdx.x * 4096;
+    for (int k = tid; k < 4096; k += 256) {
+        const int64_t i = i0 + k;
+        if (i <= n) out[i] = scan_op<OP>(b, out[i]);
+    }
+}
+
 // out[part][i], i in [0, n]: the exclusive scan of in.with(part) for every part (block_sums: n_parts x nb ints)
 template <int OP, typename F>
 static int scan_exclusive(F in, int32_t *out, int64_t out_stride, int n_parts, int64_t n, int32_t ident,
                           int32_t *block_sums, hipStream_t s) {
     const int64_t nb = (n + 1 + 4095) / 4096;  // (entry n = the total)
     k_scan_local<OP, F><<<dim3((unsigned)nb, (unsigned)n_parts), 256, 0, s>>>(in, out, out_stride, n, ident, block_sums, nb);
-    if (nb > 1) {
+    if (nb > 1 && nb <= 8192) {
+        k_scan_add_raw<OP><<<dim3((unsigned)nb, (unsigned)n_parts), 256, 0, s>>>(out, out_stride, n, block_sums, nb, ident);
+    } else if (nb > 1) {
         k_scan_blocks<OP><<<(unsigned)n_parts, 1024, 0, s>>>(block_sums, nb, ident);
         k_scan_add<OP><<<dim3((unsigned)nb, (unsigned)n_parts), 256, 0, s>>>(out, out_stride, n, block_sums, nb);
     }
