@@ -102,13 +102,13 @@ __global__ void k_mf_maxdepth(const int64_t *__restrict__ tree_off, int n_trees,
 // ahead -- taxon, separator and the operand row behind the taxon are independent of the stack, only the
 // stack walk is a dependent chain.
 // The B lanes of a (tree, direction, chunk) group walk in lockstep and share depth and value of every stack
-// entry: one copy per group, written by the group's first lane.  22 KB of LDS a wave and at most 128 VGPRs:
+// entry: one copy per group, written by the group's first lane.  22 KB of LDS a wave:
 // seven waves a CU instead of three (the walk is latency-bound: more waves is what it needs).
 constexpr int MF_LDS_LEVELS = 32;
 constexpr int MF_CHUNK = 4;
 
 template <int B, bool OUT>
-__global__ __launch_bounds__(64, 4) void k_mf_chunk(mf_params a) {
+__global__ __launch_bounds__(64, 2) void k_mf_chunk(mf_params a) {
     constexpr int G = 64 / B;
     __shared__ double l_val[MF_LDS_LEVELS][G];
     __shared__ double l_sum[MF_LDS_LEVELS][64];
