@@ -2973,7 +2973,13 @@ struct small_batch {
     // work items of k_small_addends: (node, first tree, end tree); of k_small_sum: (node, first cell)
     const int32_t *item_node, *item_t0, *item_t1;
     const int32_t *sum_node, *sum_e0;
-    const int64_t *add_ptr;  // [K] first addend of node k: addends[add_ptr[k] + tree * v0^2 + x * v0 + y]
+    // [K] first addend of node k.  Nodes of at most SMALL_TR_MAX taxa: addends[add_ptr[k] + (x * v0 + y) * ms +
+    // tree], ms = trees rounded up to even -- a cell's addends lie in tree order in ONE piece, which the one
+    // thread of that cell streams with 16-byte loads (a node of 8 taxa has 28 cells: with the trees outermost
+    // its few threads fetched a line per tree).  Larger nodes: addends[add_ptr[k] + tree * v0^2 + x * v0 + y]
+    // -- hundreds of cells, neighbouring threads read neighbouring addresses (measured both ways:
+    // tools/small_solve_bench.py).  The space reserved is v0^2 * ms either way.
+    const int64_t *add_ptr;
     double *addends;
     const int64_t *w0_ptr;   // [K] the node's v0 x v0 uncontracted weights in w0
     double *w0;
@@ -2981,6 +2987,7 @@ struct small_batch {
 
 constexpr int SMALL_Q = MAXS * MAXS / 256;  // cells of a thread at the largest node of the one-wave form
 constexpr int SMALL_MAXS = 128;             // largest node of the batched path (round 4: was MAXS)
+constexpr int SMALL_TR_MAX = 24;            // up to here a cell's addends are stored contiguously (small_batch::add_ptr)
 
 // A node of 65 .. 128 taxa (round 4; SURVEY.md 8f rank 3 asks for V <= 128): the same three
 // launches.  A tree restricted to such a node has up to 128 leaves -- two per lane while a wave
@@ -2994,6 +3001,8 @@ __device__ void small_addends_big(const small_batch &p, int k, int t0, int t1, u
     const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
     const int64_t lbase = p.leaf_ptr[k];
     double *out = p.addends + p.add_ptr[k];
+    const bool tr = v0 <= SMALL_TR_MAX;  // (never here: the big path starts above 64 taxa; kept for symmetry)
+    const int64_t cs = tr ? (p.n_trees[k] + 1) & ~1 : 1;  // stride between two cells of a tree (small_batch::add_ptr)
     const int y = tid & 127, x0 = tid >> 7;
     for (int g = t0; g < t1; g += 4) {
         __syncthreads();  // the cells of the previous four trees are done with the buffers
@@ -3040,7 +3049,7 @@ __device__ void small_addends_big(const small_batch &p, int k, int t0, int t1, u
             const int t = g + j;
             if (t >= t1) break;
             const double wt = p.tree_w[p.tree_ptr[k] + t];
-            double *row = out + (int64_t)t * ncell;
+            double *row = tr ? out + t : out + (int64_t)t * ncell;
             const int py = y < v0 ? s_pos[j][y] : -1;
             for (int x = x0; x < y && y < v0; x += 2) {
                 const int px = s_pos[j][x];
@@ -3057,7 +3066,7 @@ __device__ void small_addends_big(const small_batch &p, int k, int t0, int t1, u
 #pragma clang fp contract(off)
                     add = mv * wt;  // rounded on its own, never fused into the sum
                 }
-                row[x * v0 + y] = add;
+                row[(int64_t)(x * v0 + y) * cs] = add;
             }
         }
     }
@@ -3081,6 +3090,8 @@ __global__ __launch_bounds__(256) void k_small_addends(small_batch p) {
     const int32_t *toff = p.tree_off + p.tree_ptr[k] + k;
     const int64_t lbase = p.leaf_ptr[k];
     double *out = p.addends + p.add_ptr[k];
+    const bool tr = v0 <= SMALL_TR_MAX;
+    const int64_t cs = tr ? (p.n_trees[k] + 1) & ~1 : 1;
     const int nq = (ncell + 255) / 256;
     int cx[SMALL_Q], cy[SMALL_Q];
 #pragma unroll
@@ -3122,7 +3133,7 @@ __global__ __launch_bounds__(256) void k_small_addends(small_batch p) {
             const int t = g + j;
             if (t >= t1) break;
             const double wt = p.tree_w[p.tree_ptr[k] + t];
-            double *row = out + (int64_t)t * ncell;
+            double *row = tr ? out + t : out + (int64_t)t * ncell;
 #pragma unroll
             for (int q = 0; q < SMALL_Q; ++q) {
                 if (q >= nq) break;  // (uniform) most nodes are tiny
@@ -3141,7 +3152,7 @@ __global__ __launch_bounds__(256) void k_small_addends(small_batch p) {
 #pragma clang fp contract(off)
                     add = mv * wt;  // rounded on its own, never fused into the sum
                 }
-                row[tid + 256 * q] = add;
+                row[(int64_t)(tid + 256 * q) * cs] = add;
             }
         }
     }
@@ -3158,17 +3169,46 @@ __global__ __launch_bounds__(256) void k_small_sum(small_batch p) {
     double *w0 = p.w0 + p.w0_ptr[k];
     if (x == y) w0[e] = 0.0;
     if (x >= y) return;
-    const double *in = p.addends + p.add_ptr[k] + e;
     double acc = 0.0;
     int t = 0;
-    for (; t + 8 <= m; t += 8) {
-        double a[8];
+    // (the adds are one chain in tree order -- the reference's order, scs.py:656 -- but the LOADS need not wait
+    // for it.  With 8 loads in flight the kernel took 190 us for 5 000 trees whatever the node's size, 625 round
+    // trips, and a recursion runs it tens of thousands of times; tools/small_solve_bench.py)
+    if (v0 <= SMALL_TR_MAX) {
+        const int64_t ms = (m + 1) & ~1;
+        const double *in = p.addends + p.add_ptr[k] + (int64_t)e * ms;  // 16-byte aligned: add_ptr and ms are even
+        for (; t + 64 <= m; t += 64) {
+            double2 a[32];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = in[(int64_t)(t + j) * ncell];
+            for (int j = 0; j < 32; ++j) a[j] = *(const double2 *)(in + t + 2 * j);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = acc + a[j];
+            for (int j = 0; j < 32; ++j) {
+                acc = acc + a[j].x;
+                acc = acc + a[j].y;
+            }
+        }
+        for (; t + 8 <= m; t += 8) {
+            double2 a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = *(const double2 *)(in + t + 2 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc = acc + a[j].x;
+                acc = acc + a[j].y;
+            }
+        }
+        for (; t < m; ++t) acc = acc + in[t];
+    } else {
+        const double *in = p.addends + p.add_ptr[k] + e;
+        for (; t + 32 <= m; t += 32) {
+            double a[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) a[j] = in[(int64_t)(t + j) * ncell];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc = acc + a[j];
+        }
+        for (; t < m; ++t) acc = acc + in[(int64_t)t * ncell];
     }
-    for (; t < m; ++t) acc = acc + in[(int64_t)t * ncell];
     w0[e] = acc;
     w0[y * v0 + x] = acc;
 }
@@ -3450,7 +3490,7 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     std::vector<int64_t> add_ptr(K + 1, 0), w0_ptr(K + 1, 0);
     for (int k = 0; k < K; ++k) {
         const int64_t ncell = (int64_t)n_taxa[k] * n_taxa[k];
-        add_ptr[k + 1] = add_ptr[k] + ncell * n_trees[k];
+        add_ptr[k + 1] = add_ptr[k] + ncell * (((int64_t)n_trees[k] + 1) & ~(int64_t)1);
         w0_ptr[k + 1] = w0_ptr[k] + ncell;
         for (int t = 0; t < n_trees[k]; t += per_item) {
             item_node.push_back(k);
