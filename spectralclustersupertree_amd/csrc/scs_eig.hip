@@ -3177,15 +3177,28 @@ __global__ __launch_bounds__(256) void k_small_sum(small_batch p) {
     if (v0 <= SMALL_TR_MAX) {
         const int64_t ms = (m + 1) & ~1;
         const double *in = p.addends + p.add_ptr[k] + (int64_t)e * ms;  // 16-byte aligned: add_ptr and ms are even
-        for (; t + 64 <= m; t += 64) {
-            double2 a[32];
+        // two batches of 64 addends in flight: the next one's loads are issued before this one's adds
+        if (t + 64 <= m) {
+            double2 a[32], b[32];
 #pragma unroll
             for (int j = 0; j < 32; ++j) a[j] = *(const double2 *)(in + t + 2 * j);
+            for (; t + 128 <= m; t += 64) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) b[j] = *(const double2 *)(in + t + 64 + 2 * j);
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    acc = acc + a[j].x;
+                    acc = acc + a[j].y;
+                }
+#pragma unroll
+                for (int j = 0; j < 32; ++j) a[j] = b[j];
+            }
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
                 acc = acc + a[j].x;
                 acc = acc + a[j].y;
             }
+            t += 64;
         }
         for (; t + 8 <= m; t += 8) {
             double2 a[4];

@@ -103,6 +103,9 @@ def run(n: int, m: int, weights: bool, strategy: str = "branch", seed: int = 0, 
         "largest_problems": sorted(calls["sizes"], reverse=True)[:6],
         "calls_by_size": {"<=64": int(np.sum(sizes <= 64)), "65-512": int(np.sum((sizes > 64) & (sizes <= 512))),
                           "513-4096": int(np.sum((sizes > 512) & (sizes <= 4096))), ">4096": int(np.sum(sizes > 4096))},
+        "calls_by_size_fine": {f"{lo}-{hi}": int(np.sum((sizes >= lo) & (sizes <= hi)))
+                               for lo, hi in ((2, 4), (5, 8), (9, 16), (17, 24), (25, 32), (33, 64), (65, 96), (97, 128),
+                                              (129, 256), (257, 512), (513, 1024), (1025, 4096))},
         "every_taxon_exactly_once": bool(every_taxon_once),
         "top_level_parts_equal_top_level_labels": bool(top_parts_match),
         "every_call_partitions_its_taxa": bool(partitions_ok),
