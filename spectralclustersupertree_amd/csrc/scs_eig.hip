@@ -777,18 +777,16 @@ __device__ void jacobi_eig_waves(L &s) {
     __syncthreads();
 }
 
-__device__ void jacobi_eig(jacobi_lds &s, int n) {
-    if (n == 12) return jacobi_eig_waves<12>(s);
-    if (n == 8) return jacobi_eig_waves<8>(s);
-    if (n == 4) return jacobi_eig_waves<4>(s);
-    if (n <= 24) {
-        jacobi_eig_fast(s, n);
-        return;
-    }
+// The general form, for a workgroup of NT threads (256, or 1 024: k_small_finish<1024>, round 5).  With 1 024
+// threads only the independent work items of a step are spread wider -- three per thread instead of twelve at
+// n = 64; everything whose ORDER matters (the convergence sums: per-thread partials over e = tid mod 256, wave
+// shuffles, four wave totals) is done by the first 256 threads exactly as before: the same bits.
+template <int NT>
+__device__ void jacobi_eig_generic(jacobi_lds &s, int n) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int m = n + (n & 1);  // even; a padded index has zero row/column
-    for (int e = tid; e < m * m; e += 256) {
+    for (int e = tid; e < m * m; e += NT) {
         const int i = e / m, j = e - i * m;
         s.e[i][j] = i == j ? 1.0 : 0.0;
         if (i >= n || j >= n) s.a[i][j] = 0.0;
@@ -798,7 +796,7 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
     for (int sweep = 0; sweep < 30; ++sweep) {
         // convergence: off-diagonal mass against the diagonal
         double off = 0.0, dia = 0.0;
-        for (int e = tid; e < n * n; e += 256) {
+        for (int e = tid; e < n * n && tid < 256; e += 256) {
             const int i = e / n, j = e - i * n;
             const double v = s.a[i][j];
             // dead directions carry -1e30 on the diagonal (k_small_rr): not part of the scale
@@ -810,7 +808,7 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
             off += __shfl_xor(off, o, 64);
             dia += __shfl_xor(dia, o, 64);
         }
-        if (lane == 0) {
+        if (lane == 0 && wave < 4) {
             s.red[wave] = off;
             s.red[4 + wave] = dia;
         }
@@ -853,7 +851,7 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
             __syncthreads();
             // work items: half*half 2x2 blocks of A, then m*half column pairs of E
             const int nblk = half * half;
-            for (int e = tid; e < nblk + m * half; e += 256) {
+            for (int e = tid; e < nblk + m * half; e += NT) {
                 if (e < nblk) {
                     const int kr = e / half, kc = e - kr * half;
                     const int p = s.pq[kr][0], q = s.pq[kr][1];
@@ -901,6 +899,17 @@ __device__ void jacobi_eig(jacobi_lds &s, int n) {
         s.perm[rank] = tid;
     }
     __syncthreads();
+}
+
+__device__ void jacobi_eig(jacobi_lds &s, int n) {
+    if (n == 12) return jacobi_eig_waves<12>(s);
+    if (n == 8) return jacobi_eig_waves<8>(s);
+    if (n == 4) return jacobi_eig_waves<4>(s);
+    if (n <= 24) {
+        jacobi_eig_fast(s, n);
+        return;
+    }
+    jacobi_eig_generic<256>(s, n);
 }
 
 // Sum `nparts` per-workgroup partials of `nout` outputs (partial[p * nout + e]) in a fixed
@@ -3226,7 +3235,12 @@ __global__ __launch_bounds__(256) void k_small_sum(small_batch p) {
     w0[y * v0 + x] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
+// NT = 256: the nodes of up to 24 vertices (the Jacobi variants written for 256 threads).  NT = 1 024 (round 5, late):
+// the nodes of 25 .. 64 vertices -- everything up to the eigen-solve is done by the first 256 threads as it
+// always was, the Jacobi sweeps spread their independent work items over all 1 024 (jacobi_eig_generic): the same
+// bits, a solve of 64 vertices 1.5 -> 0.7 ms.  The host launches the instance(s) a batch needs.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_small_finish(small_batch p) {
     __shared__ jacobi_lds s;
     __shared__ double s_dd[MAXS];
     __shared__ int s_gs[MAXS + 1];
@@ -3234,16 +3248,18 @@ __global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
     const int k = blockIdx.x;
     const int v = p.n_groups[k], v0 = p.n_taxa[k];
     if (v0 > MAXS) return;  // k_small_finish_big's
+    if ((v > 24) != (NT > 256)) return;  // the other instance's
+    const bool first = tid < 256;  // the threads of the 256-thread form: every strided loop below is theirs
     double(*w0)[SLD] = s.e;  // the uncontracted weights live where Jacobi later keeps its vectors
-    if (tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
+    if (first && tid <= v) s_gs[tid] = p.group_start[p.vertex_ptr[k] + k + tid];
     {
         const double *src = p.w0 + p.w0_ptr[k];
-        for (int e = tid; e < v0 * v0; e += 256) w0[e / v0][e % v0] = src[e];
+        for (int e = tid; e < v0 * v0 && first; e += 256) w0[e / v0][e % v0] = src[e];
     }
     __syncthreads();
     // ---- contraction: vertex g = taxa [gs[g], gs[g+1]); weight = max over member pairs
     // (reference: scs.py:336-387), diagonal 0
-    for (int e = tid; e < v * v; e += 256) {
+    for (int e = tid; e < v * v && first; e += 256) {
         const int g = e / v, h = e - g * v;
         double best = 0.0;
         if (g != h) {
@@ -3255,7 +3271,7 @@ __global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
     }
     __syncthreads();
     if (p.w_out)
-        for (int e = tid; e < v * v; e += 256) p.w_out[p.w_ptr[k] + e] = s.a[e / v][e % v];
+        for (int e = tid; e < v * v && first; e += 256) p.w_out[p.w_ptr[k] + e] = s.a[e / v][e % v];
     // ---- degrees as scipy takes them (column sums, rows in order; isolated -> 1)
     if (tid < v) {
         double d = 0.0;
@@ -3268,7 +3284,7 @@ __global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
     double keep[(MAXS * MAXS + 255) / 256];
     {
         int q = 0;
-        for (int e = tid; e < v * v; e += 256, ++q) {
+        for (int e = tid; e < v * v && first; e += 256, ++q) {
             const int g = e / v, h = e - g * v;
             const double x = (s.a[g][h] / s_dd[h]) / s_dd[g];
             const double y = (s.a[h][g] / s_dd[g]) / s_dd[h];
@@ -3276,10 +3292,11 @@ __global__ __launch_bounds__(256) void k_small_finish(small_batch p) {
         }
         __syncthreads();
         q = 0;
-        for (int e = tid; e < v * v; e += 256, ++q) s.a[e / v][e % v] = keep[q];
+        for (int e = tid; e < v * v && first; e += 256, ++q) s.a[e / v][e % v] = keep[q];
     }
     __syncthreads();
-    jacobi_eig(s, v);
+    if (NT > 256) jacobi_eig_generic<NT>(s, v);
+    else jacobi_eig(s, v);
     // ---- embedding: unit eigenvectors / dd, largest |entry| of each column positive, column 0
     // <-> the largest eigenvalue (sklearn/manifold/_spectral_embedding.py:373-376, 463)
     if (tid < 2) {
@@ -3659,7 +3676,16 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     sb.w0 = (double *)(slot.scratch + add_bytes);
     k_small_addends<<<(unsigned)n_items, 256, 0, s>>>(sb);
     k_small_sum<<<(unsigned)n_sums, 256, 0, s>>>(sb);
-    k_small_finish<<<K, 256, 0, s>>>(sb);
+    {
+        bool any_small = false, any_mid = false;
+        for (int k = 0; k < K; ++k) {
+            if (n_taxa[k] > MAXS) continue;
+            if (n_groups[k] > 24) any_mid = true;
+            else any_small = true;
+        }
+        if (any_small) k_small_finish<256><<<K, 256, 0, s>>>(sb);
+        if (any_mid) k_small_finish<1024><<<K, 1024, 0, s>>>(sb);
+    }
     if (any_big) {
         // (every node gets a workgroup of either kind; the one that is not its own returns at once)
         SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_small_finish_big, hipFuncAttributeMaxDynamicSharedMemorySize,
