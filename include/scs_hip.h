@@ -100,7 +100,9 @@ typedef struct scs_build_stats {
     int32_t reserved;
 } scs_build_stats;
 
-/* ABI version of this header: 103.  102 -> 103: scs_stats ends with event_pair_ms.  101 -> 102: scs_stats is
+/* ABI version of this header: 104.  103 -> 104: scs_forest_split_level, scs_forest_analyze,
+ * scs_forest_tables_download_range, scs_tables_from_forest_range, scs_small_solve_begin_level added;
+ * scs_forest_upload checks the arrays.  102 -> 103: scs_stats ends with event_pair_ms.  101 -> 102: scs_stats is
  * 24 bytes longer (n_apply32 in the old `reserved` slot, apply32_ms_total, apply32_bytes, lowp_renewals).  100 -> 101: scs_build_stats is 8 bytes longer
  * (tree_parallel_batches; the old `reserved` slot became spec_batches) and again by spec_trees /
  * spec_ms; scs_forest_* added.  Callers compare it with the value they were compiled against before passing
@@ -201,6 +203,52 @@ int scs_forest_download(scs_ctx *ctx, const scs_forest *forest, int32_t t_begin,
  * the forest was split on (the look-ahead worker's). */
 int scs_tables_from_forest(scs_ctx *ctx, const scs_forest *forest, const int32_t *relabel, int32_t n_taxa,
                            scs_tables **out);
+
+/* ---- a whole level of the recursion in one call (round 6) ---------------- */
+
+/* The reference walks the recursion depth-first, one node at a time (scs.py:139-171).  The nodes of one
+ * LEVEL below some node hold disjoint taxon sets, so their forests fit in ONE forest -- the trees of node
+ * 0, then of node 1, ... -- over one numbering of the taxa (node k owns a consecutive id range), and one
+ * call restricts all of them to all of their parts (scs.py:411-455 for every node of the level):
+ *   node_tree_end[k]  exclusive end of node k's trees in `forest` (the last entry = its tree count)
+ *   part_of[x]        part of taxon x INSIDE ITS NODE (0 .. n_parts - 1 <= 7), -1: in no child
+ *   new_id[x]         its id in the children's numbering (unique over all children), < child_taxa
+ * The children come back as ONE forest again -- part-major: the first parts of all nodes (node order),
+ * then the second parts, ... -- with its tables resident, and of it the host receives only
+ *   child_trees / child_leaves [n_parts][n_nodes]   trees (>= 2 leaves kept) and leaves of child (part, node)
+ *   present   [child_taxa]      1: the taxon occurs in a kept tree
+ *   comp_root [child_taxa]      smallest id of the taxon's connected component in the proper cluster
+ *                               graph of its child (scs.py:458-492 `_get_graph_components`; edges = shared
+ *                               root sides whatever the weight, :651-652)
+ *   sig       [child_taxa][2]   a 128-bit function of the SET of (tree, root side) the taxon occurs in:
+ *                               two taxa are contracted (scs.py:302-316) only if their sets -- hence these
+ *                               values -- are equal; distinct values prove that nothing contracts, equal
+ *                               ones send the node to the exact host routine.
+ * info[0] describes the union (monotone: all parts).  Same restriction semantics and bits as
+ * scs_forest_split. */
+int scs_forest_split_level(scs_ctx *ctx, const scs_forest *forest, const int32_t *part_of,
+                           const int32_t *new_id, int32_t n_parts, int32_t child_taxa, int32_t strategy,
+                           int32_t n_nodes, const int32_t *node_tree_end, scs_forest **out_union,
+                           scs_forest_info *info, int32_t *child_trees, int64_t *child_leaves,
+                           uint8_t *present, int32_t *comp_root, uint64_t *sig);
+
+/* comp_root [n_taxa] and sig [n_taxa][2] (as above) of a forest that carries tables: the first forest of a
+ * level-synchronous walk (a child of scs_forest_split). */
+int scs_forest_analyze(scs_ctx *ctx, const scs_forest *forest, int32_t *comp_root, uint64_t *sig);
+
+/* Tables of the trees [t_begin, t_end) of a forest that carries them to the host (tree_off
+ * [t_end - t_begin + 1] made relative to the first of them; other pointers may be null): the exact host
+ * routine for the contraction groups of a node whose signatures collide (scs.py:302-316). */
+int scs_forest_tables_download_range(scs_ctx *ctx, const scs_forest *forest, int32_t t_begin, int32_t t_end,
+                                     int64_t *tree_off, int32_t *leaf_taxon, int32_t *adj_depth,
+                                     double *adj_val, double *tree_w);
+
+/* scs_tables_from_forest for ONE node of a level forest: the trees [t_begin, t_end), whose taxon ids lie
+ * in [u_base, u_base + u_size); relabel[x - u_base] = the node's own id of taxon x (present taxa only,
+ * contraction groups consecutive), n_taxa = the node's taxon count. */
+int scs_tables_from_forest_range(scs_ctx *ctx, const scs_forest *forest, int32_t t_begin, int32_t t_end,
+                                 int32_t u_base, int32_t u_size, const int32_t *relabel, int32_t n_taxa,
+                                 scs_tables **out);
 
 /* ---- tables ------------------------------------------------------------ */
 
@@ -386,6 +434,17 @@ int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
 int scs_small_solve_begin_forest(scs_ctx *ctx, const scs_forest *forest, const int32_t *relabel,
                                  int32_t n_taxa, int32_t n_groups, const int32_t *group_start,
                                  int32_t want_w, int32_t *ticket_out);
+/* scs_small_solve_begin for the K small nodes of ONE LEVEL of the recursion, straight from the level
+ * forest's resident tables (scs_forest_split_level; reference: scs.py:110-134 for every node of the
+ * level): node k owns the trees [t_begin[k], t_begin[k] + n_trees[k]) with n_leaves[k] leaves in all and
+ * the taxon ids [u_base[k], u_base[k] + u_size[k]); relabel (all nodes' maps concatenated, u_size[k]
+ * entries each) sends id x to relabel[.. + x - u_base[k]], the node's own numbering (present taxa only,
+ * contraction groups consecutive); n_taxa / n_groups / group_start as scs_small_solve_begin. */
+int scs_small_solve_begin_level(scs_ctx *ctx, const scs_forest *forest, int32_t n_nodes,
+                                const int32_t *t_begin, const int32_t *n_trees, const int64_t *n_leaves,
+                                const int32_t *u_base, const int32_t *u_size, const int32_t *relabel,
+                                const int32_t *n_taxa, const int32_t *n_groups, const int32_t *group_start,
+                                int32_t want_w, int32_t *ticket_out);
 int scs_small_solve_end(scs_ctx *ctx, int32_t ticket, double *maps_out, double *lambda_out,
                         double *w_out);
 

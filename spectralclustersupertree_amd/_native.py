@@ -125,7 +125,7 @@ _I32 = C.c_int32
 # per argument (``data_as``) costs more than the call itself for the tiny nodes of a deep recursion;
 # dptr / iptr / lptr below check the dtype instead
 _DP = _IP = _LP = C.c_void_p
-ABI_VERSION = 103  # scs_version() of the header these bindings were written against
+ABI_VERSION = 104  # scs_version() of the header these bindings were written against
 
 SIGNATURES = {
     "scs_version": (C.c_int, []),
@@ -146,6 +146,12 @@ SIGNATURES = {
     "scs_forest_tables_host": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "scs_tables_from_forest": (C.c_int, [_P, _P, _IP, _I32, _PP]),
     "scs_forest_download": (C.c_int, [_P, _P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP]),
+    "scs_forest_split_level": (C.c_int, [_P, _P, _IP, _IP, _I32, _I32, _I32, _I32, _IP, _PP, _P, _IP, _LP, _P, _IP, _P]),
+    "scs_forest_analyze": (C.c_int, [_P, _P, _IP, _P]),
+    "scs_forest_tables_download_range": (C.c_int, [_P, _P, _I32, _I32, _LP, _IP, _IP, _DP, _DP]),
+    "scs_tables_from_forest_range": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _IP, _I32, _PP]),
+    "scs_small_solve_begin_level": (C.c_int, [_P, _P, _I32, _IP, _IP, _LP, _IP, _IP, _IP, _IP, _IP, _IP, _I32,
+                                              C.POINTER(C.c_int32)]),
     "scs_host_alloc": (C.c_int, [C.c_size_t, _PP]),
     "scs_host_free": (C.c_int, [_P]),
     "scs_tables_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _PP]),

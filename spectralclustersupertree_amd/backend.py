@@ -171,6 +171,33 @@ class Device:
             C.byref(ticket)))
         return SmallTicket(self, ticket.value, n_groups, want_w, list(nodes))
 
+    def small_solve_begin_level(self, forest: "DeviceForest", t_begin, n_trees, n_leaves, u_base, u_size, relabel,
+                                n_taxa, n_groups, group_start) -> "SmallTicket":
+        """``scs_small_solve_begin_level``: the K small nodes of one level of the recursion from the level
+        forest's resident tables (``levels.Engine``; reference: scs.py:110-134 for every node of the level).
+        All arguments are arrays over the K nodes (``relabel`` / ``group_start`` concatenated)."""
+        k = len(t_begin)
+        as32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        t_begin, n_trees, u_base, u_size = as32(t_begin), as32(n_trees), as32(u_base), as32(u_size)
+        relabel, n_taxa, n_groups, group_start = as32(relabel), as32(n_taxa), as32(n_groups), as32(group_start)
+        n_leaves = np.ascontiguousarray(n_leaves, dtype=np.int64)
+        ticket = C.c_int32(-1)
+        nv.check(self._lib.scs_small_solve_begin_level(
+            self._ctx, forest._h, k, nv.iptr(t_begin), nv.iptr(n_trees), nv.lptr(n_leaves), nv.iptr(u_base),
+            nv.iptr(u_size), nv.iptr(relabel), nv.iptr(n_taxa), nv.iptr(n_groups), nv.iptr(group_start), 0,
+            C.byref(ticket)))
+        return SmallTicket(self, ticket.value, n_groups, False, None)
+
+    def upload_range(self, forest: "DeviceForest", t_begin: int, t_end: int, u_base: int, u_size: int,
+                     relabel: np.ndarray, n_taxa: int, monotone: bool) -> "DeviceTables":
+        """``scs_tables_from_forest_range``: the tables of ONE node of a level forest as a handle for
+        ``build`` (the nodes of a level that are too large for the batched small path)."""
+        handle = C.c_void_p()
+        rl = np.ascontiguousarray(relabel, dtype=np.int32)
+        nv.check(self._lib.scs_tables_from_forest_range(self._ctx, forest._h, int(t_begin), int(t_end), int(u_base),
+                                                        int(u_size), nv.iptr(rl), int(n_taxa), C.byref(handle)))
+        return DeviceTables(self, handle, int(n_taxa), int(t_end - t_begin), bool(monotone))
+
     def copy_bandwidth(self, nbytes: int = 1 << 30, reps: int = 6) -> float:
         """Measured device-to-device copy rate of this GPU in GB/s (read + write bytes over
         time; ``scs_debug_copy_bandwidth``) -- the figure to hold beside the nominal HBM peak."""
@@ -252,6 +279,56 @@ class DeviceForest:
         return [DeviceForest(self.dev, C.c_void_p(handles[c]), int(pt[c]), int(info[c].n_trees), int(info[c].n_nodes),
                              int(info[c].n_leaves), bool(info[c].monotone)) for c in range(n_parts)]
 
+    def split_level(self, part_of: np.ndarray, new_id: np.ndarray, n_parts: int, child_taxa: int, strategy_code: int,
+                    node_tree_end: np.ndarray):
+        """``scs_forest_split_level``: every node of a level (consecutive tree ranges of this forest, ``node_tree_end``)
+        restricted to every one of its parts in ONE call (reference: scs.py:411-455 for every node of the level).
+        Returns ``(union forest, child_trees [n_parts, K], child_leaves [n_parts, K], present, comp_root, sig)``."""
+        k = len(node_tree_end)
+        handle = C.c_void_p()
+        info = nv.ForestInfo()
+        nte = np.ascontiguousarray(node_tree_end, dtype=np.int32)
+        child_trees = np.zeros((n_parts, k), dtype=np.int32)
+        child_leaves = np.zeros((n_parts, k), dtype=np.int64)
+        present = np.zeros(child_taxa, dtype=np.uint8)
+        comp_root = np.zeros(child_taxa, dtype=np.int32)
+        sig = np.zeros((child_taxa, 2), dtype=np.uint64)
+        rc = self.dev._lib.scs_forest_split_level(
+            self.dev._ctx, self._h, nv.iptr(part_of), nv.iptr(new_id), int(n_parts), int(child_taxa),
+            int(strategy_code), k, nv.iptr(nte), C.byref(handle), C.byref(info), nv.iptr(child_trees),
+            nv.lptr(child_leaves), present.ctypes.data, nv.iptr(comp_root), sig.ctypes.data)
+        if rc == nv.EUNSUP:
+            # the reference fails in ``length * tree_weight`` with a missing support (scs.py:656)
+            msg = "unsupported operand type(s) for *: 'NoneType' and 'float'"
+            raise TypeError(msg)
+        nv.check(rc)
+        union = DeviceForest(self.dev, handle, int(child_taxa), int(info.n_trees), int(info.n_nodes),
+                             int(info.n_leaves), bool(info.monotone))
+        return union, child_trees, child_leaves, present, comp_root, sig
+
+    def analyze(self):
+        """``scs_forest_analyze``: ``(comp_root [n_taxa], sig [n_taxa, 2])`` of a forest that carries tables."""
+        comp_root = np.zeros(max(self.n_taxa, 1), dtype=np.int32)
+        sig = np.zeros((max(self.n_taxa, 1), 2), dtype=np.uint64)
+        nv.check(self.dev._lib.scs_forest_analyze(self.dev._ctx, self._h, nv.iptr(comp_root), sig.ctypes.data))
+        return comp_root, sig
+
+    def tables_range(self, t_begin: int, t_end: int):
+        """``(tree_off, leaf_taxon, adj_depth, adj_val, tree_w)`` of the trees [t_begin, t_end) (host copies)."""
+        m = int(t_end - t_begin)
+        tree_off = np.zeros(m + 1, dtype=np.int64)
+        nv.check(self.dev._lib.scs_forest_tables_download_range(self.dev._ctx, self._h, int(t_begin), int(t_end),
+                                                                nv.lptr(tree_off), None, None, None, None))
+        l = int(tree_off[-1])
+        leaf_taxon = np.empty(l, dtype=np.int32)
+        adj_depth = np.empty(l, dtype=np.int32)
+        adj_val = np.empty(l, dtype=np.float64)
+        tree_w = np.empty(m, dtype=np.float64)
+        nv.check(self.dev._lib.scs_forest_tables_download_range(
+            self.dev._ctx, self._h, int(t_begin), int(t_end), nv.lptr(tree_off), nv.iptr(leaf_taxon) if l else None,
+            nv.iptr(adj_depth) if l else None, nv.dptr(adj_val) if l else None, nv.dptr(tree_w) if m else None))
+        return tree_off, leaf_taxon, adj_depth, adj_val, tree_w
+
     def tables(self):
         """``(tree_off, leaf_taxon, adj_depth, adj_val, tree_index, tree_w, present)`` of a child of
         ``split``: read-only views of the page-locked host copy the split left (no further copy; the
@@ -331,6 +408,16 @@ class SmallTicket:
             raise RuntimeError(msg)
         finally:
             graph.free()
+
+    def raw(self):
+        """Waits and returns ``(maps [sum n_groups, 2], lambdas [K, 3])`` as the library left them (a node whose
+        one-sided Jacobi ran out of sweeps carries NaN eigenvalues: the caller decides)."""
+        n_groups = self._n_groups
+        maps = np.empty((int(n_groups.sum()), 2))
+        lam = np.empty((len(n_groups), 3))
+        ticket, self._ticket = self._ticket, -1
+        nv.check(self.dev._lib.scs_small_solve_end(self.dev._ctx, ticket, nv.dptr(maps), nv.dptr(lam), None))
+        return maps, lam
 
     def result(self):
         if self._out is None:

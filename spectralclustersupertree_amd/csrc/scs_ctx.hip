@@ -34,7 +34,7 @@ extern "C" const char *scs_last_error(void) { return g_last_error.c_str(); }
 // 101 (round 5): scs_build_stats grew by tree_parallel_batches / spec_batches (round 4), scs_tables_split added
 // 102 (round 5): scs_stats grew by the mixed-precision loop's fields
 // 103: ... and by event_pair_ms
-extern "C" int scs_version(void) { return 103; }
+extern "C" int scs_version(void) { return 104; }
 
 extern "C" int scs_device_count(void) {
     int n = 0;
@@ -825,6 +825,102 @@ extern "C" int scs_tables_from_forest(scs_ctx *ctx, const scs_forest *f, const i
     if (e != hipSuccess) {
         scs_tables_free(ctx, t);
         scs_set_error("scs_tables_from_forest failed: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? SCS_ENOMEM : SCS_EHIP;
+    }
+    *out = t;
+    return SCS_OK;
+}
+
+// leaf_taxon of a tree range of a level forest through the node's renumbering of its id range
+__global__ void k_relabel_taxa_range(const int32_t *__restrict__ src, const int32_t *__restrict__ relabel, int32_t u_base,
+                                     int64_t n, int32_t *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = relabel[src[i] - u_base];
+}
+
+__global__ void k_rebase_offsets(const int64_t *__restrict__ src, int64_t n, int64_t *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] - src[0];
+}
+
+// scs_tables_from_forest for ONE node of a level forest (scs_forest_split_level): the trees [t_begin, t_end),
+// whose taxon ids lie in [u_base, u_base + u_size); relabel[x - u_base] = the node's own id of taxon x.
+extern "C" int scs_tables_from_forest_range(scs_ctx *ctx, const scs_forest *f, int32_t t_begin, int32_t t_end,
+                                            int32_t u_base, int32_t u_size, const int32_t *relabel, int32_t n_taxa,
+                                            scs_tables **out) {
+    SCS_REQUIRE(ctx && f && relabel && out, "scs_tables_from_forest_range: null argument");
+    SCS_REQUIRE(f->has_tables, "scs_tables_from_forest_range: the forest carries no tables");
+    SCS_REQUIRE(t_begin >= 0 && t_begin < t_end && t_end <= f->n_trees, "scs_tables_from_forest_range: bad tree range");
+    SCS_REQUIRE(u_base >= 0 && u_size >= 1 && (int64_t)u_base + u_size <= f->n_taxa && n_taxa >= 1,
+                "scs_tables_from_forest_range: bad taxon range");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int32_t n_trees = t_end - t_begin;
+    auto *t = new scs_tables();
+    t->h_tree_off.resize((size_t)n_trees + 1);
+    hipError_t e = hipMemcpyAsync(t->h_tree_off.data(), f->tree_off + t_begin, ((size_t)n_trees + 1) * 8,
+                                  hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        delete t;
+        scs_set_error("scs_tables_from_forest_range failed: %s", hipGetErrorString(e));
+        return SCS_EHIP;
+    }
+    const int64_t lo = t->h_tree_off[0], L = t->h_tree_off[n_trees] - lo;
+    int64_t max_leaves = 0;
+    for (int32_t i = 0; i <= n_trees; ++i) t->h_tree_off[i] -= lo;
+    for (int32_t i = 0; i < n_trees; ++i) max_leaves = std::max(max_leaves, t->h_tree_off[i + 1] - t->h_tree_off[i]);
+    if (max_leaves > n_taxa) {
+        delete t;
+        scs_set_error("scs_tables_from_forest_range: a tree has more leaves (%lld) than the node has taxa (%d)",
+                      (long long)max_leaves, n_taxa);
+        return SCS_EINVAL;
+    }
+    auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t o_off = 0;
+    const size_t o_tax = o_off + up256(((size_t)n_trees + 1) * 8);
+    const size_t o_dep = o_tax + up256((size_t)L * 4);
+    const size_t o_val = o_dep + up256((size_t)L * 4);
+    const size_t o_w = o_val + up256((size_t)L * 8);
+    const size_t o_flag = o_w + up256((size_t)n_trees * 8);
+    const size_t o_rl = o_flag + 256;
+    void *block = nullptr;
+    const int rc = scs_block_alloc(ctx, o_rl + up256((size_t)u_size * 4), &block);
+    if (rc != SCS_OK) {
+        delete t;
+        return rc;
+    }
+    t->n_taxa = n_taxa;
+    t->n_trees = n_trees;
+    t->n_leaves = L;
+    t->max_leaves = (int32_t)max_leaves;
+    t->d_block = block;
+    char *base = (char *)block;
+    t->d_tree_off = (int64_t *)(base + o_off);
+    t->d_leaf_taxon = (int32_t *)(base + o_tax);
+    t->d_adj_depth = (int32_t *)(base + o_dep);
+    t->d_adj_val = (double *)(base + o_val);
+    t->d_tree_w = (double *)(base + o_w);
+    t->d_flags = (unsigned *)(base + o_flag);
+    e = hipMemsetAsync(t->d_flags, 0, 4, s);
+    if (e == hipSuccess) {
+        k_rebase_offsets<<<(unsigned)((n_trees + 1 + 255) / 256), 256, 0, s>>>(f->tree_off + t_begin, (int64_t)n_trees + 1,
+                                                                              t->d_tree_off);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_depth, f->adj_depth + lo, (size_t)L * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && L) e = hipMemcpyAsync(t->d_adj_val, f->adj_val + lo, (size_t)L * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_tree_w, f->weights + t_begin, (size_t)n_trees * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(base + o_rl, relabel, (size_t)u_size * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && L) {
+        k_relabel_taxa_range<<<(unsigned)((L + 255) / 256), 256, 0, s>>>(f->leaf_taxon + lo, (const int32_t *)(base + o_rl),
+                                                                          u_base, L, t->d_leaf_taxon);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        scs_tables_free(ctx, t);
+        scs_set_error("scs_tables_from_forest_range failed: %s", hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? SCS_ENOMEM : SCS_EHIP;
     }
     *out = t;

@@ -3433,12 +3433,88 @@ __global__ void k_small_pack(const int64_t *__restrict__ tree_off64, const int32
     if (i < n_trees) tw[i] = tree_w[i];
 }
 
+// the same for the K nodes of a level (scs_small_solve_begin_level): node k owns the trees [t_begin[k],
+// t_begin[k] + n_trees[k]) of the level forest and the taxon ids [u_base[k], u_base[k] + u_size[k]) of its
+// universe; relabel (all nodes' maps, concatenated: rl_ptr[k] is node k's first entry) sends an id of that
+// range to the node's own numbering
+struct level_pack {
+    const int32_t *t_begin, *u_base, *rl_ptr;  // device [K]
+    const int32_t *relabel;                    // device, concatenated
+    const int32_t *tree_ptr;                   // device [K + 1] first tree of node k in the batch
+    const int64_t *leaf_ptr;                   // device [K + 1] first leaf slot of node k in the batch
+};
+
+__global__ void k_small_pack_level(const int64_t *__restrict__ tree_off64, const int32_t *__restrict__ leaf_taxon,
+                                   const int32_t *__restrict__ adj_depth, const double *__restrict__ adj_val,
+                                   const double *__restrict__ tree_w, level_pack lp, int32_t n_nodes, int64_t n_leaves,
+                                   int32_t n_trees, int32_t *__restrict__ to, int32_t *__restrict__ lt,
+                                   int32_t *__restrict__ ad, double *__restrict__ av, double *__restrict__ tw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_leaves) {
+        int32_t lo = 0, hi = n_nodes - 1;  // last k with leaf_ptr[k] <= i
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (lp.leaf_ptr[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const int64_t src = tree_off64[lp.t_begin[lo]] + (i - lp.leaf_ptr[lo]);
+        lt[i] = lp.relabel[lp.rl_ptr[lo] + (leaf_taxon[src] - lp.u_base[lo])];
+        ad[i] = adj_depth[src];
+        av[i] = adj_val[src];
+    }
+    if (i < n_trees + n_nodes) {
+        // node k's offsets sit at tree_ptr[k] + k .. tree_ptr[k + 1] + k (its trees + 1 entries)
+        int32_t lo = 0, hi = n_nodes - 1;  // last k with tree_ptr[k] + k <= i
+        while (lo < hi) {
+            const int32_t mid = (lo + hi + 1) >> 1;
+            if (lp.tree_ptr[mid] + mid <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const int32_t j = (int32_t)i - (lp.tree_ptr[lo] + lo);  // 0 .. trees of the node
+        const int32_t t0 = lp.t_begin[lo];
+        to[i] = (int32_t)(tree_off64[t0 + j] - tree_off64[t0]);
+        if (j < lp.tree_ptr[lo + 1] - lp.tree_ptr[lo]) tw[lp.tree_ptr[lo] + j] = tree_w[t0 + j];
+    }
+}
+
+struct level_src {
+    const scs_forest *forest;
+    const int32_t *t_begin, *u_base, *u_size;  // host [K]
+    const int64_t *n_leaves;                   // host [K]
+    const int32_t *relabel;                    // host, concatenated (sum of u_size entries)
+};
+
 static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
                                   const int32_t *n_trees, const int32_t *n_groups,
                                   const int32_t *tree_off, const int32_t *leaf_taxon,
                                   const int32_t *adj_depth, const double *adj_val,
                                   const double *tree_w, const int32_t *group_start, int32_t want_w,
-                                  int32_t *ticket_out, const scs_forest *src, const int32_t *relabel);
+                                  int32_t *ticket_out, const scs_forest *src, const int32_t *relabel,
+                                  const level_src *lvl = nullptr);
+
+// The K small nodes of one level of the recursion straight from the level forest's resident tables
+// (scs_forest_split_level): nothing but the renumbering and the group boundaries travels.
+extern "C" int scs_small_solve_begin_level(scs_ctx *ctx, const scs_forest *forest, int32_t n_nodes,
+                                           const int32_t *t_begin, const int32_t *n_trees, const int64_t *n_leaves,
+                                           const int32_t *u_base, const int32_t *u_size, const int32_t *relabel,
+                                           const int32_t *n_taxa, const int32_t *n_groups,
+                                           const int32_t *group_start, int32_t want_w, int32_t *ticket_out) {
+    SCS_REQUIRE(ctx && forest && t_begin && n_trees && n_leaves && u_base && u_size && relabel && n_taxa && n_groups &&
+                    group_start && ticket_out,
+                "scs_small_solve_begin_level: null argument");
+    SCS_REQUIRE(forest->has_tables, "scs_small_solve_begin_level: the forest carries no tables");
+    for (int32_t k = 0; k < n_nodes; ++k) {
+        SCS_REQUIRE(t_begin[k] >= 0 && n_trees[k] >= 1 && (int64_t)t_begin[k] + n_trees[k] <= forest->n_trees,
+                    "scs_small_solve_begin_level: node %d: bad tree range", k);
+        SCS_REQUIRE(u_base[k] >= 0 && u_size[k] >= 1 && (int64_t)u_base[k] + u_size[k] <= forest->n_taxa,
+                    "scs_small_solve_begin_level: node %d: bad taxon range", k);
+        SCS_REQUIRE(n_leaves[k] >= 2 * (int64_t)n_trees[k] && n_leaves[k] <= (int64_t)n_trees[k] * n_taxa[k],
+                    "scs_small_solve_begin_level: node %d: bad leaf count", k);
+    }
+    level_src lvl{forest, t_begin, u_base, u_size, n_leaves, relabel};
+    return small_solve_begin_impl(ctx, n_nodes, n_taxa, n_trees, n_groups, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                  group_start, want_w, ticket_out, nullptr, nullptr, &lvl);
+}
 
 extern "C" int scs_small_solve_begin(scs_ctx *ctx, int32_t n_nodes, const int32_t *n_taxa,
                                      const int32_t *n_trees, const int32_t *n_groups,
@@ -3471,7 +3547,8 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
                                   const int32_t *tree_off, const int32_t *leaf_taxon,
                                   const int32_t *adj_depth, const double *adj_val,
                                   const double *tree_w, const int32_t *group_start, int32_t want_w,
-                                  int32_t *ticket_out, const scs_forest *src, const int32_t *relabel) {
+                                  int32_t *ticket_out, const scs_forest *src, const int32_t *relabel,
+                                  const level_src *lvl) {
     const bool w_out = want_w != 0;
     SCS_REQUIRE(n_nodes >= 1, "scs_small_solve: need at least one node");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
@@ -3494,8 +3571,8 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
         SCS_REQUIRE(n_groups[k] >= 2 && n_groups[k] <= n_taxa[k], "scs_small_solve: node %d: bad group count %d",
                     k, n_groups[k]);
         SCS_REQUIRE(n_trees[k] >= 1, "scs_small_solve: node %d has no tree", k);
-        const int32_t *to = src ? nullptr : tree_off + toff_at;
-        if (!src) {
+        const int32_t *to = (src || lvl) ? nullptr : tree_off + toff_at;
+        if (!src && !lvl) {
             SCS_REQUIRE(to[0] == 0, "scs_small_solve: node %d: tree_off must start at 0", k);
             for (int t = 0; t < n_trees[k]; ++t)
                 SCS_REQUIRE(to[t + 1] >= to[t] && to[t + 1] - to[t] <= n_taxa[k],
@@ -3506,7 +3583,7 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
         for (int g = 0; g < n_groups[k]; ++g)
             SCS_REQUIRE(gs[g] < gs[g + 1], "scs_small_solve: node %d: empty group %d", k, g);
         tree_ptr[k + 1] = tree_ptr[k] + n_trees[k];
-        leaf_ptr[k + 1] = leaf_ptr[k] + (src ? src->n_leaves : (int64_t)to[n_trees[k]]);
+        leaf_ptr[k + 1] = leaf_ptr[k] + (lvl ? lvl->n_leaves[k] : src ? src->n_leaves : (int64_t)to[n_trees[k]]);
         vertex_ptr[k + 1] = vertex_ptr[k] + n_groups[k];
         w_ptr[k + 1] = w_ptr[k] + (int64_t)n_groups[k] * n_groups[k];
         toff_at += n_trees[k] + 1;
@@ -3561,6 +3638,13 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     // (a resident node: the leaf arrays above are filled on the device; only the header travels --
     // up to o_to -- and the renumbering behind it)
     const size_t o_rl = at; if (src && relabel) at += up8((size_t)src->n_taxa * 4);
+    // a level: t_begin | u_base | rl_ptr [K] each, then the concatenated renumbering
+    std::vector<int32_t> rl_ptr(lvl ? K + 1 : 0, 0);
+    for (int k = 0; lvl && k < K; ++k) rl_ptr[k + 1] = rl_ptr[k] + lvl->u_size[k];
+    const size_t o_ltb = at; if (lvl) at += up8((size_t)K * 4);
+    const size_t o_lub = at; if (lvl) at += up8((size_t)K * 4);
+    const size_t o_lrp = at; if (lvl) at += up8((size_t)K * 4);
+    const size_t o_lrl = at; if (lvl) at += up8((size_t)rl_ptr[K] * 4);
     const size_t in_bytes = at;
     const size_t o_maps = at; at += (size_t)vertex_ptr[K] * 16;
     const size_t o_lam = at; at += (size_t)K * 24;
@@ -3625,7 +3709,30 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     memcpy(h + o_sn, sum_node.data(), n_sums * 4);
     memcpy(h + o_s0, sum_e0.data(), n_sums * 4);
     memcpy(h + o_gs, group_start, (size_t)n_gs * 4);
-    if (!src) {
+    if (lvl) {
+        // header and group boundaries, the level's per-node ranges and renumbering; the leaf arrays are
+        // packed on the device from the level forest's tables
+        memcpy(h + o_ltb, lvl->t_begin, (size_t)K * 4);
+        memcpy(h + o_lub, lvl->u_base, (size_t)K * 4);
+        memcpy(h + o_lrp, rl_ptr.data(), (size_t)K * 4);
+        memcpy(h + o_lrl, lvl->relabel, (size_t)rl_ptr[K] * 4);
+        SCS_HIP_CHECK(hipMemcpyAsync(d, h, o_to, hipMemcpyHostToDevice, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(d + o_gs, h + o_gs, up8((size_t)n_gs * 4), hipMemcpyHostToDevice, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(d + o_ltb, h + o_ltb, in_bytes - o_ltb, hipMemcpyHostToDevice, s));
+        level_pack lp;
+        lp.t_begin = (const int32_t *)(d + o_ltb);
+        lp.u_base = (const int32_t *)(d + o_lub);
+        lp.rl_ptr = (const int32_t *)(d + o_lrp);
+        lp.relabel = (const int32_t *)(d + o_lrl);
+        lp.tree_ptr = (const int32_t *)(d + o_tp);
+        lp.leaf_ptr = (const int64_t *)(d + o_lp);
+        const scs_forest *lf = lvl->forest;
+        const int64_t work = std::max<int64_t>(n_leaf, n_tree + K);
+        k_small_pack_level<<<(unsigned)((work + 255) / 256), 256, 0, s>>>(
+            lf->tree_off, lf->leaf_taxon, lf->adj_depth, lf->adj_val, lf->weights, lp, K, n_leaf, (int32_t)n_tree,
+            (int32_t *)(d + o_to), (int32_t *)(d + o_lt), (int32_t *)(d + o_ad), (double *)(d + o_av),
+            (double *)(d + o_tw));
+    } else if (!src) {
         memcpy(h + o_to, tree_off, (size_t)n_toff * 4);
         memcpy(h + o_lt, leaf_taxon, (size_t)n_leaf * 4);
         memcpy(h + o_ad, adj_depth, (size_t)n_leaf * 4);

@@ -618,6 +618,26 @@ __global__ void k_par_tree_id(const int64_t *__restrict__ node_off, int32_t n_tr
     tree_id[i] = lo;
 }
 
+// scs_forest_upload's argument check on the uploaded copy: every later kernel walks `parent` upwards and
+// indexes by `taxon` without looking again (a non-root without a smaller parent would walk out of its tree
+// or never stop)
+__global__ void k_validate_forest(const int64_t *__restrict__ node_off, const int32_t *__restrict__ parent,
+                                  const int32_t *__restrict__ taxon, int32_t n_trees, int32_t n_taxa, int64_t n,
+                                  int32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int32_t lo = 0, hi = n_trees - 1;  // last t with node_off[t] <= i
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (node_off[mid] <= i) lo = mid;
+        else hi = mid - 1;
+    }
+    const int64_t rel = i - node_off[lo];
+    const int32_t q = parent[i], x = taxon[i];
+    const bool ok = (rel == 0 ? q == -1 : (q >= 0 && q < rel)) && x >= -1 && x < n_taxa;
+    if (!ok) atomicExch(flag, 1);
+}
+
 __global__ void k_par_pc(par_params p) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n_nodes) return;
@@ -798,6 +818,217 @@ __global__ void k_par_trees(par_params p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Level mode (round 6): ONE split for a whole level of the recursion.
+//
+// The nodes of one level of the recursion below some node hold disjoint taxon sets, so their forests can
+// live in ONE forest -- the trees of node 0, then of node 1, ... -- over one numbering of the taxa (a
+// "universe": node k owns a consecutive id range), and one call restricts all of them to all of their
+// parts: part_of[x] is the part of taxon x INSIDE ITS NODE (0 .. 7), new_id[x] its id in the next level's
+// universe.  The children come back as ONE forest again (part-major: the first parts of all nodes, then the
+// second parts, ...; inside a part the parent's tree order, i.e. node by node), with its tables, and the
+// host learns only what it needs to go on: trees and leaves per child, present taxa, the connected
+// components of the proper cluster graph of every child and a 128-bit signature per taxon whose equality
+// is NECESSARY for two taxa to be contracted (reference: scs.py:122 `_get_graph_components`, :302-316 the
+// contraction relation; restriction :411-455).  What used to be one scs_forest_split + one download of
+// 16 bytes per leaf + a host union-find per NODE is one call per LEVEL.
+//
+// k_split_scan is one workgroup; a level forest has millions of trees: the three prefix sums run on the
+// multi-block scans of the node-parallel family instead.
+struct f_cnt_pos {
+    const int32_t *a;
+    int64_t stride;
+    __device__ f_cnt_pos with(int part) const { return f_cnt_pos{a + (int64_t)part * stride, stride}; }
+    __device__ int32_t operator()(int64_t i) const { return a[i] > 0 ? 1 : 0; }
+};
+struct f_cnt {
+    const int32_t *a;
+    int64_t stride;
+    __device__ f_cnt with(int part) const { return f_cnt{a + (int64_t)part * stride, stride}; }
+    __device__ int32_t operator()(int64_t i) const { return a[i]; }
+};
+
+// sc_*: [n_parts][M + 1] exclusive sums (entry M = the part's total) of kept trees, nodes, leaves
+__global__ __launch_bounds__(256) void k_split_finalize(split_params p, const int32_t *__restrict__ sc_keep,
+                                                        const int32_t *__restrict__ sc_nodes,
+                                                        const int32_t *__restrict__ sc_leaves) {
+    const int M = p.n_trees;
+    const int b = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    int64_t node_base = 0, leaf_base = 0;
+    for (int c = 0; c < b; ++c) {
+        node_base += sc_nodes[(int64_t)c * (M + 1) + M];
+        leaf_base += sc_leaves[(int64_t)c * (M + 1) + M];
+    }
+    const int64_t row = (int64_t)b * (M + 1);
+    const int32_t ea = sc_keep[row + t], eb = sc_nodes[row + t], ec = sc_leaves[row + t];
+    const bool keep = p.leaves_cnt[(int64_t)b * M + t] > 0;
+    p.tree_pos[(int64_t)b * M + t] = keep ? ea : -1;
+    p.node_start[(int64_t)b * M + t] = node_base + eb;
+    p.leaf_start[(int64_t)b * M + t] = leaf_base + ec;
+    int64_t *cno = p.c_node_off + row, *cto = p.c_tree_off + row;
+    if (keep) {
+        cno[ea] = eb;
+        cto[ea] = ec;
+    }
+    if (t == M - 1) {
+        const int64_t trees = sc_keep[row + M], nodes = sc_nodes[row + M], leaves = sc_leaves[row + M];
+        p.totals[b * 4 + 0] = trees;
+        p.totals[b * 4 + 1] = nodes;
+        p.totals[b * 4 + 2] = leaves;
+        p.totals[b * 4 + 3] = node_base;
+        cno[trees] = nodes;
+        cto[trees] = leaves;
+    }
+}
+
+// offsets of the union of all parts' children (tree order: part-major), trees and leaves per child
+__global__ __launch_bounds__(256) void k_level_union(split_params p, int32_t n_nodes,
+                                                     const int32_t *__restrict__ node_tree_end,
+                                                     int64_t *__restrict__ u_node_off, int64_t *__restrict__ u_tree_off,
+                                                     int32_t *__restrict__ child_trees, int64_t *__restrict__ child_leaves) {
+    const int M = p.n_trees;
+    const int b = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    int64_t tree_base = 0, leaf_base = 0;
+    for (int c = 0; c < b; ++c) {
+        tree_base += p.totals[c * 4 + 0];
+        leaf_base += p.totals[c * 4 + 2];
+    }
+    const int64_t node_base = p.totals[b * 4 + 3];
+    const int32_t pos = p.tree_pos[(int64_t)b * M + t];
+    if (pos >= 0) {
+        const int64_t row = (int64_t)b * (M + 1);
+        u_node_off[tree_base + pos] = node_base + p.c_node_off[row + pos];
+        u_tree_off[tree_base + pos] = leaf_base + p.c_tree_off[row + pos];
+        // the node of the parent level this tree belongs to: first k with node_tree_end[k] > t
+        int32_t lo = 0, hi = n_nodes - 1;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (node_tree_end[mid] > t) hi = mid;
+            else lo = mid + 1;
+        }
+        atomicAdd(&child_trees[(int64_t)b * n_nodes + lo], 1);
+        atomicAdd((unsigned long long *)&child_leaves[(int64_t)b * n_nodes + lo],
+                  (unsigned long long)p.leaves_cnt[(int64_t)b * M + t]);
+    }
+    if (t == M - 1 && b == p.n_parts - 1) {
+        const int64_t trees = tree_base + p.totals[b * 4 + 0];
+        u_node_off[trees] = node_base + p.totals[b * 4 + 1];
+        u_tree_off[trees] = leaf_base + p.totals[b * 4 + 2];
+    }
+}
+
+// ---- analysis of a forest's tables: components and contraction signatures ------------------
+// Two taxa are adjacent in the proper cluster graph iff they share a root side in some tree
+// (scs.py:651-652, whatever the weight), so the components are those of "join consecutive leaves of a side":
+// leaf p and p + 1 unless the gap between them is a root gap (adj_depth 0; the padding slot behind a
+// tree's last leaf is 0 too).  Lock-free union-find, the larger root hooked under the smaller: a set's
+// root is its smallest member -- the order the host numbers components in.
+__device__ __forceinline__ int32_t uf_find(int32_t *parent, int32_t x) {
+    int32_t q = parent[x];
+    while (q != x) {
+        const int32_t g = parent[q];
+        if (g != q) parent[x] = g;  // (path halving; a benign race: only ever towards an ancestor)
+        x = q;
+        q = g;
+    }
+    return x;
+}
+
+__global__ void k_uf_init(int32_t *parent, int32_t n, unsigned long long *sig) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        parent[i] = i;
+        sig[2 * i] = 0;
+        sig[2 * i + 1] = 0;
+    }
+}
+
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct f_side_start {
+    const int32_t *adj_depth;
+    const int64_t *n_leaves;  // (device: the union's leaf count is only known there)
+    __device__ f_side_start with(int) const { return *this; }
+    __device__ int32_t operator()(int64_t i) const {
+        if (i >= *n_leaves) return -1;
+        return (i == 0 || adj_depth[i - 1] == 0) ? (int32_t)i : -1;
+    }
+};
+
+__global__ void k_leaf_total(const int64_t *totals, int n_parts, int64_t *out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int64_t l = 0;
+        for (int b = 0; b < n_parts; ++b) l += totals[b * 4 + 2];
+        *out = l;
+    }
+}
+
+// per leaf: join with the next leaf of the side; add the side's key to the taxon's signature.  A taxon's
+// signature is the SET of (tree, root side) it occurs in (flatten.contraction_groups: two taxa are contracted
+// iff their sets are equal); the sum of a 2 x 64-bit mix of the side's first leaf slot over that set is equal
+// for equal sets -- so distinct sums PROVE that nothing is contracted, and equal sums send the node to the
+// exact host routine.
+__global__ void k_analyze_leaves(const int32_t *__restrict__ leaf_taxon, const int32_t *__restrict__ adj_depth,
+                                 const int32_t *__restrict__ side_excl, const int64_t *__restrict__ n_leaves,
+                                 int32_t *parent, unsigned long long *sig) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= *n_leaves) return;
+    const int32_t x = leaf_taxon[p];
+    const bool start = p == 0 || adj_depth[p - 1] == 0;
+    const unsigned long long side = (unsigned long long)(start ? (int32_t)p : side_excl[p]);
+    atomicAdd(&sig[2 * x], mix64(side * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull));
+    atomicAdd(&sig[2 * x + 1], mix64((side + 0x2545F4914F6CDD1Dull) * 0xD1342543DE82EF95ull));
+    if (adj_depth[p] == 0) return;  // a root gap, or the tree's last leaf
+    int32_t u = x, v = leaf_taxon[p + 1];
+    for (;;) {
+        u = uf_find(parent, u);
+        v = uf_find(parent, v);
+        if (u == v) break;
+        if (u < v) {
+            const int32_t w = u;
+            u = v;
+            v = w;
+        }
+        const int32_t old = atomicCAS(&parent[u], u, v);  // hook the larger root under the smaller
+        if (old == u) break;
+        u = old;
+    }
+}
+
+__global__ void k_uf_flatten(int32_t *parent, int32_t n, int32_t *root) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) root[i] = uf_find(parent, i);
+}
+
+// components and signatures of the tables [0, *d_n_leaves) over n_taxa ids: comp_root / sig are device
+// outputs ([n_taxa] / [n_taxa][2]); scratch from `alloc`
+template <typename A>
+static int analyze_tables(A &alloc, const int32_t *leaf_taxon, const int32_t *adj_depth, const int64_t *d_n_leaves,
+                          int64_t leaf_cap, int32_t n_taxa, int32_t *comp_root, unsigned long long *sig, hipStream_t s) {
+    int32_t *parent = nullptr, *side = nullptr, *block_sums = nullptr;
+    SCS_TRY(alloc((size_t)n_taxa * 4, (void **)&parent));
+    SCS_TRY(alloc((size_t)(leaf_cap + 1) * 4, (void **)&side));
+    SCS_TRY(alloc((size_t)((leaf_cap + 1 + 4095) / 4096 + 1) * 4, (void **)&block_sums));
+    k_uf_init<<<(unsigned)((n_taxa + 255) / 256), 256, 0, s>>>(parent, n_taxa, sig);
+    SCS_TRY((scan_exclusive<SCAN_MAX>(f_side_start{adj_depth, d_n_leaves}, side, leaf_cap + 1, 1, leaf_cap, -1,
+                                      block_sums, s)));
+    if (leaf_cap > 0)
+        k_analyze_leaves<<<(unsigned)((leaf_cap + 255) / 256), 256, 0, s>>>(leaf_taxon, adj_depth, side, d_n_leaves,
+                                                                            parent, sig);
+    k_uf_flatten<<<(unsigned)((n_taxa + 255) / 256), 256, 0, s>>>(parent, n_taxa, comp_root);
+    SCS_HIP_CHECK(hipGetLastError());
+    return SCS_OK;
+}
+
 }  // namespace
 
 extern "C" int scs_forest_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, const int64_t *node_off,
@@ -832,7 +1063,22 @@ extern "C" int scs_forest_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees, 
     SCS_HIP_CHECK(hipMemcpyAsync(f->length, length, (size_t)N * 8, hipMemcpyHostToDevice, s));
     SCS_HIP_CHECK(hipMemcpyAsync(f->support, support, (size_t)N * 8, hipMemcpyHostToDevice, s));
     SCS_HIP_CHECK(hipMemcpyAsync(f->weights, weights, (size_t)n_trees * 8, hipMemcpyHostToDevice, s));
+    // the arrays are checked where they now are (preorder parents, taxon ids in range)
+    int32_t *d_flag = nullptr;
+    SCS_TRY(scs_block_alloc(ctx, 64, (void **)&d_flag));
+    struct flag_guard {
+        scs_ctx *ctx;
+        void *p;
+        ~flag_guard() { scs_block_release(ctx, p); }
+    } fg{ctx, d_flag};
+    SCS_HIP_CHECK(hipMemsetAsync(d_flag, 0, 4, s));
+    k_validate_forest<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(f->node_off, f->parent, f->taxon, n_trees, n_taxa, N, d_flag);
+    SCS_HIP_CHECK(hipGetLastError());
+    int32_t bad = 0;
+    SCS_HIP_CHECK(hipMemcpyAsync(&bad, d_flag, 4, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));  // (the caller's arrays may go away)
+    SCS_REQUIRE(bad == 0, "scs_forest_upload: malformed tree arrays (a parent that is not an earlier node of the "
+                          "tree, a root with a parent, or a taxon id outside [-1, n_taxa))");
     SCS_REQUIRE(n_leaves >= n_trees && n_leaves <= N, "scs_forest_upload: bad leaf count");
     f->n_leaves = n_leaves;  // (the number of nodes with taxon >= 0: sizes the children's arrays)
     *out = f.release();
@@ -845,20 +1091,61 @@ extern "C" int scs_forest_free(scs_ctx *ctx, scs_forest *f) {
     return SCS_OK;
 }
 
+// level mode (scs_forest_split_level): the nodes of the level as consecutive tree ranges of `f`, and what
+// the host wants back per child and per taxon of the children's universe
+struct level_args {
+    int32_t n_nodes = 0;
+    const int32_t *node_tree_end = nullptr;  // host [n_nodes]: exclusive end of node k's trees (the last = n_trees)
+    int32_t child_taxa = 0;                  // size of the children's universe (new_id < child_taxa)
+    int32_t *child_trees = nullptr;          // host out [n_parts][n_nodes]
+    int64_t *child_leaves = nullptr;         // host out [n_parts][n_nodes]
+    uint8_t *present = nullptr;              // host out [child_taxa]
+    int32_t *comp_root = nullptr;            // host out [child_taxa]
+    uint64_t *sig = nullptr;                 // host out [child_taxa][2]
+};
+
 static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of, const int32_t *new_id,
                         int32_t n_parts, const int32_t *part_taxa, int32_t strategy, scs_forest **out_forests,
-                        scs_forest_info *info, bool force_serial);
+                        scs_forest_info *info, bool force_serial, const level_args *lv = nullptr);
 
 extern "C" int scs_forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of, const int32_t *new_id,
                                 int32_t n_parts, const int32_t *part_taxa, int32_t strategy,
                                 scs_forest **out_forests, scs_forest_info *info) {
+    SCS_REQUIRE(part_taxa != nullptr, "scs_forest_split: null argument");
     return forest_split(ctx, f, part_of, new_id, n_parts, part_taxa, strategy, out_forests, info, false);
+}
+
+extern "C" int scs_forest_split_level(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of,
+                                      const int32_t *new_id, int32_t n_parts, int32_t child_taxa, int32_t strategy,
+                                      int32_t n_nodes, const int32_t *node_tree_end, scs_forest **out_union,
+                                      scs_forest_info *info, int32_t *child_trees, int64_t *child_leaves,
+                                      uint8_t *present, int32_t *comp_root, uint64_t *sig) {
+    SCS_REQUIRE(ctx && f && node_tree_end && out_union && info && child_trees && child_leaves && present &&
+                    comp_root && sig,
+                "scs_forest_split_level: null argument");
+    SCS_REQUIRE(n_nodes >= 1 && child_taxa >= 1, "scs_forest_split_level: need at least one node and one taxon");
+    int32_t prev = 0;
+    for (int32_t k = 0; k < n_nodes; ++k) {
+        SCS_REQUIRE(node_tree_end[k] >= prev, "scs_forest_split_level: node_tree_end must not decrease");
+        prev = node_tree_end[k];
+    }
+    SCS_REQUIRE(prev == f->n_trees, "scs_forest_split_level: the nodes must cover the forest's trees");
+    level_args lv;
+    lv.n_nodes = n_nodes;
+    lv.node_tree_end = node_tree_end;
+    lv.child_taxa = child_taxa;
+    lv.child_trees = child_trees;
+    lv.child_leaves = child_leaves;
+    lv.present = present;
+    lv.comp_root = comp_root;
+    lv.sig = sig;
+    return forest_split(ctx, f, part_of, new_id, n_parts, nullptr, strategy, out_union, info, false, &lv);
 }
 
 static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_of, const int32_t *new_id,
                         int32_t n_parts, const int32_t *part_taxa, int32_t strategy, scs_forest **out_forests,
-                        scs_forest_info *info, bool force_serial) {
-    SCS_REQUIRE(ctx && f && part_of && new_id && part_taxa && out_forests && info, "scs_forest_split: null argument");
+                        scs_forest_info *info, bool force_serial, const level_args *lv) {
+    SCS_REQUIRE(ctx && f && part_of && new_id && out_forests && info, "scs_forest_split: null argument");
     SCS_REQUIRE(n_parts >= 1 && n_parts <= SPLIT_MAX_PARTS, "scs_forest_split: 1 .. %d parts (asked: %d)",
                 SPLIT_MAX_PARTS, n_parts);
     SCS_REQUIRE(strategy >= 0 && strategy <= 3, "scs_forest_split: strategy must be 0 .. 3");
@@ -867,9 +1154,17 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
     const int M = f->n_trees;
     const int64_t N = f->n_nodes, L = std::max<int64_t>(f->n_leaves, 1);
     const int32_t T = f->n_taxa;
-    for (int b = 0; b < n_parts; ++b) {
-        out_forests[b] = nullptr;
-        SCS_REQUIRE(part_taxa[b] >= 0 && part_taxa[b] <= T, "scs_forest_split: bad taxon count of part %d", b);
+    const bool level = lv != nullptr;
+    const int32_t K = level ? lv->n_nodes : 0;
+    // the children's taxon ids: per part 0 .. part_taxa[b] - 1; level mode: one universe for all parts
+    const int32_t TC = level ? lv->child_taxa : T;
+    if (level) {
+        out_forests[0] = nullptr;
+    } else {
+        for (int b = 0; b < n_parts; ++b) {
+            out_forests[b] = nullptr;
+            SCS_REQUIRE(part_taxa[b] >= 0 && part_taxa[b] <= T, "scs_forest_split: bad taxon count of part %d", b);
+        }
     }
 
     // scratch of this call (returned to the context's block cache at the end)
@@ -899,8 +1194,8 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
     p.length = f->length;
     p.support = f->support;
     p.weights = f->weights;
-    // ---- inputs: [flags (16 ints) | part_of | new_id] in ONE copy
-    const size_t in_ints = 16 + 2 * (size_t)T;
+    // ---- inputs: [flags (16 ints) | part_of | new_id | level mode: node_tree_end] in ONE copy
+    const size_t in_ints = 16 + 2 * (size_t)T + (size_t)K;
     int32_t *d_in = nullptr;
     SCS_TRY(scratch.alloc(in_ints * 4, (void **)&d_in));
     {
@@ -908,6 +1203,7 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         for (int b = 0; b < SPLIT_MAX_PARTS; ++b) h_in[1 + b] = 1;  // monotone until a negative length is met
         memcpy(h_in.data() + 16, part_of, (size_t)T * 4);
         memcpy(h_in.data() + 16 + T, new_id, (size_t)T * 4);
+        if (level) memcpy(h_in.data() + 16 + 2 * (size_t)T, lv->node_tree_end, (size_t)K * 4);
         // (a pageable source is staged by the runtime before the call returns)
         SCS_HIP_CHECK(hipMemcpyAsync(d_in, h_in.data(), in_ints * 4, hipMemcpyHostToDevice, s));
     }
@@ -930,7 +1226,8 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
     const int64_t NC = std::max<int64_t>(2 * L, 2);
     SCS_TRY(scratch.alloc((size_t)NC * 4, (void **)&p.cdepth));
     SCS_TRY(scratch.alloc((size_t)NC * 8, (void **)&p.cval));
-    SCS_TRY(region->alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_node_off));
+    if (lv) SCS_TRY(scratch.alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_node_off));
+    else SCS_TRY(region->alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_node_off));
     SCS_TRY(region->alloc((size_t)NC * 4, (void **)&p.c_parent));
     SCS_TRY(region->alloc((size_t)NC * 4, (void **)&p.c_taxon));
     SCS_TRY(region->alloc((size_t)NC * 8, (void **)&p.c_length));
@@ -943,18 +1240,63 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
                  o_adep = o_ltax + (size_t)L * 4, o_flags = o_adep + (size_t)L * 4, o_pres = o_flags + 64,
                  out_bytes = (o_pres + (size_t)n_parts * T + 15) / 16 * 16;
     unsigned char *d_out = nullptr;
-    SCS_TRY(region->alloc(out_bytes, (void **)&d_out));
-    p.totals = (int64_t *)(d_out + o_tot);
-    p.c_tree_off = (int64_t *)(d_out + o_toff);
-    p.c_weights = (double *)(d_out + o_w);
-    p.c_adj_val = (double *)(d_out + o_aval);
-    p.c_tree_index = (int32_t *)(d_out + o_tidx);
-    p.c_leaf_taxon = (int32_t *)(d_out + o_ltax);
-    p.c_adj_depth = (int32_t *)(d_out + o_adep);
-    p.c_present = d_out + o_pres;
-    p.present_ld = T;
-    SCS_HIP_CHECK(hipMemsetAsync(p.c_present, 0, (size_t)n_parts * T, s));
+    // level mode: the tables stay on the device; the host gets ONE small block --
+    //   totals [n_parts][4] i64 | child_leaves [n_parts][K] i64 | sig [TC][2] u64 | flags copy [16] i32 |
+    //   child_trees [n_parts][K] i32 | comp_root [TC] i32 | present [TC] u8
+    const size_t s_tot = 0, s_cl = s_tot + (size_t)n_parts * 4 * 8, s_sig = s_cl + (size_t)n_parts * K * 8,
+                 s_flags = s_sig + (size_t)TC * 16, s_ct = s_flags + 64, s_root = s_ct + (size_t)n_parts * K * 4,
+                 s_pres = s_root + (size_t)TC * 4, small_bytes = (s_pres + (size_t)TC + 15) / 16 * 16;
+    unsigned char *d_small = nullptr;
+    int64_t *u_node_off = nullptr, *u_tree_off = nullptr, *d_leaf_total = nullptr;
+    if (!level) {
+        SCS_TRY(region->alloc(out_bytes, (void **)&d_out));
+        p.totals = (int64_t *)(d_out + o_tot);
+        p.c_tree_off = (int64_t *)(d_out + o_toff);
+        p.c_weights = (double *)(d_out + o_w);
+        p.c_adj_val = (double *)(d_out + o_aval);
+        p.c_tree_index = (int32_t *)(d_out + o_tidx);
+        p.c_leaf_taxon = (int32_t *)(d_out + o_ltax);
+        p.c_adj_depth = (int32_t *)(d_out + o_adep);
+        p.c_present = d_out + o_pres;
+        p.present_ld = T;
+        SCS_HIP_CHECK(hipMemsetAsync(p.c_present, 0, (size_t)n_parts * T, s));
+    } else {
+        // (a kept tree has two or more leaves: at most L / 2 trees in all)
+        const size_t mt = (size_t)std::min<int64_t>((int64_t)pm, L / 2 + 1);
+        SCS_TRY(region->alloc(small_bytes + 64, (void **)&d_small));
+        SCS_TRY(scratch.alloc((size_t)n_parts * (M + 1) * 8, (void **)&p.c_tree_off));
+        SCS_TRY(region->alloc((mt + 1) * 8, (void **)&u_node_off));
+        SCS_TRY(region->alloc((mt + 1) * 8, (void **)&u_tree_off));
+        SCS_TRY(region->alloc(mt * 8, (void **)&p.c_weights));
+        SCS_TRY(region->alloc(mt * 4, (void **)&p.c_tree_index));
+        SCS_TRY(region->alloc((size_t)L * 8, (void **)&p.c_adj_val));
+        SCS_TRY(region->alloc((size_t)L * 4, (void **)&p.c_leaf_taxon));
+        SCS_TRY(region->alloc((size_t)L * 4, (void **)&p.c_adj_depth));
+        p.totals = (int64_t *)(d_small + s_tot);
+        d_leaf_total = (int64_t *)(d_small + small_bytes);
+        p.c_present = d_small + s_pres;
+        p.present_ld = 0;  // ONE array for all parts: the children's ids are unique across the parts
+        SCS_HIP_CHECK(hipMemsetAsync(d_small, 0, small_bytes + 64, s));
+    }
 
+    // the offsets of every (part, tree): one workgroup while the trees are few, multi-block scans for the
+    // millions of trees of a level forest
+    auto split_scan = [&]() -> int {
+        if (M <= 32768 || N >= ((int64_t)1 << 31) - 8) {
+            k_split_scan<<<1, 1024, 0, s>>>(p);
+            return SCS_OK;
+        }
+        int32_t *sc = nullptr, *bs = nullptr;
+        const int64_t row = (int64_t)M + 1;
+        SCS_TRY(scratch.alloc((size_t)3 * n_parts * row * 4, (void **)&sc));
+        SCS_TRY(scratch.alloc((size_t)((row + 4095) / 4096 + 1) * 4 * SPLIT_MAX_PARTS, (void **)&bs));
+        int32_t *sc_keep = sc, *sc_nodes = sc + (int64_t)n_parts * row, *sc_leaves = sc + (int64_t)2 * n_parts * row;
+        SCS_TRY((scan_exclusive<SCAN_SUM>(f_cnt_pos{p.leaves_cnt, M}, sc_keep, row, n_parts, M, 0, bs, s)));
+        SCS_TRY((scan_exclusive<SCAN_SUM>(f_cnt{p.nodes_cnt, M}, sc_nodes, row, n_parts, M, 0, bs, s)));
+        SCS_TRY((scan_exclusive<SCAN_SUM>(f_cnt{p.leaves_cnt, M}, sc_leaves, row, n_parts, M, 0, bs, s)));
+        k_split_finalize<<<dim3((unsigned)((M + 255) / 256), (unsigned)n_parts), 256, 0, s>>>(p, sc_keep, sc_nodes, sc_leaves);
+        return SCS_OK;
+    };
     // Big trees: every step per NODE (scans, walks); small ones: a thread per tree on an LDS copy.
     const int par_min = getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES") ? atoi(getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES")) : 32;
     const bool parallel = !force_serial && N < ((int64_t)1 << 31) - 8 && (double)N / M > (double)par_min;
@@ -1013,7 +1355,7 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         q.c_adj_depth = p.c_adj_depth;
         q.c_adj_val = p.c_adj_val;
         q.c_present = p.c_present;
-        q.present_ld = T;
+        q.present_ld = p.present_ld;
         k_par_pc<<<gn, 256, 0, s>>>(q);
         SCS_TRY((scan_exclusive<SCAN_MAX>(f_key{q.pc, 0}, q.prev, N + 1, n_parts, N, -1, block_sums, s)));
         SCS_TRY((scan_exclusive<SCAN_SUM>(f_ind{q.pc, 0}, q.rank, N + 1, n_parts, N, 0, block_sums, s)));
@@ -1025,7 +1367,7 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         SCS_TRY((scan_exclusive<SCAN_SUM>(f_mark{q.mark, N}, q.kpos, N + 1, n_parts, N, 0, block_sums, s)));
         k_par_nodes<<<gm, 256, 0, s>>>(q);
         p.tpb = SPLIT_THREADS;
-        k_split_scan<<<1, 1024, 0, s>>>(p);
+        SCS_TRY(split_scan());
         k_par_nodes_fill<<<gn, 256, 0, s>>>(q);
         k_par_values<<<gn, 256, 0, s>>>(q);
         k_par_tables<<<gn, 256, 0, s>>>(q);
@@ -1046,9 +1388,85 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_split_fill, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)SPLIT_FILL_LDS));
         k_split_count<<<grid, SPLIT_THREADS, 0, s>>>(p);
-        k_split_scan<<<1, 1024, 0, s>>>(p);
+        SCS_TRY(split_scan());
         k_split_fill<<<grid, SPLIT_THREADS, SPLIT_FILL_LDS, s>>>(p);
         SCS_HIP_CHECK(hipGetLastError());
+    }
+    if (level) {
+        // ---- the union of the children, what the host needs of it, and its analysis -- one small copy back
+        int32_t *d_ct = (int32_t *)(d_small + s_ct);
+        int64_t *d_cl = (int64_t *)(d_small + s_cl);
+        k_level_union<<<dim3((unsigned)((M + 255) / 256), (unsigned)n_parts), 256, 0, s>>>(
+            p, K, d_in + 16 + 2 * (size_t)T, u_node_off, u_tree_off, d_ct, d_cl);
+        k_leaf_total<<<1, 64, 0, s>>>(p.totals, n_parts, d_leaf_total);
+        SCS_HIP_CHECK(hipGetLastError());
+        auto sc_alloc = [&](size_t bytes, void **out) { return scratch.alloc(bytes, out); };
+        SCS_TRY(analyze_tables(sc_alloc, p.c_leaf_taxon, p.c_adj_depth, d_leaf_total, L, TC,
+                               (int32_t *)(d_small + s_root), (unsigned long long *)(d_small + s_sig), s));
+        SCS_HIP_CHECK(hipMemcpyAsync(d_small + s_flags, p.flags, 64, hipMemcpyDeviceToDevice, s));
+        unsigned char *h_small = nullptr;
+        SCS_TRY(scs_pinned_get(ctx, small_bytes, (void **)&h_small));
+        struct pinned_guard {
+            scs_ctx *ctx;
+            void *p;
+            ~pinned_guard() { scs_pinned_release(ctx, p); }
+        } guard{ctx, h_small};
+        SCS_HIP_CHECK(hipMemcpyAsync(h_small, d_small, small_bytes, hipMemcpyDeviceToHost, s));
+        SCS_HIP_CHECK(hipStreamSynchronize(s));
+        const int64_t *h_tot = (const int64_t *)(h_small + s_tot);
+        const int32_t *h_flags = (const int32_t *)(h_small + s_flags);
+        if (parallel && h_flags[9]) {
+            // a root path longer than PAR_PATH (a comb): the one-thread-per-tree kernels take this split
+            region.reset();
+            return forest_split(ctx, f, part_of, new_id, n_parts, part_taxa, strategy, out_forests, info, true, lv);
+        }
+        if (h_flags[0] == -3) {
+            scs_set_error("scs_forest_split: an internal node without support under the bootstrap weighting");
+            return SCS_EUNSUP;
+        }
+        if (h_flags[0] != 0) {
+            scs_set_error("scs_forest_split: malformed tree arrays (not preorder, or inconsistent leaf counts)");
+            return SCS_EINVAL;
+        }
+        int64_t trees = 0, nodes = 0, leaves = 0;
+        int32_t mono = 1;
+        for (int b = 0; b < n_parts; ++b) {
+            trees += h_tot[b * 4 + 0];
+            nodes += h_tot[b * 4 + 1];
+            leaves += h_tot[b * 4 + 2];
+            mono = mono && h_flags[1 + b];
+        }
+        memcpy(lv->child_trees, h_small + s_ct, (size_t)n_parts * K * 4);
+        memcpy(lv->child_leaves, h_small + s_cl, (size_t)n_parts * K * 8);
+        memcpy(lv->present, h_small + s_pres, (size_t)TC);
+        memcpy(lv->comp_root, h_small + s_root, (size_t)TC * 4);
+        memcpy(lv->sig, h_small + s_sig, (size_t)TC * 16);
+        auto c = std::unique_ptr<scs_forest>(new scs_forest());
+        c->n_taxa = TC;
+        c->n_trees = (int32_t)trees;
+        c->n_nodes = nodes;
+        c->n_leaves = leaves;
+        c->region = region;
+        c->node_off = u_node_off;
+        c->tree_off = u_tree_off;
+        c->parent = p.c_parent;
+        c->taxon = p.c_taxon;
+        c->length = p.c_length;
+        c->support = p.c_support;
+        c->weights = p.c_weights;
+        c->tree_index = p.c_tree_index;
+        c->leaf_taxon = p.c_leaf_taxon;
+        c->adj_depth = p.c_adj_depth;
+        c->adj_val = p.c_adj_val;
+        c->present = p.c_present;
+        c->has_tables = true;  // (on the device only: h_* stay null)
+        c->tree_id = nullptr;  // (c_tree_id numbers a part's trees from 0: the union makes its own on first use)
+        info[0].n_trees = (int32_t)trees;
+        info[0].monotone = mono;
+        info[0].n_nodes = nodes;
+        info[0].n_leaves = leaves;
+        out_forests[0] = c.release();
+        return SCS_OK;
     }
     SCS_HIP_CHECK(hipMemcpyAsync(d_out + o_flags, p.flags, 64, hipMemcpyDeviceToDevice, s));
     unsigned char *h_out = nullptr;
@@ -1167,5 +1585,65 @@ extern "C" int scs_forest_download(scs_ctx *ctx, const scs_forest *f, int32_t t_
     if (weights && m) SCS_HIP_CHECK(hipMemcpyAsync(weights, f->weights + t_begin, m * 8, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));
     for (size_t t = 0; t <= m; ++t) node_off[t] -= lo;  // (relative to the first downloaded tree)
+    return SCS_OK;
+}
+
+
+// Components and contraction signatures of a forest that carries tables (a child of scs_forest_split or the
+// union of scs_forest_split_level), over its n_taxa ids -- what scs_forest_split_level reports for its
+// children, for a level's first forest (reference: scs.py:122, :302-316).
+extern "C" int scs_forest_analyze(scs_ctx *ctx, const scs_forest *f, int32_t *comp_root, uint64_t *sig) {
+    SCS_REQUIRE(ctx && f && comp_root && sig, "scs_forest_analyze: null argument");
+    SCS_REQUIRE(f->has_tables, "scs_forest_analyze: the forest carries no tables (not a child of scs_forest_split)");
+    SCS_REQUIRE(f->n_leaves < ((int64_t)1 << 31) - 8, "scs_forest_analyze: too many leaves");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    struct scratch_t {
+        scs_ctx *ctx;
+        std::vector<void *> blocks;
+        ~scratch_t() {
+            for (void *p : blocks) scs_block_release(ctx, p);
+        }
+        int alloc(size_t bytes, void **out) {
+            SCS_TRY(scs_block_alloc(ctx, bytes, out));
+            blocks.push_back(*out);
+            return SCS_OK;
+        }
+    } scratch{ctx, {}};
+    const int32_t T = f->n_taxa;
+    const size_t o_sig = 0, o_root = (size_t)T * 16, o_n = (o_root + (size_t)T * 4 + 15) / 16 * 16, bytes = o_n + 16;
+    unsigned char *d = nullptr;
+    SCS_TRY(scratch.alloc(bytes, (void **)&d));
+    const int64_t L = f->n_leaves;
+    SCS_HIP_CHECK(hipMemcpyAsync(d + o_n, &L, 8, hipMemcpyHostToDevice, s));
+    auto sc_alloc = [&](size_t b, void **out) { return scratch.alloc(b, out); };
+    SCS_TRY(analyze_tables(sc_alloc, f->leaf_taxon, f->adj_depth, (const int64_t *)(d + o_n), L, T,
+                           (int32_t *)(d + o_root), (unsigned long long *)(d + o_sig), s));
+    SCS_HIP_CHECK(hipMemcpyAsync(sig, d + o_sig, (size_t)T * 16, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(comp_root, d + o_root, (size_t)T * 4, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    return SCS_OK;
+}
+
+// tables of the trees [t_begin, t_end) of a forest that carries them (tree_off made relative to the first of
+// them; any output may be null): the exact host routines of a flagged node (contraction groups)
+extern "C" int scs_forest_tables_download_range(scs_ctx *ctx, const scs_forest *f, int32_t t_begin, int32_t t_end,
+                                                int64_t *tree_off, int32_t *leaf_taxon, int32_t *adj_depth,
+                                                double *adj_val, double *tree_w) {
+    SCS_REQUIRE(ctx && f && tree_off, "scs_forest_tables_download_range: null argument");
+    SCS_REQUIRE(f->has_tables, "scs_forest_tables_download_range: the forest carries no tables");
+    SCS_REQUIRE(t_begin >= 0 && t_begin <= t_end && t_end <= f->n_trees, "scs_forest_tables_download_range: bad tree range");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t m = (size_t)(t_end - t_begin);
+    SCS_HIP_CHECK(hipMemcpyAsync(tree_off, f->tree_off + t_begin, (m + 1) * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t lo = tree_off[0], l = tree_off[m] - lo;
+    if (leaf_taxon && l) SCS_HIP_CHECK(hipMemcpyAsync(leaf_taxon, f->leaf_taxon + lo, (size_t)l * 4, hipMemcpyDeviceToHost, s));
+    if (adj_depth && l) SCS_HIP_CHECK(hipMemcpyAsync(adj_depth, f->adj_depth + lo, (size_t)l * 4, hipMemcpyDeviceToHost, s));
+    if (adj_val && l) SCS_HIP_CHECK(hipMemcpyAsync(adj_val, f->adj_val + lo, (size_t)l * 8, hipMemcpyDeviceToHost, s));
+    if (tree_w && m) SCS_HIP_CHECK(hipMemcpyAsync(tree_w, f->weights + t_begin, m * 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    for (size_t t = 0; t <= m; ++t) tree_off[t] -= lo;
     return SCS_OK;
 }

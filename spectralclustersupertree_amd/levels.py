@@ -1,0 +1,500 @@
+"""A whole subtree of the recursion level by level (round 6).
+
+The reference walks ``construct_supertree`` depth-first, one node at a time, threading ONE
+``RandomState`` through every node (reference: src/sc_supertree/scs.py:139-171): a node's labels need
+its embedding, its children need its labels, and the labels are drawn from a stream whose position
+depends on everything the walk has visited before.  On the device that order made the deep recursion
+a chain of tens of thousands of sub-millisecond round trips.  Two facts break the chain:
+
+* a node's EMBEDDING depends on its forest alone (the ARPACK start vector is drawn and not used,
+  ``scs.spectral_bipartition_device``), and
+* the PARTITION k-means finds on that embedding hardly ever depends on its draws (ten k-means++ starts
+  of a two-cluster problem on what is in effect one coordinate) -- only which part is NUMBERED 0 does,
+  i.e. the order in which the two children are visited.
+
+So a subtree is first solved **level by level with provisional labels** (``Engine``): every level of the
+subtree is ONE forest on the device (the trees of its nodes one after the other, the nodes' taxa as
+consecutive ranges of one numbering), ONE ``scs_forest_split_level`` restricts all nodes of a level to all
+of their parts and reports -- from the device -- present taxa, connected components and contraction
+signatures of every child, ONE ``scs_small_solve_begin_level`` embeds all small nodes of the level, and the
+host assigns labels from a private stream.  Then the walk proper (``Engine.build``) visits the nodes in the
+reference's order with the caller's ``RandomState``: it draws what the reference draws (the start vector,
+then scikit-learn's k-means on the stored embedding), and where the true partition equals the provisional
+one -- labels equal or swapped -- the children are already there.  Where it does not (a tie that the draws
+decide), that node's forest comes back from the device and its subtree is redone on the node-by-node
+path with the true labels.  **Labels always come from the true draws**: the result is the reference's,
+bit for bit, whatever the provisional labels were.
+"""
+
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from spectralclustersupertree_amd import _native as nv
+from spectralclustersupertree_amd import flatten as fl
+from spectralclustersupertree_amd.tree import TreeNode, connect_trees, tip_names_to_tree
+from spectralclustersupertree_amd.treearrays import _STRATEGY_CODE, ResidentArrays, TreeArrays
+
+TIPS, GRAFT, COMPS, SPECTRAL, EMPTY, FALLBACK = 0, 1, 2, 3, 4, 5
+MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
+
+# diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
+stats = {"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
+         "exact_group_nodes": 0}
+
+
+def reset_stats() -> None:
+    stats.update({"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
+                  "fallbacks": 0, "exact_group_nodes": 0})
+
+
+def max_taxa() -> int:
+    """Largest node whose subtree is solved level by level (SCS_SPEC_MAX_TAXA; 0 switches the engine off)."""
+    return int(os.environ.get("SCS_SPEC_MAX_TAXA", "2048") or 0)
+
+
+def min_nodes() -> int:
+    """Smallest forest (tree nodes) worth the engine's launches (SCS_SPEC_MIN_NODES)."""
+    return int(os.environ.get("SCS_SPEC_MIN_NODES", "4000") or 0)
+
+
+class SpecRoot:
+    """Marker in a child's ``pre`` slot: this child's subtree goes through ``construct``."""
+
+
+def wanted(sub, n_component: int) -> bool:
+    """Whether the subtree of child ``sub`` (``n_component`` taxa) is solved level by level."""
+    cap = max_taxa()
+    if cap <= 0 or n_component > cap or n_component <= 2 or sub.n_trees < 2:
+        return False
+    n_nodes = sub.n_nodes if isinstance(sub, ResidentArrays) else len(sub.parent)
+    return n_nodes >= min_nodes()
+
+
+def construct(sub, pcg_weighting, contract_edges, random_state, team=None, ahead=None) -> TreeNode:
+    """The subtree of ``sub`` (a child forest of a split): ``scs._construct_node``'s result, same draws."""
+    from spectralclustersupertree_amd import scs
+
+    present = sub.present_taxa()
+    if sub.n_trees == 1 or len(present) <= 2:
+        return scs._construct_node(sub, pcg_weighting, contract_edges, random_state, None, team, None, ahead)
+    dev = team.solo if team is not None else scs.default_device()
+    engine = Engine(sub, pcg_weighting, contract_edges, dev, team, ahead)
+    try:
+        engine.run()
+    except nv.ScsError as exc:
+        if exc.code != nv.ENOMEM:
+            raise
+        # not enough device memory for the levels of this subtree beside what else is resident: node by node
+        engine.levels.clear()
+        return scs._construct_node(sub, pcg_weighting, contract_edges, random_state, None, team, None, ahead)
+    return engine.build(0, 0, random_state)
+
+
+class Level:
+    """One level of a speculative subtree: K nodes as consecutive tree ranges of ``forest`` and consecutive
+    id ranges of its taxon numbering (struct of arrays; see ``Engine``)."""
+
+    __slots__ = ("forest", "K", "T", "t_lo", "t_hi", "n_leaves", "u_lo", "u_sz", "gid", "present", "comp_root",
+                 "sig", "kind", "n_pres", "v_off", "n_groups", "maps", "prov", "members", "sorted_taxa", "seg_start",
+                 "seg_len", "seg_child", "node_seg", "graft", "monotone")
+
+
+class Engine:
+    def __init__(self, sub, strategy: str, contract_edges: bool, dev, team=None, ahead=None) -> None:
+        self.sub, self.strategy, self.contract, self.dev = sub, strategy, bool(contract_edges), dev
+        self.team, self.ahead = team, ahead
+        self.levels: list[Level] = []
+        self.prov_rs = np.random.RandomState(0x5C5)  # the provisional labels' private stream
+        self.weights_ok = bool(np.all(np.asarray(sub.weights) >= 0))
+        self.small_max = dev.SMALL_MAX_TAXA
+
+    # ------------------------------------------------------------------ level 0
+    def _first_level(self) -> Level:
+        sub, dev = self.sub, self.dev
+        k = int(sub.n_taxa)
+        lev = Level()
+        if (isinstance(sub, ResidentArrays) and sub._tables is not None and sub.strategy == self.strategy
+                and sub.forest.dev is dev and sub.forest._h):
+            forest = sub.forest
+            comp_root, sig = forest.analyze()
+            present = np.zeros(k, dtype=np.uint8)
+            present[sub.present_taxa()] = 1
+            lev.monotone = bool(forest.monotone_flag)
+        else:
+            host = sub.to_host() if isinstance(sub, ResidentArrays) else sub
+            res = ResidentArrays.from_host(host, dev)
+            # the trees are a split's children (nothing to splice): restricting them to ALL their taxa
+            # returns them as they are -- with their tables on the device, and the analysis of those
+            forest, child_trees, _, present, comp_root, sig = res.forest.split_level(
+                np.zeros(k, dtype=np.int32), np.arange(k, dtype=np.int32), 1, k, _STRATEGY_CODE[self.strategy],
+                np.asarray([res.forest.n_trees], dtype=np.int32))
+            if int(child_trees[0, 0]) != sub.n_trees:
+                msg = "levels: a child forest changed under the identity restriction"
+                raise AssertionError(msg)
+            lev.monotone = bool(forest.monotone_flag)
+        lev.forest = forest
+        lev.K, lev.T = 1, k
+        lev.t_lo = np.zeros(1, dtype=np.int32)
+        lev.t_hi = np.asarray([forest.n_trees], dtype=np.int32)
+        lev.n_leaves = np.asarray([forest.n_leaves], dtype=np.int64)
+        lev.u_lo = np.zeros(1, dtype=np.int32)
+        lev.u_sz = np.asarray([k], dtype=np.int32)
+        lev.gid = np.arange(k, dtype=np.int32)
+        lev.present, lev.comp_root, lev.sig = present, comp_root[:k], sig[:k]
+        return lev
+
+    # ------------------------------------------------------------------ all levels
+    def run(self) -> None:
+        stats["roots"] += 1
+        lev = self._first_level()
+        while lev is not None:
+            self.levels.append(lev)
+            stats["levels"] += 1
+            stats["nodes"] += lev.K
+            lev = self._process(lev)
+
+    def _monotone(self, lev: Level) -> bool:
+        return self.strategy in ("one", "depth", "branch") and lev.monotone and self.weights_ok
+
+    def _process(self, lev: Level):
+        """Classify the nodes of ``lev``, embed its spectral nodes, label them provisionally, split the
+        level's forest into the next level (None when no node has a part left to split)."""
+        K, T = lev.K, lev.T
+        u_lo, u_sz = lev.u_lo, lev.u_sz
+        nid = np.repeat(np.arange(K, dtype=np.int32), u_sz)
+        pres = lev.present.astype(bool)
+        m = (lev.t_hi - lev.t_lo).astype(np.int64)
+        pres_i = pres.astype(np.int32)
+        n_pres = np.add.reduceat(pres_i, u_lo)
+        cs_pres = np.concatenate(([0], np.cumsum(pres_i)))  # exclusive prefix counts
+        prank = (cs_pres[:-1] - cs_pres[u_lo][nid]).astype(np.int32)  # rank among the node's present taxa
+        is_root = (lev.comp_root == np.arange(T, dtype=np.int32)) & pres
+        root_i = is_root.astype(np.int32)
+        n_comp = np.add.reduceat(root_i, u_lo)
+        kind = np.full(K, SPECTRAL, dtype=np.int8)
+        kind[n_comp > 1] = COMPS
+        kind[n_pres <= 2] = TIPS
+        kind[m == 1] = GRAFT
+        kind[m == 0] = EMPTY
+        lev.kind, lev.n_pres = kind, n_pres
+        lev.graft, lev.members = {}, {}
+        for k in np.flatnonzero(kind == GRAFT):
+            lev.graft[int(k)] = self._graft(lev, int(k))
+
+        # ---- spectral nodes: contraction groups (exact routine only where signatures collide)
+        spectral = kind == SPECTRAL
+        vertex_of = prank.copy()  # vertex of a present taxon (its group after contraction)
+        relabel = np.where(pres, prank, 0).astype(np.int32)  # id in the node's (contracted) numbering
+        n_groups = np.where(spectral, n_pres, 0).astype(np.int32)
+        gs_patch: dict[int, np.ndarray] = {}
+        if self.contract and spectral.any():
+            idx = np.flatnonzero(pres & spectral[nid])
+            if len(idx) > 1:
+                s0, s1, nn = lev.sig[idx, 0], lev.sig[idx, 1], nid[idx]
+                order = np.lexsort((s1, s0, nn))
+                a, b, c = nn[order], s0[order], s1[order]
+                eq = (a[1:] == a[:-1]) & (b[1:] == b[:-1]) & (c[1:] == c[:-1])
+                for k in np.unique(a[1:][eq]):
+                    self._exact_groups(lev, int(k), prank, vertex_of, relabel, n_groups, gs_patch)
+        lev.n_groups = n_groups
+        v_ptr = np.concatenate(([0], np.cumsum(n_groups, dtype=np.int64)))
+        lev.v_off = v_ptr
+        lev.maps = np.zeros((int(v_ptr[-1]), 2))
+        lev.prov = np.zeros(int(v_ptr[-1]), dtype=np.int8)
+        stats["spectral"] += int(spectral.sum())
+
+        # ---- embeddings: the small nodes of the level in batches, the larger ones one by one
+        small = np.flatnonzero(spectral & (n_pres <= self.small_max))
+        if len(small):
+            self._solve_small(lev, small, m, relabel, nid, gs_patch)
+        for k in np.flatnonzero(spectral & (n_pres > self.small_max)):
+            self._solve_large(lev, int(k), relabel, gs_patch)
+        # ---- provisional labels
+        from spectralclustersupertree_amd import kmeans2
+
+        for k in np.flatnonzero(kind == SPECTRAL):  # (a node whose batched solve failed has left this kind)
+            v0, v1 = int(v_ptr[k]), int(v_ptr[k + 1])
+            lev.prov[v0:v1] = kmeans2.labels(lev.maps[v0:v1], self.prov_rs)
+
+        # ---- parts of every node, sorted by (node, part, taxon)
+        tpart = np.full(T, -1, dtype=np.int64)
+        comps = kind == COMPS
+        if comps.any():
+            cs_root = np.concatenate(([0], np.cumsum(root_i)))
+            sel = pres & comps[nid]
+            tpart[sel] = cs_root[lev.comp_root[sel]] - cs_root[u_lo[nid[sel]]]
+        spectral = kind == SPECTRAL
+        if spectral.any():
+            sel = pres & spectral[nid]
+            tpart[sel] = lev.prov[v_ptr[nid[sel]] + vertex_of[sel]]
+        valid = np.flatnonzero(tpart >= 0)
+        if len(valid) == 0:
+            lev.sorted_taxa = np.zeros(0, dtype=np.int32)
+            lev.seg_start = lev.seg_len = lev.seg_child = np.zeros(0, dtype=np.int64)
+            lev.node_seg = np.zeros(K + 1, dtype=np.int64)
+            return None
+        pmax = int(tpart.max()) + 1
+        key = nid[valid].astype(np.int64) * pmax + tpart[valid]
+        order = np.argsort(key, kind="stable")
+        skey = key[order]
+        lev.sorted_taxa = valid[order].astype(np.int32)
+        first = np.concatenate(([True], skey[1:] != skey[:-1]))
+        seg_start = np.flatnonzero(first)
+        seg_len = np.diff(np.concatenate((seg_start, [len(skey)])))
+        seg_node = (skey[seg_start] // pmax).astype(np.int64)
+        lev.seg_start, lev.seg_len = seg_start, seg_len
+        lev.node_seg = np.searchsorted(seg_node, np.arange(K + 1))  # segments of node k: [node_seg[k], node_seg[k + 1])
+        splitting = seg_len > 2
+        cs_split = np.concatenate(([0], np.cumsum(splitting.astype(np.int64))))
+        slot = cs_split[:-1] - cs_split[lev.node_seg[seg_node]]  # index among the node's splitting parts
+        too_many = np.unique(seg_node[splitting & (slot >= MAX_PARTS)])
+        if len(too_many):
+            # more than eight parts to restrict to (many components): that node goes node by node
+            kind[too_many] = FALLBACK
+            splitting &= ~np.isin(seg_node, too_many)
+        lev.seg_child = np.full(len(seg_start), -1, dtype=np.int64)
+        child_seg = np.flatnonzero(splitting)
+        if len(child_seg) == 0:
+            return None
+        # ---- the next level: children ordered (slot, node) -- the tree order of the union forest
+        child_seg = child_seg[np.argsort(slot[child_seg] * K + seg_node[child_seg], kind="stable")]
+        lev.seg_child[child_seg] = np.arange(len(child_seg))
+        lens = seg_len[child_seg]
+        starts_new = np.cumsum(lens) - lens
+        total = int(lens.sum())
+        pos = np.repeat(seg_start[child_seg] - starts_new, lens) + np.arange(total)
+        taxa_new = lev.sorted_taxa[pos]
+        part_of = np.full(T, -1, dtype=np.int32)
+        new_id = np.zeros(T, dtype=np.int32)
+        part_of[taxa_new] = np.repeat(slot[child_seg], lens).astype(np.int32)
+        new_id[taxa_new] = np.arange(total, dtype=np.int32)
+        n_parts = int(slot[child_seg].max()) + 1
+        union, child_trees, child_leaves, present, comp_root, sig = lev.forest.split_level(
+            part_of, new_id, n_parts, total, _STRATEGY_CODE[self.strategy], lev.t_hi)
+        nxt = Level()
+        nxt.forest = union
+        nxt.monotone = bool(union.monotone_flag)
+        nxt.K, nxt.T = len(child_seg), total
+        cs, cn = slot[child_seg], seg_node[child_seg]
+        counts = child_trees[cs, cn].astype(np.int64)
+        t_hi = np.cumsum(counts)
+        nxt.t_lo = (t_hi - counts).astype(np.int32)
+        nxt.t_hi = t_hi.astype(np.int32)
+        nxt.n_leaves = child_leaves[cs, cn].astype(np.int64)
+        nxt.u_lo = starts_new.astype(np.int32)
+        nxt.u_sz = lens.astype(np.int32)
+        nxt.gid = lev.gid[taxa_new]
+        nxt.present, nxt.comp_root, nxt.sig = present, comp_root, sig
+        return nxt
+
+    # ------------------------------------------------------------------ pieces of a level
+    def _node_arrays(self, lev: Level, k: int) -> TreeArrays:
+        """Node ``k`` of ``lev`` as host arrays (taxa numbered 0 .. u_sz - 1): the node-by-node path's input."""
+        node_off, parent, taxon, length, support, weights = lev.forest.download(int(lev.t_lo[k]), int(lev.t_hi[k]))
+        lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
+        taxon = np.where(taxon >= 0, taxon - lo, -1).astype(np.int32)
+        gids = lev.gid[lo:lo + sz]
+        sub = self.sub
+        out = TreeArrays(n_taxa=sz, node_off=node_off, parent=parent, taxon=taxon, length=length, support=support,
+                         weights=weights, taxa=sub.taxa, ids=gids if sub.ids is None else np.asarray(sub.ids)[gids])
+        out.resident_device = sub.resident_device
+        return out
+
+    def _graft(self, lev: Level, k: int) -> TreeNode:
+        return self._node_arrays(lev, k).to_tree(0)  # reference: scs.py:96-98
+
+    def _exact_groups(self, lev, k, prank, vertex_of, relabel, n_groups, gs_patch) -> None:
+        """Two taxa of node ``k`` carry the same signature: its contraction groups from the exact host
+        routine on the node's tables (reference: scs.py:302-316; ``flatten.contraction_groups``)."""
+        stats["exact_group_nodes"] += 1
+        lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
+        tree_off, leaf_taxon, adj_depth, adj_val, tree_w = lev.forest.tables_range(int(lev.t_lo[k]), int(lev.t_hi[k]))
+        n = int(lev.n_pres[k])
+        local = prank[leaf_taxon].astype(np.int32)  # (every leaf's taxon is present)
+        tables = fl.TreeTables(n_taxa=n, tree_off=tree_off, leaf_taxon=local, adj_depth=adj_depth, adj_val=adj_val,
+                               tree_w=tree_w)
+        groups = fl.contraction_groups(tables)
+        ng = int(groups.max()) + 1
+        if ng == n:
+            return  # (the signatures collided, the sets do not)
+        order = np.lexsort((np.arange(n), groups))  # by group, then id: scs.relabel_for_contraction
+        new_of_old = np.empty(n, dtype=np.int32)
+        new_of_old[order] = np.arange(n, dtype=np.int32)
+        counts = np.bincount(groups, minlength=ng)
+        group_start = np.zeros(ng + 1, dtype=np.int32)
+        np.cumsum(counts, out=group_start[1:])
+        seg = slice(lo, lo + sz)
+        here = lev.present[seg].astype(bool)
+        rl = relabel[seg]
+        rl[here] = new_of_old[prank[seg][here]]
+        vo = vertex_of[seg]
+        vo[here] = groups[prank[seg][here]]
+        n_groups[k] = ng
+        gs_patch[k] = group_start
+        # members of every vertex as ids among the node's present taxa (perm[group_start[g] : group_start[g + 1]])
+        lev.members[k] = (order.astype(np.int32), group_start)
+
+    def _group_starts(self, nodes, n_groups, gs_patch) -> np.ndarray:
+        ng1 = n_groups[nodes].astype(np.int64) + 1
+        starts = np.cumsum(ng1) - ng1
+        out = (np.arange(int(ng1.sum())) - np.repeat(starts, ng1)).astype(np.int32)
+        for i, k in enumerate(nodes):
+            patch = gs_patch.get(int(k))
+            if patch is not None:
+                out[int(starts[i]):int(starts[i]) + len(patch)] = patch
+        return out
+
+    def _solve_small(self, lev, small, m, relabel, nid, gs_patch) -> None:
+        """``scs_small_solve_begin_level`` over the level's small spectral nodes, in batches bounded by the
+        addend scratch (trees x cells per node)."""
+        cap = int(float(os.environ.get("SCS_SPEC_BATCH_GB", "8")) * (1 << 30))
+        cost = lev.n_pres[small].astype(np.int64) ** 2 * ((m[small] + 1) & ~1) * 8
+        at = 0
+        while at < len(small):
+            end, used = at, 0
+            while end < len(small) and (end == at or used + cost[end] <= cap):
+                used += int(cost[end])
+                end += 1
+            nodes = small[at:end]
+            at = end
+            sel = np.zeros(lev.K, dtype=bool)
+            sel[nodes] = True
+            ticket = self.dev.small_solve_begin_level(
+                lev.forest, lev.t_lo[nodes], (lev.t_hi - lev.t_lo)[nodes], lev.n_leaves[nodes], lev.u_lo[nodes],
+                lev.u_sz[nodes], relabel[sel[nid]], lev.n_pres[nodes], lev.n_groups[nodes],
+                self._group_starts(nodes, lev.n_groups, gs_patch))
+            maps, lam = ticket.raw()
+            ok = np.all(np.isfinite(lam), axis=1)
+            ng = lev.n_groups[nodes].astype(np.int64)
+            src = np.cumsum(ng) - ng
+            if ok.all() and len(nodes) and np.all(np.diff(nodes) == 1):
+                lev.maps[int(lev.v_off[nodes[0]]):int(lev.v_off[nodes[-1] + 1])] = maps
+            else:
+                for i, k in enumerate(nodes):
+                    if ok[i]:
+                        lev.maps[int(lev.v_off[k]):int(lev.v_off[k + 1])] = maps[int(src[i]):int(src[i] + ng[i])]
+            for k in nodes[~ok]:
+                lev.kind[k] = FALLBACK  # the one-sided Jacobi ran out of sweeps: this node goes node by node
+
+    def _solve_large(self, lev, k, relabel, gs_patch) -> None:
+        """A node above the batched path's size: build, contract, LOBPCG on its slice of the level's tables."""
+        from spectralclustersupertree_amd import scs
+
+        lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
+        dtab = self.dev.upload_range(lev.forest, int(lev.t_lo[k]), int(lev.t_hi[k]), lo, sz, relabel[lo:lo + sz],
+                                     int(lev.n_pres[k]), self._monotone(lev))
+        try:
+            graph = dtab.build()
+        finally:
+            dtab.free()
+        try:
+            gs = gs_patch.get(k)
+            if gs is not None:
+                graph = graph.contract(gs)
+            maps, _ = scs._fiedler_checked(graph, None, scs.DEFAULT_TOL, scs.DEFAULT_MAX_ITER, 0)
+        finally:
+            graph.free()
+        lev.maps[int(lev.v_off[k]):int(lev.v_off[k + 1])] = maps
+
+    # ------------------------------------------------------------------ the walk proper
+    def _names(self, lev: Level, uids) -> list[str]:
+        name = self.sub.name
+        gid = lev.gid
+        return [name(int(gid[int(u)])) for u in uids]
+
+    def _sequential(self, lev: Level, k: int, random_state, parts=None) -> TreeNode:
+        """Node ``k`` on the node-by-node path: from its top (``parts`` None) or from its children down."""
+        from spectralclustersupertree_amd import scs
+
+        stats["fallbacks"] += 1
+        arrays = self._node_arrays(lev, k)
+        if parts is None:
+            return scs._construct_node(arrays, self.strategy, self.contract, random_state, None, self.team, None,
+                                       self.ahead)
+        return scs._construct_children(arrays, parts, self.strategy, self.contract, random_state, None, self.team,
+                                       self.ahead)
+
+    def build(self, li: int, k: int, random_state) -> TreeNode:
+        """The subtree of node ``k`` of level ``li`` in the reference's order of visits and draws
+        (reference: scs.py:96-174)."""
+        from spectralclustersupertree_amd import kmeans2, scs
+
+        lev = self.levels[li]
+        kind = int(lev.kind[k])
+        lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
+        if kind == GRAFT:
+            return lev.graft[k]
+        if kind == TIPS:
+            here = lo + np.flatnonzero(lev.present[lo:lo + sz])
+            return tip_names_to_tree(self._names(lev, here))
+        if kind == FALLBACK:
+            return self._sequential(lev, k, random_state)
+        s0, s1 = int(lev.node_seg[k]), int(lev.node_seg[k + 1])
+        segs = list(range(s0, s1))
+        if kind == SPECTRAL:
+            v0, v1 = int(lev.v_off[k]), int(lev.v_off[k + 1])
+            maps = lev.maps[v0:v1]
+            # the reference's draws: the ARPACK start vector (sklearn/utils/_arpack.py:31-33), then k-means
+            random_state.uniform(-1, 1, v1 - v0)
+            labels = np.asarray(kmeans2.labels(maps, random_state))
+            prov = lev.prov[v0:v1]
+            if scs._node_trace is not None:
+                self._trace(lev, k, labels, maps)
+            if np.array_equal(labels, prov):
+                pass
+            elif np.array_equal(labels, 1 - prov):
+                segs.reverse()  # (both labels occur, or the arrays would be equal: two segments)
+                if len(segs) == 1:  # (all vertices in one cluster: nothing to swap)
+                    segs = list(range(s0, s1))
+            else:
+                # the draws decided a tie differently: this node's children from its own forest, node by node
+                stats["mismatches"] += 1
+                stats["mismatch_sizes"].append(int(v1 - v0))
+                present_local = np.flatnonzero(lev.present[lo:lo + sz])
+                parts: list[list[int]] = [[], []]
+                for g, lab in enumerate(labels):
+                    parts[int(lab)].extend(int(present_local[int(i)]) for i in self._members(lev, k, g))
+                return self._sequential(lev, k, random_state, parts)
+        nxt = self.levels[li + 1] if li + 1 < len(self.levels) else None
+        for s in segs:  # reference: scs.py:63-65 reached from :158 -- before any child is entered
+            c = int(lev.seg_child[s])
+            if c >= 0 and int(nxt.kind[c]) == EMPTY:
+                msg = "There must be at least one tree to make a supertree."
+                raise ValueError(msg)
+        child_trees: list = []
+        for s in segs:
+            a = int(lev.seg_start[s])
+            uids = lev.sorted_taxa[a:a + int(lev.seg_len[s])]
+            c = int(lev.seg_child[s])
+            if c < 0:
+                if len(uids) > 2:  # a part of a node that left the engine (more than eight parts)
+                    msg = "levels: a part without a child"
+                    raise AssertionError(msg)
+                child_trees.append(tip_names_to_tree(self._names(lev, uids)))
+                continue
+            child_trees.append(self.build(li + 1, c, random_state))
+            clo, csz = int(nxt.u_lo[c]), int(nxt.u_sz[c])
+            missing = clo + np.flatnonzero(nxt.present[clo:clo + csz] == 0)
+            if len(missing):  # taxa no surviving tree holds (scs.py:166-170)
+                child_trees.extend(TreeNode(x) for x in self._names(nxt, missing))
+        return connect_trees(child_trees)
+
+    def _members(self, lev: Level, k: int, g: int):
+        """Vertex ``g`` of spectral node ``k``: ids among the node's present taxa."""
+        mem = lev.members.get(k)
+        if mem is None:
+            return (g,)
+        perm, group_start = mem
+        return perm[int(group_start[g]):int(group_start[g + 1])]
+
+    def _trace(self, lev: Level, k: int, labels, maps) -> None:
+        from spectralclustersupertree_amd import scs
+
+        lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
+        here = lo + np.flatnonzero(lev.present[lo:lo + sz])
+        names = self._names(lev, here)
+        vertices = [tuple(names[int(i)] for i in self._members(lev, k, g)) for g in range(len(labels))]
+        scs._node_trace.append({"vertices": vertices, "labels": labels.copy(), "maps": np.array(maps, copy=True)})

@@ -519,6 +519,10 @@ def _construct(arrays: TreeArrays, pcg_weighting, contract_edges, random_state,
         # worth a launch (treearrays.ResidentArrays, scs_forest_split); the device is only
         # created when such a split arrives (a run that never gets there touches none)
         arrays.resident_device = (lambda: team.solo) if team is not None else default_device
+    if bipartition is None:
+        from spectralclustersupertree_amd import levels
+
+        levels.reset_stats()
     with _warm_allocator():
         return _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre)
 
@@ -678,6 +682,14 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
         for i, c in enumerate(comp):
             parts[int(c)].append(int(present[i]))
 
+    return _construct_children(arrays, parts, pcg_weighting, contract_edges, random_state, given, team, ahead)
+
+
+def _construct_children(arrays, parts, pcg_weighting, contract_edges, random_state, given=None, team=None,
+                        ahead=None) -> TreeNode:
+    """The second half of a recursion node (reference: scs.py:139-174): the forest restricted to every part
+    (ids of ``arrays``), the children's subtrees in the order of ``parts``, joined under a new root."""
+    name = arrays.name
     forked = (team is not None and team.world > 1 and team.child_rng == "forked")
     # ---- the children: ONE sweep of this node's forest restricts it to every part (host),
     # then one batched launch for the small ones
@@ -702,6 +714,15 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
             # an empty list and raises (reference: scs.py:63-65 reached from :158)
             msg = "There must be at least one tree to make a supertree."
             raise ValueError(msg)
+    speculate = given is None and not forked and _small_path() and (team is None or team.world == 1)
+    if speculate:
+        # (round 6) a child of at most SCS_SPEC_MAX_TAXA taxa: its whole subtree level by level with provisional
+        # labels (levels.Engine), verified against the true draws when the walk gets there
+        from spectralclustersupertree_amd import levels
+
+        for child in children:
+            if child[0] == "sub" and levels.wanted(child[2], len(child[1])):
+                child[3] = levels.SpecRoot()
     if given is None and not forked and _small_path():
         _presolve_small_children(children, pcg_weighting, contract_edges, team, ahead)
 
@@ -717,6 +738,8 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
             rng = np.random.RandomState(random_state.randint(0, 2**31 - 1))
             dealt.append((len(child_trees), len(dealt) % team.world, sub, rng))
             child_trees.append(None)
+        elif speculate and isinstance(child_pre, levels.SpecRoot):
+            child_trees.append(levels.construct(sub, pcg_weighting, contract_edges, random_state, team, ahead))
         else:
             child_trees.append(_construct_node(sub, pcg_weighting, contract_edges, random_state, given, team,
                                                child_pre, ahead))
@@ -758,7 +781,7 @@ def _presolve_small_children(children, pcg_weighting, contract_edges, team, ahea
     batch, where = [], []
     small_dev = None
     for child in children:
-        if child[0] != "sub":
+        if child[0] != "sub" or child[3] is not None:  # (not None: a speculative subtree root, levels.SpecRoot)
             continue
         sub = child[2]
         if sub.n_trees == 1:
