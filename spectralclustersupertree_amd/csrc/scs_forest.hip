@@ -884,11 +884,9 @@ __global__ __launch_bounds__(256) void k_split_finalize(split_params p, const in
     }
 }
 
-// offsets of the union of all parts' children (tree order: part-major), trees and leaves per child
-__global__ __launch_bounds__(256) void k_level_union(split_params p, int32_t n_nodes,
-                                                     const int32_t *__restrict__ node_tree_end,
-                                                     int64_t *__restrict__ u_node_off, int64_t *__restrict__ u_tree_off,
-                                                     int32_t *__restrict__ child_trees, int64_t *__restrict__ child_leaves) {
+// offsets of the union of all parts' children (tree order: part-major)
+__global__ __launch_bounds__(256) void k_level_union(split_params p, int64_t *__restrict__ u_node_off,
+                                                     int64_t *__restrict__ u_tree_off) {
     const int M = p.n_trees;
     const int b = blockIdx.y;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -904,22 +902,41 @@ __global__ __launch_bounds__(256) void k_level_union(split_params p, int32_t n_n
         const int64_t row = (int64_t)b * (M + 1);
         u_node_off[tree_base + pos] = node_base + p.c_node_off[row + pos];
         u_tree_off[tree_base + pos] = leaf_base + p.c_tree_off[row + pos];
-        // the node of the parent level this tree belongs to: first k with node_tree_end[k] > t
-        int32_t lo = 0, hi = n_nodes - 1;
-        while (lo < hi) {
-            const int32_t mid = (lo + hi) >> 1;
-            if (node_tree_end[mid] > t) hi = mid;
-            else lo = mid + 1;
-        }
-        atomicAdd(&child_trees[(int64_t)b * n_nodes + lo], 1);
-        atomicAdd((unsigned long long *)&child_leaves[(int64_t)b * n_nodes + lo],
-                  (unsigned long long)p.leaves_cnt[(int64_t)b * M + t]);
     }
     if (t == M - 1 && b == p.n_parts - 1) {
         const int64_t trees = tree_base + p.totals[b * 4 + 0];
         u_node_off[trees] = node_base + p.totals[b * 4 + 1];
         u_tree_off[trees] = leaf_base + p.totals[b * 4 + 2];
     }
+}
+
+// trees and leaves of child (part b, node k): the part's kept trees carry their index in the parent forest
+// in increasing order (c_tree_index), so a node's share is a range of them -- two binary searches, no atomics
+__global__ void k_level_counts(split_params p, int32_t n_nodes, const int32_t *__restrict__ node_tree_end,
+                               int32_t *__restrict__ child_trees, int64_t *__restrict__ child_leaves) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)p.n_parts * n_nodes) return;
+    const int b = (int)(i / n_nodes), k = (int)(i - (int64_t)b * n_nodes);
+    int64_t tree_base = 0;
+    for (int c = 0; c < b; ++c) tree_base += p.totals[c * 4 + 0];
+    const int32_t trees = (int32_t)p.totals[b * 4 + 0];
+    const int32_t *idx = p.c_tree_index + tree_base;
+    const int32_t t_lo = k ? node_tree_end[k - 1] : 0, t_hi = node_tree_end[k];
+    int32_t pos[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int32_t want = e ? t_hi : t_lo;  // first kept tree with index >= want
+        int32_t lo = 0, hi = trees;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (idx[mid] < want) lo = mid + 1;
+            else hi = mid;
+        }
+        pos[e] = lo;
+    }
+    const int64_t *cto = p.c_tree_off + (int64_t)b * (p.n_trees + 1);
+    child_trees[i] = pos[1] - pos[0];
+    child_leaves[i] = cto[pos[1]] - cto[pos[0]];
 }
 
 // ---- analysis of a forest's tables: components and contraction signatures ------------------
@@ -1004,6 +1021,67 @@ __global__ void k_analyze_leaves(const int32_t *__restrict__ leaf_taxon, const i
     }
 }
 
+// The same for a universe of at most ANALYZE_LDS_TAXA ids (every level below a node of that size): thousands of
+// trees over a few hundred taxa make every leaf's two signature adds -- and the union-find's hooks -- land on the
+// same few addresses (measured: 470 us a level, the atomics serialised in the L2).  A workgroup folds a run of
+// leaves in LDS first (its own union-find and partial signatures) and publishes one add per taxon it met and
+// one union per taxon it hooked.  Sums mod 2^64 and set unions: the order does not matter.
+constexpr int ANALYZE_LDS_TAXA = 2048;
+constexpr int ANALYZE_LEAVES_PER_BLOCK = 256 * 32;
+
+__device__ __forceinline__ void uf_union(int32_t *parent, int32_t u, int32_t v) {
+    for (;;) {
+        u = uf_find(parent, u);
+        v = uf_find(parent, v);
+        if (u == v) return;
+        if (u < v) {
+            const int32_t w = u;
+            u = v;
+            v = w;
+        }
+        const int32_t old = atomicCAS(&parent[u], u, v);  // hook the larger root under the smaller
+        if (old == u) return;
+        u = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_analyze_leaves_lds(const int32_t *__restrict__ leaf_taxon,
+                                                            const int32_t *__restrict__ adj_depth,
+                                                            const int32_t *__restrict__ side_excl,
+                                                            const int64_t *__restrict__ n_leaves, int32_t n_taxa,
+                                                            int32_t *parent, unsigned long long *sig) {
+    __shared__ int32_t l_par[ANALYZE_LDS_TAXA];
+    __shared__ unsigned long long l_sig[2 * ANALYZE_LDS_TAXA];
+    const int64_t L = *n_leaves;
+    const int64_t p0 = (int64_t)blockIdx.x * ANALYZE_LEAVES_PER_BLOCK;
+    if (p0 >= L) return;
+    for (int x = threadIdx.x; x < n_taxa; x += 256) {
+        l_par[x] = x;
+        l_sig[2 * x] = 0;
+        l_sig[2 * x + 1] = 0;
+    }
+    __syncthreads();
+    const int64_t p1 = p0 + ANALYZE_LEAVES_PER_BLOCK < L ? p0 + ANALYZE_LEAVES_PER_BLOCK : L;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int32_t x = leaf_taxon[p];
+        const bool start = p == 0 || adj_depth[p - 1] == 0;
+        const unsigned long long side = (unsigned long long)(start ? (int32_t)p : side_excl[p]);
+        atomicAdd(&l_sig[2 * x], mix64(side * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull));
+        atomicAdd(&l_sig[2 * x + 1], mix64((side + 0x2545F4914F6CDD1Dull) * 0xD1342543DE82EF95ull));
+        if (adj_depth[p] != 0) uf_union(l_par, x, leaf_taxon[p + 1]);
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < n_taxa; x += 256) {
+        const unsigned long long a = l_sig[2 * x], b = l_sig[2 * x + 1];
+        if (a | b) {  // (a taxon this run of leaves never met adds nothing; a met one adds its mixes, never 0 | 0 in practice)
+            atomicAdd(&sig[2 * x], a);
+            atomicAdd(&sig[2 * x + 1], b);
+        }
+        const int32_t q = l_par[x];
+        if (q != x) uf_union(parent, x, q);
+    }
+}
+
 __global__ void k_uf_flatten(int32_t *parent, int32_t n, int32_t *root) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) root[i] = uf_find(parent, i);
@@ -1021,7 +1099,10 @@ static int analyze_tables(A &alloc, const int32_t *leaf_taxon, const int32_t *ad
     k_uf_init<<<(unsigned)((n_taxa + 255) / 256), 256, 0, s>>>(parent, n_taxa, sig);
     SCS_TRY((scan_exclusive<SCAN_MAX>(f_side_start{adj_depth, d_n_leaves}, side, leaf_cap + 1, 1, leaf_cap, -1,
                                       block_sums, s)));
-    if (leaf_cap > 0)
+    if (leaf_cap > 0 && n_taxa <= ANALYZE_LDS_TAXA)
+        k_analyze_leaves_lds<<<(unsigned)((leaf_cap + ANALYZE_LEAVES_PER_BLOCK - 1) / ANALYZE_LEAVES_PER_BLOCK), 256, 0, s>>>(
+            leaf_taxon, adj_depth, side, d_n_leaves, n_taxa, parent, sig);
+    else if (leaf_cap > 0)
         k_analyze_leaves<<<(unsigned)((leaf_cap + 255) / 256), 256, 0, s>>>(leaf_taxon, adj_depth, side, d_n_leaves,
                                                                             parent, sig);
     k_uf_flatten<<<(unsigned)((n_taxa + 255) / 256), 256, 0, s>>>(parent, n_taxa, comp_root);
@@ -1396,8 +1477,9 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         // ---- the union of the children, what the host needs of it, and its analysis -- one small copy back
         int32_t *d_ct = (int32_t *)(d_small + s_ct);
         int64_t *d_cl = (int64_t *)(d_small + s_cl);
-        k_level_union<<<dim3((unsigned)((M + 255) / 256), (unsigned)n_parts), 256, 0, s>>>(
-            p, K, d_in + 16 + 2 * (size_t)T, u_node_off, u_tree_off, d_ct, d_cl);
+        k_level_union<<<dim3((unsigned)((M + 255) / 256), (unsigned)n_parts), 256, 0, s>>>(p, u_node_off, u_tree_off);
+        k_level_counts<<<(unsigned)(((int64_t)n_parts * K + 255) / 256), 256, 0, s>>>(p, K, d_in + 16 + 2 * (size_t)T,
+                                                                                     d_ct, d_cl);
         k_leaf_total<<<1, 64, 0, s>>>(p.totals, n_parts, d_leaf_total);
         SCS_HIP_CHECK(hipGetLastError());
         auto sc_alloc = [&](size_t bytes, void **out) { return scratch.alloc(bytes, out); };

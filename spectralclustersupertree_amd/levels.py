@@ -29,6 +29,7 @@ bit for bit, whatever the provisional labels were.
 from __future__ import annotations
 
 import os
+import time
 
 import numpy as np
 
@@ -42,12 +43,14 @@ MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 
 # diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
 stats = {"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
-         "exact_group_nodes": 0}
+         "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
+         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0}
 
 
 def reset_stats() -> None:
     stats.update({"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
-                  "fallbacks": 0, "exact_group_nodes": 0})
+                  "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
+                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0})
 
 
 def max_taxa() -> int:
@@ -90,7 +93,11 @@ def construct(sub, pcg_weighting, contract_edges, random_state, team=None, ahead
         # not enough device memory for the levels of this subtree beside what else is resident: node by node
         engine.levels.clear()
         return scs._construct_node(sub, pcg_weighting, contract_edges, random_state, None, team, None, ahead)
-    return engine.build(0, 0, random_state)
+    t0 = time.perf_counter()
+    try:
+        return engine.build(0, 0, random_state)
+    finally:
+        stats["t_build"] += time.perf_counter() - t0  # (nested engines of redone subtrees count twice)
 
 
 class Level:
@@ -149,7 +156,9 @@ class Engine:
     # ------------------------------------------------------------------ all levels
     def run(self) -> None:
         stats["roots"] += 1
+        t0 = time.perf_counter()
         lev = self._first_level()
+        stats["t_first"] += time.perf_counter() - t0
         while lev is not None:
             self.levels.append(lev)
             stats["levels"] += 1
@@ -162,6 +171,8 @@ class Engine:
     def _process(self, lev: Level):
         """Classify the nodes of ``lev``, embed its spectral nodes, label them provisionally, split the
         level's forest into the next level (None when no node has a part left to split)."""
+        t_begin = time.perf_counter()
+        t_dev = 0.0
         K, T = lev.K, lev.T
         u_lo, u_sz = lev.u_lo, lev.u_sz
         nid = np.repeat(np.arange(K, dtype=np.int32), u_sz)
@@ -208,16 +219,25 @@ class Engine:
 
         # ---- embeddings: the small nodes of the level in batches, the larger ones one by one
         small = np.flatnonzero(spectral & (n_pres <= self.small_max))
+        t1 = time.perf_counter()
         if len(small):
             self._solve_small(lev, small, m, relabel, nid, gs_patch)
+        t2 = time.perf_counter()
         for k in np.flatnonzero(spectral & (n_pres > self.small_max)):
             self._solve_large(lev, int(k), relabel, gs_patch)
+            stats["n_large"] += 1
+        t3 = time.perf_counter()
         # ---- provisional labels
         from spectralclustersupertree_amd import kmeans2
 
         for k in np.flatnonzero(kind == SPECTRAL):  # (a node whose batched solve failed has left this kind)
             v0, v1 = int(v_ptr[k]), int(v_ptr[k + 1])
             lev.prov[v0:v1] = kmeans2.labels(lev.maps[v0:v1], self.prov_rs)
+        t4 = time.perf_counter()
+        stats["t_small"] += t2 - t1
+        stats["t_large"] += t3 - t2
+        stats["t_labels"] += t4 - t3
+        t_dev = t4 - t1
 
         # ---- parts of every node, sorted by (node, part, taxon)
         tpart = np.full(T, -1, dtype=np.int64)
@@ -235,6 +255,7 @@ class Engine:
             lev.sorted_taxa = np.zeros(0, dtype=np.int32)
             lev.seg_start = lev.seg_len = lev.seg_child = np.zeros(0, dtype=np.int64)
             lev.node_seg = np.zeros(K + 1, dtype=np.int64)
+            stats["t_host"] += time.perf_counter() - t_begin - t_dev
             return None
         pmax = int(tpart.max()) + 1
         key = nid[valid].astype(np.int64) * pmax + tpart[valid]
@@ -258,6 +279,7 @@ class Engine:
         lev.seg_child = np.full(len(seg_start), -1, dtype=np.int64)
         child_seg = np.flatnonzero(splitting)
         if len(child_seg) == 0:
+            stats["t_host"] += time.perf_counter() - t_begin - t_dev
             return None
         # ---- the next level: children ordered (slot, node) -- the tree order of the union forest
         child_seg = child_seg[np.argsort(slot[child_seg] * K + seg_node[child_seg], kind="stable")]
@@ -272,8 +294,12 @@ class Engine:
         part_of[taxa_new] = np.repeat(slot[child_seg], lens).astype(np.int32)
         new_id[taxa_new] = np.arange(total, dtype=np.int32)
         n_parts = int(slot[child_seg].max()) + 1
+        t5 = time.perf_counter()
         union, child_trees, child_leaves, present, comp_root, sig = lev.forest.split_level(
             part_of, new_id, n_parts, total, _STRATEGY_CODE[self.strategy], lev.t_hi)
+        t6 = time.perf_counter()
+        stats["t_split"] += t6 - t5
+        t_dev += t6 - t5
         nxt = Level()
         nxt.forest = union
         nxt.monotone = bool(union.monotone_flag)
@@ -288,6 +314,7 @@ class Engine:
         nxt.u_sz = lens.astype(np.int32)
         nxt.gid = lev.gid[taxa_new]
         nxt.present, nxt.comp_root, nxt.sig = present, comp_root, sig
+        stats["t_host"] += time.perf_counter() - t_begin - t_dev
         return nxt
 
     # ------------------------------------------------------------------ pieces of a level

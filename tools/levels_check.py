@@ -53,7 +53,7 @@ def main() -> int:
     bad = 0
     shapes = [(40, 12, None), (120, 30, 80), (300, 40, None), (700, 60, 400), (1500, 40, None), (2500, 100, None)]
     if args.big:
-        shapes = [(5000, 500, None), (20000, 1000, None)]
+        shapes = [(20000, 1000, None), (20000, 5000, None)]
     for case in range(args.cases):
         n, m, leaves = shapes[case % len(shapes)]
         strategy = ("branch", "depth", "one", "bootstrap")[case % 4]
@@ -74,7 +74,9 @@ def main() -> int:
               f"{'same' if same else 'DIFFERENT'}  engine {a[3]:.2f} s, node by node {b[3]:.2f} s; "
               f"{len(a[2])} spectral calls; roots {st['roots']} levels {st['levels']} nodes {st['nodes']} "
               f"mismatches {st['mismatches']} {st['mismatch_sizes'][:8]} fallbacks {st['fallbacks']} "
-              f"exact-group nodes {st['exact_group_nodes']}", flush=True)
+              f"exact-group nodes {st['exact_group_nodes']}\n      first {st['t_first']:.2f} host {st['t_host']:.2f} small {st['t_small']:.2f} "
+              f"large {st['t_large']:.2f} ({st['n_large']}) labels {st['t_labels']:.2f} split {st['t_split']:.2f} "
+              f"build(walk) {st['t_build']:.2f}", flush=True)
         bad += not same
     print("FAILED" if bad else "all cases identical")
     return 1 if bad else 0

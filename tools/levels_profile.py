@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""cProfile of one whole recursion with the level-synchronous engine (tools/levels_check.py's input shapes).
+
+    python tools/levels_profile.py TAXA TREES [STRATEGY] [--no-profile]
+"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+import warnings
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    n, m = int(sys.argv[1]), int(sys.argv[2])
+    strategy = sys.argv[3] if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else "branch"
+    from spectralclustersupertree_amd import levels, scs, synthetic
+
+    sys.setrecursionlimit(1_000_000)
+    warnings.simplefilter("ignore")
+    arrays = synthetic.tree_arrays(3, n, m, random_weights=True)
+    scs.default_device()
+    # warm-up on a small input (library self-tests, contexts)
+    scs._construct(synthetic.tree_arrays(5, 300, 30), strategy, True, np.random.RandomState(0))
+    rs = np.random.RandomState(0)
+    prof = None if "--no-profile" in sys.argv else cProfile.Profile()
+    t0 = time.perf_counter()
+    if prof:
+        prof.enable()
+    tree = scs._construct(arrays, strategy, True, rs)
+    if prof:
+        prof.disable()
+    dt = time.perf_counter() - t0
+    st = dict(levels.stats)
+    st["mismatch_sizes"] = sorted(st["mismatch_sizes"], reverse=True)[:12]
+    print(f"{n} taxa / {m} trees {strategy}: {dt:.2f} s; next draw {rs.randint(1 << 30)}; {st}")
+    if prof:
+        pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
+        pstats.Stats(prof).sort_stats("tottime").print_stats(30)
+
+
+if __name__ == "__main__":
+    main()
