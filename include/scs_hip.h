@@ -232,6 +232,13 @@ int scs_forest_split_level(scs_ctx *ctx, const scs_forest *forest, const int32_t
                            scs_forest_info *info, int32_t *child_trees, int64_t *child_leaves,
                            uint8_t *present, int32_t *comp_root, uint64_t *sig);
 
+/* The trees [t_begin, t_end) of a forest as a forest of its own WITHOUT copying a node (the slice points
+ * into the arrays of `forest` and keeps them alive; taxon ids stay those of `forest`): one node of a level
+ * forest whose subtree is taken up again from its own trees when the true draws did not confirm its
+ * provisional partition (scs.py:139-171: the labels of record are the stream's).  Free with
+ * scs_forest_free. */
+int scs_forest_slice(scs_ctx *ctx, const scs_forest *forest, int32_t t_begin, int32_t t_end, scs_forest **out);
+
 /* comp_root [n_taxa] and sig [n_taxa][2] (as above) of a forest that carries tables: the first forest of a
  * level-synchronous walk (a child of scs_forest_split). */
 int scs_forest_analyze(scs_ctx *ctx, const scs_forest *forest, int32_t *comp_root, uint64_t *sig);

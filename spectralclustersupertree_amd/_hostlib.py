@@ -55,6 +55,9 @@ def load() -> C.CDLL:
         lib.scs_host_kmeans2.restype = C.c_int
         lib.scs_host_kmeans2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_int32, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.scs_host_kmeans2_provisional.restype = C.c_int
+        lib.scs_host_kmeans2_provisional.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p]
         _lib = lib
     return _lib
 

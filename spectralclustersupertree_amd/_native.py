@@ -148,6 +148,7 @@ SIGNATURES = {
     "scs_forest_download": (C.c_int, [_P, _P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP]),
     "scs_forest_split_level": (C.c_int, [_P, _P, _IP, _IP, _I32, _I32, _I32, _I32, _IP, _PP, _P, _IP, _LP, _P, _IP, _P]),
     "scs_forest_analyze": (C.c_int, [_P, _P, _IP, _P]),
+    "scs_forest_slice": (C.c_int, [_P, _P, _I32, _I32, _PP]),
     "scs_forest_tables_download_range": (C.c_int, [_P, _P, _I32, _I32, _LP, _IP, _IP, _DP, _DP]),
     "scs_tables_from_forest_range": (C.c_int, [_P, _P, _I32, _I32, _I32, _I32, _IP, _I32, _PP]),
     "scs_small_solve_begin_level": (C.c_int, [_P, _P, _I32, _IP, _IP, _LP, _IP, _IP, _IP, _IP, _IP, _IP, _I32,

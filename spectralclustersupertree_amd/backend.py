@@ -306,6 +306,15 @@ class DeviceForest:
                              int(info.n_leaves), bool(info.monotone))
         return union, child_trees, child_leaves, present, comp_root, sig
 
+    def slice(self, t_begin: int, t_end: int) -> "DeviceForest":
+        """``scs_forest_slice``: the trees [t_begin, t_end) as a forest of their own, nothing copied (taxon ids stay
+        this forest's)."""
+        handle = C.c_void_p()
+        nv.check(self.dev._lib.scs_forest_slice(self.dev._ctx, self._h, int(t_begin), int(t_end), C.byref(handle)))
+        out = DeviceForest(self.dev, handle, self.n_taxa, int(t_end - t_begin), 0, 0, self.monotone_flag)
+        out._base = self  # (the slice points into this forest's arrays)
+        return out
+
     def analyze(self):
         """``scs_forest_analyze``: ``(comp_root [n_taxa], sig [n_taxa, 2])`` of a forest that carries tables."""
         comp_root = np.zeros(max(self.n_taxa, 1), dtype=np.int32)

@@ -512,12 +512,28 @@ extern "C" int scs_ctx_create_local(int device, int rank, scs_local_group *group
 int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lock(ctx->cache_mu);
     if (bytes < 256) bytes = 256;
-    for (auto &b : ctx->blocks)
-        if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096) {
-            b.in_use = true;
-            *out = b.p;
-            return SCS_OK;
-        }
+    // the smallest free block that is large enough and at most twice the request
+    int pick = -1;
+    for (size_t i = 0; i < ctx->blocks.size(); ++i) {
+        const auto &b = ctx->blocks[i];
+        if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 &&
+            (pick < 0 || b.bytes < ctx->blocks[pick].bytes))
+            pick = (int)i;
+    }
+    if (pick >= 0) {
+        ctx->blocks[pick].in_use = true;
+        *out = ctx->blocks[pick].p;
+        return SCS_OK;
+    }
+    // (round 6) new blocks come in size classes a quarter octave apart: the level-synchronous recursion asks
+    // for a slightly different size with every level, and blocks of exactly the size asked for were seldom
+    // good for the next request -- the cache grew to its limit and every release above it is a hipFree (a
+    // device-wide synchronisation; 0.28 ms per forest freed in the configs[4] recursion)
+    if (bytes <= ((size_t)8 << 30)) {
+        size_t cap = 256;
+        while (cap < bytes) cap += cap / 4 >= 256 ? cap / 4 : 256;
+        bytes = cap;
+    }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {

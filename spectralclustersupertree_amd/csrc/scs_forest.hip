@@ -1729,3 +1729,63 @@ extern "C" int scs_forest_tables_download_range(scs_ctx *ctx, const scs_forest *
     for (size_t t = 0; t <= m; ++t) tree_off[t] -= lo;
     return SCS_OK;
 }
+
+
+__global__ void k_slice_offsets(const int64_t *__restrict__ src, int64_t n, int64_t *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i] - src[0];
+}
+
+// The trees [t_begin, t_end) of a forest as a forest of its own WITHOUT copying a node: the slice points into
+// the arrays of `f` (and keeps them alive), only the offsets are made anew.  Taxon ids stay those of `f`.
+// One node of a level forest whose subtree the recursion takes up again from its own trees (a provisional
+// partition that the true draws did not confirm, levels.py).
+extern "C" int scs_forest_slice(scs_ctx *ctx, const scs_forest *f, int32_t t_begin, int32_t t_end, scs_forest **out) {
+    SCS_REQUIRE(ctx && f && out, "scs_forest_slice: null argument");
+    SCS_REQUIRE(t_begin >= 0 && t_begin < t_end && t_end <= f->n_trees, "scs_forest_slice: bad tree range");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int32_t m = t_end - t_begin;
+    auto c = std::unique_ptr<scs_forest>(new scs_forest());
+    c->region = std::make_shared<forest_region>();
+    c->region->ctx = ctx;
+    c->region->base = f->region;
+    int64_t ends[4] = {0, 0, 0, 0};  // node_off[t_begin], node_off[t_end], tree_off[t_begin], tree_off[t_end]
+    SCS_HIP_CHECK(hipMemcpyAsync(&ends[0], f->node_off + t_begin, 8, hipMemcpyDeviceToHost, s));
+    SCS_HIP_CHECK(hipMemcpyAsync(&ends[1], f->node_off + t_end, 8, hipMemcpyDeviceToHost, s));
+    if (f->has_tables) {
+        SCS_HIP_CHECK(hipMemcpyAsync(&ends[2], f->tree_off + t_begin, 8, hipMemcpyDeviceToHost, s));
+        SCS_HIP_CHECK(hipMemcpyAsync(&ends[3], f->tree_off + t_end, 8, hipMemcpyDeviceToHost, s));
+    }
+    SCS_TRY(c->region->alloc((size_t)(m + 1) * 8, (void **)&c->node_off));
+    k_slice_offsets<<<(unsigned)((m + 1 + 255) / 256), 256, 0, s>>>(f->node_off + t_begin, (int64_t)m + 1, c->node_off);
+    if (f->has_tables) {
+        SCS_TRY(c->region->alloc((size_t)(m + 1) * 8, (void **)&c->tree_off));
+        k_slice_offsets<<<(unsigned)((m + 1 + 255) / 256), 256, 0, s>>>(f->tree_off + t_begin, (int64_t)m + 1, c->tree_off);
+    }
+    SCS_HIP_CHECK(hipGetLastError());
+    SCS_HIP_CHECK(hipStreamSynchronize(s));
+    const int64_t n0 = ends[0], l0 = ends[2];
+    c->n_taxa = f->n_taxa;
+    c->n_trees = m;
+    c->n_nodes = ends[1] - ends[0];
+    c->n_leaves = f->has_tables ? ends[3] - ends[2] : 0;
+    c->parent = f->parent + n0;
+    c->taxon = f->taxon + n0;
+    c->length = f->length + n0;
+    c->support = f->support + n0;
+    c->weights = f->weights + t_begin;
+    c->has_tables = f->has_tables;
+    if (f->has_tables) {
+        c->leaf_taxon = f->leaf_taxon + l0;
+        c->adj_depth = f->adj_depth + l0;
+        c->adj_val = f->adj_val + l0;
+        c->tree_index = f->tree_index ? f->tree_index + t_begin : nullptr;
+        c->present = f->present;
+    } else {
+        // (the leaf count sizes a split's outputs: without tables it is not known here -- count the leaves)
+        c->n_leaves = c->n_nodes;
+    }
+    *out = c.release();
+    return SCS_OK;
+}

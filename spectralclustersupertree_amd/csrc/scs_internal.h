@@ -233,6 +233,7 @@ struct scs_graph {
 // device arrays a split leaves behind for ALL children: one allocation each, children are slices
 struct forest_region {
     scs_ctx *ctx = nullptr;
+    std::shared_ptr<forest_region> base;  // a slice (scs_forest_slice) keeps the arrays it points into alive
     std::vector<void *> blocks;
     void *host_block = nullptr;  // page-locked copy of the children's tables (scs_pinned_get)
     ~forest_region() {

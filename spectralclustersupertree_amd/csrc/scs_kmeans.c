@@ -310,3 +310,61 @@ int scs_host_kmeans2(const scs_km_blas *blas, int32_t n, const double *x, const 
     free(buf);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * PROVISIONAL labels of the K nodes of one level of the recursion (round 6, levels.py): the same ten
+ * seedings and Lloyd runs on each node's embedding, from draws of the engine's private stream.  These
+ * labels only pick the partition the device goes on with; the walk proper assigns every node's labels
+ * again with the caller's RandomState through kmeans2.labels and compares (reference order of draws:
+ * scs.py:139-171) -- so nothing here has to reproduce numpy's rounding: the centring, the tolerance and the
+ * cumulative distribution are computed in plain C.  A node whose seeding empties a cluster is split at the
+ * mean of its Fiedler column.
+ *   vptr[K + 1]   first vertex of node k in maps / labels_out      maps [vptr[K]][2]      draws [K][30]
+ * Returns 0 or -1. */
+int scs_host_kmeans2_provisional(const scs_km_blas *blas, int32_t n_nodes, const int64_t *vptr, const double *maps,
+                                 const double *draws, int32_t *labels_out) {
+    if (!blas || n_nodes < 0 || !vptr || !maps || !draws || !labels_out) return -1;
+    int64_t cap = 0;
+    for (int32_t k = 0; k < n_nodes; ++k)
+        if (vptr[k + 1] - vptr[k] > cap) cap = vptr[k + 1] - vptr[k];
+    if (cap == 0) return 0;
+    double *buf = (double *)malloc(sizeof(double) * 4 * (size_t)cap);
+    if (!buf) return -1;
+    double *x = buf, *x_sq = buf + 2 * cap, *cdf = buf + 3 * cap;
+    int rc = 0;
+    for (int32_t k = 0; k < n_nodes && rc == 0; ++k) {
+        const int64_t v0 = vptr[k];
+        const int32_t n = (int32_t)(vptr[k + 1] - v0);
+        if (n <= 0) continue;
+        int32_t *lab = labels_out + v0;
+        if (n == 1) {
+            lab[0] = 0;
+            continue;
+        }
+        const double *m = maps + 2 * v0;
+        double s0 = 0.0, s1 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            s0 += m[2 * i];
+            s1 += m[2 * i + 1];
+        }
+        const double mean0 = s0 / n, mean1 = s1 / n;
+        double q0 = 0.0, q1 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double a = m[2 * i] - mean0, b = m[2 * i + 1] - mean1;
+            x[2 * i] = a;
+            x[2 * i + 1] = b;
+            x_sq[i] = a * a + b * b;
+            q0 += a * a;
+            q1 += b * b;
+            cdf[i] = (double)(i + 1) / n;
+        }
+        cdf[n - 1] = 1.0;
+        const double tol = (q0 / n + q1 / n) / 2.0 * 1e-4;
+        const int one = scs_host_kmeans2(blas, n, x, x_sq, cdf, draws + 30 * (size_t)k, 10, tol, 300, lab, NULL, NULL);
+        if (one < 0) rc = -1;
+        if (one > 0)
+            for (int i = 0; i < n; ++i) lab[i] = x[2 * i + 1] > 0.0 ? 1 : 0;
+    }
+    free(buf);
+    return rc;
+}

@@ -489,6 +489,31 @@ def fast_path_active() -> bool:
     return _state["ok"]
 
 
+def provisional_labels(maps, vptr, random_state) -> np.ndarray | None:
+    """Labels of K embeddings at once (``maps`` concatenated, node k = rows ``vptr[k] : vptr[k + 1]``) from draws
+    of ``random_state`` -- ``scs_host_kmeans2_provisional``: the partition the level-synchronous recursion goes on
+    with, NOT the labels of record (``levels.Engine.build`` assigns those with ``labels`` and the caller's
+    stream).  None when the C path is not available (the caller then labels node by node)."""
+    whole = _whole() if fast_path_active() else None
+    if whole is None:
+        return None
+    lib, table = whole
+    vptr = np.ascontiguousarray(vptr, dtype=np.int64)
+    k = len(vptr) - 1
+    maps = np.ascontiguousarray(maps, dtype=np.float64)
+    out = np.zeros(int(vptr[-1]), dtype=np.int32)
+    if k == 0 or len(out) == 0:
+        return out
+    if not np.all(np.isfinite(maps)):
+        return None
+    draws = random_state.random_sample(30 * k)
+    rc = lib.scs_host_kmeans2_provisional(table, k, vptr.ctypes.data, maps.ctypes.data, draws.ctypes.data,
+                                          out.ctypes.data)
+    if rc != 0:
+        return None
+    return out
+
+
 def labels(maps, random_state) -> np.ndarray:
     """Cluster labels (0 / 1) of the rows of `maps`, equal to
     ``sklearn.cluster.k_means(maps, 2, random_state=random_state, n_init=10)[1]``; draws from

@@ -106,7 +106,7 @@ class Level:
 
     __slots__ = ("forest", "K", "T", "t_lo", "t_hi", "n_leaves", "u_lo", "u_sz", "gid", "present", "comp_root",
                  "sig", "kind", "n_pres", "v_off", "n_groups", "maps", "prov", "members", "sorted_taxa", "seg_start",
-                 "seg_len", "seg_child", "node_seg", "graft", "monotone")
+                 "seg_len", "seg_child", "node_seg", "graft", "monotone", "shift")
 
 
 class Engine:
@@ -143,6 +143,7 @@ class Engine:
                 raise AssertionError(msg)
             lev.monotone = bool(forest.monotone_flag)
         lev.forest = forest
+        lev.shift = 0
         lev.K, lev.T = 1, k
         lev.t_lo = np.zeros(1, dtype=np.int32)
         lev.t_hi = np.asarray([forest.n_trees], dtype=np.int32)
@@ -230,16 +231,21 @@ class Engine:
         # ---- provisional labels
         from spectralclustersupertree_amd import kmeans2
 
-        for k in np.flatnonzero(kind == SPECTRAL):  # (a node whose batched solve failed has left this kind)
-            v0, v1 = int(v_ptr[k]), int(v_ptr[k + 1])
-            lev.prov[v0:v1] = kmeans2.labels(lev.maps[v0:v1], self.prov_rs)
+        # (a node whose batched solve failed has left the kind: its rows of maps are zero, its labels unused)
+        prov = kmeans2.provisional_labels(lev.maps, v_ptr, self.prov_rs)
+        if prov is not None:
+            lev.prov[:] = prov
+        else:
+            for k in np.flatnonzero(kind == SPECTRAL):
+                v0, v1 = int(v_ptr[k]), int(v_ptr[k + 1])
+                lev.prov[v0:v1] = kmeans2.labels(lev.maps[v0:v1], self.prov_rs)
         t4 = time.perf_counter()
         stats["t_small"] += t2 - t1
         stats["t_large"] += t3 - t2
         stats["t_labels"] += t4 - t3
         t_dev = t4 - t1
 
-        # ---- parts of every node, sorted by (node, part, taxon)
+        # ---- part of every taxon inside its node
         tpart = np.full(T, -1, dtype=np.int64)
         comps = kind == COMPS
         if comps.any():
@@ -250,6 +256,16 @@ class Engine:
         if spectral.any():
             sel = pres & spectral[nid]
             tpart[sel] = lev.prov[v_ptr[nid[sel]] + vertex_of[sel]]
+        stats["t_host"] += time.perf_counter() - t_begin - t_dev
+        return self._split(lev, tpart, nid)
+
+    def _split(self, lev: Level, tpart: np.ndarray, nid: np.ndarray):
+        """The parts of every node (``tpart``: part of a taxon inside its node, -1 none) sorted by (node, part,
+        taxon), and ONE ``scs_forest_split_level`` for all parts of more than two taxa: the next level."""
+        t_begin = time.perf_counter()
+        t_dev = 0.0
+        K, T = lev.K, lev.T
+        kind = lev.kind
         valid = np.flatnonzero(tpart >= 0)
         if len(valid) == 0:
             lev.sorted_taxa = np.zeros(0, dtype=np.int32)
@@ -294,6 +310,14 @@ class Engine:
         part_of[taxa_new] = np.repeat(slot[child_seg], lens).astype(np.int32)
         new_id[taxa_new] = np.arange(total, dtype=np.int32)
         n_parts = int(slot[child_seg].max()) + 1
+        if lev.forest.n_taxa != T:
+            # a slice of a larger level's forest (``redo``): its taxa keep the ids of that level
+            wide = np.full(lev.forest.n_taxa, -1, dtype=np.int32)
+            wide[lev.shift:lev.shift + T] = part_of
+            part_of = wide
+            wide = np.zeros(lev.forest.n_taxa, dtype=np.int32)
+            wide[lev.shift:lev.shift + T] = new_id
+            new_id = wide
         t5 = time.perf_counter()
         union, child_trees, child_leaves, present, comp_root, sig = lev.forest.split_level(
             part_of, new_id, n_parts, total, _STRATEGY_CODE[self.strategy], lev.t_hi)
@@ -302,6 +326,7 @@ class Engine:
         t_dev += t6 - t5
         nxt = Level()
         nxt.forest = union
+        nxt.shift = 0
         nxt.monotone = bool(union.monotone_flag)
         nxt.K, nxt.T = len(child_seg), total
         cs, cn = slot[child_seg], seg_node[child_seg]
@@ -444,6 +469,54 @@ class Engine:
         return scs._construct_children(arrays, parts, self.strategy, self.contract, random_state, None, self.team,
                                        self.ahead)
 
+    def redo(self, lev: Level, k: int, labels: np.ndarray) -> "Engine":
+        """Spectral node ``k`` of ``lev`` once more from ITS OWN trees with the labels of record: a new engine
+        whose first level is that node alone (a slice of the level's forest, nothing copied) with ``labels`` in
+        the place of the provisional ones, and everything below it level by level again."""
+        e = Engine(self.sub, self.strategy, self.contract, self.dev, self.team, self.ahead)
+        e.prov_rs = self.prov_rs
+        lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
+        v0, v1 = int(lev.v_off[k]), int(lev.v_off[k + 1])
+        l0 = Level()
+        l0.forest = lev.forest.slice(int(lev.t_lo[k]), int(lev.t_hi[k]))
+        l0.shift = lo + lev.shift if lev.forest.n_taxa != lev.T else lo
+        l0.monotone = lev.monotone
+        l0.K, l0.T = 1, sz
+        l0.t_lo = np.zeros(1, dtype=np.int32)
+        l0.t_hi = np.asarray([int(lev.t_hi[k] - lev.t_lo[k])], dtype=np.int32)
+        l0.n_leaves = lev.n_leaves[k:k + 1].copy()
+        l0.u_lo = np.zeros(1, dtype=np.int32)
+        l0.u_sz = np.asarray([sz], dtype=np.int32)
+        l0.gid = lev.gid[lo:lo + sz]
+        l0.present = lev.present[lo:lo + sz]
+        l0.comp_root = l0.sig = None
+        l0.kind = np.asarray([SPECTRAL], dtype=np.int8)
+        l0.n_pres = lev.n_pres[k:k + 1].copy()
+        l0.n_groups = lev.n_groups[k:k + 1].copy()
+        l0.v_off = np.asarray([0, v1 - v0], dtype=np.int64)
+        l0.maps = lev.maps[v0:v1]
+        l0.prov = np.asarray(labels, dtype=np.int8)
+        l0.graft = {}
+        mem = lev.members.get(k)
+        l0.members = {} if mem is None else {0: mem}
+        # vertex of every present taxon
+        here = np.flatnonzero(l0.present)
+        vertex_of = np.arange(len(here), dtype=np.int64)
+        if mem is not None:
+            perm, group_start = mem
+            vertex_of[perm] = np.repeat(np.arange(len(group_start) - 1), np.diff(group_start))
+        tpart = np.full(sz, -1, dtype=np.int64)
+        tpart[here] = l0.prov[vertex_of]
+        stats["levels"] += 1
+        e.levels.append(l0)
+        nxt = e._split(l0, tpart, np.zeros(sz, dtype=np.int32))
+        while nxt is not None:
+            e.levels.append(nxt)
+            stats["levels"] += 1
+            stats["nodes"] += nxt.K
+            nxt = e._process(nxt)
+        return e
+
     def build(self, li: int, k: int, random_state) -> TreeNode:
         """The subtree of node ``k`` of level ``li`` in the reference's order of visits and draws
         (reference: scs.py:96-174)."""
@@ -477,14 +550,32 @@ class Engine:
                 if len(segs) == 1:  # (all vertices in one cluster: nothing to swap)
                     segs = list(range(s0, s1))
             else:
-                # the draws decided a tie differently: this node's children from its own forest, node by node
+                # the draws decided a tie differently: the subtree below this node once more, from the node's own
+                # trees with the labels of record
                 stats["mismatches"] += 1
                 stats["mismatch_sizes"].append(int(v1 - v0))
-                present_local = np.flatnonzero(lev.present[lo:lo + sz])
-                parts: list[list[int]] = [[], []]
-                for g, lab in enumerate(labels):
-                    parts[int(lab)].extend(int(present_local[int(i)]) for i in self._members(lev, k, g))
-                return self._sequential(lev, k, random_state, parts)
+                t0 = time.perf_counter()
+                try:
+                    again = self.redo(lev, k, labels)
+                except nv.ScsError as exc:
+                    if exc.code != nv.ENOMEM:
+                        raise
+                    again = None
+                stats["t_redo"] += time.perf_counter() - t0
+                if again is None:  # (no room on the device: node by node, from host arrays)
+                    present_local = np.flatnonzero(lev.present[lo:lo + sz])
+                    parts: list[list[int]] = [[], []]
+                    for g, lab in enumerate(labels):
+                        parts[int(lab)].extend(int(present_local[int(i)]) for i in self._members(lev, k, g))
+                    return self._sequential(lev, k, random_state, parts)
+                first = again.levels[0]
+                return again._children(0, list(range(int(first.node_seg[0]), int(first.node_seg[1]))), random_state)
+        return self._children(li, segs, random_state)
+
+    def _children(self, li: int, segs, random_state) -> TreeNode:
+        """The subtrees of a node's parts (segments ``segs`` of level ``li``, in the order of the visit) joined
+        under a new root (reference: scs.py:139-174)."""
+        lev = self.levels[li]
         nxt = self.levels[li + 1] if li + 1 < len(self.levels) else None
         for s in segs:  # reference: scs.py:63-65 reached from :158 -- before any child is entered
             c = int(lev.seg_child[s])

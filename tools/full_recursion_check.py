@@ -90,7 +90,14 @@ def run(n: int, m: int, weights: bool, strategy: str = "branch", seed: int = 0, 
         if len(seen) != len(set(seen)):
             partitions_ok = False
     newick = tree.get_newick()
-    sizes = np.asarray(calls["sizes"])
+    sizes = np.asarray([len(e["labels"]) for e in trace] if trace else calls["sizes"])
+    from spectralclustersupertree_amd import levels
+
+    engine = dict(levels.stats)
+    engine["mismatch_sizes"] = sorted(engine["mismatch_sizes"], reverse=True)[:20]
+    for key in list(engine):
+        if isinstance(engine[key], float):
+            engine[key] = round(engine[key], 3)
     return {
         "n_taxa": n, "n_trees": m, "per_tree_weights": weights, "pcg_weighting": strategy, "seed": seed,
         "generate_s": round(t_gen, 2),
@@ -98,9 +105,12 @@ def run(n: int, m: int, weights: bool, strategy: str = "branch", seed: int = 0, 
         "top_level_s": round(calls["first_s"], 3),
         "top_level_what": "spectral_bipartition_device at the root: contraction groups, tables upload, "
                           "scs_pcg_build, scs_fiedler, k_means",
-        "spectral_calls": int(calls["n"]),
+        "spectral_calls": int(len(trace)),
+        "spectral_calls_on_the_node_by_node_path": int(calls["n"]),
+        "level_engine": engine,
+        "level_engine_max_taxa": levels.max_taxa(),
         "in_spectral_calls_s": round(calls["t"], 2),
-        "largest_problems": sorted(calls["sizes"], reverse=True)[:6],
+        "largest_problems": sorted(sizes.tolist(), reverse=True)[:6],
         "calls_by_size": {"<=64": int(np.sum(sizes <= 64)), "65-512": int(np.sum((sizes > 64) & (sizes <= 512))),
                           "513-4096": int(np.sum((sizes > 512) & (sizes <= 4096))), ">4096": int(np.sum(sizes > 4096))},
         "calls_by_size_fine": {f"{lo}-{hi}": int(np.sum((sizes >= lo) & (sizes <= hi)))
