@@ -51,12 +51,17 @@ class Ahead:
     """``make_device()`` is called once, on the worker thread, for the worker's own context;
     a job is a callable taking the device it runs on."""
 
-    def __init__(self, make_device) -> None:
+    def __init__(self, make_device, workers: int = 1) -> None:
         self._make_device = make_device
         self._lock = threading.Lock()
         self._cv = threading.Condition(self._lock)
         self._queue: collections.deque[Job] = collections.deque()
-        self._thread: threading.Thread | None = None
+        # (round 6) several workers, each with a context of its own: the level-synchronous recursion hands over
+        # ALL larger nodes of a level at once -- latency-bound solves of a few hundred to a few thousand
+        # vertices that run side by side on the chip.  A thread is started when a job finds none idle.
+        self._max_workers = max(1, int(workers))
+        self._threads: list[threading.Thread] = []
+        self._idle = 0
         self._closed = False
         self.stats = {"submitted": 0, "by_worker": 0, "by_walk": 0}
 
@@ -70,9 +75,10 @@ class Ahead:
                 raise RuntimeError(msg)
             self._queue.append(job)
             self.stats["submitted"] += 1
-            if self._thread is None:
-                self._thread = threading.Thread(target=self._worker, name="scs-ahead", daemon=True)
-                self._thread.start()
+            if self._idle < len(self._queue) and len(self._threads) < self._max_workers:
+                thread = threading.Thread(target=self._worker, name=f"scs-ahead-{len(self._threads)}", daemon=True)
+                self._threads.append(thread)
+                thread.start()
             self._cv.notify()
         return job
 
@@ -104,9 +110,9 @@ class Ahead:
             self._closed = True
             self._queue.clear()
             self._cv.notify_all()
-        if self._thread is not None:
-            self._thread.join()
-            self._thread = None
+        for thread in self._threads:
+            thread.join()
+        self._threads = []
 
     def __enter__(self):
         return self
@@ -121,8 +127,10 @@ class Ahead:
         try:
             while True:
                 with self._cv:
+                    self._idle += 1
                     while not self._queue and not self._closed:
                         self._cv.wait()
+                    self._idle -= 1
                     if self._closed:
                         return
                     job = self._queue.popleft()

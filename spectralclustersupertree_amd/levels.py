@@ -221,12 +221,23 @@ class Engine:
         # ---- embeddings: the small nodes of the level in batches, the larger ones one by one
         small = np.flatnonzero(spectral & (n_pres <= self.small_max))
         t1 = time.perf_counter()
+        large = np.flatnonzero(spectral & (n_pres > self.small_max))
+        jobs = []
+        if self.ahead is not None and len(large) > 1:
+            # the larger nodes of the level side by side on the look-ahead workers' contexts (largest first),
+            # while this thread batches the small ones -- and then takes whatever nobody has started
+            for k in sorted((int(k) for k in large), key=lambda k: -int(n_pres[k])):
+                jobs.append((k, self.ahead.submit(self._large_job(lev, k, relabel, gs_patch))))
         if len(small):
             self._solve_small(lev, small, m, relabel, nid, gs_patch)
         t2 = time.perf_counter()
-        for k in np.flatnonzero(spectral & (n_pres > self.small_max)):
-            self._solve_large(lev, int(k), relabel, gs_patch)
-            stats["n_large"] += 1
+        if jobs:
+            for k, job in jobs:
+                lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = self.ahead.result(job, self.dev)
+        else:
+            for k in large:
+                lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = self._large_job(lev, int(k), relabel, gs_patch)(self.dev)
+        stats["n_large"] += len(large)
         t3 = time.perf_counter()
         # ---- provisional labels
         from spectralclustersupertree_amd import kmeans2
@@ -431,25 +442,31 @@ class Engine:
             for k in nodes[~ok]:
                 lev.kind[k] = FALLBACK  # the one-sided Jacobi ran out of sweeps: this node goes node by node
 
-    def _solve_large(self, lev, k, relabel, gs_patch) -> None:
-        """A node above the batched path's size: build, contract, LOBPCG on its slice of the level's tables."""
+    def _large_job(self, lev, k, relabel, gs_patch):
+        """A node above the batched path's size: build, contract, LOBPCG on its slice of the level's tables --
+        as a job for any context on this GPU (``ahead.Ahead``); returns the embedding."""
         from spectralclustersupertree_amd import scs
 
         lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
-        dtab = self.dev.upload_range(lev.forest, int(lev.t_lo[k]), int(lev.t_hi[k]), lo, sz, relabel[lo:lo + sz],
-                                     int(lev.n_pres[k]), self._monotone(lev))
-        try:
-            graph = dtab.build()
-        finally:
-            dtab.free()
-        try:
-            gs = gs_patch.get(k)
-            if gs is not None:
-                graph = graph.contract(gs)
-            maps, _ = scs._fiedler_checked(graph, None, scs.DEFAULT_TOL, scs.DEFAULT_MAX_ITER, 0)
-        finally:
-            graph.free()
-        lev.maps[int(lev.v_off[k]):int(lev.v_off[k + 1])] = maps
+        forest, t_lo, t_hi = lev.forest, int(lev.t_lo[k]), int(lev.t_hi[k])
+        rl = relabel[lo:lo + sz].copy()
+        n, mono, gs = int(lev.n_pres[k]), self._monotone(lev), gs_patch.get(k)
+
+        def job(dev):
+            dtab = dev.upload_range(forest, t_lo, t_hi, lo, sz, rl, n, mono)
+            try:
+                graph = dtab.build()
+            finally:
+                dtab.free()
+            try:
+                if gs is not None:
+                    graph = graph.contract(gs)
+                maps, _ = scs._fiedler_checked(graph, None, scs.DEFAULT_TOL, scs.DEFAULT_MAX_ITER, 0)
+            finally:
+                graph.free()
+            return maps
+
+        return job
 
     # ------------------------------------------------------------------ the walk proper
     def _names(self, lev: Level, uids) -> list[str]:

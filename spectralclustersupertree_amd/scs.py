@@ -612,7 +612,7 @@ def _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipart
             def second_context():
                 return Device((team.solo if team is not None else default_device()).index)
 
-            with Ahead(second_context) as queue:
+            with Ahead(second_context, workers=int(os.environ.get("SCS_AHEAD_WORKERS", "3") or 1)) as queue:
                 global _last_ahead_stats
                 try:
                     return _construct_node(arrays, pcg_weighting, contract_edges, random_state, None, team, pre,

@@ -54,7 +54,7 @@ def test_the_worker_has_a_device_of_its_own_and_a_needed_job_runs_on_the_callers
         # a queued job: the asker runs it itself, at once, on its own device
         assert q.result(later[3], mine) == (3, mine.owner)
         gate.set()
-        assert q.result(first, mine) == ("first", "scs-ahead")
+        assert q.result(first, mine) == ("first", "scs-ahead-0")
         assert [q.result(j, mine)[0] for j in later] == list(range(5))
         assert q.stats["by_walk"] >= 1
     assert FakeDevice.made == made + 2  # mine + the worker's, made on the worker thread
@@ -96,3 +96,28 @@ def test_a_worker_that_cannot_make_its_device_fails_the_job_not_the_process():
         _until(lambda: job.state != 0)
         with pytest.raises(OSError, match="no GPU"):
             q.result(job, None)
+
+
+def test_several_workers_take_jobs_side_by_side_each_on_a_device_of_its_own():
+    """Round 6: the level-synchronous recursion hands over all larger nodes of a level at once."""
+    gate = threading.Event()
+    running = []
+    lock = threading.Lock()
+
+    def work(dev, tag):
+        with lock:
+            running.append(dev.owner)
+        gate.wait(5)
+        return tag, dev.owner
+
+    mine = FakeDevice()
+    made = FakeDevice.made
+    with Ahead(FakeDevice, workers=3) as q:
+        jobs = [q.submit(lambda dev, i=i: work(dev, i)) for i in range(6)]
+        _until(lambda: len(running) == 3)  # three jobs under way at once, none waiting for another
+        assert len(set(running)) == 3
+        gate.set()
+        got = [q.result(j, mine) for j in jobs]
+        assert [g[0] for g in got] == list(range(6))
+        assert q.stats["by_worker"] + q.stats["by_walk"] == 6
+    assert FakeDevice.made == made + 3
