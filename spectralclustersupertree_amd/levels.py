@@ -243,7 +243,7 @@ class Engine:
         from spectralclustersupertree_amd import kmeans2
 
         # (a node whose batched solve failed has left the kind: its rows of maps are zero, its labels unused)
-        prov = kmeans2.provisional_labels(lev.maps, v_ptr, self.prov_rs)
+        prov = self._provisional(lev, v_ptr)
         if prov is not None:
             lev.prov[:] = prov
         else:
@@ -352,6 +352,43 @@ class Engine:
         nxt.present, nxt.comp_root, nxt.sig = present, comp_root, sig
         stats["t_host"] += time.perf_counter() - t_begin - t_dev
         return nxt
+
+    def _provisional(self, lev: Level, v_ptr: np.ndarray):
+        """Provisional labels of all spectral nodes of the level: the partition MOST OFTEN found among
+        ``SCS_SPEC_VOTES`` label assignments from different draws.  Which partition the labels of record will be is
+        a draw from the same distribution (ten k-means++ starts, the best kept); where that distribution has a
+        dominant partition, betting on the one seen most often is right more often than betting on one sample.
+        Measured (20 000 taxa / 5 000 trees): 178 / 151 / 145 / 143 unconfirmed partitions with 1 / 3 / 5 / 9 votes --
+        the nodes that matter are close to a coin flip -- for 0.15 / 0.42 / 0.65 / 1.18 s of label assignments: the
+        default is ONE."""
+        from spectralclustersupertree_amd import kmeans2
+
+        votes = max(1, int(os.environ.get("SCS_SPEC_VOTES", "1") or 1))
+        runs = []
+        for _ in range(votes):
+            lab = kmeans2.provisional_labels(lev.maps, v_ptr, self.prov_rs)
+            if lab is None:
+                return None
+            runs.append(lab)
+        if votes == 1 or len(runs[0]) == 0:
+            return runs[0]
+        nodes = np.flatnonzero(np.diff(v_ptr) > 0)
+        starts = v_ptr[nodes].astype(np.int64)
+        seg = np.repeat(np.arange(len(nodes)), np.diff(v_ptr)[nodes])
+        # the partition, whatever the numbering: every label relative to the node's first vertex
+        canon = [lab ^ lab[starts][seg] for lab in runs]
+        agree = np.zeros((votes, len(nodes)), dtype=np.int32)
+        for i in range(votes):
+            for j in range(i + 1, votes):
+                same = np.add.reduceat((canon[i] != canon[j]).astype(np.int32), starts) == 0
+                agree[i] += same
+                agree[j] += same
+        best = np.argmax(agree, axis=0)  # (the first of equals: run 0 when all differ)
+        out = runs[0].copy()
+        for i in range(1, votes):
+            pick = (best == i)[seg]
+            out[pick] = runs[i][pick]
+        return out
 
     # ------------------------------------------------------------------ pieces of a level
     def _node_arrays(self, lev: Level, k: int) -> TreeArrays:
