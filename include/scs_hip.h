@@ -136,6 +136,10 @@ int scs_ctx_create_local(int device, int rank, scs_local_group *group, scs_ctx *
 
 int scs_ctx_destroy(scs_ctx *ctx);
 int scs_ctx_synchronize(scs_ctx *ctx);
+/* Give back the device memory the context only keeps for a next call of the same size (the cached W buffer
+ * and its single-precision image, free cached blocks above keep_bytes, free page-locked blocks).  No
+ * reference counterpart; the recursion calls it behind its largest nodes. */
+int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes);
 /* The communicator as it sees itself: kind (0 none, 1 RCCL, 2 in-process team), the world / rank
  * it was created with, and what ncclCommCount / ncclCommUserRank report (-1: not available).
  * No reference counterpart (the reference has no parallelism, scs.py:239 n_jobs = 1). */
@@ -456,6 +460,14 @@ int scs_small_solve_end(scs_ctx *ctx, int32_t ticket, double *maps_out, double *
                         double *w_out);
 
 /* ---- diagnostics used by the parity tests ------------------------------ */
+
+/* The stop / renew / confirm rules of scs_fiedler's loop (csrc/scs_policy.h; what stands in for ARPACK's
+ * tol = 0 behind scs.py:252) on a scripted sequence of residuals, no device involved: actions_out[i] = 0 go
+ * on, 1 stop for the confirmation (the next residual of the script is the one measured through W), 2 renew
+ * S X / S P through W, 3 / 4 the loop ended converged / not converged, -1 behind the end.  image != 0: the
+ * loop starts on the single-precision image of W. */
+int scs_debug_loop_policy(double tol, int32_t lowp_mode, double lowp_tol, double lowp_tol2, int32_t image,
+                          int32_t n, const double *residuals, int32_t *actions_out);
 
 /* Eigen-decomposition of a dense symmetric n x n matrix (n <= 64) by the
  * device Jacobi kernel that serves the Rayleigh-Ritz step: eigenvalues

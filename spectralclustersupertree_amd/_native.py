@@ -138,6 +138,7 @@ SIGNATURES = {
     "scs_ctx_create_local": (C.c_int, [C.c_int, C.c_int, _P, _PP]),
     "scs_ctx_destroy": (C.c_int, [_P]),
     "scs_ctx_synchronize": (C.c_int, [_P]),
+    "scs_ctx_trim": (C.c_int, [_P, C.c_int64]),
     "scs_ctx_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "scs_forest_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP, C.c_int64, _PP]),
     "scs_forest_free": (C.c_int, [_P, _P]),
@@ -171,6 +172,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_int32)]),
     "scs_small_solve_begin_forest": (C.c_int, [_P, _P, _IP, _I32, _I32, _IP, _I32, _P]),
     "scs_small_solve_end": (C.c_int, [_P, _I32, _DP, _DP, _DP]),
+    "scs_debug_loop_policy": (C.c_int, [C.c_double, _I32, C.c_double, C.c_double, _I32, _I32, _DP, _IP]),
     "scs_debug_jacobi": (C.c_int, [_P, _DP, _I32, _DP, _DP]),
     "scs_debug_gram": (C.c_int, [_P, _DP, _DP, _I32, _I32, _I32, _I32, _DP]),
     "scs_debug_apply": (C.c_int, [_P, _P, _DP, _I32, _DP]),

@@ -73,6 +73,11 @@ class Device:
     def synchronize(self) -> None:
         nv.check(self._lib.scs_ctx_synchronize(self._ctx))
 
+    def trim(self, keep_bytes: int = 0) -> None:
+        """``scs_ctx_trim``: give back the cached W buffer, its image and the free cached blocks above
+        ``keep_bytes`` (the recursion calls it behind its largest nodes)."""
+        nv.check(self._lib.scs_ctx_trim(self._ctx, int(keep_bytes)))
+
     def comm_info(self) -> dict:
         """The communicator as it sees itself (``scs_ctx_comm_info``): kind, the world / rank it was
         created with and what ncclCommCount / ncclCommUserRank report (-1: not available)."""

@@ -477,7 +477,15 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
     size_t bytes = rows * (size_t)g->ld * sizeof(double);
     if (bytes < 16) bytes = 16;
     // the cached buffer fits when it is large enough and at most twice the need (+1 MiB)
-    if (ctx->w_cache && ctx->w_cache_bytes >= bytes && ctx->w_cache_bytes <= 2 * bytes + (1u << 20)) {
+    if (bytes <= SCS_W_BLOCK_MAX) {
+        const int rc = scs_block_alloc(ctx, bytes, (void **)&g->d_w);
+        if (rc != SCS_OK) {
+            delete g;
+            return rc;
+        }
+        g->w_bytes = bytes;
+        g->w_block = true;
+    } else if (ctx->w_cache && ctx->w_cache_bytes >= bytes && ctx->w_cache_bytes <= 2 * bytes + (1u << 20)) {
         g->d_w = ctx->w_cache;
         g->w_bytes = ctx->w_cache_bytes;
         ctx->w_cache = nullptr;
@@ -508,7 +516,8 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
         hipError_t e = hipMemset2DAsync(g->d_w + (n - col0), (size_t)g->ld * 8, 0,
                                         (size_t)(g->ld - (n - col0)) * 8, rows, stream);
         if (e != hipSuccess) {
-            hipFree(g->d_w);
+            if (g->w_block) scs_block_release(ctx, g->d_w);
+            else hipFree(g->d_w);
             delete g;
             scs_set_error("cannot clear the padding of W: %s", hipGetErrorString(e));
             return SCS_EHIP;
@@ -525,7 +534,11 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
         if (ctx) hipStreamSynchronize(ctx->stream);
         scs_matfree_release(g);
     }
-    if (ctx && g->d_w) {
+    if (ctx && g->d_w && g->w_block) {
+        // (stream order protects the block: whoever takes it next enqueues behind this graph's kernels -- or,
+        // on another stream of the context, behind a synchronisation of its own, as every cached block)
+        scs_block_release(ctx, g->d_w);
+    } else if (ctx && g->d_w) {
         // keep the larger of the two buffers for the next graph; the kernels that used this
         // one are ordered before any later use by the context's stream
         if (!ctx->w_cache || g->w_bytes >= ctx->w_cache_bytes) {

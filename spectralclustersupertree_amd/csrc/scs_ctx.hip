@@ -672,6 +672,51 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     return SCS_OK;
 }
 
+// Give back what the context only keeps for a next call of the same size: the cached W buffer and its
+// single-precision image, every free cached block above `keep_bytes` in all (largest first), the free
+// page-locked blocks.  The recursion calls it behind its largest nodes: the root's 80 GB buffer serves no
+// later node (sizes only shrink), and memory held back here is memory the level forests, the look-ahead
+// workers' contexts and the runtime's own scratch cannot have.
+extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
+    SCS_REQUIRE(ctx != nullptr, "scs_ctx_trim: null context");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lock(ctx->cache_mu);
+    if (ctx->w_cache) {
+        hipFree(ctx->w_cache);
+        ctx->w_cache = nullptr;
+        ctx->w_cache_bytes = 0;
+    }
+    if (ctx->w32_cache) {
+        hipFree(ctx->w32_cache);
+        ctx->w32_cache = nullptr;
+        ctx->w32_cache_bytes = 0;
+    }
+    size_t free_bytes = 0;
+    for (auto &b : ctx->blocks)
+        if (!b.in_use) free_bytes += b.bytes;
+    const size_t keep = keep_bytes > 0 ? (size_t)keep_bytes : 0;
+    while (free_bytes > keep) {
+        size_t pick = ctx->blocks.size();
+        for (size_t i = 0; i < ctx->blocks.size(); ++i)
+            if (!ctx->blocks[i].in_use && (pick == ctx->blocks.size() || ctx->blocks[i].bytes > ctx->blocks[pick].bytes))
+                pick = i;
+        if (pick == ctx->blocks.size()) break;
+        free_bytes -= ctx->blocks[pick].bytes;
+        hipFree(ctx->blocks[pick].p);
+        ctx->blocks.erase(ctx->blocks.begin() + pick);
+    }
+    for (size_t i = 0; i < ctx->pinned.size();) {
+        if (!ctx->pinned[i].in_use && keep == 0) {
+            hipHostFree(ctx->pinned[i].p);
+            ctx->pinned.erase(ctx->pinned.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+    return SCS_OK;
+}
+
 extern "C" int scs_ctx_synchronize(scs_ctx *ctx) {
     SCS_REQUIRE(ctx != nullptr, "scs_ctx_synchronize: null context");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));

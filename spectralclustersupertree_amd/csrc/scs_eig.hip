@@ -16,6 +16,7 @@
 #include <cmath>
 
 #include "scs_internal.h"
+#include "scs_policy.h"
 #include "scs_symm.h"
 #include "scs_matfree.h"
 #include "scs_symm_tri.h"
@@ -2559,7 +2560,12 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
 
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));  // (begun at the top: the degrees are needed from here on)
     sv.use32 = want32 && sv.tri && sv.tri_ct == 2 && g->have_w32;
-    int lowp_state = sv.use32 ? 1 : 0;  // image in use: 1 + the renewals of S X / S P made so far; 0: off
+    scs_loop_policy policy;  // the stop / renew / confirm rules (scs_policy.h)
+    policy.tol = tol;
+    policy.lowp_mode = lowp_mode;
+    policy.lowp_tol = lowp_tol;
+    policy.lowp_tol2 = lowp_tol2;
+    policy.lowp_state = sv.use32 ? 1 : 0;  // image in use: 1 + the renewals of S X / S P made so far; 0: off
     const bool constrained = g->n_isolated == 0;
     const int want = constrained ? 1 : 2;
 
@@ -2616,9 +2622,6 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     SCS_TRY(res_part.alloc((size_t)res_blocks * b * 8));
     std::vector<double> h_rn(b), h_th(b + 1);
     int iter = 0;
-    double best_res = 1e300;
-    int since_best = 0;
-    int refreshes = 0;
     bool converged = false;
     double final_res[2] = {0.0, 0.0};
 
@@ -2729,46 +2732,28 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             scs_set_error("scs_fiedler: NaN residual at iteration %d", iter);
             return SCS_EHIP;
         }
-        bool stop = worst <= tol;
-        if (worst < 0.5 * best_res) {
-            best_res = worst;
-            since_best = 0;
-        } else if (++since_best >= 12 && worst < 1e-9) {
-            stop = true;  // stagnated at the floating-point floor
-        } else if (best_res < 1e-6 && worst > 100.0 * best_res) {
-            // moving away from where it had been: the confirmation renews S X through W and restarts the
-            // search directions (no loop this solver runs should come here; a guard, not a path)
-            stop = true;
-        }
-        if (!stop && lowp_state >= 2 && since_best >= 8) {
-            // the image's rounding has become the floor (a loop that, S X and S P renewed, has not halved its
-            // residual in eight iterations): on through the confirmation below -- X renewed through W, search
-            // directions restarted, the rest of the solve in double precision.  (Only after the first
-            // renewal: LOBPCG has plateaus of its own -- ten iterations at 4e-5 on the `bootstrap` workload --
-            // and up there the image's rounding is five orders of magnitude below the residual.)
-            stop = true;
-        }
-        if (!stop && ((lowp_state == 1 && (worst <= lowp_tol || (since_best >= 8 && worst < 1e-6))) ||
-                      (lowp_state == 2 && (worst <= lowp_tol2 || (since_best >= 4 && worst < lowp_tol))))) {
+        const int action = policy.step(worst);
+        const bool stop = action == scs_loop_policy::STOP;
+        if (action == scs_loop_policy::RENEW) {
             // S X and S P anew through W itself, behind the iteration already enqueued (its Gram matrix,
             // formed with the old products, steers one more Rayleigh-Ritz step: coefficients only).
             // What the image adds to S X afterwards is its rounding (~1e-10 ||S||) times the steps still
             // to be taken, which are of the size of the residual over the spectral gap: one renewal clears
             // what the long early steps left (measured: without it 15 more iterations); a second one is
             // made when the residual stops halving (four iterations) or passes SCS_LOWP_TOL2 (default: off).
+            // After the FIRST renewal a loop that has not halved its residual in eight iterations stops for the
+            // confirmation (the image's rounding has become the floor); before it LOBPCG has plateaus of its own
+            // -- ten iterations at 4e-5 on the `bootstrap` workload -- five orders above the image's rounding.
             sv.use32 = false;
             SCS_TRY(sv.apply(Q, 0, AQ, 0));
             SCS_TRY(sv.apply(Q, b, AQ, b));
-            lowp_state = lowp_mode >= 2 ? lowp_state + 1 : 0;
-            sv.use32 = lowp_mode >= 2;
+            sv.use32 = policy.image_in_use();
             ++st->lowp_renewals;
         }
         if (stop) {
             sv.use32 = false;  // the confirmation, and whatever follows it, through W
-            lowp_state = 0;
             // confirm against a freshly applied operator (AX drifts by linear updates)
-            if (refreshes < 3) {
-                ++refreshes;
+            if (policy.begin_confirmation()) {
                 SCS_TRY(sv.apply(Q, 0, AQ, 0));
                 SCS_TRY(sv.gram(X, q3, b, AX, q3, b, G, sv.use_mfma));
                 k_fill_int<<<1, 64, 0, s>>>(MASK, 48, 1);
@@ -2786,12 +2771,11 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
                 double w2 = 0.0;
                 for (int j = 0; j < want; ++j) w2 = std::max(w2, std::sqrt(h_rn[j]));
                 for (int j = 0; j < want; ++j) final_res[constrained ? 1 : j] = std::sqrt(h_rn[j]);
-                if (w2 <= tol || (since_best >= 12 && w2 < 1e-9) || refreshes >= 3) {
-                    converged = w2 <= tol;
+                bool conv = false;
+                if (policy.confirm(w2, &conv)) {
+                    converged = conv;
                     break;
                 }
-                best_res = w2;
-                since_best = 0;
                 if (fused) k_unit_coeffs<<<(3 * b * b + 255) / 256, 256, 0, s>>>(T, D, b);
                 rr_solve = 0;
             } else {
@@ -2928,7 +2912,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     if (n >= 4096 && getenv("SCS_TRACE_SOLVES") && atoi(getenv("SCS_TRACE_SOLVES")))
         fprintf(stderr, "[solve] V %d block %d iterations %d applies %d image %d renewals %d refreshes %d solve_ms %.3f "
                         "wall_ms %.3f residual %.3e gap %.3e\n", n, b, iter, sv.n_apply, sv.n_apply32, st->lowp_renewals,
-                refreshes, st->solve_ms,
+                policy.confirmations, st->solve_ms,
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t_entry).count(),
                 std::max(final_res[0], final_res[1]), st->lambda[1] - st->lambda_next);
     if (!converged) {
@@ -3917,5 +3901,45 @@ extern "C" int scs_debug_apply(scs_ctx *ctx, scs_graph *g, const double *x, int3
     SCS_HIP_CHECK(hipMemcpyAsync(y, sv.yloc.d() + (g->upper ? (size_t)g->row_begin * b : 0),
                                  (size_t)sv.rows * b * 8, hipMemcpyDeviceToHost, ctx->stream));
     SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SCS_OK;
+}
+
+
+// The loop's decision rules on a scripted sequence of residuals (no device): actions_out[i] = 0 go on, 1 stop
+// (the NEXT residual of the script is then taken as the confirmation's: the loop ends there or goes on in double
+// precision), 2 renew, 3 = ended converged, 4 = ended not converged; entries behind the end are -1.
+extern "C" int scs_debug_loop_policy(double tol, int32_t lowp_mode, double lowp_tol, double lowp_tol2,
+                                     int32_t image, int32_t n, const double *residuals, int32_t *actions_out) {
+    SCS_REQUIRE(residuals && actions_out && n >= 0, "scs_debug_loop_policy: bad arguments");
+    scs_loop_policy p;
+    p.tol = tol;
+    p.lowp_mode = lowp_mode;
+    p.lowp_tol = lowp_tol;
+    p.lowp_tol2 = lowp_tol2;
+    p.lowp_state = image ? 1 : 0;
+    bool ended = false;
+    for (int32_t i = 0; i < n; ++i) {
+        if (ended) {
+            actions_out[i] = -1;
+            continue;
+        }
+        const int a = p.step(residuals[i]);
+        actions_out[i] = a;
+        if (a == scs_loop_policy::STOP) {
+            if (!p.begin_confirmation()) {
+                actions_out[i] = residuals[i] <= tol ? 3 : 4;
+                ended = true;
+            } else if (i + 1 < n) {
+                bool conv = false;
+                ++i;
+                if (p.confirm(residuals[i], &conv)) {
+                    actions_out[i] = conv ? 3 : 4;
+                    ended = true;
+                } else {
+                    actions_out[i] = 0;
+                }
+            }
+        }
+    }
     return SCS_OK;
 }

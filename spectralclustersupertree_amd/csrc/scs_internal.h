@@ -52,6 +52,10 @@ constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_
 constexpr size_t SCS_SCRATCH_KEEP = (size_t)1 << 30;
 constexpr size_t SCS_PINNED_KEEP = (size_t)2 << 30;  // free page-locked host blocks kept per context
 constexpr size_t SCS_BLOCK_KEEP = (size_t)32 << 30;  // free cached blocks kept per context (of 288 GB)
+// (round 6) a graph's W of at most this size comes from the block cache: the recursion builds thousands of
+// graphs of a few MB to a few hundred MB, and the one-buffer w_cache -- which keeps the LARGER of two buffers,
+// i.e. the root's, for ever -- served none of them: a hipMalloc and a hipFree (a device-wide synchronisation) each
+constexpr size_t SCS_W_BLOCK_MAX = (size_t)2 << 30;
 
 struct scs_ctx;
 // cached device blocks of a context (scs_ctx.hip)
@@ -214,6 +218,7 @@ struct scs_graph {
     int32_t col0 = 0;
     bool upper = false;
     size_t w_bytes = 0;     // size of the d_w allocation (may exceed the need: reused buffer)
+    bool w_block = false;   // d_w comes from the context's block cache (graphs of at most SCS_W_BLOCK_MAX bytes)
     // degree data for all V vertices (filled lazily by scs_graph_prepare_degrees)
     bool have_deg = false;
     void *deg_stage = nullptr;  // page-locked copy in flight (scs_graph_prepare_degrees_begin)
