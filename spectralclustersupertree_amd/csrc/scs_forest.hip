@@ -1241,6 +1241,14 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
     const int32_t TC = level ? lv->child_taxa : T;
     if (level) {
         out_forests[0] = nullptr;
+        // a level's forests stay resident until the walk has verified them; with the device nearly full the
+        // runtime cannot even place a launch's private scratch (it aborts the process): refuse early, the caller
+        // takes the subtree node by node (spectralclustersupertree_amd/levels.py)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < ((size_t)6 << 30)) {
+            scs_set_error("scs_forest_split_level: %.1f GB of device memory left", (double)free_b / (1u << 30));
+            return SCS_ENOMEM;
+        }
     } else {
         for (int b = 0; b < n_parts; ++b) {
             out_forests[b] = nullptr;
@@ -1383,7 +1391,9 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
     const bool parallel = !force_serial && N < ((int64_t)1 << 31) - 8 && (double)N / M > (double)par_min;
     int32_t *c_tree_id = nullptr;
     if (parallel) {
-        SCS_TRY(region->alloc((size_t)NC * 4, (void **)&c_tree_id));
+        // (the union of a level makes its own tree ids on first use: c_tree_id numbers a part's trees from 0)
+        if (level) SCS_TRY(scratch.alloc((size_t)NC * 4, (void **)&c_tree_id));
+        else SCS_TRY(region->alloc((size_t)NC * 4, (void **)&c_tree_id));
         par_params q;
         memset(&q, 0, sizeof(q));
         q.n_trees = M;
