@@ -441,6 +441,10 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
                   + "), RCCL all-gather of the Krylov block per iteration"),
             "lobpcg_block": stats["block"],
             "tol": args.tol,
+            # the arithmetic is fp64 throughout; what the loop's operator STREAMS is disclosed here
+            "precision": ("fp64 arithmetic; the LOBPCG loop applies the operator from a single-precision image of W "
+                          "(search directions only), S X / S P renewed and the result confirmed through the fp64 W"
+                          if acc["n_apply32"] > 0 else "fp64 throughout (no single-precision image of W)"),
         },
         "roofline": dominant,
         "roofline_other": other,
@@ -716,7 +720,8 @@ def main() -> int:
                         "line); its one-GPU time, the strong-scaling baseline, is other_workloads.cfg3.value "
                         "of the N = 1 line and same_workload_on_one_gpu.value of every N > 1 line",
         "vs_baseline": None,
-        "dtype": "f64",
+        "dtype": ("f64 (loop operator: fp32 image of W; fp64 renewal + confirmation)"
+                  if main_rep.get("config", {}).get("precision", "").startswith("fp64 arithmetic;") else "f64"),
         "data": "synthetic",
         "value_definition": "SURVEY.md 8d / BASELINE.md 3.3 protocol: tables host -> HBM (page-locked source; "
                             "the chunks behind the first tree batch overlap the build's first kernels, all of "
@@ -752,6 +757,28 @@ def main() -> int:
                     part["peak_measured"] = round(copy_gbs * scale, 1)
                     part["frac_of_measured"] = round(part["achieved"] / (copy_gbs * scale), 4)
 
+    t_bench0 = time.perf_counter()
+    budget_s = float(os.environ.get("SCS_BENCH_BUDGET_S", "400"))  # wall clock the extra legs below may use in all
+    if world == 1 and not args.no_extra and "fp32 image" in result.get("dtype", ""):
+        # the same workload with the loop in double precision throughout (SCS_LOWP=0): the price of NOT using the
+        # image, in the same line as the headline
+        old_lowp = os.environ.get("SCS_LOWP")
+        os.environ["SCS_LOWP"] = "0"
+        try:
+            rep = run_workload(name, args, dev, dist, rank, world, min(args.steps, 5), 1, full=False, planted=args.planted)
+            rep.pop("_maps", None)
+            result["value_all_double"] = rep["value"]
+            result["all_double"] = {"value": rep["value"], "ms_per_step": rep["ms_per_step"],
+                                    "fiedler_ms": rep["stages"]["fiedler_ms"],
+                                    "lobpcg_iterations": rep["stages"]["lobpcg_iterations"],
+                                    "precision": rep["config"]["precision"]}
+        except Exception as exc:  # noqa: BLE001 - report, never hide the main line
+            result["all_double"] = {"error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            if old_lowp is None:
+                del os.environ["SCS_LOWP"]
+            else:
+                os.environ["SCS_LOWP"] = old_lowp
     if world == 1 and args.workload is None and not args.no_extra:
         # seeds 0, 1, 2 (median) and one planted input, lambda2 / lambda3 printed
         seeds = {str(args.seed): {"value": main_rep["value"], "lambda2": main_rep["stages"]["lambda2"],
@@ -787,7 +814,42 @@ def main() -> int:
                                                      "roofline_path", "stages", "parity") if k in rep}
             except Exception as exc:  # noqa: BLE001 - report, never hide the main line
                 others[extra] = {"error": str(exc)}
+        # configs[4] (100 000 taxa / 5 000 weighted trees, W = 80 GB): its top level, one step; and its "full
+        # recursion" leg -- construct_supertree's whole walk with the property checks of
+        # tools/full_recursion_check.py -- so that the driver's own run carries both.  Each is skipped (and says
+        # so) when the time the extras may use is nearly spent.
+        spent = time.perf_counter() - t_bench0
+        if os.environ.get("SCS_BENCH_CFG4", "1") != "0":
+            if spent + 90 <= budget_s:
+                try:
+                    t0 = time.perf_counter()
+                    rep = run_workload("cfg4", args, dev, dist, rank, world, 1, 0, full=False)
+                    rep.pop("_maps", None)
+                    others["cfg4"] = {k: rep[k] for k in ("value", "steps", "config", "roofline", "roofline_other",
+                                                           "roofline_path", "stages", "parity") if k in rep}
+                    others["cfg4"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+                except Exception as exc:  # noqa: BLE001 - report, never hide the main line
+                    others["cfg4"] = {"error": f"{type(exc).__name__}: {exc}"}
+            else:
+                others["cfg4"] = {"skipped": f"{spent:.0f} s of the {budget_s:.0f} s for extra legs already used"}
         result["other_workloads"] = others
+        spent = time.perf_counter() - t_bench0
+        if os.environ.get("SCS_BENCH_RECURSION", "1") != "0":
+            if spent + 150 <= budget_s:
+                try:
+                    dev.trim()  # (the recursion runs on the process-wide context: give the 80 GB buffer back)
+                    sys.path.insert(0, str(ROOT / "tools"))
+                    import full_recursion_check
+
+                    t0 = time.perf_counter()
+                    rec = full_recursion_check.run(100000, 5000, True, log=lambda s_: None)
+                    rec["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+                    rec["workload"] = "configs[4] full recursion: construct_supertree on 100 000 taxa / 5 000 weighted trees, branch"
+                    result["recursion"] = rec
+                except Exception as exc:  # noqa: BLE001 - report, never hide the main line
+                    result["recursion"] = {"error": f"{type(exc).__name__}: {exc}"}
+            else:
+                result["recursion"] = {"skipped": f"{spent:.0f} s of the {budget_s:.0f} s for extra legs already used"}
 
     dev.close()
     # N > 1: rank 0 also times the SAME workload alone on its GPU (one warm-up + one pass,

@@ -44,13 +44,13 @@ MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 # diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
 stats = {"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
          "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
-         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0}
+         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0}
 
 
 def reset_stats() -> None:
     stats.update({"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
                   "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
-                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0})
+                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0})
 
 
 def max_taxa() -> int:
@@ -106,7 +106,7 @@ class Level:
 
     __slots__ = ("forest", "K", "T", "t_lo", "t_hi", "n_leaves", "u_lo", "u_sz", "gid", "present", "comp_root",
                  "sig", "kind", "n_pres", "v_off", "n_groups", "maps", "prov", "members", "sorted_taxa", "seg_start",
-                 "seg_len", "seg_child", "node_seg", "graft", "monotone", "shift")
+                 "seg_len", "seg_child", "node_seg", "graft", "monotone", "shift", "defer")
 
 
 class Engine:
@@ -233,7 +233,13 @@ class Engine:
         t2 = time.perf_counter()
         if jobs:
             for k, job in jobs:
-                lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = self.ahead.result(job, self.dev)
+                try:
+                    got = self.ahead.result(job, self.dev)
+                except RuntimeError:
+                    # several nodes in flight need more device memory than one: what failed on a worker's context
+                    # is solved once more on this thread's own (a failure of the node itself just repeats)
+                    got = self._large_job(lev, k, relabel, gs_patch)(self.dev)
+                lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = got
         else:
             for k in large:
                 lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = self._large_job(lev, int(k), relabel, gs_patch)(self.dev)
@@ -243,7 +249,9 @@ class Engine:
         from spectralclustersupertree_amd import kmeans2
 
         # (a node whose batched solve failed has left the kind: its rows of maps are zero, its labels unused)
-        prov = self._provisional(lev, v_ptr)
+        prov, defer = self._provisional(lev, v_ptr)
+        lev.defer = defer if defer is not None else np.zeros(K, dtype=bool)
+        stats["deferred"] += int(lev.defer.sum())
         if prov is not None:
             lev.prov[:] = prov
         else:
@@ -263,7 +271,7 @@ class Engine:
             cs_root = np.concatenate(([0], np.cumsum(root_i)))
             sel = pres & comps[nid]
             tpart[sel] = cs_root[lev.comp_root[sel]] - cs_root[u_lo[nid[sel]]]
-        spectral = kind == SPECTRAL
+        spectral = (kind == SPECTRAL) & ~lev.defer  # (a deferred node has no provisional parts)
         if spectral.any():
             sel = pres & spectral[nid]
             tpart[sel] = lev.prov[v_ptr[nid[sel]] + vertex_of[sel]]
@@ -354,41 +362,40 @@ class Engine:
         return nxt
 
     def _provisional(self, lev: Level, v_ptr: np.ndarray):
-        """Provisional labels of all spectral nodes of the level: the partition MOST OFTEN found among
-        ``SCS_SPEC_VOTES`` label assignments from different draws.  Which partition the labels of record will be is
-        a draw from the same distribution (ten k-means++ starts, the best kept); where that distribution has a
-        dominant partition, betting on the one seen most often is right more often than betting on one sample.
-        Measured (20 000 taxa / 5 000 trees): 178 / 151 / 145 / 143 unconfirmed partitions with 1 / 3 / 5 / 9 votes --
-        the nodes that matter are close to a coin flip -- for 0.15 / 0.42 / 0.65 / 1.18 s of label assignments: the
-        default is ONE."""
+        """Provisional labels of all spectral nodes of the level, and which nodes to DEFER.
+
+        Which partition the labels of record will be is a draw from a distribution (ten k-means++ starts, the best
+        kept).  For nearly all nodes that distribution is one point; for a few -- a Fiedler vector without a gap
+        between its two clusters -- it is close to a coin flip between two partitions, and everything computed
+        below a wrong guess is thrown away (measured at configs[4]: 880 unconfirmed partitions of 61 436 cost a third
+        of the engine's work, the largest at 2 019, 1 877, 1 608 vertices).  So the labels are assigned
+        ``SCS_SPEC_VOTES`` times from different draws: a node on which the votes AGREE goes on with that partition;
+        a node on which they do not is deferred -- nothing below it is computed now, the walk takes its subtree up
+        again (``redo``) when it arrives there with the labels of record."""
         from spectralclustersupertree_amd import kmeans2
 
-        votes = max(1, int(os.environ.get("SCS_SPEC_VOTES", "1") or 1))
+        votes = max(1, int(os.environ.get("SCS_SPEC_VOTES", "3") or 1))
         runs = []
         for _ in range(votes):
             lab = kmeans2.provisional_labels(lev.maps, v_ptr, self.prov_rs)
             if lab is None:
-                return None
+                return None, None
             runs.append(lab)
+        defer = np.zeros(lev.K, dtype=bool)
         if votes == 1 or len(runs[0]) == 0:
-            return runs[0]
-        nodes = np.flatnonzero(np.diff(v_ptr) > 0)
+            return runs[0], defer
+        sizes = np.diff(v_ptr)
+        nodes = np.flatnonzero(sizes > 0)
         starts = v_ptr[nodes].astype(np.int64)
-        seg = np.repeat(np.arange(len(nodes)), np.diff(v_ptr)[nodes])
+        seg = np.repeat(np.arange(len(nodes)), sizes[nodes])
         # the partition, whatever the numbering: every label relative to the node's first vertex
         canon = [lab ^ lab[starts][seg] for lab in runs]
-        agree = np.zeros((votes, len(nodes)), dtype=np.int32)
-        for i in range(votes):
-            for j in range(i + 1, votes):
-                same = np.add.reduceat((canon[i] != canon[j]).astype(np.int32), starts) == 0
-                agree[i] += same
-                agree[j] += same
-        best = np.argmax(agree, axis=0)  # (the first of equals: run 0 when all differ)
-        out = runs[0].copy()
+        differ = np.zeros(len(nodes), dtype=bool)
         for i in range(1, votes):
-            pick = (best == i)[seg]
-            out[pick] = runs[i][pick]
-        return out
+            differ |= np.add.reduceat((canon[0] != canon[i]).astype(np.int32), starts) != 0
+        min_defer = int(os.environ.get("SCS_SPEC_DEFER_MIN", "8") or 0)
+        defer[nodes[differ & (sizes[nodes] >= min_defer)]] = True
+        return runs[0], defer
 
     # ------------------------------------------------------------------ pieces of a level
     def _node_arrays(self, lev: Level, k: int) -> TreeArrays:
@@ -551,6 +558,7 @@ class Engine:
         l0.maps = lev.maps[v0:v1]
         l0.prov = np.asarray(labels, dtype=np.int8)
         l0.graft = {}
+        l0.defer = np.zeros(1, dtype=bool)
         mem = lev.members.get(k)
         l0.members = {} if mem is None else {0: mem}
         # vertex of every present taxon
@@ -597,17 +605,22 @@ class Engine:
             prov = lev.prov[v0:v1]
             if scs._node_trace is not None:
                 self._trace(lev, k, labels, maps)
-            if np.array_equal(labels, prov):
+            deferred = bool(lev.defer[k])
+            if deferred:
+                pass  # (nothing was computed below this node: the labels of record decide now)
+            elif np.array_equal(labels, prov):
                 pass
             elif np.array_equal(labels, 1 - prov):
                 segs.reverse()  # (both labels occur, or the arrays would be equal: two segments)
                 if len(segs) == 1:  # (all vertices in one cluster: nothing to swap)
                     segs = list(range(s0, s1))
             else:
+                deferred = True
                 # the draws decided a tie differently: the subtree below this node once more, from the node's own
                 # trees with the labels of record
                 stats["mismatches"] += 1
                 stats["mismatch_sizes"].append(int(v1 - v0))
+            if deferred:
                 t0 = time.perf_counter()
                 try:
                     again = self.redo(lev, k, labels)

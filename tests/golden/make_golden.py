@@ -34,6 +34,15 @@ from spectralclustersupertree_amd.tree import make_tree  # noqa: E402
 OUT = Path(__file__).resolve().parent / "vectors"
 SEED = 12345
 
+ZERO_WEIGHT_CASES = [
+    ("zero_weight_branch", ["((a:1,b:1,x:1):0.0,((c:1,d:1):0.5,(e:1,f:1):0.25):1.0)",
+                            "((a:1,c:1):1.0,(b:1,(d:1,e:1):0.5):1.0)",
+                            "(((a:1,e:1):0.0,f:1):0.0,(b:1,c:1):2.0)",
+                            "((x:1,(a:1,b:1):0.0):0.0,(d:1,f:1):1.5)"], "branch"),
+    ("zero_weight_bootstrap", ["((a,b,x)0,((c,d)80,(e,f)60)90)", "((a,c)70,(b,(d,e)50)75)",
+                               "(((a,e)0,f)0,(b,c)95)", "((x,(a,b)0)0,(d,f)65)"], "bootstrap"),
+]
+
 
 def vector_from_trees(name, trees, weights, strategy, contract):
     names = sorted(so._all_tips(trees))
@@ -80,8 +89,28 @@ def main():
         trees = [make_tree(s) for s in c.trees]
         vector_from_trees(f"inline_{nm}", trees, c.weights or [1.0] * len(trees), c.pcg_weighting,
                           c.contract_edges)
+    # round 6 ("the 12 inline cases"): the other inline cases that reach the spectral step
+    for nm in ("two_squares", "weights_1001_1", "weights_1_2", "weights_1_1001", "depth_one", "depth_branch",
+               "branch_one", "branch_depth", "bootstrap_one", "bootstrap_depth"):
+        c = by_name[nm]
+        trees = [make_tree(s) for s in c.trees]
+        vector_from_trees(f"inline_{nm}", trees, c.weights or [1.0] * len(trees), c.pcg_weighting,
+                          c.contract_edges)
+    # ... and "one zero-branch-length case": an edge of the proper cluster graph exists wherever two taxa share a
+    # root side (scs.py:651-652), whatever its weight (:655-658) -- here taxon x is joined to a and b only through
+    # zero-length / zero-support clades: ONE component, and a zero row of W (scikit-learn warns "Graph is not fully
+    # connected", sets that vertex's degree factor to 1 and still splits, scipy/sparse/csgraph/_laplacian.py:552-557)
+    for nm, newicks, strat in ZERO_WEIGHT_CASES:
+        vector_from_trees(nm, [make_tree(s) for s in newicks], [1.0] * len(newicks), strat, True)
     trees = [make_tree(x.strip()) for x in (DATA_DIR / "supertriplets_source.tre").read_text().splitlines() if x.strip()]
     vector_from_trees("fixture_supertriplets_top", trees, [1.0] * len(trees), "depth", True)
+    # top-level W of the dcm fixture under `one` and `branch` (two components: the solve never fires there,
+    # tests/test_spectral_cluster_supertree.py:50-61, :244-248 -- the vectors pin W and the contraction groups)
+    trees = [make_tree(x.strip()) for x in (DATA_DIR / "dcm_source_trees.tre").read_text().splitlines() if x.strip()]
+    for strat in ("one", "branch"):
+        vector_from_trees(f"fixture_dcm_top_{strat}", trees, [1.0] * len(trees), strat, False)
+    vector_from_tables("synthetic_256_branch", synthetic.make_tables(256, 256, 32, "branch", random_weights=True), "branch")
+    vector_from_tables("synthetic_1000_depth", synthetic.make_tables(1000, 1000, 100, "depth"), "depth")
     for strat in ("one", "depth", "branch", "bootstrap"):
         vector_from_tables(f"synthetic_64_{strat}", synthetic.make_tables(64, 64, 8, strat, leaves_per_tree=50), strat)
     vector_from_tables("synthetic_200_branch_weighted",

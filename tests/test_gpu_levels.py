@@ -108,6 +108,7 @@ def test_wrong_provisional_labels_are_all_repaired(monkeypatch, engine_everywher
     from spectralclustersupertree_amd import kmeans2
 
     arrays = synthetic.tree_arrays(77, 600, 40, random_weights=True)
+    monkeypatch.setenv("SCS_SPEC_VOTES", "1")  # (one label assignment per node: the spoiled one is what the engine bets on)
     monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "0")
     want = _run(arrays, "branch", True, 9)
     monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "1000000")
@@ -143,6 +144,52 @@ def test_wrong_provisional_labels_are_all_repaired(monkeypatch, engine_everywher
     got = _run(arrays, "branch", True, 9)
     assert got == want
     assert levels.stats["fallbacks"] >= 10
+
+
+def test_nodes_on_which_the_votes_disagree_are_deferred_not_guessed(monkeypatch, engine_everywhere):
+    """Three label assignments per node from different draws: where they do not agree the engine computes
+    nothing below the node (no work to throw away) and the walk takes the subtree up again with the labels of
+    record -- the same supertree, labels and stream position as with one vote, and as node by node."""
+    arrays = synthetic.tree_arrays(123, 1500, 30, random_weights=True)
+    monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "0")
+    want = _run(arrays, "branch", True, 2)
+    monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "1000000")
+    got = {}
+    for votes in ("1", "3", "5"):
+        monkeypatch.setenv("SCS_SPEC_VOTES", votes)
+        monkeypatch.setenv("SCS_SPEC_DEFER_MIN", "0")
+        got[votes] = (_run(arrays, "branch", True, 2), dict(levels.stats))
+        assert got[votes][0] == want
+    assert got["1"][1]["deferred"] == 0
+    assert got["3"][1]["deferred"] >= 1 and got["5"][1]["deferred"] >= got["3"][1]["deferred"]
+    # fewer bets lost than with one vote, and fewer nodes computed in vain
+    assert got["5"][1]["mismatches"] <= got["1"][1]["mismatches"]
+
+
+def test_a_larger_node_that_fails_on_a_worker_is_solved_on_the_engines_own_context(monkeypatch, engine_everywhere):
+    """The larger nodes of a level go to the look-ahead workers' contexts; a job that fails there (two nodes in
+    flight need more device memory than one) is solved again on the engine's own context: the same result."""
+    import threading
+
+    arrays = synthetic.tree_arrays(31, 1800, 24, random_weights=True)
+    want = _run(arrays, "branch", True, 4)
+    real, failed = levels.Engine._large_job, []
+
+    def flaky(self, lev, k, relabel, gs_patch):
+        job = real(self, lev, k, relabel, gs_patch)
+
+        def run(dev):
+            if threading.current_thread().name.startswith("scs-ahead"):
+                failed.append(k)
+                msg = "libscs_hip error -3: out of device memory (simulated)"
+                raise RuntimeError(msg)
+            return job(dev)
+
+        return run
+
+    monkeypatch.setattr(levels.Engine, "_large_job", flaky)
+    assert _run(arrays, "branch", True, 4) == want
+    assert failed
 
 
 def test_forests_that_fall_apart_and_single_tree_nodes(engine_everywhere):

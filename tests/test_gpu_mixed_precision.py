@@ -1,0 +1,103 @@
+"""The mixed-precision LOBPCG loop -- the product's DEFAULT for every graph of 4 096 ... ~65 000 vertices on one
+device (``csrc/scs_eig.hip``: the loop's SYMM streams a single-precision image of W, S X / S P are renewed and the
+result confirmed through W itself) -- held against the ORACLE, not against the product's own all-double loop:
+scikit-learn's ``spectral_embedding`` + ``k_means`` on the same matrix with the same RandomState, exactly the
+calls of the reference (src/sc_supertree/scs.py:235-252 -> sklearn/manifold/_spectral_embedding.py:299-467,
+sklearn/cluster/_spectral.py:759-766).
+
+Bar (BASELINE.json north_star): Fiedler entries within 1e-10 -- on the embedding AND on the unit-norm eigenvector
+ARPACK returns (the stricter scale) -- and identical labels.  Every case must actually have run on the image
+(``n_apply32 > 0``).  Five kinds of graphs x five sizes; three seeds each up to 8 192 vertices and one above (the
+dense LU of scikit-learn's shift-invert solve is 10-40 s a case there); ``SCS_SLOW_TESTS=1`` runs all three seeds
+at every size (``profiles/r06_mixed_precision_vs_sklearn.log`` is that run).
+"""
+
+import os
+import time
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import scs_oracle as so
+from oracle import tables_oracle as to
+from spectralclustersupertree_amd import synthetic
+from spectralclustersupertree_amd.backend import Device
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-10  # north_star: "Fiedler-vector entries within 1e-10 fp64"
+SLOW = bool(int(os.environ.get("SCS_SLOW_TESTS", "0") or 0))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    d = Device(0)
+    yield d
+    d.close()
+
+
+def _tables(kind: str, n: int, seed: int):
+    if kind == "branch + weights":
+        return synthetic.make_tables(seed, n, 24, "branch", random_weights=True)
+    if kind == "depth":
+        return synthetic.make_tables(seed, n, 16, "depth")
+    if kind == "one":
+        return synthetic.make_tables(seed, n, 40, "one")
+    if kind == "planted SPR":
+        return synthetic.make_tables(seed, n, 12, "branch", random_weights=True, planted_spr=int(np.ceil(0.02 * n)))
+    if kind == "partial coverage":
+        # seven trees over 55 % of the taxa each: ~0.4 % of the taxa occur in no tree (isolated vertices: both
+        # leading pairs are iterated, no deflation) while the rest stays one component
+        return synthetic.make_tables(seed, n, 7, "branch", leaves_per_tree=int(0.55 * n), random_weights=True)
+    raise ValueError(kind)
+
+
+KINDS = ["branch + weights", "depth", "one", "planted SPR", "partial coverage"]
+SIZES = [4096, 6000, 8192, 12000, 16384]
+CASES = [(kind, n, seed) for kind in KINDS for n in SIZES for seed in (0, 1, 2) if SLOW or n <= 8192 or seed == 0]
+
+
+@pytest.mark.parametrize(("kind", "n", "seed"), CASES)
+def test_default_solve_on_the_image_matches_scikit_learn(dev, monkeypatch, kind, n, seed):
+    from sklearn.cluster import k_means
+
+    monkeypatch.delenv("SCS_LOWP", raising=False)  # the product's default
+    tables = _tables(kind, n, 1000 * seed + n)
+    dtab = dev.upload(tables)
+    graph = dtab.build()
+    try:
+        w = graph.download()
+        rs = np.random.RandomState(seed)
+        v0 = rs.uniform(-1, 1, n)  # (the reference's first draw: sklearn/utils/_arpack.py:31-33)
+        maps, stats = graph.fiedler(v0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            _, labels, _ = k_means(maps, 2, random_state=rs, n_init=10, verbose=False)
+    finally:
+        graph.free()
+        dtab.free()
+    assert stats["converged"] == 1, stats
+    assert stats["n_apply32"] > 0, stats  # the loop under test is the one that ran
+    assert np.array_equal(w, w.T)
+    t0 = time.perf_counter()
+    rs_ref = np.random.RandomState(seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # ("Graph is not fully connected": isolated vertices)
+        ref = to.sign_flip_columns(so.spectral_maps(w, rs_ref))
+        _, labels_ref, _ = k_means(ref, 2, random_state=rs_ref, n_init=10, verbose=False)
+    t_ref = time.perf_counter() - t0
+    _, dd = to.normalized_operator(w)
+    isolated = int(np.count_nonzero(w.sum(axis=0) == 0))
+    gap = stats["lambda"][1] - stats["lambda_next"]
+    err_maps = float(np.max(np.abs(maps[:, 1] - ref[:, 1])))
+    err_unit = float(np.max(np.abs((maps[:, 1] - ref[:, 1]) * dd)))
+    err_col0 = float(np.max(np.abs(maps[:, 0] - ref[:, 0])))
+    mism = int(np.count_nonzero(labels != labels_ref))
+    mism = min(mism, n - mism)  # label names are arbitrary
+    print(f"MIXED {kind!r} V {n} seed {seed}: iterations {stats['iterations']} image applies {stats['n_apply32']} "
+          f"renewals {stats['lowp_renewals']} residual {max(stats['resid']):.2e} lambda2 {stats['lambda'][1]:.10f} "
+          f"gap {gap:.2e} isolated {isolated} err_maps {err_maps:.2e} err_unit {err_unit:.2e} err_col0 {err_col0:.2e} "
+          f"labels_mismatched {mism} stream_equal {rs.randint(1 << 30) == rs_ref.randint(1 << 30)} sklearn {t_ref:.1f} s")
+    assert err_maps <= TOL and err_unit <= TOL and err_col0 <= TOL
+    assert mism == 0

@@ -279,6 +279,77 @@ def test_whole_recursion_without_contraction():
     assert all(len(v) == 1 for e in trace for v in e["vertices"])
 
 
+def _copy(tree: TreeNode) -> TreeNode:
+    return TreeNode(tree.name, [_copy(c) for c in tree.children], tree.length, tree.support)
+
+
+def zero_weight_forest(seed, n_taxa, n_trees, leaves, n_loose):
+    """A forest in which ``n_loose`` extra taxa z0, z1, ... are joined to the rest ONLY through clades of zero
+    weight: in every tree that holds them they hang off a root child of branch length 0.0 and support 0.0, so
+    every proper cluster they take part in adds 0.0 -- an edge of the proper cluster graph all the same
+    (reference: scs.py:651-652 adjacency, :655-658 weight).  Their rows of W are zero at the top level: the
+    C-graph is one component, scikit-learn sees isolated vertices (degree factor 1, "Graph is not fully
+    connected", scipy/sparse/csgraph/_laplacian.py:552-557) and still splits."""
+    trees = synthetic.tree_objects(seed, n_taxa, n_trees, leaves_per_tree=leaves)
+    rs = np.random.RandomState(seed)
+    out = []
+    for t, tree in enumerate(trees):
+        tree = _copy(tree)
+        # supports everywhere (the bootstrap weighting needs one on every inner node)
+        stack = [tree]
+        while stack:
+            node = stack.pop()
+            if node.children:
+                node.support = float(rs.randint(50, 101))
+                stack.extend(node.children)
+        here = [f"z{i}" for i in range(n_loose) if rs.rand() < 0.7]
+        if here:
+            side = tree.children[int(rs.randint(len(tree.children)))]
+            kids = [c for c in tree.children if c is not side]
+            loose = TreeNode(None, [side] + [TreeNode(z, None, 0.1) for z in here], 0.0, 0.0)
+            tree = TreeNode(None, [loose] + kids, None, tree.support)
+        out.append(tree)
+    return out
+
+
+@pytest.mark.parametrize("strategy", ["branch", "bootstrap"])
+def test_whole_recursion_with_zero_weight_edges(strategy):
+    # SURVEY 8c "one zero-branch-length case" / 7 "components use co-occurrence, not weight": nodes whose C-graph
+    # is one component while W has zero rows -- through the whole recursion, against the oracle node by node
+    trees = zero_weight_forest(17, 150, 24, 110, 6)
+    names = sorted({n for t in trees for n in t.get_tip_names()})
+    tables = fl_tables(trees, strategy, names)
+    w, _ = to_dense(tables)
+    assert int(fl_components(tables).max()) == 0  # ONE component of the proper cluster graph ...
+    zero_rows = [names[i] for i in np.flatnonzero(w.sum(axis=0) == 0)]
+    assert len(zero_rows) >= 3 and all(z.startswith("z") for z in zero_rows)  # ... and isolated rows of W
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")  # (scikit-learn: "Graph is not fully connected")
+        trace, ties = compare_with_oracle(trees, None, strategy, seed=4, ties_allowed=True)
+    assert len(trace) >= 20
+    assert len(ties) <= len(trace) // 10
+    # the top-level call saw the loose taxa as vertices of their own
+    assert all((z,) in trace[0]["vertices"] for z in zero_rows)
+
+
+def fl_tables(trees, strategy, names):
+    from spectralclustersupertree_amd import flatten as fl
+
+    return fl.flatten_trees(trees, [1.0] * len(trees), strategy, names)
+
+
+def fl_components(tables):
+    from spectralclustersupertree_amd import flatten as fl
+
+    return fl.pcg_components(tables)
+
+
+def to_dense(tables):
+    from oracle import tables_oracle as to
+
+    return to.pcg_dense(tables)
+
+
 def test_device_work_queued_ahead_changes_nothing(monkeypatch):
     # ahead.Ahead: the larger right siblings are built and solved on a worker thread with a second
     # context while the walk is in the left subtree -- the supertree, every label vector and the
@@ -314,11 +385,14 @@ def test_a_look_ahead_job_that_fails_on_the_worker_is_solved_by_the_walk(monkeyp
     trees, weights = recursion_input(21, 900, 24, 600, 30, weighted=False)
     taxa = sorted({n for t in trees for n in t.get_tip_names()})
     arrays = TreeArrays.from_trees(trees, weights or [1.0] * len(trees), taxa)
+    # (the node-by-node walk with its look-ahead queue: below SCS_SPEC_MAX_TAXA the level-synchronous engine would
+    # take these nodes -- its own hand-over to the workers is tests/test_gpu_levels.py's)
+    monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "0")
     want = canonical(construct_supertree(arrays, pcg_weighting="branch", random_state=np.random.RandomState(4)))
     real, failed = scs._solve_node, []
 
     def flaky(dev, *args, **kwargs):
-        if threading.current_thread().name == "scs-ahead":
+        if threading.current_thread().name.startswith("scs-ahead"):
             failed.append(1)
             msg = "libscs_hip error -3: out of device memory (simulated)"
             raise RuntimeError(msg)
