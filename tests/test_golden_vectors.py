@@ -80,6 +80,11 @@ def test_device_reproduces_golden(path):
             g = dtab.build()
             dtab.free()
         assert np.array_equal(g.download(), z["a"])  # bit-exact
+        if int(fl.pcg_components(tables).max()) > 0:
+            # several components (the dcm fixture's top level, tests/test_spectral_cluster_supertree.py:50-61):
+            # the recursion splits by components there and never solves (scs.py:122-139) -- the vector pins W
+            g.free()
+            return
         rs = np.random.RandomState(int(z["seed"]))
         v0 = rs.uniform(-1, 1, z["a"].shape[0])
         maps, stats = g.fiedler(v0)
