@@ -488,6 +488,13 @@ def run_workload(name, args, dev, dist, rank, world, steps, warmup, full, seed=N
         report["stages"]["allgathers_per_step"] = acc["n_ag"] / steps
         report["stages"]["allgather_bytes_received_per_rank"] = stats.get("allgather_bytes", 0.0)
         report["stages"]["multi_rank_mode"] = mode
+        # what THIS rank (rank 0 prints its own) streams per operator application: the double-precision launches
+        # (8 bytes a cell of its rows, or 4 V^2 / world in the upper-triangle job) and -- round 6, row-partitioned
+        # layout -- the launches on the single-precision image of its rows (4 bytes a cell)
+        report["stages"]["rank_rows"] = int(re_ - rb)
+        report["stages"]["rank_apply_bytes_per_launch"] = stats["apply_bytes"]
+        report["stages"]["rank_apply32_bytes_per_launch"] = apply32_bytes
+        report["stages"]["rank_launches_per_step"] = {"double": n_apply_step, "image": n_apply32_step}
     # HBM traffic from the committed PMC passes of this workload, if any
     try:
         pmc_key = name if name != "custom" else f"custom_{n}_{m}_{strategy}"

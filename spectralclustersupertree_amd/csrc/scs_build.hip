@@ -298,14 +298,16 @@ template <bool IMG>
 __global__ __launch_bounds__(256) void k_degrees(const double *__restrict__ w, int64_t ld, int n,
                                                   int rows, int row_begin,
                                                   double *__restrict__ deg_full,
-                                                  float *__restrict__ w32 = nullptr) {
+                                                  float *__restrict__ w32 = nullptr, int w32_full = 0) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const double *row = w + (int64_t)r * ld;
     double s0 = 0.0, s1 = 0.0;
     const int n2 = n & ~1;
-    const int c0 = (row_begin + r) / 512 * 512;  // (the image is streamed in 128 x 512 tiles)
+    // (one device: the image is streamed in 128 x 512 tiles from the diagonal tile on; a row-partitioned rank
+    // streams whole rows -- w32_full)
+    const int c0 = w32_full ? 0 : (row_begin + r) / 512 * 512;
     float *row32 = IMG ? w32 + (int64_t)r * ld : nullptr;
     for (int j = lane * 2; j < n2; j += 128) {
         const double2 v = *(const double2 *)(row + j);
@@ -492,8 +494,9 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
         ctx->w_cache_bytes = 0;
     } else {
         hipError_t e = hipMalloc((void **)&g->d_w, bytes);
-        if (e != hipSuccess && (ctx->w_cache || ctx->w32_cache)) {  // make room and try once more
+        if (e != hipSuccess) {  // make room and try once more
             (void)hipGetLastError();
+            scs_block_drop_free(ctx);
             if (ctx->w_cache) hipFree(ctx->w_cache);
             ctx->w_cache = nullptr;
             ctx->w_cache_bytes = 0;
@@ -1432,7 +1435,10 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
         SCS_HIP_CHECK(hipMemcpyAsync(g->deg_stage, g->d_deg, (size_t)n * 8, hipMemcpyDeviceToHost, s));
         return SCS_OK;
     }
-    bool need_img = want_w32 && !g->have_w32 && ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && rows == n;
+    // (round 6: a row-partitioned rank keeps the image of ITS rows, all columns -- what k_symm streams)
+    const bool img_rows = ctx->comm.world > 1 && !g->upper;
+    bool need_img = want_w32 && !g->have_w32 && !g->upper &&
+                    (img_rows || (ctx->comm.world == 1 && g->row_begin == 0 && rows == n));
     if (g->have_deg && !need_img) return SCS_OK;
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -1456,10 +1462,21 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
         }
     }
     if (!need_img && g->have_deg) return SCS_OK;
+    if (need_img && img_rows && g->have_deg) {
+        // the degrees are known (a second solve on this graph): only the image is missing -- no collective here
+        // (a rank whose image could not be allocated has returned above; it streams W in double precision)
+        dev_buf tmp;
+        SCS_TRY(tmp.alloc((size_t)n * 8));
+        k_degrees<true><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, (double *)tmp.p, g->d_w32, 1);
+        SCS_HIP_CHECK(hipGetLastError());
+        SCS_HIP_CHECK(hipStreamSynchronize(s));  // tmp goes out of scope
+        g->have_w32 = true;
+        return SCS_OK;
+    }
     if (!g->d_deg) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_deg));
     if (!g->d_dinv) SCS_TRY(scs_block_alloc(ctx, (size_t)n * 8, (void **)&g->d_dinv));
     const int world = ctx->comm.world;
-    if (need_img) {
+    if (need_img && !img_rows) {
         // (a graph whose degrees are known already gets them again, bit for bit, beside the image)
         k_degrees<true><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg, g->d_w32);
         g->have_w32 = true;
@@ -1476,6 +1493,10 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
                                                                 g->col0, (double *)send.p);
             k_degrees_upper_cols<<<(n - g->col0 + 255) / 256, 256, 0, s>>>(
                 g->d_w, g->ld, n, g->row_begin, g->row_end, g->col0, (double *)send.p);
+        } else if (need_img) {
+            k_degrees<true><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, (double *)send.p,
+                                                           g->d_w32, 1);
+            g->have_w32 = true;
         } else
         k_degrees<false><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin,
                                                         (double *)send.p);

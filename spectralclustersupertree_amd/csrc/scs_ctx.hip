@@ -612,6 +612,18 @@ void scs_pinned_release(scs_ctx *ctx, void *p) {
     }
 }
 
+void scs_block_drop_free(scs_ctx *ctx) {
+    std::lock_guard<std::mutex> lock(ctx->cache_mu);
+    for (size_t i = 0; i < ctx->blocks.size();) {
+        if (!ctx->blocks[i].in_use) {
+            hipFree(ctx->blocks[i].p);
+            ctx->blocks.erase(ctx->blocks.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+}
+
 void scs_block_release(scs_ctx *ctx, void *p) {
     if (!p) return;
     std::lock_guard<std::mutex> lock(ctx->cache_mu);

@@ -2000,7 +2000,12 @@ struct solver {
         dim3 grid((unsigned)rowblocks, (unsigned)nseg);
         switch (b) {
             case 4:
-                k_symm<4, 4, 4, 3><<<grid, 256, 0, s>>>(g->d_w, ld, rows, zin, ypart.d(), mps);
+                if (use32) {
+                    ++n_apply32;
+                    k_symm<4, 4, 4, 3, float><<<grid, 256, 0, s>>>(g->d_w32, ld, rows, zin, ypart.d(), mps);
+                } else {
+                    k_symm<4, 4, 4, 3><<<grid, 256, 0, s>>>(g->d_w, ld, rows, zin, ypart.d(), mps);
+                }
                 break;
             case 8:
                 k_symm<8, 4, 2, 2><<<grid, 256, 0, s>>>(g->d_w, ld, rows, zin, ypart.d(), mps);
@@ -2030,6 +2035,7 @@ struct solver {
         SCS_TRY(z.alloc((size_t)b * ldz * 8));
         SCS_HIP_CHECK(hipMemsetAsync(z.p, 0, (size_t)b * ldz * 8, s));
         w_bytes_per_apply = 8.0 * rows * (double)n;
+        w32_bytes_per_apply = 4.0 * rows * (double)n;  // (k_symm on the image of a rank's rows; the symmetric schedule sets its own)
         if (g->mf)  // both sweeps read the leaf arrays (16 bytes a leaf); the slabs are written and read once
             w_bytes_per_apply = 2.0 * 16.0 * (double)g->mf->tb->n_leaves +
                                 2.0 * 2.0 * 8.0 * (double)g->mf->tb->n_trees * (double)n * b;
@@ -2480,11 +2486,14 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // (an image above SCS_LOWP_MAX_BYTES, default 16 GiB -- about 65 000 vertices -- is not made: what it
     // saves a solve of that size, some 80 ms, is less than what an allocation of tens of GB can cost)
     const double lowp_max_bytes = getenv("SCS_LOWP_MAX_BYTES") ? atof(getenv("SCS_LOWP_MAX_BYTES")) : 16.0 * (1u << 30);
-    const bool image_ok = !g->mf && lowp_mode > 0 && n >= 4096 && loop_fused && ctx->comm.world == 1 && !g->upper &&
-                          (g->have_w32 || 4.0 * (double)n * (double)g->ld <= lowp_max_bytes) &&
-                          g->row_begin == 0 && g->row_end == n &&
-                        !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
-                        !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
+    // (round 6: a row-partitioned job -- whole rows on every rank, k_symm -- keeps the image of each rank's rows:
+    // the first real multi-GPU run streams per rank what the one-GPU run streams, not twice that)
+    const bool image_rows = ctx->comm.world > 1 && !g->upper;
+    const bool image_one = ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && g->row_end == n &&
+                           !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
+                           !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
+    const bool image_ok = !g->mf && lowp_mode > 0 && n >= 4096 && loop_fused && (image_one || image_rows) &&
+                          (g->have_w32 || 4.0 * (double)(g->row_end - g->row_begin) * (double)g->ld <= lowp_max_bytes);
     // default width: 4 while the panel kernels and the 3b x 3b Rayleigh-Ritz solve weigh
     // against the SYMM stream, 8 once streaming W dominates (measured crossover ~ 16k) -- unless the
     // loop can stream the single-precision image, which exists at width 4: half the bytes an
@@ -2559,7 +2568,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     const double drop_tol = 1e-13;
 
     SCS_TRY(scs_graph_prepare_degrees(ctx, g));  // (begun at the top: the degrees are needed from here on)
-    sv.use32 = want32 && sv.tri && sv.tri_ct == 2 && g->have_w32;
+    sv.use32 = want32 && g->have_w32 && (sv.tri ? sv.tri_ct == 2 : (image_rows && !sv.part_mode));
     scs_loop_policy policy;  // the stop / renew / confirm rules (scs_policy.h)
     policy.tol = tol;
     policy.lowp_mode = lowp_mode;

@@ -51,7 +51,12 @@ constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_
 // size cost 0.4 ms of every 21 ms step; the workspace of a memory-bound job, tens of GB, is not)
 constexpr size_t SCS_SCRATCH_KEEP = (size_t)1 << 30;
 constexpr size_t SCS_PINNED_KEEP = (size_t)2 << 30;  // free page-locked host blocks kept per context
-constexpr size_t SCS_BLOCK_KEEP = (size_t)32 << 30;  // free cached blocks kept per context (of 288 GB)
+// free cached blocks kept per context (of 288 GB).  Round 6: 32 -> 64 GB -- the level forests of one subtree of
+// the recursion are ~20 GB and are all handed back at once when its walk is done; with 32 GB the cache overflowed
+// there every time and every release above the limit is a hipFree (5 657 forests freed at 0.9 ms each in the
+// configs[4] recursion, the next subtree's hipMallocs on top).  Allocations that fail drop the cache and retry
+// (scs_block_alloc, the W buffer, the image), and scs_ctx_trim hands it back behind the largest nodes.
+constexpr size_t SCS_BLOCK_KEEP = (size_t)64 << 30;
 // (round 6) a graph's W of at most this size comes from the block cache: the recursion builds thousands of
 // graphs of a few MB to a few hundred MB, and the one-buffer w_cache -- which keeps the LARGER of two buffers,
 // i.e. the root's, for ever -- served none of them: a hipMalloc and a hipFree (a device-wide synchronisation) each
@@ -61,6 +66,8 @@ struct scs_ctx;
 // cached device blocks of a context (scs_ctx.hip)
 int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out);
 void scs_block_release(scs_ctx *ctx, void *p);
+// every free cached block back to the runtime (an allocation outside the cache has failed)
+void scs_block_drop_free(scs_ctx *ctx);
 // cached page-locked host blocks of a context (scs_ctx.hip): the download side of scs_forest_split
 int scs_pinned_get(scs_ctx *ctx, size_t bytes, void **out);
 void scs_pinned_release(scs_ctx *ctx, void *p);

@@ -25,11 +25,27 @@
 constexpr int SYMM_SUB = 128;       // columns per sub-chunk (two per lane)
 constexpr int SYMM_LD_ALIGN = 512;  // leading dimension granularity (doubles)
 
-template <int B, int RPW, int S, int MINW = 2>
-__global__ __launch_bounds__(256, MINW) void k_symm(const double *__restrict__ w, int64_t ld,
+// WT = float (round 6): the same launch on the SINGLE-PRECISION IMAGE of a rank's rows (row-partitioned jobs:
+// the mixed-precision LOBPCG loop of scs_eig.hip, until round 5 one-device only) -- a lane's two columns are one
+// 8-byte load, every product and sum stays in double precision, half the bytes streamed.
+template <typename WT>
+struct symm_pair;
+template <>
+struct symm_pair<double> {
+    typedef double2 type;
+};
+template <>
+struct symm_pair<float> {
+    typedef float2 type;
+};
+
+template <int B, int RPW, int S, int MINW = 2, typename WT = double>
+__global__ __launch_bounds__(256, MINW) void k_symm(const WT *__restrict__ w, int64_t ld,
                                                      int rows, const double *__restrict__ zt,
                                                      double *__restrict__ ypart,
                                                      int macros_per_seg) {
+    typedef typename symm_pair<WT>::type wpair;
+    constexpr int WB = (int)sizeof(WT);  // bytes per element of W
     static_assert(B % 4 == 0, "block width must be a multiple of 4");
     static_assert(SYMM_LD_ALIGN % (S * SYMM_SUB) == 0, "S*128 must divide the ld granularity");
     constexpr int MC = S * SYMM_SUB;  // columns per macro-chunk
@@ -49,7 +65,7 @@ __global__ __launch_bounds__(256, MINW) void k_symm(const double *__restrict__ w
     for (int i = 0; i < RPW; ++i) {
         int r = r0 + i;
         r = r < rows ? r : rows - 1;  // clamped rows are computed but never stored
-        rowp[i] = (const char *)(w + (int64_t)r * ld) + lane * 16;
+        rowp[i] = (const char *)(w + (int64_t)r * ld) + lane * 2 * WB;
     }
     // z piece q of this thread: k = tid/64 + 4q, column pair tid%64
     const char *zp = (const char *)zt + ((int64_t)(tid >> 6) * ld + 2 * (tid & 63)) * 8;
@@ -61,12 +77,13 @@ __global__ __launch_bounds__(256, MINW) void k_symm(const double *__restrict__ w
 #pragma unroll
         for (int k = 0; k < B; ++k) acc[i][k] = 0.0;
 
-    double2 a[S][RPW];
+    wpair a[S][RPW];
     double2 zr[ZPT];
 
     // ---- prologue: first macro-chunk into registers / LDS buffer 0
     {
         const int64_t cb = (int64_t)m_begin * MC * 8;
+        const int64_t cbw = (int64_t)m_begin * MC * WB;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -74,7 +91,7 @@ __global__ __launch_bounds__(256, MINW) void k_symm(const double *__restrict__ w
                 zr[q] = *(const double2 *)(zp + cb + s * (SYMM_SUB * 8) + q * zstep);
 #pragma unroll
             for (int i = 0; i < RPW; ++i)
-                a[s][i] = *(const double2 *)(rowp[i] + cb + s * (SYMM_SUB * 8));
+                a[s][i] = *(const wpair *)(rowp[i] + cbw + s * (SYMM_SUB * WB));
 #pragma unroll
             for (int q = 0; q < ZPT; ++q)
                 *(double2 *)&zs[0][(tid >> 6) + 4 * q][s * SYMM_SUB + 2 * (tid & 63)] = zr[q];
@@ -85,6 +102,7 @@ __global__ __launch_bounds__(256, MINW) void k_symm(const double *__restrict__ w
     int buf = 0;
     for (int m = m_begin; m < m_end - 1; ++m) {
         const int64_t nb = (int64_t)(m + 1) * MC * 8;  // byte offset of the next macro-chunk
+        const int64_t nbw = (int64_t)(m + 1) * MC * WB;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -96,14 +114,14 @@ __global__ __launch_bounds__(256, MINW) void k_symm(const double *__restrict__ w
                 const double2 zz = *(const double2 *)(zrow + k * MC);
 #pragma unroll
                 for (int i = 0; i < RPW; ++i) {
-                    acc[i][k] = fma(a[s][i].x, zz.x, acc[i][k]);
-                    acc[i][k] = fma(a[s][i].y, zz.y, acc[i][k]);
+                    acc[i][k] = fma((double)a[s][i].x, zz.x, acc[i][k]);
+                    acc[i][k] = fma((double)a[s][i].y, zz.y, acc[i][k]);
                 }
             }
             // refill this pipeline stage for the next macro-chunk
 #pragma unroll
             for (int i = 0; i < RPW; ++i)
-                a[s][i] = *(const double2 *)(rowp[i] + nb + s * (SYMM_SUB * 8));
+                a[s][i] = *(const wpair *)(rowp[i] + nbw + s * (SYMM_SUB * WB));
 #pragma unroll
             for (int q = 0; q < ZPT; ++q)
                 *(double2 *)&zs[buf ^ 1][(tid >> 6) + 4 * q][s * SYMM_SUB + 2 * (tid & 63)] = zr[q];
@@ -120,8 +138,8 @@ __global__ __launch_bounds__(256, MINW) void k_symm(const double *__restrict__ w
             const double2 zz = *(const double2 *)(zrow + k * MC);
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
-                acc[i][k] = fma(a[s][i].x, zz.x, acc[i][k]);
-                acc[i][k] = fma(a[s][i].y, zz.y, acc[i][k]);
+                acc[i][k] = fma((double)a[s][i].x, zz.x, acc[i][k]);
+                acc[i][k] = fma((double)a[s][i].y, zz.y, acc[i][k]);
             }
         }
     }

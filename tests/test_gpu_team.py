@@ -89,6 +89,60 @@ def test_sharded_build_contract_fiedler_matches_single_rank(world):
         assert np.max(np.abs(maps - maps_single)) <= 1e-10
 
 
+@pytest.mark.parametrize(("world", "n", "kind"), [(2, 4608, "branch"), (4, 6000, "depth"), (3, 5000, "planted")])
+def test_row_partitioned_job_streams_the_image_of_its_rows(world, n, kind, monkeypatch):
+    """Round 6: the mixed-precision loop (single-precision image of W for the search directions, S X / S P
+    renewed and the result confirmed through W) in the row-partitioned layout north_star names -- every rank
+    keeps the image of ITS rows, k_symm streams it.  The embedding of 2 / 3 / 4 in-process ranks stays within
+    1e-10 of one device AND of scikit-learn (the reference's own call, scs.py:235-252), every rank ran on the
+    image, all ranks hold the same bits."""
+    from oracle import scs_oracle as so
+
+    monkeypatch.delenv("SCS_LOWP", raising=False)
+    if kind == "planted":
+        tables = synthetic.make_tables(n, n, 12, "branch", random_weights=True, planted_spr=int(np.ceil(0.02 * n)))
+    else:
+        tables = synthetic.make_tables(n, n, 20, kind, random_weights=(kind == "branch"))
+    v0 = np.random.RandomState(1).uniform(-1, 1, n)
+    with Device(0) as dev:
+        dtab = dev.upload(tables)
+        g = dtab.build()
+        w = g.download()
+        maps_single, stats_single = g.fiedler(v0)
+        g.free()
+        dtab.free()
+    assert stats_single["n_apply32"] > 0
+    splits = row_splits(n, world, None)
+    teams = LocalTeams(world)
+
+    def rank_work(team):
+        dtab = team.device.upload(tables)
+        g = dtab.build(splits[team.rank], splits[team.rank + 1], shared=True)
+        maps, stats = g.fiedler(v0)
+        again, stats2 = g.fiedler(v0)  # (the image is there already; the degrees are not gathered again)
+        g.free()
+        dtab.free()
+        return maps, stats, again, stats2
+
+    try:
+        out = teams.run(rank_work)
+    finally:
+        teams.close()
+    ref = to.sign_flip_columns(so.spectral_maps(w, np.random.RandomState(1)))
+    _, dd = to.normalized_operator(w)
+    rows = [splits[r + 1] - splits[r] for r in range(world)]
+    for r, (maps, stats, again, stats2) in enumerate(out):
+        assert stats["converged"] == 1 and stats["block"] == 4
+        assert stats["n_apply32"] > 0 and stats2["n_apply32"] > 0, stats
+        # per rank and launch: 4 bytes a cell of its rows, half of what the double-precision launch streams
+        assert stats["apply32_bytes"] < 0.55 * stats["apply_bytes"]
+        assert abs(stats["apply32_bytes"] - (4.0 * rows[r] * n + 8.0 * n * 4 + 8.0 * rows[r] * 4)) <= 1.0
+        assert np.array_equal(maps, out[0][0]) and np.array_equal(again, maps)
+        assert float(np.max(np.abs((maps[:, 1] - maps_single[:, 1]) * dd))) <= 1e-10
+        assert float(np.max(np.abs(maps[:, 1] - ref[:, 1]))) <= 1e-10
+        assert float(np.max(np.abs((maps[:, 1] - ref[:, 1]) * dd))) <= 1e-10
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_bipartition_through_a_team_equals_single_device(world):
     tables, _, _ = _twin_tables(500, 12, 470, 90, strategy="depth")
