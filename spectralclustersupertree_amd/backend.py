@@ -12,6 +12,7 @@ import os
 
 import numpy as np
 
+from spectralclustersupertree_amd import _env
 from spectralclustersupertree_amd import _native as nv
 from spectralclustersupertree_amd.flatten import TreeTables
 
@@ -22,7 +23,7 @@ DEFAULT_MAX_ITER = 2000
 def _resident_solve() -> bool:
     """SCS_RESIDENT_SOLVE=0 (diagnostic): small nodes pack their tables on the host even when the
     tables are resident on the device."""
-    return bool(int(os.environ.get("SCS_RESIDENT_SOLVE", "1") or 0))
+    return bool(int(_env.probe("SCS_RESIDENT_SOLVE", "1")))
 
 
 class Device:
@@ -115,7 +116,7 @@ class Device:
     # -- batched small nodes --------------------------------------------------
     # largest node of the batched path (SMALL_MAXS of libscs_hip: two-sided Jacobi in LDS up to 64
     # vertices, one-sided up to 128 -- SURVEY.md 8f rank 3).  SCS_SMALL_MAX_TAXA moves the limit down.
-    SMALL_MAX_TAXA = max(2, min(128, int(os.environ.get("SCS_SMALL_MAX_TAXA", "128") or 128)))
+    SMALL_MAX_TAXA = max(2, min(128, int(_env.probe("SCS_SMALL_MAX_TAXA", "128"))))
 
     def small_solve(self, nodes, want_w: bool = False):
         """K small recursion nodes in one launch (``scs_small_solve``; reference: scs.py:110-134
@@ -444,7 +445,7 @@ class SmallTicket:
             nv.check(self.dev._lib.scs_small_solve_end(self.dev._ctx, ticket, nv.dptr(maps), nv.dptr(lam),
                                                        nv.dptr(w) if want_w else None))
             redo = {}
-            if os.environ.get("SCS_DEBUG_SMALL_FAIL"):  # test hook: pretend the one-sided Jacobi gave up
+            if _env.probe("SCS_DEBUG_SMALL_FAIL", ""):  # test hook: pretend the one-sided Jacobi gave up
                 lam[n_groups > 64] = np.nan
             if not np.all(np.isfinite(lam)):
                 # the one-sided Jacobi of a node of more than 64 vertices ran out of sweeps (NaN

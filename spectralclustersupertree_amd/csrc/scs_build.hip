@@ -564,7 +564,7 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
     if (ctx) {
         if (g->d_w32) {
             std::lock_guard<std::mutex> lock(ctx->cache_mu);
-            if (getenv("SCS_TRACE_SOLVES") && atoi(getenv("SCS_TRACE_SOLVES")) && ctx->w32_cache)
+            if (scs_dbg("SCS_TRACE_SOLVES") && atoi(scs_dbg("SCS_TRACE_SOLVES")) && ctx->w32_cache)
                 fprintf(stderr, "[image] hipFree of %.2f GB\n",
                         std::min(g->w32_bytes, ctx->w32_cache_bytes) / 1073741824.0);
             if (!ctx->w32_cache || g->w32_bytes > ctx->w32_cache_bytes) {
@@ -677,7 +677,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     SCS_REQUIRE((flags & (SCS_BUILD_SHARED | SCS_BUILD_UPPER)) != (SCS_BUILD_SHARED | SCS_BUILD_UPPER),
                 "scs_pcg_build: SCS_BUILD_SHARED and SCS_BUILD_UPPER exclude each other");
     const bool monotone = (flags & SCS_BUILD_MONOTONE) != 0 &&
-                          !(getenv("SCS_NO_MONOTONE") && atoi(getenv("SCS_NO_MONOTONE")));
+                          !(scs_dbg("SCS_NO_MONOTONE") && atoi(scs_dbg("SCS_NO_MONOTONE")));
     const int n = tb->n_taxa;
     SCS_REQUIRE(row_begin >= 0 && row_begin < row_end && row_end <= n,
                 "scs_pcg_build: bad row range [%d, %d) for %d taxa", row_begin, row_end, n);
@@ -749,7 +749,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // and every rank's share is ordered for its own XCDs (all ranks compute all shares, so
     // entry world * k + r of the list is still rank r's k-th tile).
     {
-        const bool per_xcd = !(getenv("SCS_TILE_ORDER") && atoi(getenv("SCS_TILE_ORDER")) == 0);
+        const bool per_xcd = !(scs_dbg("SCS_TILE_ORDER") && atoi(scs_dbg("SCS_TILE_ORDER")) == 0);
         auto xcd_reorder = [](std::vector<int2> &v) {
             if (v.size() <= 8) return;
             std::vector<int2> per[8];
@@ -780,7 +780,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     size_t chunk_doubles = 0;
     // the exchange of a shared build: point to point by default, one all-gather on request
     const bool exchange_allgather =
-        getenv("SCS_EXCHANGE") && std::string(getenv("SCS_EXCHANGE")) == "allgather";
+        scs_dbg("SCS_EXCHANGE") && std::string(scs_dbg("SCS_EXCHANGE")) == "allgather";
     if (shared) {
         all_tiles.swap(tiles);
         for (size_t i = rank; i < all_tiles.size(); i += world) tiles.push_back(all_tiles[i]);
@@ -807,7 +807,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // 3.1 ms = 0.056 us per tile and tree against 1.9 us per tree for the producer / consumer walk:
     // up to 24 tiles.
     bool tree_par = sym && !scatter && !tiles.empty() && tiles.size() <= 24 && tb->n_trees >= 128;
-    if (const char *e = getenv("SCS_TREE_PARALLEL")) tree_par = sym && !scatter && !tiles.empty() && atoi(e) != 0;
+    if (const char *e = scs_dbg("SCS_TREE_PARALLEL")) tree_par = sym && !scatter && !tiles.empty() && atoi(e) != 0;
     const size_t cells_per_tree = tiles.size() * (size_t)SCS_TR * cols_per_tile * 8;
 
     // ---- producer / consumer workgroups (scs_mono_wide.h): two tiles of ONE row block per workgroup,
@@ -822,18 +822,18 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // 1 000 taxa x 5 000 trees 11.1 -> 9.5 ms, 3 000 x 5 000 15.5 -> 11.2, 3 000 x 300 1.03 -> 0.78;
     // up to 24 tiles the tree-parallel build below is faster still when the trees are many.)
     // (diagnostic switches are read on every call: tests and A/B tools set them in-process)
-    const size_t wide_min_tiles = getenv("SCS_WIDE_MIN_TILES") ? (size_t)atoi(getenv("SCS_WIDE_MIN_TILES")) : 13;
+    const size_t wide_min_tiles = scs_dbg("SCS_WIDE_MIN_TILES") ? (size_t)atoi(scs_dbg("SCS_WIDE_MIN_TILES")) : 13;
     // Partial-coverage forests: when an average tree holds less than 1 / 64 of a tile's 64 + 256 rows
     // and columns' worth of the taxa -- less than about 1.5 % of them -- most (tile, tree) steps add
     // +0.0 everywhere; every tile then walks its own list of trees (k_tile_lists; the 4-wave kernel:
     // its step is the cheapest to skip).  SCS_TILE_LISTS=0 / 1 force either way.
     bool listed = monotone && !scatter && !tiles.empty() && tb->n_trees > 0 &&
                   (double)tb->n_leaves / ((double)tb->n_trees * std::max(n, 1)) < 1.0 / 64.0;
-    if (const char *e = getenv("SCS_TILE_LISTS")) listed = monotone && !scatter && !tiles.empty() && atoi(e) != 0;
+    if (const char *e = scs_dbg("SCS_TILE_LISTS")) listed = monotone && !scatter && !tiles.empty() && atoi(e) != 0;
     if (listed) tree_par = false;
     int wide_mode = (monotone && !scatter && !tree_par && !listed && tiles.size() >= wide_min_tiles) ? 3 : 0;
     bool wide_forced = false;  // an explicit SCS_WIDE=1 also lifts the trees-per-batch gate below
-    if (const char *e = getenv("SCS_WIDE")) {
+    if (const char *e = scs_dbg("SCS_WIDE")) {
         wide_mode = (monotone && !scatter && !tiles.empty() && atoi(e)) ? 3 : 0;
         wide_forced = wide_mode != 0;
         if (wide_mode) listed = false;
@@ -891,7 +891,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // slower -- 50 000 leaves: 785 ms instead of 697 ms at any stream priority: the
         // preparation kernels take CU slots a few at a time, the tiles fall out of step and the
         // new tables push the current ones out of the caches.  The batches stay sequential.)
-        const int batch_trees_env = getenv("SCS_BATCH_TREES") ? atoi(getenv("SCS_BATCH_TREES")) : 0;
+        const int batch_trees_env = scs_dbg("SCS_BATCH_TREES") ? atoi(scs_dbg("SCS_BATCH_TREES")) : 0;
         int max_batch_trees = 256;
         {
             const double avg_leaves = (double)tb->n_leaves / std::max(M, 1);
@@ -985,7 +985,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // prologue, its tile stores and the thin last round of its launch, and below ~100 trees
         // that costs more than the shorter steps save (measured at 10 000 leaves: 64 + 218 + 218
         // trees 6.93 ms either way, 218 + 218 with the 4-wave kernel in front 6.5).
-        const int wide_min_trees = wide_forced ? 1 : (getenv("SCS_WIDE_MIN_TREES") ? atoi(getenv("SCS_WIDE_MIN_TREES")) : 96);
+        const int wide_min_trees = wide_forced ? 1 : (scs_dbg("SCS_WIDE_MIN_TREES") ? atoi(scs_dbg("SCS_WIDE_MIN_TREES")) : 96);
         // (with many rounds of workgroups per launch -- 50 000 leaves: 150 -- the prologue and the thin
         // last round are noise and the short first batch is the producer / consumer kernel's too:
         // 64 trees 25 -> 18 ms there)
@@ -1072,12 +1072,12 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             mp.split_tiles = 0;
             mp.lists = nullptr;
             mp.list_cnt = nullptr;
-            const bool stamp = getenv("SCS_ACC_STAMP") && atoi(getenv("SCS_ACC_STAMP"));
+            const bool stamp = scs_dbg("SCS_ACC_STAMP") && atoi(scs_dbg("SCS_ACC_STAMP"));
             if (wide_b) {
                 wide_params wp;
                 wp.m = mp;
                 wp.groups = (const int4 *)d_groups.p;
-                const int spec_prio = getenv("SCS_SPEC_PRIO") ? atoi(getenv("SCS_SPEC_PRIO")) : 2;
+                const int spec_prio = scs_dbg("SCS_SPEC_PRIO") ? atoi(scs_dbg("SCS_SPEC_PRIO")) : 2;
                 wp.producer_prio = spec_prio;
                 const unsigned ng = (unsigned)groups.size();
                 dev_buf d_st8;
@@ -1453,7 +1453,7 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
             ctx->w32_cache_bytes = 0;
         } else if (hipMalloc((void **)&g->d_w32, need) == hipSuccess) {
             g->w32_bytes = need;
-            if (getenv("SCS_TRACE_SOLVES") && atoi(getenv("SCS_TRACE_SOLVES")))
+            if (scs_dbg("SCS_TRACE_SOLVES") && atoi(scs_dbg("SCS_TRACE_SOLVES")))
                 fprintf(stderr, "[image] hipMalloc of %.2f GB\n", need / 1073741824.0);
         } else {
             (void)hipGetLastError();

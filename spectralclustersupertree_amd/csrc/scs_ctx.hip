@@ -1066,7 +1066,7 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
             // 1 / (1 + L / 2200), ~90 trees at 10 000 x 500 -- was measured with SCS_FIRST_TREES:
             // 64 / 80 / 96 / 112 trees first give 17.17 / 17.07 / 17.11 / 17.16 ms a step: within the
             // run-to-run spread, the rule stays.)
-            const int first_env = getenv("SCS_FIRST_TREES") ? atoi(getenv("SCS_FIRST_TREES")) : 0;
+            const int first_env = scs_dbg("SCS_FIRST_TREES") ? atoi(scs_dbg("SCS_FIRST_TREES")) : 0;
             first = std::min(per, first_env > 0 ? first_env : 64);
             chunk = per;
         }

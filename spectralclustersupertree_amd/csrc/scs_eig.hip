@@ -1672,7 +1672,7 @@ extern "C" int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tb, int32_t
     m->stack_total = soff[M];
     // chunks per direction: pieces of a few hundred leaves, at most 16 (SCS_MF_CHUNKS overrides)
     m->chunks = std::max(1, std::min(16, tb->max_leaves / 256));
-    if (getenv("SCS_MF_CHUNKS")) m->chunks = std::max(1, std::min(64, atoi(getenv("SCS_MF_CHUNKS"))));
+    if (scs_dbg("SCS_MF_CHUNKS")) m->chunks = std::max(1, std::min(64, atoi(scs_dbg("SCS_MF_CHUNKS"))));
     const size_t strips = (size_t)2 * max_block * (size_t)m->chunks * (size_t)m->stack_total;
     const size_t slots = (size_t)2 * max_block * (size_t)m->chunks * (size_t)M;
     const size_t slab_bytes = (size_t)2 * M * (size_t)n * max_block * 8;
@@ -1926,7 +1926,7 @@ struct solver {
                                                                       tile_list, tri_pdir.d(), ptr_eff)
 #define TRI(B_, CT_, RPW_, D_) TRI_T(B_, CT_, RPW_, D_, double, w_eff)
         const int2 *tile_list = (const int2 *)tri_tiles.p + (use32 ? 2 * tri_ntiles : 0) + (tri_backwards ? ntiles : 0);
-        static const bool no_flip = getenv("SCS_TRI_NO_FLIP") && atoi(getenv("SCS_TRI_NO_FLIP"));
+        static const bool no_flip = scs_dbg("SCS_TRI_NO_FLIP") && atoi(scs_dbg("SCS_TRI_NO_FLIP"));
         tri_backwards = !no_flip && !tri_backwards;
         if (use32) {
             // (b = 4, 128 x 512 tiles: 8 % faster than 256-column ones, tools/symm_tri_bench.hip)
@@ -2072,10 +2072,10 @@ struct solver {
         // W is symmetric: with all of it on this device only the tiles on and above the
         // diagonal need streaming (small matrices keep k_symm, whose column segments fill the
         // chip better).  SCS_NO_TRI=1 keeps the full stream.
-        static const bool no_tri = getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"));
+        static const bool no_tri = scs_dbg("SCS_NO_TRI") && atoi(scs_dbg("SCS_NO_TRI"));
         tri = !g->mf && !no_tri && world == 1 && rows == n && g->row_begin == 0 && n >= 4096 && (b == 4 || b == 8);
         if (tri) {
-            if (getenv("SCS_TRI_CT")) tri_ct = atoi(getenv("SCS_TRI_CT"));
+            if (scs_dbg("SCS_TRI_CT")) tri_ct = atoi(scs_dbg("SCS_TRI_CT"));
             const int tw = tri_ct * 128;
             const int n_rb = (n + TRI_TH - 1) / TRI_TH;
             tri_nct = (n + tw - 1) / tw;
@@ -2168,7 +2168,7 @@ struct solver {
 
     // ---- fused iteration (scs_panel.h), block widths 4 and 8 ----
     static int panel_cap() {
-        static const int cap = getenv("SCS_PANEL_BLOCKS") ? std::max(1, std::min(512, atoi(getenv("SCS_PANEL_BLOCKS")))) : PANEL_BLOCKS_MAX;
+        static const int cap = scs_dbg("SCS_PANEL_BLOCKS") ? std::max(1, std::min(512, atoi(scs_dbg("SCS_PANEL_BLOCKS")))) : PANEL_BLOCKS_MAX;
         return cap;
     }
     int panel_blocks16() const { return std::max(1, std::min(panel_cap(), ((n + 15) / 16 + 3) / 4)); }
@@ -2447,7 +2447,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // against 3.0 ms for LOBPCG, 4.5 against 3.5 ms at 120 -- the crossover is near 100.
     // SCS_DENSE_MAX=n moves the limit (<= 128; 64 switches the path off); an asked-for block
     // width keeps the iterative path too.
-    static const int dense_max = getenv("SCS_DENSE_MAX") ? std::min(atoi(getenv("SCS_DENSE_MAX")), DENSE2_MAX) : 96;
+    static const int dense_max = scs_dbg("SCS_DENSE_MAX") ? std::min(atoi(scs_dbg("SCS_DENSE_MAX")), DENSE2_MAX) : 96;
     if (n > MAXS && n <= dense_max && block == 0 && ctx->comm.world == 1 && !g->upper) {
         SCS_TRY(fiedler_dense_onesided(ctx, g, maps_out, st));
         SCS_HIP_CHECK(hipEventRecord(ev_b, s));
@@ -2477,12 +2477,12 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // stays with the image.  The confirmation at the end always applies W, and a solve it sends back into the loop
     // continues without the image.
     const int lowp_mode = getenv("SCS_LOWP") ? atoi(getenv("SCS_LOWP")) : 2;
-    const double lowp_tol = getenv("SCS_LOWP_TOL") ? atof(getenv("SCS_LOWP_TOL")) : 1e-8;
-    const double lowp_tol2 = getenv("SCS_LOWP_TOL2") ? atof(getenv("SCS_LOWP_TOL2")) : 0.0;
+    const double lowp_tol = scs_dbg("SCS_LOWP_TOL") ? atof(scs_dbg("SCS_LOWP_TOL")) : 1e-8;
+    const double lowp_tol2 = scs_dbg("SCS_LOWP_TOL2") ? atof(scs_dbg("SCS_LOWP_TOL2")) : 0.0;
     // (only the default loop hands its Rayleigh-Ritz solve the one-sided entries: small_rr_body)
-    const bool loop_fused = !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP"))) &&
-                            !(getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"))) &&
-                            !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
+    const bool loop_fused = !(scs_dbg("SCS_LEGACY_LOOP") && atoi(scs_dbg("SCS_LEGACY_LOOP"))) &&
+                            !(scs_dbg("SCS_SPLIT_SMALL") && atoi(scs_dbg("SCS_SPLIT_SMALL"))) &&
+                            !(scs_dbg("SCS_FOLD_PASS2") && !atoi(scs_dbg("SCS_FOLD_PASS2")));
     // (an image above SCS_LOWP_MAX_BYTES, default 16 GiB -- about 65 000 vertices -- is not made: what it
     // saves a solve of that size, some 80 ms, is less than what an allocation of tens of GB can cost)
     const double lowp_max_bytes = getenv("SCS_LOWP_MAX_BYTES") ? atof(getenv("SCS_LOWP_MAX_BYTES")) : 16.0 * (1u << 30);
@@ -2490,8 +2490,8 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // the first real multi-GPU run streams per rank what the one-GPU run streams, not twice that)
     const bool image_rows = ctx->comm.world > 1 && !g->upper;
     const bool image_one = ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && g->row_end == n &&
-                           !(getenv("SCS_NO_TRI") && atoi(getenv("SCS_NO_TRI"))) &&
-                           !(getenv("SCS_TRI_CT") && atoi(getenv("SCS_TRI_CT")) != 2);
+                           !(scs_dbg("SCS_NO_TRI") && atoi(scs_dbg("SCS_NO_TRI"))) &&
+                           !(scs_dbg("SCS_TRI_CT") && atoi(scs_dbg("SCS_TRI_CT")) != 2);
     const bool image_ok = !g->mf && lowp_mode > 0 && n >= 4096 && loop_fused && (image_one || image_rows) &&
                           (g->have_w32 || 4.0 * (double)(g->row_end - g->row_begin) * (double)g->ld <= lowp_max_bytes);
     // default width: 4 while the panel kernels and the 3b x 3b Rayleigh-Ritz solve weigh
@@ -2528,7 +2528,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     sv.b = b;
     sv.rows = g->row_end - g->row_begin;
     sv.world = ctx->comm.world;
-    sv.use_mfma = !(getenv("SCS_NO_MFMA") && atoi(getenv("SCS_NO_MFMA")));
+    sv.use_mfma = !(scs_dbg("SCS_NO_MFMA") && atoi(scs_dbg("SCS_NO_MFMA")));
     sv.gram_blocks = 256;
     SCS_TRY(gather_full_rows(ctx, g, sv.splits));
     int max_rows = 0;
@@ -2637,7 +2637,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // Fused iteration (scs_panel.h) for the default block widths; SCS_LEGACY_LOOP=1 keeps
     // the one-kernel-per-step formulation (also used for widths 12 and 16).
     const bool fused = (b == 4 || b == 8) &&
-                       !(getenv("SCS_LEGACY_LOOP") && atoi(getenv("SCS_LEGACY_LOOP")));
+                       !(scs_dbg("SCS_LEGACY_LOOP") && atoi(scs_dbg("SCS_LEGACY_LOOP")));
     if (fused) {
         if (!ctx->h_report) {
             SCS_HIP_CHECK(hipHostMalloc((void **)&ctx->h_report, 64 * sizeof(double),
@@ -2649,10 +2649,10 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     }
     const double *uvec = constrained ? sv.u.d() : nullptr;
     // SCS_SPLIT_SMALL=1: the small solves as one-workgroup kernels of their own (the round-3 loop)
-    const bool split_small = getenv("SCS_SPLIT_SMALL") && atoi(getenv("SCS_SPLIT_SMALL"));
-    sv.fold_pass2 = fused && !split_small && !(getenv("SCS_FOLD_PASS2") && !atoi(getenv("SCS_FOLD_PASS2")));
+    const bool split_small = scs_dbg("SCS_SPLIT_SMALL") && atoi(scs_dbg("SCS_SPLIT_SMALL"));
+    sv.fold_pass2 = fused && !split_small && !(scs_dbg("SCS_FOLD_PASS2") && !atoi(scs_dbg("SCS_FOLD_PASS2")));
     sv.overlap_pass1 = sv.fold_pass2 && sv.tri && !sv.part_mode && sv.world == 1 &&
-                       !(getenv("SCS_OVERLAP_PASS1") && !atoi(getenv("SCS_OVERLAP_PASS1")));
+                       !(scs_dbg("SCS_OVERLAP_PASS1") && !atoi(scs_dbg("SCS_OVERLAP_PASS1")));
     if (sv.overlap_pass1) SCS_TRY(sv.coef1.alloc((size_t)(3 * 8 + 4) * 8 * 8));
     sv.fold_u = uvec;
     sv.fold_mask_r = MASK + 2 * b;
@@ -2735,7 +2735,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         double worst = 0.0;
         for (int j = 0; j < want; ++j) worst = std::max(worst, std::sqrt(h_rn[j]));
         for (int j = 0; j < want; ++j) final_res[constrained ? 1 : j] = std::sqrt(h_rn[j]);
-        static const bool trace_res = getenv("SCS_TRACE_RESIDUAL") && atoi(getenv("SCS_TRACE_RESIDUAL"));
+        static const bool trace_res = scs_dbg("SCS_TRACE_RESIDUAL") && atoi(scs_dbg("SCS_TRACE_RESIDUAL"));
         if (trace_res) fprintf(stderr, "[lobpcg] it %3d  residual %.3e  theta %.12g %.12g\n", iter, worst, h_th[0], h_th[1]);
         if (!(worst == worst)) {
             scs_set_error("scs_fiedler: NaN residual at iteration %d", iter);
@@ -2918,7 +2918,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
         // bytes one all-gather delivers to this rank: `world` chunks of `chunk` doubles
         st->allgather_bytes = sv.world > 1 ? 8.0 * (double)sv.chunk * sv.world : 0.0;
     }
-    if (n >= 4096 && getenv("SCS_TRACE_SOLVES") && atoi(getenv("SCS_TRACE_SOLVES")))
+    if (n >= 4096 && scs_dbg("SCS_TRACE_SOLVES") && atoi(scs_dbg("SCS_TRACE_SOLVES")))
         fprintf(stderr, "[solve] V %d block %d iterations %d applies %d image %d renewals %d refreshes %d solve_ms %.3f "
                         "wall_ms %.3f residual %.3e gap %.3e\n", n, b, iter, sv.n_apply, sv.n_apply32, st->lowp_renewals,
                 policy.confirmations, st->solve_ms,
@@ -3546,7 +3546,7 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     SCS_REQUIRE(n_nodes >= 1, "scs_small_solve: need at least one node");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     // (a stream of its own: scs_internal.h; SCS_SMALL_STREAM=0 keeps the batch on the main stream)
-    const bool own_stream = !(getenv("SCS_SMALL_STREAM") && !atoi(getenv("SCS_SMALL_STREAM")));
+    const bool own_stream = !(scs_dbg("SCS_SMALL_STREAM") && !atoi(scs_dbg("SCS_SMALL_STREAM")));
     if (own_stream && !ctx->small_stream)
         SCS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->small_stream, hipStreamNonBlocking));
     hipStream_t s = own_stream ? ctx->small_stream : ctx->stream;

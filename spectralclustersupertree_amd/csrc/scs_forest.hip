@@ -1387,7 +1387,7 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         return SCS_OK;
     };
     // Big trees: every step per NODE (scans, walks); small ones: a thread per tree on an LDS copy.
-    const int par_min = getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES") ? atoi(getenv("SCS_FOREST_PARALLEL_MIN_TREE_NODES")) : 32;
+    const int par_min = scs_dbg("SCS_FOREST_PARALLEL_MIN_TREE_NODES") ? atoi(scs_dbg("SCS_FOREST_PARALLEL_MIN_TREE_NODES")) : 32;
     const bool parallel = !force_serial && N < ((int64_t)1 << 31) - 8 && (double)N / M > (double)par_min;
     int32_t *c_tree_id = nullptr;
     if (parallel) {

@@ -40,6 +40,23 @@ void scs_set_error(const char *fmt, ...);
         if (rc_ != SCS_OK) return rc_;                                                       \
     } while (0)
 
+// ---- environment switches ---------------------------------------------------
+// Two kinds (DESIGN.md section 12 has the table).  SUPPORTED switches select a documented behaviour and are read
+// with getenv where they apply (SCS_LOWP, SCS_LOWP_MAX_BYTES, SCS_WS_LIMIT_MB, SCS_HOST_THREADS here; SCS_DEVICE,
+// SCS_TEAM, SCS_MULTI_MODE, SCS_SHARD_MIN_VERTICES, SCS_CHILD_RNG, SCS_AHEAD, SCS_AHEAD_WORKERS,
+// SCS_SPEC_MAX_TAXA, SCS_KMEANS, SCS_MALLOC_TUNE, SCS_RDZV_PORT in the Python host).  PROBE switches -- the A/B
+// paths of measurements that are committed under profiles/, thresholds, traces -- exist for tools/ and tests/ only
+// and are read through scs_dbg, which answers "unset" unless SCS_DEBUG=1 was in the environment when the
+// library was loaded: in a production process no probe path can be reached, whatever else is exported.
+#include <cstdlib>
+static inline const char *scs_dbg(const char *name) {
+    static const bool on = [] {
+        const char *e = getenv("SCS_DEBUG");
+        return e && atoi(e) != 0;
+    }();
+    return on ? getenv(name) : nullptr;
+}
+
 // ---- tile geometry of the accumulate kernel --------------------------------
 constexpr int SCS_TR = 64;    // rows of W per tile (one block record)
 constexpr int SCS_TCW = 256;  // threads per workgroup = columns per column group

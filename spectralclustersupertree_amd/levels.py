@@ -33,6 +33,7 @@ import time
 
 import numpy as np
 
+from spectralclustersupertree_amd import _env
 from spectralclustersupertree_amd import _native as nv
 from spectralclustersupertree_amd import flatten as fl
 from spectralclustersupertree_amd.tree import TreeNode, connect_trees, tip_names_to_tree
@@ -60,7 +61,7 @@ def max_taxa() -> int:
 
 def min_nodes() -> int:
     """Smallest forest (tree nodes) worth the engine's launches (SCS_SPEC_MIN_NODES)."""
-    return int(os.environ.get("SCS_SPEC_MIN_NODES", "4000") or 0)
+    return int(_env.probe("SCS_SPEC_MIN_NODES", "4000"))
 
 
 class SpecRoot:
@@ -75,7 +76,7 @@ def wanted(sub, n_component: int) -> bool:
     cap = max_taxa()
     if cap <= 0 or n_component <= 2 or sub.n_trees < 2:
         return False
-    if n_component > cap and not int(os.environ.get("SCS_SPEC_ABOVE_CAP", "1") or 0):
+    if n_component > cap and not int(_env.probe("SCS_SPEC_ABOVE_CAP", "1")):
         return False  # (diagnostic: nodes above the cap on the node-by-node path, as in the first half of round 6)
     n_nodes = sub.n_nodes if isinstance(sub, ResidentArrays) else len(sub.parent)
     return n_nodes >= min_nodes()
@@ -382,7 +383,7 @@ class Engine:
         # (measured at 20 000 taxa / 5 000 trees, profiles/r06_levels_votes.txt: 1 / 3 / 5 votes -> 19 510 / 14 200 /
         # 13 346 nodes computed for 12 400 needed, 178 / 76 / 55 bets lost -- and 6.1 / 6.7 / 6.9 s: what is no longer
         # computed in vain is computed later, one deferred subtree after the other, at the walk's pace.  Default: one.)
-        votes = max(1, int(os.environ.get("SCS_SPEC_VOTES", "1") or 1))
+        votes = max(1, int(_env.probe("SCS_SPEC_VOTES", "1")))
         runs = []
         for _ in range(votes):
             lab = kmeans2.provisional_labels(lev.maps, v_ptr, self.prov_rs)
@@ -404,7 +405,7 @@ class Engine:
         differ = np.zeros(len(nodes), dtype=bool)
         for i in range(1, votes):
             differ |= np.add.reduceat((canon[0] != canon[i]).astype(np.int32), starts) != 0
-        min_defer = int(os.environ.get("SCS_SPEC_DEFER_MIN", "8") or 0)
+        min_defer = int(_env.probe("SCS_SPEC_DEFER_MIN", "8"))
         defer[nodes[differ & (sizes[nodes] >= min_defer)]] = True
         return runs[0], defer
 
@@ -468,7 +469,7 @@ class Engine:
     def _solve_small(self, lev, small, m, relabel, nid, gs_patch) -> None:
         """``scs_small_solve_begin_level`` over the level's small spectral nodes, in batches bounded by the
         addend scratch (trees x cells per node)."""
-        cap = int(float(os.environ.get("SCS_SPEC_BATCH_GB", "8")) * (1 << 30))
+        cap = int(float(_env.probe("SCS_SPEC_BATCH_GB", "8")) * (1 << 30))
         cost = lev.n_pres[small].astype(np.int64) ** 2 * ((m[small] + 1) & ~1) * 8
         at = 0
         while at < len(small):

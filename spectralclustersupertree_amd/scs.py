@@ -32,6 +32,7 @@ from collections.abc import Sequence
 
 import numpy as np
 
+from spectralclustersupertree_amd import _env
 from spectralclustersupertree_amd import flatten as fl
 from spectralclustersupertree_amd.backend import DEFAULT_MAX_ITER, DEFAULT_TOL, Device
 from spectralclustersupertree_amd.treearrays import TreeArrays
@@ -353,7 +354,7 @@ def _small_path() -> bool:
     (tables upload, build, contract, solve) instead of ``scs_small_solve``."""
     import os
 
-    return not int(os.environ.get("SCS_NO_SMALL_PATH", "0") or 0)
+    return not int(_env.probe("SCS_NO_SMALL_PATH", "0"))
 
 
 def prepare_node(tables: fl.TreeTables, contract_edges: bool):
@@ -509,7 +510,7 @@ def _begin_small() -> bool:
     needed it).  SCS_BEGIN_SMALL=0 (diagnostic): one waited-for batch per node when no worker runs."""
     import os
 
-    return bool(int(os.environ.get("SCS_BEGIN_SMALL", "1") or 0))
+    return bool(int(_env.probe("SCS_BEGIN_SMALL", "1")))
 
 
 def _ahead_enabled() -> bool:

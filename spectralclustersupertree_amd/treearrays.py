@@ -363,18 +363,18 @@ def resident_split_wanted(forest, n_parts: int) -> bool:
     mark bit per part), and enough tree nodes that three launches and two round trips are
     cheaper than the host's sweep (SCS_DEVICE_SPLIT=0 switches the path off,
     SCS_DEVICE_SPLIT_MIN_NODES moves the threshold)."""
-    import os
+    from spectralclustersupertree_amd import _env
 
-    if not int(os.environ.get("SCS_DEVICE_SPLIT", "1") or 0):
+    if not int(_env.probe("SCS_DEVICE_SPLIT", "1")):
         return False
     if n_parts > 8 or forest.n_trees == 0:
         return False
     n_nodes = forest.n_nodes if isinstance(forest, ResidentArrays) else len(forest.parent)
-    if n_nodes < int(os.environ.get("SCS_DEVICE_SPLIT_MIN_NODES", "20000") or 0):
+    if n_nodes < int(_env.probe("SCS_DEVICE_SPLIT_MIN_NODES", "20000")):
         return False
     # (small trees: one thread per tree on an LDS copy; big ones: every step per node -- scs_forest.hip;
     # SCS_DEVICE_SPLIT_MAX_TREE_NODES keeps forests of bigger trees on the host: measurements)
-    cap = int(os.environ.get("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "0") or 0)
+    cap = int(_env.probe("SCS_DEVICE_SPLIT_MAX_TREE_NODES", "0"))
     return cap <= 0 or n_nodes <= forest.n_trees * cap
 
 

@@ -10,6 +10,13 @@ for p in (str(ROOT), str(ROOT / "tests")):
 
 sys.setrecursionlimit(10000)
 
+# The tests hold the product's A/B paths against each other (SCS_SPLIT_SMALL, SCS_TREE_PARALLEL, SCS_SPEC_VOTES,
+# ...): probe switches, which the libraries and the package only look at when SCS_DEBUG=1 was in the environment
+# at load time (csrc/scs_internal.h scs_dbg, spectralclustersupertree_amd/_env.py).  Set before anything loads.
+import os  # noqa: E402
+
+os.environ.setdefault("SCS_DEBUG", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

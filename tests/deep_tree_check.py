@@ -1,6 +1,9 @@
 """One-off check of the 64-bit key path on naturally deep trees (run on the GPU box):
 caterpillar trees with 70 000 leaves have LCA depths up to 69 998, which do not fit next to
 a 17-bit position in 32 bits."""
+import os as _os
+
+_os.environ.setdefault("SCS_DEBUG", "1")  # (the sweeps force probe paths: csrc/scs_internal.h scs_dbg)
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -4,6 +4,9 @@ and weights.  Prints a summary line; exits non-zero on any failure.
 
     python tests/fuzz_parity.py [--seconds 120] [--seed 0]
 """
+import os as _os
+
+_os.environ.setdefault("SCS_DEBUG", "1")  # (the sweeps force probe paths: csrc/scs_internal.h scs_dbg)
 import argparse, sys, time, warnings
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

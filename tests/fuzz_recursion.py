@@ -13,6 +13,9 @@ topology, the RandomState left in the same state.  Forests of a few trees tie ex
 clade are equivalent towards the rest); a tie must be PROVEN
 (tests/test_gpu_recursion.compare_with_oracle) to be followed.
 """
+import os as _os
+
+_os.environ.setdefault("SCS_DEBUG", "1")  # (the sweeps force probe paths: csrc/scs_internal.h scs_dbg)
 import argparse
 import sys
 import time

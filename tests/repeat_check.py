@@ -1,4 +1,7 @@
 """W must be the same bits on every build (and the oracle's): builds interleaved with solves."""
+import os as _os
+
+_os.environ.setdefault("SCS_DEBUG", "1")  # (the sweeps force probe paths: csrc/scs_internal.h scs_dbg)
 import sys
 
 import numpy as np

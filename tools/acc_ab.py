@@ -9,6 +9,8 @@ repetition -- sampled rows against the C oracle and the two matrices against eac
 """
 import json
 import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import sys
 from pathlib import Path
 

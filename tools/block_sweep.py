@@ -1,6 +1,9 @@
 """LOBPCG block width at a BASELINE.json size: iterations and time of scs_fiedler for b = 4, 8
 (and the automatic choice) on the same graph (run on the GPU box).
     python tools/block_sweep.py [taxa] [trees] [seed]"""
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import json, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $out/sq2 -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extra --no-parity > /dev/null 2> $out/sq2.err
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $out/sq3 -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline --no-extra --no-parity > /dev/null 2> $out/sq3.err
 echo "SQ passes done"
-SCS_ACC_STAMP=1 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-parity > /dev/null 2> $out/stamps.txt || true
+SCS_DEBUG=1 SCS_ACC_STAMP=1 python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra --no-parity > /dev/null 2> $out/stamps.txt || true
 python3 bench.py > $out/bench_default.json 2> $out/bench_default.err
 echo "default bench done"
 # configs[3] on one device and configs[2]'s shape under `bootstrap` (k_accumulate_gen): kernel times and traffic

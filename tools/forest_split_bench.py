@@ -1,6 +1,9 @@
 """Where the time of a device-side forest split goes (round 5): one parent forest, split again and
 again; Python-side wall time of the split call and of the tables download, per call.
     python tools/forest_split_bench.py [taxa] [trees] [reps]      (rocprofv3 --kernel-trace --stats for kernel times)"""
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import argparse
 import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import sys
 from pathlib import Path
 

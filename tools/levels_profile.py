@@ -5,6 +5,8 @@
 """
 import cProfile
 import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import pstats
 import sys
 import time

@@ -11,6 +11,10 @@ matrix-free pair to the dense one (eigenvalue, embedding column, unit-norm eigen
 """
 from __future__ import annotations
 
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
+
 import argparse
 import json
 import sys

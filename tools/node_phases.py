@@ -1,6 +1,9 @@
 """Where the wall time of a whole recursion goes, by phase, WITHOUT a profiler (perf_counter
 around the handful of calls a node makes; run on the GPU box).
     python tools/node_phases.py [taxa] [trees]"""
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import json, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -6,6 +6,9 @@ with the same device bipartition; prints one JSON line.
 
     python tools/recursion_bench.py [--taxa 2000] [--trees 50] [--leaves 1500] [--strategy branch]
 """
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import argparse, json, sys, time, warnings
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

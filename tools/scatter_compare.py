@@ -6,6 +6,9 @@
 One JSON line: build times of both formulations on the same tables, the largest relative
 difference of the two matrices, and the pair updates the scatter performed (each one two
 8-byte read-modify-writes at random addresses of W: SURVEY.md section 8d's 16 U bytes)."""
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import argparse, json, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

@@ -1,5 +1,8 @@
 """Latency of one batched small-node solve by node size: wall time of begin + end per call.
     python tools/small_solve_bench.py [trees] [reps] [sizes ...]        (rocprofv3 --kernel-trace + tools/trace_tail.py for the launches)"""
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))

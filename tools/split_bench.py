@@ -1,6 +1,9 @@
 """TreeArrays.split by phase on a deep-recursion-shaped forest (thousands of tiny trees), for a
 range of helper thread counts (run on the GPU box: its host cores are what the recursion runs on).
     python tools/split_bench.py [taxa] [trees]"""
+import os
+
+os.environ.setdefault("SCS_DEBUG", "1")  # (tools may use the probe switches: csrc/scs_internal.h scs_dbg)
 import ctypes as C, os, subprocess, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
