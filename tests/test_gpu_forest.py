@@ -220,3 +220,34 @@ def test_tables_of_a_larger_node_straight_from_the_resident_forest(dev, monkeypa
             assert np.array_equal(got[("1", False)], got[("0", True)])
     finally:
         other.close()
+
+
+def test_upload_refuses_malformed_arrays(dev):
+    """``scs_forest_upload`` checks the arrays where they arrive (round 6): every later kernel walks ``parent``
+    upwards and indexes by ``taxon`` without looking again -- a non-root without an earlier parent would walk out of
+    its tree or never stop (the node-parallel family only flagged it after the whole pipeline had run)."""
+    from spectralclustersupertree_amd import _native as nv
+    from spectralclustersupertree_amd.backend import DeviceForest
+
+    arrays = synthetic.tree_arrays(3, 40, 6)
+    good = (np.ascontiguousarray(arrays.node_off), arrays.parent.copy(), arrays.taxon.copy(), arrays.length.copy(),
+            arrays.support.copy(), arrays.weights.copy())
+    n_leaves = int(np.count_nonzero(arrays.taxon >= 0))
+
+    def upload(parent=None, taxon=None):
+        f = DeviceForest.upload(dev, arrays.n_taxa, good[0], good[1] if parent is None else parent,
+                                good[2] if taxon is None else taxon, good[3], good[4], good[5], n_leaves)
+        f.free()
+
+    upload()  # the arrays as they are: fine
+    for where, value in ((5, 5), (5, 7), (3, -1), (int(arrays.node_off[2]), 0)):
+        bad = good[1].copy()
+        bad[where] = value  # its own parent / a later node / a second root / a root with a parent
+        with pytest.raises(nv.ScsError) as err:
+            upload(parent=bad)
+        assert err.value.code == nv.EINVAL and "malformed" in str(err.value)
+    for value in (arrays.n_taxa, -2):
+        bad = good[2].copy()
+        bad[np.flatnonzero(bad >= 0)[0]] = value
+        with pytest.raises(nv.ScsError):
+            upload(taxon=bad)
