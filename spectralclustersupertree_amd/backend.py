@@ -410,9 +410,10 @@ class SmallTicket:
             if group_start is not None:
                 graph = graph.contract(group_start)
             last = None
-            for block, iters in ((4, DEFAULT_MAX_ITER), (8, 4 * DEFAULT_MAX_ITER)):
-                if graph.shape[0] <= 3 * block + 2:
-                    continue
+            # (a graph too small for an explicit block width -- a 65..128-taxon node may contract to a handful of
+            # vertices -- takes the library's default path: ADVICE r05)
+            widths = [(b, it) for b, it in ((4, DEFAULT_MAX_ITER), (8, 4 * DEFAULT_MAX_ITER)) if graph.shape[0] > 3 * b + 2]
+            for block, iters in widths or [(0, 4 * DEFAULT_MAX_ITER)]:
                 try:
                     maps, stats = graph.fiedler(None, block=block, max_iter=iters)
                     lam = np.array([stats["lambda"][0], stats["lambda"][1], stats["lambda_next"]])

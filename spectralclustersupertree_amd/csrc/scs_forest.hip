@@ -1476,8 +1476,17 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         while (tpb > 8 && (double)N / M * tpb > 0.85 * SPLIT_CAP) tpb >>= 1;
         p.tpb = tpb;
         const unsigned grid = (unsigned)((M + tpb - 1) / tpb);
-        SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_split_fill, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)SPLIT_FILL_LDS));
+        // (once per process: a recursion makes tens of thousands of splits; a part with less LDS per workgroup than
+        // the staging area needs refuses here, and the caller restricts on the host -- ADVICE r05)
+        SCS_REQUIRE((size_t)ctx->max_lds_bytes >= SPLIT_FILL_LDS,
+                    "scs_forest_split: the device offers %d bytes of LDS per workgroup, the staged split needs %zu",
+                    ctx->max_lds_bytes, SPLIT_FILL_LDS);
+        static bool fill_attr_set = false;
+        if (!fill_attr_set) {
+            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_split_fill, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)SPLIT_FILL_LDS));
+            fill_attr_set = true;
+        }
         k_split_count<<<grid, SPLIT_THREADS, 0, s>>>(p);
         SCS_TRY(split_scan());
         k_split_fill<<<grid, SPLIT_THREADS, SPLIT_FILL_LDS, s>>>(p);
