@@ -45,13 +45,13 @@ MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 # diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
 stats = {"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
          "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
-         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0}
+         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": []}
 
 
 def reset_stats() -> None:
     stats.update({"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
                   "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
-                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0})
+                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": []})
 
 
 def max_taxa() -> int:
@@ -509,6 +509,14 @@ class Engine:
         n, mono, gs = int(lev.n_pres[k]), self._monotone(lev), gs_patch.get(k)
 
         def job(dev):
+            t_job = time.perf_counter()
+            try:
+                return run(dev)
+            finally:
+                if n >= 4096:
+                    stats.setdefault("big_jobs", []).append((n, round(time.perf_counter() - t_job, 3)))
+
+        def run(dev):
             dtab = dev.upload_range(forest, t_lo, t_hi, lo, sz, rl, n, mono)
             try:
                 graph = dtab.build()

@@ -29,6 +29,8 @@ worst = 0.0
 fails = []
 while time.time() < t_end:
     n = int(rng.choice([rng.randint(3, 65), rng.randint(65, 400), rng.randint(400, 2500)]))
+    if rng.randint(0, 12) == 0:
+        n = int(rng.randint(4096, 9001))  # (round 6: the sizes where the mixed-precision loop is the default)
     m = int(rng.randint(1, 30))
     if n > 128 and n <= 900 and rng.randint(0, 4) == 0:
         # (forests of many trees on a few tiles: the tree-parallel build; above ~800 taxa the

@@ -373,7 +373,7 @@ def test_mixed_precision_loop_reaches_the_same_pair(dev, monkeypatch, n, m, weig
         maps, st = out[mode]
         assert st["converged"] == 1 and st["n_apply32"] > 0 and st["lowp_renewals"] <= 2, st
         assert abs(st["lambda"][1] - st0["lambda"][1]) <= 1e-13
-        assert float(np.max(np.abs(maps[:, 1] - maps0[:, 1]))) <= 1e-9 * scale
+        assert float(np.max(np.abs(maps[:, 1] - maps0[:, 1]))) <= 1e-10 * scale  # (the bar itself; vs scikit-learn: test_gpu_mixed_precision.py)
         assert st["iterations"] <= st0["iterations"] + 6, (st, st0)
     assert out["2"][1]["n_apply32"] >= out["1"][1]["n_apply32"]
     assert np.array_equal(again[0], out["2"][0])
@@ -402,7 +402,7 @@ def test_symmetric_schedule_with_isolated_vertices_converges(dev, monkeypatch, s
         assert st["converged"] == 1 and st["iterations"] < 150, st
     assert abs(s0["lambda"][1] - s2["lambda"][1]) <= 1e-13
     if abs(s0["lambda"][1] - s0["lambda_next"]) > 1e-6:
-        assert float(np.max(np.abs(m0[:, 1] - m2[:, 1]))) <= 1e-9 * float(np.max(np.abs(m0[:, 1])))
+        assert float(np.max(np.abs(m0[:, 1] - m2[:, 1]))) <= 1e-10 * float(np.max(np.abs(m0[:, 1])))
 
 
 @pytest.mark.parametrize("n", [3, 4, 8, 33, 64, 65, 80, 96])

@@ -100,6 +100,9 @@ def run(n: int, m: int, weights: bool, strategy: str = "branch", seed: int = 0, 
 
     engine = dict(levels.stats)
     engine["mismatch_sizes"] = sorted(engine["mismatch_sizes"], reverse=True)[:20]
+    big = engine.pop("big_jobs", [])
+    engine["solves_of_4096_vertices_and_more"] = {"count": len(big), "seconds": round(sum(t for _, t in big), 2),
+                                                  "largest": sorted(big, reverse=True)[:12]}
     for key in list(engine):
         if isinstance(engine[key], float):
             engine[key] = round(engine[key], 3)

@@ -8,7 +8,9 @@ coverage -- partial coverage gives isolated vertices, where both leading pairs a
 independent trees, per-tree weights or not) and solves it twice on the same graph: SCS_LOWP=0 (every
 operator application streams W) and the default (the loop's applications stream the single-precision image).
 Checked: both converge to the tolerance (the residual either reports is measured through W itself), the
-eigenvalue agrees to 1e-13, the embedding column to 1e-9 of its scale, the iteration count within +15 %.
+eigenvalue agrees to 1e-13, the embedding column to 1e-10 of its scale (two solves that each stop at a residual of 1e-13
+may differ by 4e-13 / gap where the gap is narrow), the iteration count within +15 %.  The comparison with scikit-learn itself is
+tests/test_gpu_mixed_precision.py.
 Prints one line per case and a summary; exit status 1 on any failure.
 """
 from __future__ import annotations
@@ -71,7 +73,7 @@ def main() -> int:
         gap = abs(s0["lambda"][1] - s0["lambda_next"])
         dmap = float(np.max(np.abs(m2[:, col] - m0[:, col]))) / scale
         ok = (s0["converged"] == s2["converged"] and abs(s0["lambda"][1] - s2["lambda"][1]) <= 1e-13 and
-              (gap < 1e-9 or dmap <= 1e-9) and s2["iterations"] <= 1.15 * s0["iterations"] + 3)
+              (gap < 1e-9 or dmap <= max(1e-10, 4e-13 / gap)) and s2["iterations"] <= 1.15 * s0["iterations"] + 3)
         more += s2["iterations"] > s0["iterations"]
         bad += not ok
         print(f"case {case:3d} V {n:5d} trees {m:3d} {strategy:6s} partial {int(partial)} planted {int(planted)} weights {int(weights)} "

@@ -41,6 +41,8 @@ def main():
     dt = time.perf_counter() - t0
     st = dict(levels.stats)
     st["mismatch_sizes"] = sorted(st["mismatch_sizes"], reverse=True)[:12]
+    big = st.pop("big_jobs", [])
+    print("solves of 4 096 vertices and more:", len(big), "jobs,", round(sum(t for _, t in big), 2), "s in all;", sorted(big, reverse=True)[:40])
     print(f"{n} taxa / {m} trees {strategy}: {dt:.2f} s; next draw {rs.randint(1 << 30)}; {st}")
     if prof:
         pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
