@@ -43,13 +43,13 @@ TIPS, GRAFT, COMPS, SPECTRAL, EMPTY, FALLBACK = 0, 1, 2, 3, 4, 5
 MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 
 # diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
-stats = {"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
+stats = {"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
          "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
          "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": []}
 
 
 def reset_stats() -> None:
-    stats.update({"roots": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
+    stats.update({"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
                   "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
                   "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": []})
 
@@ -104,6 +104,42 @@ def construct(sub, pcg_weighting, contract_edges, random_state, team=None, ahead
         return engine.build(0, 0, random_state)
     finally:
         stats["t_build"] += time.perf_counter() - t0  # (nested engines of redone subtrees count twice)
+
+
+def parts_wanted(arrays, parts) -> bool:
+    """Whether the children of a node of the node-by-node walk (its forest ``arrays``, its ``parts``) are taken by ONE
+    engine from the node's own forest (``construct_parts``)."""
+    if max_taxa() <= 0 or arrays.n_trees < 1 or _env.probe("SCS_SPEC_FROM_PARTS", "1") == "0":
+        return False
+    splitting = sum(1 for p in parts if len(p) > 2)
+    if splitting < 1 or splitting > MAX_PARTS:
+        return False
+    n_nodes = arrays.n_nodes if isinstance(arrays, ResidentArrays) else len(arrays.parent)
+    return n_nodes >= min_nodes()
+
+
+def construct_parts(arrays, parts, pcg_weighting, contract_edges, random_state, team=None, ahead=None) -> TreeNode:
+    """The second half of a node of the node-by-node walk (``scs._construct_children``: the forest restricted to
+    every part, the children's subtrees in the order of ``parts``, joined under a new root; reference:
+    scs.py:139-174) -- with ONE level split of the node's own forest instead of ``scs_forest_split`` + a download
+    of the children's tables, and all children as the first level of one engine: their embeddings run side by
+    side, their components and contraction signatures come from the device."""
+    from spectralclustersupertree_amd import scs
+
+    dev = team.solo if team is not None else scs.default_device()
+    engine = Engine(arrays, pcg_weighting, contract_edges, dev, team, ahead)
+    try:
+        first = engine.run_parts(parts)
+    except nv.ScsError as exc:
+        if exc.code != nv.ENOMEM:
+            raise
+        engine.levels.clear()
+        return None  # (the caller goes on node by node)
+    t0 = time.perf_counter()
+    try:
+        return engine._children(0, list(range(int(first.node_seg[0]), int(first.node_seg[1]))), random_state)
+    finally:
+        stats["t_build"] += time.perf_counter() - t0
 
 
 class Level:
@@ -171,6 +207,55 @@ class Engine:
             stats["levels"] += 1
             stats["nodes"] += lev.K
             lev = self._process(lev)
+
+    def run_parts(self, parts) -> Level:
+        """The engine below a node whose parts are KNOWN (taxon ids of ``self.sub``): a first level that is that node
+        alone, split into ``parts`` (only its node arrays are needed on the device), then level by level."""
+        stats["roots"] += 1
+        stats["from_parts"] += 1
+        t0 = time.perf_counter()
+        sub, dev = self.sub, self.dev
+        if isinstance(sub, ResidentArrays) and sub.forest.dev is dev and sub.forest._h:
+            forest = sub.forest
+        else:
+            host = sub.to_host() if isinstance(sub, ResidentArrays) else sub
+            forest = ResidentArrays.from_host(host, dev).forest
+        k = int(sub.n_taxa)
+        l0 = Level()
+        l0.forest, l0.shift, l0.monotone = forest, 0, True
+        l0.K, l0.T = 1, k
+        l0.t_lo = np.zeros(1, dtype=np.int32)
+        l0.t_hi = np.asarray([forest.n_trees], dtype=np.int32)
+        l0.n_leaves = np.zeros(1, dtype=np.int64)
+        l0.u_lo = np.zeros(1, dtype=np.int32)
+        l0.u_sz = np.asarray([k], dtype=np.int32)
+        l0.gid = np.arange(k, dtype=np.int32)
+        l0.present = np.zeros(k, dtype=np.uint8)
+        l0.comp_root = l0.sig = None
+        l0.kind = np.asarray([COMPS], dtype=np.int8)
+        l0.n_pres = np.zeros(1, dtype=np.int64)
+        l0.n_groups = np.zeros(1, dtype=np.int32)
+        l0.v_off = np.zeros(2, dtype=np.int64)
+        l0.maps = np.zeros((0, 2))
+        l0.prov = np.zeros(0, dtype=np.int8)
+        l0.graft, l0.members = {}, {}
+        l0.defer = np.zeros(1, dtype=bool)
+        tpart = np.full(k, -1, dtype=np.int64)
+        for b, ids in enumerate(parts):
+            if len(ids):
+                ids = np.asarray(ids, dtype=np.int64)
+                tpart[ids] = b
+                l0.present[ids] = 1
+        stats["t_first"] += time.perf_counter() - t0
+        stats["levels"] += 1
+        self.levels.append(l0)
+        nxt = self._split(l0, tpart, np.zeros(k, dtype=np.int32))
+        while nxt is not None:
+            self.levels.append(nxt)
+            stats["levels"] += 1
+            stats["nodes"] += nxt.K
+            nxt = self._process(nxt)
+        return l0
 
     def _monotone(self, lev: Level) -> bool:
         return self.strategy in ("one", "depth", "branch") and lev.monotone and self.weights_ok

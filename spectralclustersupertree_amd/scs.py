@@ -702,6 +702,15 @@ def _construct_children(arrays, parts, pcg_weighting, contract_edges, random_sta
     (ids of ``arrays``), the children's subtrees in the order of ``parts``, joined under a new root."""
     name = arrays.name
     forked = (team is not None and team.world > 1 and team.child_rng == "forked")
+    if given is None and not forked and _small_path() and (team is None or team.world == 1):
+        # (round 6) all children as the first level of ONE level-synchronous engine, straight from this node's
+        # forest: no download of the children's tables, their embeddings side by side (levels.construct_parts)
+        from spectralclustersupertree_amd import levels
+
+        if levels.parts_wanted(arrays, parts):
+            tree = levels.construct_parts(arrays, parts, pcg_weighting, contract_edges, random_state, team, ahead)
+            if tree is not None:
+                return tree
     # ---- the children: ONE sweep of this node's forest restricts it to every part (host),
     # then one batched launch for the small ones
     children: list = []  # ("tips", ids) | ["sub", ids, sub, pre]

@@ -87,17 +87,23 @@ CASES = [(60, 10, 40, "branch", True), (200, 30, 120, "depth", True), (700, 40, 
          (1200, 60, 800, "bootstrap", True), (2500, 30, None, "branch", True)]
 
 
+@pytest.mark.parametrize("from_parts", [True, False])
 @pytest.mark.parametrize("n, m, leaves, strategy, contract", CASES)
-def test_engine_equals_the_node_by_node_walk(monkeypatch, n, m, leaves, strategy, contract):
+def test_engine_equals_the_node_by_node_walk(monkeypatch, n, m, leaves, strategy, contract, from_parts):
+    """``from_parts``: the engine starts at the root's own forest and parts (levels.construct_parts, the
+    default) or at every child after the node-by-node split (levels.construct: what a node of more than
+    eight parts still does)."""
     kw = {} if leaves is None else {"leaves_per_tree": leaves}
     arrays = synthetic.tree_arrays(n + m, n, m, random_weights=True, **kw)
     monkeypatch.setenv("SCS_SPEC_MIN_NODES", "0")
     monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "1000000")
+    monkeypatch.setenv("SCS_SPEC_FROM_PARTS", "1" if from_parts else "0")
     with_engine = _run(arrays, strategy, contract, 5)
     st = dict(levels.stats)
     monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "0")
     node_by_node = _run(arrays, strategy, contract, 5)
     assert levels.stats["roots"] == 0 and st["roots"] >= 1
+    assert (st["from_parts"] >= 1) == from_parts
     assert with_engine == node_by_node
 
 
