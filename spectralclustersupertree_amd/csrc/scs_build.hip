@@ -389,12 +389,12 @@ namespace {
 struct dev_buf {
     void *p = nullptr;
     ~dev_buf() {
-        if (p) hipFree(p);
+        if (p) scs_dev_free(p);
     }
     int alloc(size_t bytes) {
-        if (p) hipFree(p);
+        if (p) scs_dev_free(p);
         p = nullptr;
-        SCS_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        SCS_HIP_CHECK(scs_dev_malloc(&p, bytes ? bytes : 16));
         return SCS_OK;
     }
 };
@@ -424,7 +424,7 @@ struct pooled_buf {
     ~pooled_buf() {
         auto &sl = ctx->scratch[slot];
         if (sl.cap > SCS_SCRATCH_KEEP) {
-            hipFree(sl.p);
+            scs_dev_free(sl.p);
             sl.p = nullptr;
             sl.cap = 0;
         }
@@ -433,10 +433,10 @@ struct pooled_buf {
         auto &sl = ctx->scratch[slot];
         if (bytes < 16) bytes = 16;
         if (sl.cap < bytes) {
-            if (sl.p) hipFree(sl.p);
+            if (sl.p) scs_dev_free(sl.p);
             sl.p = nullptr;
             sl.cap = 0;
-            SCS_HIP_CHECK(hipMalloc(&sl.p, bytes));
+            SCS_HIP_CHECK(scs_dev_malloc(&sl.p, bytes));
             sl.cap = bytes;
         }
         p = sl.p;
@@ -493,20 +493,20 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
         ctx->w_cache = nullptr;
         ctx->w_cache_bytes = 0;
     } else {
-        hipError_t e = hipMalloc((void **)&g->d_w, bytes);
+        hipError_t e = scs_dev_malloc((void **)&g->d_w, bytes);
         if (e != hipSuccess) {  // make room and try once more
             (void)hipGetLastError();
             scs_block_drop_free(ctx);
-            if (ctx->w_cache) hipFree(ctx->w_cache);
+            if (ctx->w_cache) scs_dev_free(ctx->w_cache);
             ctx->w_cache = nullptr;
             ctx->w_cache_bytes = 0;
             {
                 std::lock_guard<std::mutex> lock(ctx->cache_mu);
-                if (ctx->w32_cache) hipFree(ctx->w32_cache);
+                if (ctx->w32_cache) scs_dev_free(ctx->w32_cache);
                 ctx->w32_cache = nullptr;
                 ctx->w32_cache_bytes = 0;
             }
-            e = hipMalloc((void **)&g->d_w, bytes);
+            e = scs_dev_malloc((void **)&g->d_w, bytes);
         }
         if (e != hipSuccess) {
             delete g;
@@ -520,7 +520,7 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
                                         (size_t)(g->ld - (n - col0)) * 8, rows, stream);
         if (e != hipSuccess) {
             if (g->w_block) scs_block_release(ctx, g->d_w);
-            else hipFree(g->d_w);
+            else scs_dev_free(g->d_w);
             delete g;
             scs_set_error("cannot clear the padding of W: %s", hipGetErrorString(e));
             return SCS_EHIP;
@@ -545,14 +545,14 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
         // keep the larger of the two buffers for the next graph; the kernels that used this
         // one are ordered before any later use by the context's stream
         if (!ctx->w_cache || g->w_bytes >= ctx->w_cache_bytes) {
-            if (ctx->w_cache) hipFree(ctx->w_cache);
+            if (ctx->w_cache) scs_dev_free(ctx->w_cache);
             ctx->w_cache = g->d_w;
             ctx->w_cache_bytes = g->w_bytes;
         } else {
-            hipFree(g->d_w);
+            scs_dev_free(g->d_w);
         }
     } else {
-        hipFree(g->d_w);
+        scs_dev_free(g->d_w);
     }
     // (the two V-vectors come from the context's block cache: a hipFree each cost every step of the
     // benchmark and every node of a recursion a device-wide synchronisation)
@@ -568,19 +568,19 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
                 fprintf(stderr, "[image] hipFree of %.2f GB\n",
                         std::min(g->w32_bytes, ctx->w32_cache_bytes) / 1073741824.0);
             if (!ctx->w32_cache || g->w32_bytes > ctx->w32_cache_bytes) {
-                if (ctx->w32_cache) hipFree(ctx->w32_cache);
+                if (ctx->w32_cache) scs_dev_free(ctx->w32_cache);
                 ctx->w32_cache = g->d_w32;
                 ctx->w32_cache_bytes = g->w32_bytes;
             } else {
-                hipFree(g->d_w32);
+                scs_dev_free(g->d_w32);
             }
         }
         if (g->d_deg) scs_block_release(ctx, g->d_deg);
         if (g->d_dinv) scs_block_release(ctx, g->d_dinv);
     } else {
-        hipFree(g->d_w32);
-        hipFree(g->d_deg);
-        hipFree(g->d_dinv);
+        scs_dev_free(g->d_w32);
+        scs_dev_free(g->d_deg);
+        scs_dev_free(g->d_dinv);
     }
     delete g;
     return SCS_OK;
@@ -1345,7 +1345,7 @@ extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *gro
     scs_graph *ng = nullptr;
     SCS_TRY(graph_alloc(ctx, n_groups, g_begin, g_end, ctx->stream, &ng));
     int32_t *d_gs = nullptr;
-    hipError_t e = hipMalloc((void **)&d_gs, (size_t)(n_groups + 1) * 4);
+    hipError_t e = scs_dev_malloc((void **)&d_gs, (size_t)(n_groups + 1) * 4);
     if (e != hipSuccess) {
         scs_graph_free(ctx, ng);
         scs_set_error("scs_graph_contract: hipMalloc failed: %s", hipGetErrorString(e));
@@ -1358,7 +1358,7 @@ extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *gro
                                               n_groups, ng->d_w, ng->ld);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    hipFree(d_gs);
+    scs_dev_free(d_gs);
     if (e != hipSuccess) {
         scs_graph_free(ctx, ng);
         scs_set_error("scs_graph_contract: kernel failed: %s", hipGetErrorString(e));
@@ -1451,7 +1451,7 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
             g->w32_bytes = ctx->w32_cache_bytes;
             ctx->w32_cache = nullptr;
             ctx->w32_cache_bytes = 0;
-        } else if (hipMalloc((void **)&g->d_w32, need) == hipSuccess) {
+        } else if (scs_dev_malloc((void **)&g->d_w32, need) == hipSuccess) {
             g->w32_bytes = need;
             if (scs_dbg("SCS_TRACE_SOLVES") && atoi(scs_dbg("SCS_TRACE_SOLVES")))
                 fprintf(stderr, "[image] hipMalloc of %.2f GB\n", need / 1073741824.0);

@@ -13,6 +13,9 @@
 
 #include "scs_internal.h"
 
+#include <chrono>
+#include <pthread.h>
+
 #include <algorithm>
 #include <cmath>
 
@@ -509,6 +512,31 @@ extern "C" int scs_ctx_create_local(int device, int rank, scs_local_group *group
     return SCS_OK;
 }
 
+static const auto g_t_start = std::chrono::steady_clock::now();
+static void alloc_trace(const char *what, size_t bytes, std::chrono::steady_clock::time_point t0) {
+    const auto t1 = std::chrono::steady_clock::now();
+    const double dt = std::chrono::duration<double>(t1 - t0).count();
+    if (dt > 0.005)
+        fprintf(stderr, "[%9.3f s] thread %lx: %s %.3f GB took %.3f s\n",
+                std::chrono::duration<double>(t0 - g_t_start).count(), (unsigned long)pthread_self(), what, bytes / 1e9, dt);
+}
+
+hipError_t scs_dev_malloc_impl(void **p, size_t bytes) {
+    if (!scs_dbg("SCS_ALLOC_TRACE")) return hipMalloc(p, bytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, bytes);
+    alloc_trace("hipMalloc", bytes, t0);
+    return e;
+}
+
+hipError_t scs_dev_free(void *p) {
+    if (!scs_dbg("SCS_ALLOC_TRACE")) return hipFree(p);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipFree(p);
+    alloc_trace("hipFree", 0, t0);
+    return e;
+}
+
 int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
     std::lock_guard<std::mutex> lock(ctx->cache_mu);
     if (bytes < 256) bytes = 256;
@@ -535,29 +563,29 @@ int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
         bytes = cap;
     }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = scs_dev_malloc(&p, bytes);
     if (e != hipSuccess) {
         // make room: drop every free block (and the cached W buffer) and try once more
         (void)hipGetLastError();
         for (size_t i = 0; i < ctx->blocks.size();) {
             if (!ctx->blocks[i].in_use) {
-                hipFree(ctx->blocks[i].p);
+                scs_dev_free(ctx->blocks[i].p);
                 ctx->blocks.erase(ctx->blocks.begin() + i);
             } else {
                 ++i;
             }
         }
         if (ctx->w_cache) {
-            hipFree(ctx->w_cache);
+            scs_dev_free(ctx->w_cache);
             ctx->w_cache = nullptr;
             ctx->w_cache_bytes = 0;
         }
         if (ctx->w32_cache) {
-            hipFree(ctx->w32_cache);
+            scs_dev_free(ctx->w32_cache);
             ctx->w32_cache = nullptr;
             ctx->w32_cache_bytes = 0;
         }
-        e = hipMalloc(&p, bytes);
+        e = scs_dev_malloc(&p, bytes);
         if (e != hipSuccess) {
             scs_set_error("cannot allocate %zu bytes of device memory: %s", bytes, hipGetErrorString(e));
             return SCS_ENOMEM;
@@ -616,7 +644,7 @@ void scs_block_drop_free(scs_ctx *ctx) {
     std::lock_guard<std::mutex> lock(ctx->cache_mu);
     for (size_t i = 0; i < ctx->blocks.size();) {
         if (!ctx->blocks[i].in_use) {
-            hipFree(ctx->blocks[i].p);
+            scs_dev_free(ctx->blocks[i].p);
             ctx->blocks.erase(ctx->blocks.begin() + i);
         } else {
             ++i;
@@ -640,7 +668,7 @@ void scs_block_release(scs_ctx *ctx, void *p) {
                 pick = i;
         if (pick == ctx->blocks.size()) break;
         free_bytes -= ctx->blocks[pick].bytes;
-        hipFree(ctx->blocks[pick].p);
+        scs_dev_free(ctx->blocks[pick].p);
         ctx->blocks.erase(ctx->blocks.begin() + pick);
     }
 }
@@ -660,23 +688,23 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     if (ctx->h_report) hipHostFree(ctx->h_report);
     for (auto &sl : ctx->scratch)
-        if (sl.p) hipFree(sl.p);
+        if (sl.p) scs_dev_free(sl.p);
     for (auto &e : ctx->build_events)
         if (e) hipEventDestroy(e);
     for (auto &e : ctx->solve_events)
         if (e) hipEventDestroy(e);
-    if (ctx->w_cache) hipFree(ctx->w_cache);
-    if (ctx->w32_cache) hipFree(ctx->w32_cache);
-    for (auto &b : ctx->blocks) hipFree(b.p);
+    if (ctx->w_cache) scs_dev_free(ctx->w_cache);
+    if (ctx->w32_cache) scs_dev_free(ctx->w32_cache);
+    for (auto &b : ctx->blocks) scs_dev_free(b.p);
     // (a page-locked block still lent to a forest's host-side tables stays: arrays may still view it)
     for (auto &b : ctx->pinned)
         if (!b.in_use) hipHostFree(b.p);
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     for (auto &sl : ctx->small_slots) {
         if (sl.done) hipEventDestroy(sl.done);
-        if (sl.dev) hipFree(sl.dev);
+        if (sl.dev) scs_dev_free(sl.dev);
         if (sl.host) hipHostFree(sl.host);
-        if (sl.scratch) hipFree(sl.scratch);
+        if (sl.scratch) scs_dev_free(sl.scratch);
     }
     ctx->small_slots.clear();
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
@@ -695,12 +723,12 @@ extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
     SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     std::lock_guard<std::mutex> lock(ctx->cache_mu);
     if (ctx->w_cache) {
-        hipFree(ctx->w_cache);
+        scs_dev_free(ctx->w_cache);
         ctx->w_cache = nullptr;
         ctx->w_cache_bytes = 0;
     }
     if (ctx->w32_cache) {
-        hipFree(ctx->w32_cache);
+        scs_dev_free(ctx->w32_cache);
         ctx->w32_cache = nullptr;
         ctx->w32_cache_bytes = 0;
     }
@@ -715,7 +743,7 @@ extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
                 pick = i;
         if (pick == ctx->blocks.size()) break;
         free_bytes -= ctx->blocks[pick].bytes;
-        hipFree(ctx->blocks[pick].p);
+        scs_dev_free(ctx->blocks[pick].p);
         ctx->blocks.erase(ctx->blocks.begin() + pick);
     }
     for (size_t i = 0; i < ctx->pinned.size();) {
@@ -825,7 +853,7 @@ extern "C" int scs_tables_free(scs_ctx *ctx, scs_tables *t) {
         (void)scs_tables_finish(ctx, t);  // nothing may still be writing into the block
         scs_block_release(ctx, t->d_block);
     } else if (t->d_block) {
-        hipFree(t->d_block);
+        scs_dev_free(t->d_block);
     }
     delete t;
     return SCS_OK;

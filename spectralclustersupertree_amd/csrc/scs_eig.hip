@@ -1610,22 +1610,22 @@ __global__ void k_dense_s(const double *__restrict__ w, int64_t ld, int n,
 void scs_matfree_release(scs_graph *g) {
     mf_data *m = g->mf;
     if (!m) return;
-    hipFree(m->d_stack_off);
-    hipFree(m->st_val);
-    hipFree(m->st_sum);
-    hipFree(m->st_dep);
-    hipFree(m->sm_val);
-    hipFree(m->sm_sum);
-    hipFree(m->sm_dep);
-    hipFree(m->cy_pa);
-    hipFree(m->cy_ps);
-    hipFree(m->cy_dep);
-    hipFree(m->sm_cnt);
-    hipFree(m->sm_root);
-    hipFree(m->cy_cnt);
-    hipFree(m->x);
-    hipFree(m->y);
-    hipFree(m->slabs);
+    scs_dev_free(m->d_stack_off);
+    scs_dev_free(m->st_val);
+    scs_dev_free(m->st_sum);
+    scs_dev_free(m->st_dep);
+    scs_dev_free(m->sm_val);
+    scs_dev_free(m->sm_sum);
+    scs_dev_free(m->sm_dep);
+    scs_dev_free(m->cy_pa);
+    scs_dev_free(m->cy_ps);
+    scs_dev_free(m->cy_dep);
+    scs_dev_free(m->sm_cnt);
+    scs_dev_free(m->sm_root);
+    scs_dev_free(m->cy_cnt);
+    scs_dev_free(m->x);
+    scs_dev_free(m->y);
+    scs_dev_free(m->slabs);
     delete m;
     g->mf = nullptr;
 }
@@ -1655,14 +1655,14 @@ extern "C" int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tb, int32_t
     };
     // strips: a tree's stack never holds more entries than its deepest separator
     int32_t *d_maxd = nullptr;
-    if (hipMalloc((void **)&d_maxd, (size_t)M * 4) != hipSuccess) return fail(SCS_ENOMEM);
+    if (scs_dev_malloc((void **)&d_maxd, (size_t)M * 4) != hipSuccess) return fail(SCS_ENOMEM);
     hipMemsetAsync(d_maxd, 0, (size_t)M * 4, s);
     k_mf_maxdepth<<<(unsigned)(((tb->n_leaves + 63) / 64 + 255) / 256), 256, 0, s>>>(tb->d_tree_off, M, tb->d_adj_depth,
                                                                                      tb->n_leaves, d_maxd);
     std::vector<int32_t> maxd((size_t)M);
     hipError_t e = hipMemcpyAsync(maxd.data(), d_maxd, (size_t)M * 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    hipFree(d_maxd);
+    scs_dev_free(d_maxd);
     if (e != hipSuccess) {
         scs_set_error("scs_graph_matrix_free: %s", hipGetErrorString(e));
         return fail(SCS_EHIP);
@@ -1676,22 +1676,22 @@ extern "C" int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tb, int32_t
     const size_t strips = (size_t)2 * max_block * (size_t)m->chunks * (size_t)m->stack_total;
     const size_t slots = (size_t)2 * max_block * (size_t)m->chunks * (size_t)M;
     const size_t slab_bytes = (size_t)2 * M * (size_t)n * max_block * 8;
-    if (hipMalloc((void **)&m->d_stack_off, (size_t)(M + 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&m->st_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&m->st_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&m->st_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
-        hipMalloc((void **)&m->sm_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&m->sm_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&m->sm_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
-        hipMalloc((void **)&m->cy_pa, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&m->cy_ps, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        hipMalloc((void **)&m->cy_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
-        hipMalloc((void **)&m->sm_cnt, slots * 4) != hipSuccess ||
-        hipMalloc((void **)&m->sm_root, slots * 4) != hipSuccess ||
-        hipMalloc((void **)&m->cy_cnt, slots * 4) != hipSuccess ||
-        hipMalloc((void **)&m->x, (size_t)n * max_block * 8) != hipSuccess ||
-        hipMalloc((void **)&m->y, (size_t)n * max_block * 8) != hipSuccess ||
-        hipMalloc((void **)&m->slabs, slab_bytes) != hipSuccess) {
+    if (scs_dev_malloc((void **)&m->d_stack_off, (size_t)(M + 1) * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->st_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->st_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->st_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        scs_dev_malloc((void **)&m->sm_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->sm_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->sm_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        scs_dev_malloc((void **)&m->cy_pa, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->cy_ps, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->cy_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        scs_dev_malloc((void **)&m->sm_cnt, slots * 4) != hipSuccess ||
+        scs_dev_malloc((void **)&m->sm_root, slots * 4) != hipSuccess ||
+        scs_dev_malloc((void **)&m->cy_cnt, slots * 4) != hipSuccess ||
+        scs_dev_malloc((void **)&m->x, (size_t)n * max_block * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->y, (size_t)n * max_block * 8) != hipSuccess ||
+        scs_dev_malloc((void **)&m->slabs, slab_bytes) != hipSuccess) {
         (void)hipGetLastError();
         scs_set_error("scs_graph_matrix_free: cannot allocate %.1f GB of slabs", slab_bytes / 1073741824.0);
         return fail(SCS_ENOMEM);
@@ -1787,14 +1787,14 @@ struct dbuf {
     scs_ctx *owner = nullptr;
     ~dbuf() {
         if (p && owner) scs_block_release(owner, p);
-        else if (p) hipFree(p);
+        else if (p) scs_dev_free(p);
     }
     int alloc(size_t bytes) {
         if (t_ctx) {
             owner = t_ctx;
             return scs_block_alloc(t_ctx, bytes, &p);
         }
-        SCS_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 16));
+        SCS_HIP_CHECK(scs_dev_malloc(&p, bytes ? bytes : 16));
         return SCS_OK;
     }
     double *d() const { return (double *)p; }
@@ -3663,13 +3663,13 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     }
     scs_ctx::small_slot &slot = ctx->small_slots[pick];
     if (slot.cap < total) {
-        if (slot.dev) hipFree(slot.dev);
+        if (slot.dev) scs_dev_free(slot.dev);
         if (slot.host) hipHostFree(slot.host);
         slot.dev = nullptr;
         slot.host = nullptr;
         slot.cap = 0;
         const size_t cap = std::max<size_t>(total * 2, (size_t)1 << 20);
-        SCS_HIP_CHECK(hipMalloc((void **)&slot.dev, cap));
+        SCS_HIP_CHECK(scs_dev_malloc((void **)&slot.dev, cap));
         SCS_HIP_CHECK(hipHostMalloc((void **)&slot.host, cap, hipHostMallocDefault));
         slot.cap = cap;
     }
@@ -3679,11 +3679,11 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     const size_t add_bytes = ((size_t)std::max<int64_t>(add_ptr[K], 1) * 8 + 255) / 256 * 256;
     const size_t w0_bytes = (size_t)std::max<int64_t>(w0_ptr[K], 1) * 8;
     if (slot.scratch_cap < add_bytes + w0_bytes) {
-        if (slot.scratch) hipFree(slot.scratch);
+        if (slot.scratch) scs_dev_free(slot.scratch);
         slot.scratch = nullptr;
         slot.scratch_cap = 0;
         const size_t cap = std::max<size_t>((add_bytes + w0_bytes) * 3 / 2, (size_t)1 << 20);
-        SCS_HIP_CHECK(hipMalloc((void **)&slot.scratch, cap));
+        SCS_HIP_CHECK(scs_dev_malloc((void **)&slot.scratch, cap));
         slot.scratch_cap = cap;
     }
     unsigned char *h = slot.host, *d = slot.dev;

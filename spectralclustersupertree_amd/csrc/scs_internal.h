@@ -57,6 +57,16 @@ static inline const char *scs_dbg(const char *name) {
     return on ? getenv(name) : nullptr;
 }
 
+// ---- device memory ------------------------------------------------------------
+// Every hipMalloc / hipFree of the library goes through these two (scs_ctx.hip): one place to trace them
+// (SCS_ALLOC_TRACE, a probe switch: calls of more than 5 ms with the calling thread and the time since start).
+hipError_t scs_dev_malloc_impl(void **p, size_t bytes);
+hipError_t scs_dev_free(void *p);
+template <typename T>
+static inline hipError_t scs_dev_malloc(T **p, size_t bytes) {
+    return scs_dev_malloc_impl((void **)p, bytes);
+}
+
 // ---- tile geometry of the accumulate kernel --------------------------------
 constexpr int SCS_TR = 64;    // rows of W per tile (one block record)
 constexpr int SCS_TCW = 256;  // threads per workgroup = columns per column group

@@ -45,13 +45,13 @@ MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 # diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
 stats = {"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
          "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
-         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": []}
+         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": [], "redo_log": [], "split_log": []}
 
 
 def reset_stats() -> None:
     stats.update({"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
                   "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
-                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": []})
+                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": [], "redo_log": [], "split_log": []})
 
 
 def max_taxa() -> int:
@@ -433,6 +433,8 @@ class Engine:
             part_of, new_id, n_parts, total, _STRATEGY_CODE[self.strategy], lev.t_hi)
         t6 = time.perf_counter()
         stats["t_split"] += t6 - t5
+        if t6 - t5 >= 0.005:
+            stats["split_log"].append((int(lev.n_leaves.sum()), round(t6 - t5, 4)))
         t_dev += t6 - t5
         nxt = Level()
         nxt.forest = union
@@ -736,6 +738,7 @@ class Engine:
                         raise
                     again = None
                 stats["t_redo"] += time.perf_counter() - t0
+                stats["redo_log"].append((int(v1 - v0), time.perf_counter() - t0, 0 if again is None else len(again.levels)))
                 if again is None:  # (no room on the device: node by node, from host arrays)
                     present_local = np.flatnonzero(lev.present[lo:lo + sz])
                     parts: list[list[int]] = [[], []]

@@ -103,6 +103,14 @@ def run(n: int, m: int, weights: bool, strategy: str = "branch", seed: int = 0, 
     big = engine.pop("big_jobs", [])
     engine["solves_of_4096_vertices_and_more"] = {"count": len(big), "seconds": round(sum(t for _, t in big), 2),
                                                   "largest": sorted(big, reverse=True)[:12]}
+    splits = engine.pop("split_log", [])
+    engine["level_splits_of_5_ms_and_more"] = {"count": len(splits), "seconds": round(sum(t for _, t in splits), 2),
+                                                    "largest": sorted(splits, reverse=True)[:12]}
+    redo = engine.pop("redo_log", [])
+    engine["redo_by_vertices"] = {
+        f"{lo + 1}-{hi}": {"nodes": len(sel), "seconds": round(sum(r[1] for r in sel), 3), "levels": sum(r[2] for r in sel)}
+        for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 512), (512, 2048), (2048, 1 << 30))
+        if (sel := [r for r in redo if lo < r[0] <= hi])}
     for key in list(engine):
         if isinstance(engine[key], float):
             engine[key] = round(engine[key], 3)

@@ -42,6 +42,15 @@ def main():
     st = dict(levels.stats)
     st["mismatch_sizes"] = sorted(st["mismatch_sizes"], reverse=True)[:12]
     big = st.pop("big_jobs", [])
+    splits = st.pop("split_log", [])
+    print("level splits of 5 ms and more (leaves, s):", len(splits), "splits,", round(sum(t for _, t in splits), 2), "s in all;",
+          sorted(splits, reverse=True)[:16])
+    redo = st.pop("redo_log", [])
+    for lo, hi in ((0, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 512), (512, 2048), (2048, 1 << 30)):
+        sel = [r for r in redo if lo < r[0] <= hi]
+        if sel:
+            print(f"redo of nodes of {lo + 1}..{hi} vertices: {len(sel)} nodes, {sum(r[1] for r in sel):.3f} s, "
+                  f"{sum(r[2] for r in sel)} levels")
     print("solves of 4 096 vertices and more:", len(big), "jobs,", round(sum(t for _, t in big), 2), "s in all;", sorted(big, reverse=True)[:40])
     print(f"{n} taxa / {m} trees {strategy}: {dt:.2f} s; next draw {rs.randint(1 << 30)}; {st}")
     if prof:
