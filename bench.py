@@ -844,7 +844,8 @@ def main() -> int:
         if os.environ.get("SCS_BENCH_RECURSION", "1") != "0":
             if spent + 150 <= budget_s:
                 try:
-                    dev.trim()  # (the recursion runs on the process-wide context: give the 80 GB buffer back)
+                    # (the recursion runs on the process-wide context; the device's arena -- csrc/scs_arena.h --
+                    # is shared by all contexts of the process, so the memory the legs above left free serves it)
                     sys.path.insert(0, str(ROOT / "tools"))
                     import full_recursion_check
 

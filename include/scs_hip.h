@@ -100,7 +100,8 @@ typedef struct scs_build_stats {
     int32_t reserved;
 } scs_build_stats;
 
-/* ABI version of this header: 104.  103 -> 104: scs_forest_split_level, scs_forest_analyze,
+/* ABI version of this header: 105.  104 -> 105: scs_debug_arena_stats added; scs_ctx_trim's keep_bytes counts the
+ * free bytes of the device's arena.  103 -> 104: scs_forest_split_level, scs_forest_analyze,
  * scs_forest_tables_download_range, scs_tables_from_forest_range, scs_small_solve_begin_level added;
  * scs_forest_upload checks the arrays.  102 -> 103: scs_stats ends with event_pair_ms.  101 -> 102: scs_stats is
  * 24 bytes longer (n_apply32 in the old `reserved` slot, apply32_ms_total, apply32_bytes, lowp_renewals).  100 -> 101: scs_build_stats is 8 bytes longer
@@ -136,10 +137,17 @@ int scs_ctx_create_local(int device, int rank, scs_local_group *group, scs_ctx *
 
 int scs_ctx_destroy(scs_ctx *ctx);
 int scs_ctx_synchronize(scs_ctx *ctx);
-/* Give back the device memory the context only keeps for a next call of the same size (the cached W buffer
- * and its single-precision image, free cached blocks above keep_bytes, free page-locked blocks).  No
- * reference counterpart; the recursion calls it behind its largest nodes. */
+/* Device memory: every block of the library is carved out of a per-device ARENA shared by all contexts of the
+ * process (csrc/scs_arena.h) -- slabs taken from the driver stay with the process until they are handed back
+ * here, or until the driver refuses a request (then whole free slabs go back and the request is tried again).
+ * scs_ctx_trim hands back whole free slabs, largest first, until at most keep_bytes of free arena memory remain
+ * on the context's device (0: everything that is free), and with keep_bytes == 0 the context's free
+ * page-locked host blocks.  No reference counterpart. */
 int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes);
+/* The arena of a device, for tests and reports: out8 = {bytes of slabs held, bytes in use, slabs, chunks,
+ * released chunks not yet safe for other contexts, driver allocations so far, driver releases so far,
+ * requests served so far}. */
+int scs_debug_arena_stats(int device, int64_t *out8);
 /* The communicator as it sees itself: kind (0 none, 1 RCCL, 2 in-process team), the world / rank
  * it was created with, and what ncclCommCount / ncclCommUserRank report (-1: not available).
  * No reference counterpart (the reference has no parallelism, scs.py:239 n_jobs = 1). */

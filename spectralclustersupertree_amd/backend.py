@@ -75,9 +75,18 @@ class Device:
         nv.check(self._lib.scs_ctx_synchronize(self._ctx))
 
     def trim(self, keep_bytes: int = 0) -> None:
-        """``scs_ctx_trim``: give back the cached W buffer, its image and the free cached blocks above
-        ``keep_bytes`` (the recursion calls it behind its largest nodes)."""
+        """``scs_ctx_trim``: hand whole free slabs of the device's arena back to the driver until at most
+        ``keep_bytes`` of free arena memory remain (the arena is shared by every context of the process on this
+        device and never shrinks by itself)."""
         nv.check(self._lib.scs_ctx_trim(self._ctx, int(keep_bytes)))
+
+    def arena_stats(self) -> dict:
+        """``scs_debug_arena_stats`` of this context's device."""
+        out = (C.c_int64 * 8)()
+        nv.check(self._lib.scs_debug_arena_stats(int(self.index), out))
+        keys = ("slab_bytes", "used_bytes", "slabs", "chunks", "pending_chunks", "driver_allocations",
+                "driver_releases", "requests")
+        return dict(zip(keys, (int(x) for x in out)))
 
     def comm_info(self) -> dict:
         """The communicator as it sees itself (``scs_ctx_comm_info``): kind, the world / rank it was

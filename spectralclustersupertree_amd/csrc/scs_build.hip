@@ -387,14 +387,16 @@ __global__ void k_dinv(const double *__restrict__ deg, int n, double *__restrict
 namespace {
 
 struct dev_buf {
+    scs_ctx *ctx;
     void *p = nullptr;
+    explicit dev_buf(scs_ctx *c) : ctx(c) {}
     ~dev_buf() {
         if (p) scs_dev_free(p);
     }
     int alloc(size_t bytes) {
         if (p) scs_dev_free(p);
         p = nullptr;
-        SCS_HIP_CHECK(scs_dev_malloc(&p, bytes ? bytes : 16));
+        SCS_HIP_CHECK(scs_dev_malloc(ctx, &p, bytes ? bytes : 16));
         return SCS_OK;
     }
 };
@@ -436,7 +438,7 @@ struct pooled_buf {
             if (sl.p) scs_dev_free(sl.p);
             sl.p = nullptr;
             sl.cap = 0;
-            SCS_HIP_CHECK(scs_dev_malloc(&sl.p, bytes));
+            SCS_HIP_CHECK(scs_dev_malloc(ctx, &sl.p, bytes));
             sl.cap = bytes;
         }
         p = sl.p;
@@ -478,8 +480,9 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
     const size_t rows = (size_t)(row_end - row_begin);
     size_t bytes = rows * (size_t)g->ld * sizeof(double);
     if (bytes < 16) bytes = 16;
-    // the cached buffer fits when it is large enough and at most twice the need (+1 MiB)
-    if (bytes <= SCS_W_BLOCK_MAX) {
+    // (round 6) W of every size is a block of the device's arena: released, it serves whatever comes next -- a
+    // level's forests, another context's W -- instead of waiting in this context for a graph of its own size
+    {
         const int rc = scs_block_alloc(ctx, bytes, (void **)&g->d_w);
         if (rc != SCS_OK) {
             delete g;
@@ -487,33 +490,6 @@ static int graph_alloc(scs_ctx *ctx, int32_t n, int32_t row_begin, int32_t row_e
         }
         g->w_bytes = bytes;
         g->w_block = true;
-    } else if (ctx->w_cache && ctx->w_cache_bytes >= bytes && ctx->w_cache_bytes <= 2 * bytes + (1u << 20)) {
-        g->d_w = ctx->w_cache;
-        g->w_bytes = ctx->w_cache_bytes;
-        ctx->w_cache = nullptr;
-        ctx->w_cache_bytes = 0;
-    } else {
-        hipError_t e = scs_dev_malloc((void **)&g->d_w, bytes);
-        if (e != hipSuccess) {  // make room and try once more
-            (void)hipGetLastError();
-            scs_block_drop_free(ctx);
-            if (ctx->w_cache) scs_dev_free(ctx->w_cache);
-            ctx->w_cache = nullptr;
-            ctx->w_cache_bytes = 0;
-            {
-                std::lock_guard<std::mutex> lock(ctx->cache_mu);
-                if (ctx->w32_cache) scs_dev_free(ctx->w32_cache);
-                ctx->w32_cache = nullptr;
-                ctx->w32_cache_bytes = 0;
-            }
-            e = scs_dev_malloc((void **)&g->d_w, bytes);
-        }
-        if (e != hipSuccess) {
-            delete g;
-            scs_set_error("cannot allocate %zu bytes for W: %s", bytes, hipGetErrorString(e));
-            return SCS_ENOMEM;
-        }
-        g->w_bytes = bytes;
     }
     if (g->ld > n - col0) {
         hipError_t e = hipMemset2DAsync(g->d_w + (n - col0), (size_t)g->ld * 8, 0,
@@ -567,13 +543,7 @@ extern "C" int scs_graph_free(scs_ctx *ctx, scs_graph *g) {
             if (scs_dbg("SCS_TRACE_SOLVES") && atoi(scs_dbg("SCS_TRACE_SOLVES")) && ctx->w32_cache)
                 fprintf(stderr, "[image] hipFree of %.2f GB\n",
                         std::min(g->w32_bytes, ctx->w32_cache_bytes) / 1073741824.0);
-            if (!ctx->w32_cache || g->w32_bytes > ctx->w32_cache_bytes) {
-                if (ctx->w32_cache) scs_dev_free(ctx->w32_cache);
-                ctx->w32_cache = g->d_w32;
-                ctx->w32_cache_bytes = g->w32_bytes;
-            } else {
-                scs_dev_free(g->d_w32);
-            }
+            scs_dev_free(g->d_w32);  // (back to the arena: the next image of this context finds it there)
         }
         if (g->d_deg) scs_block_release(ctx, g->d_deg);
         if (g->d_dinv) scs_block_release(ctx, g->d_dinv);
@@ -603,7 +573,7 @@ int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int3
         splits[1] = row_end;
         return SCS_OK;
     }
-    dev_buf send, recv;
+    dev_buf send(ctx), recv(ctx);
     SCS_TRY(send.alloc(8));
     SCS_TRY(recv.alloc(8 * (size_t)world));
     double v = (double)row_begin;
@@ -775,7 +745,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // shared: tile i of the job-wide list belongs to rank i % world and lands in slot
     // i / world of that rank's packed buffer
     std::vector<int2> all_tiles;
-    dev_buf d_all_tiles;
+    dev_buf d_all_tiles(ctx);
     cached_buf d_tile_out(ctx), d_gathered(ctx);
     size_t chunk_doubles = 0;
     // the exchange of a shared build: point to point by default, one all-gather on request
@@ -847,7 +817,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     const bool wide = wide_mode != 0;
     const int group_tiles = PIPE_NG;
     std::vector<int4> groups;
-    dev_buf d_groups;
+    dev_buf d_groups(ctx);
     if (wide) {
         rec_bytes = wide_layout<PIPE_NG>::BYTES;
         // the tiles of a row block in list order, two at a time; XCD x is handed the groups of
@@ -960,7 +930,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     float spec_ms = 0.f;
     bool single_batch_spec = false;
     pooled_buf d_pos(ctx, 1), d_st(ctx, 3), d_stoff(ctx, 4), d_rec(ctx, 5), d_cells(ctx, 6);
-    dev_buf d_pcol, d_lists, d_list_cnt;  // (partial-coverage forests: per-tile tree lists)
+    dev_buf d_pcol(ctx), d_lists(ctx), d_list_cnt(ctx);  // (partial-coverage forests: per-tile tree lists)
     int listed_batches = 0;
     for (int bi = 0; bi < n_batches; ++bi) {
         const int t0 = batch_start[bi], t1 = batch_start[bi + 1];
@@ -1080,7 +1050,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 const int spec_prio = scs_dbg("SCS_SPEC_PRIO") ? atoi(scs_dbg("SCS_SPEC_PRIO")) : 2;
                 wp.producer_prio = spec_prio;
                 const unsigned ng = (unsigned)groups.size();
-                dev_buf d_st8;
+                dev_buf d_st8(ctx);
                 if (stamp) {
                     SCS_TRY(d_st8.alloc(64));
                     SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
@@ -1116,7 +1086,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                                 100.0 * h[i] / tot, (double)h[i] / ((double)h[7] * nb));
                 }
             } else if (nt && stamp) {
-                dev_buf d_st8;
+                dev_buf d_st8(ctx);
                 SCS_TRY(d_st8.alloc(64));
                 SCS_HIP_CHECK(hipMemsetAsync(d_st8.p, 0, 64, s));
                 mp.stamps = (unsigned long long *)d_st8.p;
@@ -1249,7 +1219,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
             recv_off[p + 1] = (int64_t)recv_tiles.size() * SCS_TR * cols_per_tile;
         }
         cached_buf d_send(ctx), d_recv(ctx);
-        dev_buf d_slots, d_rtiles;
+        dev_buf d_slots(ctx), d_rtiles(ctx);
         SCS_TRY(d_send.alloc((size_t)send_off[world] * 8));
         SCS_TRY(d_recv.alloc((size_t)recv_off[world] * 8));
         SCS_TRY(d_slots.alloc(send_slots.size() * 4));
@@ -1345,7 +1315,7 @@ extern "C" int scs_graph_contract(scs_ctx *ctx, scs_graph *g, const int32_t *gro
     scs_graph *ng = nullptr;
     SCS_TRY(graph_alloc(ctx, n_groups, g_begin, g_end, ctx->stream, &ng));
     int32_t *d_gs = nullptr;
-    hipError_t e = scs_dev_malloc((void **)&d_gs, (size_t)(n_groups + 1) * 4);
+    hipError_t e = scs_dev_malloc(ctx, (void **)&d_gs, (size_t)(n_groups + 1) * 4);
     if (e != hipSuccess) {
         scs_graph_free(ctx, ng);
         scs_set_error("scs_graph_contract: hipMalloc failed: %s", hipGetErrorString(e));
@@ -1451,7 +1421,7 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
             g->w32_bytes = ctx->w32_cache_bytes;
             ctx->w32_cache = nullptr;
             ctx->w32_cache_bytes = 0;
-        } else if (scs_dev_malloc((void **)&g->d_w32, need) == hipSuccess) {
+        } else if (scs_dev_malloc(ctx, (void **)&g->d_w32, need) == hipSuccess) {
             g->w32_bytes = need;
             if (scs_dbg("SCS_TRACE_SOLVES") && atoi(scs_dbg("SCS_TRACE_SOLVES")))
                 fprintf(stderr, "[image] hipMalloc of %.2f GB\n", need / 1073741824.0);
@@ -1465,7 +1435,7 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
     if (need_img && img_rows && g->have_deg) {
         // the degrees are known (a second solve on this graph): only the image is missing -- no collective here
         // (a rank whose image could not be allocated has returned above; it streams W in double precision)
-        dev_buf tmp;
+        dev_buf tmp(ctx);
         SCS_TRY(tmp.alloc((size_t)n * 8));
         k_degrees<true><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, (double *)tmp.p, g->d_w32, 1);
         SCS_HIP_CHECK(hipGetLastError());
@@ -1484,7 +1454,7 @@ int scs_graph_prepare_degrees_begin(scs_ctx *ctx, scs_graph *g, bool want_w32) {
         k_degrees<false><<<(rows + 3) / 4, 256, 0, s>>>(g->d_w, g->ld, n, rows, g->row_begin, g->d_deg);
     } else {
         // every rank contributes a V-long vector that is zero outside its rows
-        dev_buf send, recv;
+        dev_buf send(ctx), recv(ctx);
         SCS_TRY(send.alloc((size_t)n * 8));
         SCS_TRY(recv.alloc((size_t)n * 8 * world));
         SCS_HIP_CHECK(hipMemsetAsync(send.p, 0, (size_t)n * 8, s));

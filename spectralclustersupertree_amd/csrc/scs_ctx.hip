@@ -12,6 +12,7 @@
 #include <mutex>
 
 #include "scs_internal.h"
+#include "scs_arena.h"
 
 #include <chrono>
 #include <pthread.h>
@@ -37,7 +38,7 @@ extern "C" const char *scs_last_error(void) { return g_last_error.c_str(); }
 // 101 (round 5): scs_build_stats grew by tree_parallel_batches / spec_batches (round 4), scs_tables_split added
 // 102 (round 5): scs_stats grew by the mixed-precision loop's fields
 // 103: ... and by event_pair_ms
-extern "C" int scs_version(void) { return 104; }
+extern "C" int scs_version(void) { return 105; }
 
 extern "C" int scs_device_count(void) {
     int n = 0;
@@ -461,6 +462,7 @@ static int ctx_common(int device, scs_ctx **out) {
     // scratch budget per tree batch: a quarter of what is free now, at most 64 GiB
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+    free_b += scs_arena_free_bytes(device);  // (what the arena holds free is as good as free)
     size_t lim = free_b / 4;
     const size_t cap = (size_t)64 << 30;
     ctx->ws_limit = lim < cap ? lim : cap;
@@ -521,7 +523,7 @@ static void alloc_trace(const char *what, size_t bytes, std::chrono::steady_cloc
                 std::chrono::duration<double>(t0 - g_t_start).count(), (unsigned long)pthread_self(), what, bytes / 1e9, dt);
 }
 
-hipError_t scs_dev_malloc_impl(void **p, size_t bytes) {
+static hipError_t driver_malloc(void **p, size_t bytes) {
     if (!scs_dbg("SCS_ALLOC_TRACE")) return hipMalloc(p, bytes);
     const auto t0 = std::chrono::steady_clock::now();
     const hipError_t e = hipMalloc(p, bytes);
@@ -529,7 +531,7 @@ hipError_t scs_dev_malloc_impl(void **p, size_t bytes) {
     return e;
 }
 
-hipError_t scs_dev_free(void *p) {
+static hipError_t driver_free(void *p) {
     if (!scs_dbg("SCS_ALLOC_TRACE")) return hipFree(p);
     const auto t0 = std::chrono::steady_clock::now();
     const hipError_t e = hipFree(p);
@@ -537,44 +539,144 @@ hipError_t scs_dev_free(void *p) {
     return e;
 }
 
-int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
-    std::lock_guard<std::mutex> lock(ctx->cache_mu);
-    if (bytes < 256) bytes = 256;
-    // the smallest free block that is large enough and at most twice the request
-    int pick = -1;
-    for (size_t i = 0; i < ctx->blocks.size(); ++i) {
-        const auto &b = ctx->blocks[i];
-        if (!b.in_use && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 &&
-            (pick < 0 || b.bytes < ctx->blocks[pick].bytes))
-            pick = (int)i;
-    }
-    if (pick >= 0) {
-        ctx->blocks[pick].in_use = true;
-        *out = ctx->blocks[pick].p;
-        return SCS_OK;
-    }
-    // (round 6) new blocks come in size classes a quarter octave apart: the level-synchronous recursion asks
-    // for a slightly different size with every level, and blocks of exactly the size asked for were seldom
-    // good for the next request -- the cache grew to its limit and every release above it is a hipFree (a
-    // device-wide synchronisation; 0.28 ms per forest freed in the configs[4] recursion)
-    if (bytes <= ((size_t)8 << 30)) {
-        size_t cap = 256;
-        while (cap < bytes) cap += cap / 4 >= 256 ? cap / 4 : 256;
-        bytes = cap;
-    }
-    void *p = nullptr;
-    hipError_t e = scs_dev_malloc(&p, bytes);
-    if (e != hipSuccess) {
-        // make room: drop every free block (and the cached W buffer) and try once more
-        (void)hipGetLastError();
-        for (size_t i = 0; i < ctx->blocks.size();) {
-            if (!ctx->blocks[i].in_use) {
-                scs_dev_free(ctx->blocks[i].p);
-                ctx->blocks.erase(ctx->blocks.begin() + i);
-            } else {
-                ++i;
-            }
+// ---------------------------------------------------------------------------
+// the arena of every device (scs_arena.h has the logic and the reasons)
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int ARENA_DEVICES = 16;
+struct device_arena {
+    std::mutex mu;
+    scs_arena_core core;
+    std::vector<hipEvent_t> event_pool;
+    std::atomic<bool> live{false};
+};
+device_arena g_arena[ARENA_DEVICES];
+
+bool arena_on() {
+    static const bool on = [] {
+        const char *e = scs_dbg("SCS_ARENA");  // (probe: 0 = every request straight to the driver, as before round 6)
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
+// (called with a.mu held)
+void arena_init(device_arena &a) {
+    if (a.live.load()) return;
+    a.core.back_alloc = [](size_t bytes) -> void * {
+        void *p = nullptr;
+        if (driver_malloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
         }
+        return p;
+    };
+    a.core.back_free = [](void *p) { driver_free(p); };
+    a.core.owner_mark = [&a](const void *owner) {
+        std::vector<void *> events;
+        const scs_ctx *ctx = (const scs_ctx *)owner;
+        for (hipStream_t s : {ctx->stream, ctx->small_stream, ctx->copy_stream}) {
+            if (!s) continue;
+            if (hipStreamQuery(s) == hipSuccess) continue;
+            (void)hipGetLastError();
+            hipEvent_t ev = nullptr;
+            if (!a.event_pool.empty()) {
+                ev = a.event_pool.back();
+                a.event_pool.pop_back();
+            } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                hipStreamSynchronize(s);  // (no event to be had: wait here instead)
+                continue;
+            }
+            hipEventRecord(ev, s);
+            events.push_back((void *)ev);
+        }
+        return events;
+    };
+    a.core.event_done = [](void *e) {
+        if (hipEventQuery((hipEvent_t)e) == hipSuccess) return true;
+        (void)hipGetLastError();
+        return false;
+    };
+    a.core.event_wait = [](void *e) { hipEventSynchronize((hipEvent_t)e); };
+    a.core.event_recycle = [&a](void *e) { a.event_pool.push_back((hipEvent_t)e); };
+    a.live.store(true);
+}
+}  // namespace
+
+hipError_t scs_dev_malloc_impl(scs_ctx *ctx, void **p, size_t bytes) {
+    if (!ctx || !arena_on() || ctx->device < 0 || ctx->device >= ARENA_DEVICES) return driver_malloc(p, bytes);
+    device_arena &a = g_arena[ctx->device];
+    std::lock_guard<std::mutex> lock(a.mu);
+    arena_init(a);
+    *p = a.core.alloc(bytes, ctx);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+
+hipError_t scs_dev_free(void *p) {
+    if (!p) return hipSuccess;
+    for (auto &a : g_arena) {
+        if (!a.live.load()) continue;
+        std::lock_guard<std::mutex> lock(a.mu);
+        if (a.core.release(p)) return hipSuccess;
+        for (auto &s : a.core.slabs)
+            if (s.base && (char *)p >= s.base && (char *)p < s.base + s.bytes) {
+                // (inside a slab, but no chunk in use starts here: released twice, or a pointer into a chunk)
+                fprintf(stderr, "scs_dev_free: %p is not an allocation of the arena (ignored)\n", p);
+                return hipErrorInvalidValue;
+            }
+    }
+    return driver_free(p);
+}
+
+size_t scs_arena_free_bytes(int device) {
+    if (device < 0 || device >= ARENA_DEVICES || !g_arena[device].live.load()) return 0;
+    std::lock_guard<std::mutex> lock(g_arena[device].mu);
+    return g_arena[device].core.free_bytes();
+}
+
+// a context's last act: what it still holds goes back, what it released is everybody's
+static void arena_ctx_gone(scs_ctx *ctx) {
+    if (ctx->device < 0 || ctx->device >= ARENA_DEVICES || !g_arena[ctx->device].live.load()) return;
+    std::lock_guard<std::mutex> lock(g_arena[ctx->device].mu);
+    g_arena[ctx->device].core.owner_gone(ctx);
+}
+
+static size_t arena_trim(int device, size_t keep) {
+    if (device < 0 || device >= ARENA_DEVICES || !g_arena[device].live.load()) return 0;
+    std::lock_guard<std::mutex> lock(g_arena[device].mu);
+    return g_arena[device].core.trim(keep);
+}
+
+// {bytes of slabs, bytes in use, slabs, chunks, pending chunks, driver allocations, driver releases, requests}
+extern "C" int scs_debug_arena_stats(int device, int64_t *out8) {
+    SCS_REQUIRE(out8 != nullptr && device >= 0 && device < ARENA_DEVICES, "scs_debug_arena_stats: bad argument");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    device_arena &a = g_arena[device];
+    if (!a.live.load()) return SCS_OK;
+    std::lock_guard<std::mutex> lock(a.mu);
+    int64_t n_slabs = 0;
+    for (auto &s : a.core.slabs) n_slabs += s.base != nullptr;
+    out8[0] = (int64_t)a.core.slab_bytes;
+    out8[1] = (int64_t)a.core.used_bytes;
+    out8[2] = n_slabs;
+    out8[3] = (int64_t)a.core.chunks.size();
+    out8[4] = (int64_t)a.core.n_pending;
+    out8[5] = (int64_t)a.core.n_driver_allocs;
+    out8[6] = (int64_t)a.core.n_driver_frees;
+    out8[7] = (int64_t)a.core.n_allocs;
+    return SCS_OK;
+}
+
+// A device block of a context: carved out of the device's arena (until round 6 a per-context cache of whole
+// hipMalloc blocks in size classes -- what one context had released no other could use, and every miss and
+// every release above the cache's budget was a driver call).
+int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
+    if (bytes < 256) bytes = 256;
+    if (scs_dev_malloc_impl(ctx, out, bytes) == hipSuccess) return SCS_OK;
+    {
+        // make room: the W buffer and the image this context keeps for a next graph of the same size
+        std::lock_guard<std::mutex> lock(ctx->cache_mu);
         if (ctx->w_cache) {
             scs_dev_free(ctx->w_cache);
             ctx->w_cache = nullptr;
@@ -585,15 +687,11 @@ int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out) {
             ctx->w32_cache = nullptr;
             ctx->w32_cache_bytes = 0;
         }
-        e = scs_dev_malloc(&p, bytes);
-        if (e != hipSuccess) {
-            scs_set_error("cannot allocate %zu bytes of device memory: %s", bytes, hipGetErrorString(e));
-            return SCS_ENOMEM;
-        }
     }
-    ctx->blocks.push_back({p, bytes, true});
-    *out = p;
-    return SCS_OK;
+    if (scs_dev_malloc_impl(ctx, out, bytes) == hipSuccess) return SCS_OK;
+    (void)hipGetLastError();
+    scs_set_error("cannot allocate %zu bytes of device memory", bytes);
+    return SCS_ENOMEM;
 }
 
 int scs_pinned_get(scs_ctx *ctx, size_t bytes, void **out) {
@@ -641,36 +739,13 @@ void scs_pinned_release(scs_ctx *ctx, void *p) {
 }
 
 void scs_block_drop_free(scs_ctx *ctx) {
-    std::lock_guard<std::mutex> lock(ctx->cache_mu);
-    for (size_t i = 0; i < ctx->blocks.size();) {
-        if (!ctx->blocks[i].in_use) {
-            scs_dev_free(ctx->blocks[i].p);
-            ctx->blocks.erase(ctx->blocks.begin() + i);
-        } else {
-            ++i;
-        }
-    }
+    // (the arena makes room by itself when the driver refuses a slab: scs_arena_core::alloc)
+    (void)ctx;
 }
 
 void scs_block_release(scs_ctx *ctx, void *p) {
-    if (!p) return;
-    std::lock_guard<std::mutex> lock(ctx->cache_mu);
-    size_t free_bytes = 0;
-    for (auto &b : ctx->blocks) {
-        if (b.p == p) b.in_use = false;
-        if (!b.in_use) free_bytes += b.bytes;
-    }
-    // keep at most SCS_BLOCK_KEEP bytes of free blocks: release the largest ones first
-    while (free_bytes > SCS_BLOCK_KEEP) {
-        size_t pick = ctx->blocks.size();
-        for (size_t i = 0; i < ctx->blocks.size(); ++i)
-            if (!ctx->blocks[i].in_use && (pick == ctx->blocks.size() || ctx->blocks[i].bytes > ctx->blocks[pick].bytes))
-                pick = i;
-        if (pick == ctx->blocks.size()) break;
-        free_bytes -= ctx->blocks[pick].bytes;
-        scs_dev_free(ctx->blocks[pick].p);
-        ctx->blocks.erase(ctx->blocks.begin() + pick);
-    }
+    (void)ctx;
+    if (p) scs_dev_free(p);
 }
 
 extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
@@ -695,7 +770,6 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
         if (e) hipEventDestroy(e);
     if (ctx->w_cache) scs_dev_free(ctx->w_cache);
     if (ctx->w32_cache) scs_dev_free(ctx->w32_cache);
-    for (auto &b : ctx->blocks) scs_dev_free(b.p);
     // (a page-locked block still lent to a forest's host-side tables stays: arrays may still view it)
     for (auto &b : ctx->pinned)
         if (!b.in_use) hipHostFree(b.p);
@@ -708,6 +782,7 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     }
     ctx->small_slots.clear();
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
+    arena_ctx_gone(ctx);
     delete ctx;
     return SCS_OK;
 }
@@ -732,20 +807,8 @@ extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
         ctx->w32_cache = nullptr;
         ctx->w32_cache_bytes = 0;
     }
-    size_t free_bytes = 0;
-    for (auto &b : ctx->blocks)
-        if (!b.in_use) free_bytes += b.bytes;
     const size_t keep = keep_bytes > 0 ? (size_t)keep_bytes : 0;
-    while (free_bytes > keep) {
-        size_t pick = ctx->blocks.size();
-        for (size_t i = 0; i < ctx->blocks.size(); ++i)
-            if (!ctx->blocks[i].in_use && (pick == ctx->blocks.size() || ctx->blocks[i].bytes > ctx->blocks[pick].bytes))
-                pick = i;
-        if (pick == ctx->blocks.size()) break;
-        free_bytes -= ctx->blocks[pick].bytes;
-        scs_dev_free(ctx->blocks[pick].p);
-        ctx->blocks.erase(ctx->blocks.begin() + pick);
-    }
+    arena_trim(ctx->device, keep);
     for (size_t i = 0; i < ctx->pinned.size();) {
         if (!ctx->pinned[i].in_use && keep == 0) {
             hipHostFree(ctx->pinned[i].p);

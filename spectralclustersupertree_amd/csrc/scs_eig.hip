@@ -1655,7 +1655,7 @@ extern "C" int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tb, int32_t
     };
     // strips: a tree's stack never holds more entries than its deepest separator
     int32_t *d_maxd = nullptr;
-    if (scs_dev_malloc((void **)&d_maxd, (size_t)M * 4) != hipSuccess) return fail(SCS_ENOMEM);
+    if (scs_dev_malloc((scs_ctx *)nullptr, (void **)&d_maxd, (size_t)M * 4) != hipSuccess) return fail(SCS_ENOMEM);
     hipMemsetAsync(d_maxd, 0, (size_t)M * 4, s);
     k_mf_maxdepth<<<(unsigned)(((tb->n_leaves + 63) / 64 + 255) / 256), 256, 0, s>>>(tb->d_tree_off, M, tb->d_adj_depth,
                                                                                      tb->n_leaves, d_maxd);
@@ -1676,22 +1676,22 @@ extern "C" int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tb, int32_t
     const size_t strips = (size_t)2 * max_block * (size_t)m->chunks * (size_t)m->stack_total;
     const size_t slots = (size_t)2 * max_block * (size_t)m->chunks * (size_t)M;
     const size_t slab_bytes = (size_t)2 * M * (size_t)n * max_block * 8;
-    if (scs_dev_malloc((void **)&m->d_stack_off, (size_t)(M + 1) * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->st_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->st_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->st_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
-        scs_dev_malloc((void **)&m->sm_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->sm_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->sm_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
-        scs_dev_malloc((void **)&m->cy_pa, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->cy_ps, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->cy_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
-        scs_dev_malloc((void **)&m->sm_cnt, slots * 4) != hipSuccess ||
-        scs_dev_malloc((void **)&m->sm_root, slots * 4) != hipSuccess ||
-        scs_dev_malloc((void **)&m->cy_cnt, slots * 4) != hipSuccess ||
-        scs_dev_malloc((void **)&m->x, (size_t)n * max_block * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->y, (size_t)n * max_block * 8) != hipSuccess ||
-        scs_dev_malloc((void **)&m->slabs, slab_bytes) != hipSuccess) {
+    if (scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->d_stack_off, (size_t)(M + 1) * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->st_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->st_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->st_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->sm_val, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->sm_sum, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->sm_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->cy_pa, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->cy_ps, std::max<size_t>(strips, 1) * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->cy_dep, std::max<size_t>(strips, 1) * 4) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->sm_cnt, slots * 4) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->sm_root, slots * 4) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->cy_cnt, slots * 4) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->x, (size_t)n * max_block * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->y, (size_t)n * max_block * 8) != hipSuccess ||
+        scs_dev_malloc((scs_ctx *)nullptr, (void **)&m->slabs, slab_bytes) != hipSuccess) {
         (void)hipGetLastError();
         scs_set_error("scs_graph_matrix_free: cannot allocate %.1f GB of slabs", slab_bytes / 1073741824.0);
         return fail(SCS_ENOMEM);
@@ -1794,7 +1794,7 @@ struct dbuf {
             owner = t_ctx;
             return scs_block_alloc(t_ctx, bytes, &p);
         }
-        SCS_HIP_CHECK(scs_dev_malloc(&p, bytes ? bytes : 16));
+        SCS_HIP_CHECK(scs_dev_malloc((scs_ctx *)nullptr, &p, bytes ? bytes : 16));
         return SCS_OK;
     }
     double *d() const { return (double *)p; }
@@ -3669,7 +3669,7 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
         slot.host = nullptr;
         slot.cap = 0;
         const size_t cap = std::max<size_t>(total * 2, (size_t)1 << 20);
-        SCS_HIP_CHECK(scs_dev_malloc((void **)&slot.dev, cap));
+        SCS_HIP_CHECK(scs_dev_malloc(ctx, (void **)&slot.dev, cap));
         SCS_HIP_CHECK(hipHostMalloc((void **)&slot.host, cap, hipHostMallocDefault));
         slot.cap = cap;
     }
@@ -3683,7 +3683,7 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
         slot.scratch = nullptr;
         slot.scratch_cap = 0;
         const size_t cap = std::max<size_t>((add_bytes + w0_bytes) * 3 / 2, (size_t)1 << 20);
-        SCS_HIP_CHECK(scs_dev_malloc((void **)&slot.scratch, cap));
+        SCS_HIP_CHECK(scs_dev_malloc(ctx, (void **)&slot.scratch, cap));
         slot.scratch_cap = cap;
     }
     unsigned char *h = slot.host, *d = slot.dev;

@@ -1245,7 +1245,7 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         // runtime cannot even place a launch's private scratch (it aborts the process): refuse early, the caller
         // takes the subtree node by node (spectralclustersupertree_amd/levels.py)
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < ((size_t)6 << 30)) {
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + scs_arena_free_bytes(ctx->device) < ((size_t)6 << 30)) {
             scs_set_error("scs_forest_split_level: %.1f GB of device memory left", (double)free_b / (1u << 30));
             return SCS_ENOMEM;
         }

@@ -60,12 +60,17 @@ static inline const char *scs_dbg(const char *name) {
 // ---- device memory ------------------------------------------------------------
 // Every hipMalloc / hipFree of the library goes through these two (scs_ctx.hip): one place to trace them
 // (SCS_ALLOC_TRACE, a probe switch: calls of more than 5 ms with the calling thread and the time since start).
-hipError_t scs_dev_malloc_impl(void **p, size_t bytes);
+// With a context they take from / give back to the device's ARENA (scs_arena.h: slabs kept from the driver,
+// requests carved out of them); without one (the matrix-free comparison of tools/) straight from the driver.
+struct scs_ctx;
+hipError_t scs_dev_malloc_impl(scs_ctx *ctx, void **p, size_t bytes);
 hipError_t scs_dev_free(void *p);
 template <typename T>
-static inline hipError_t scs_dev_malloc(T **p, size_t bytes) {
-    return scs_dev_malloc_impl((void **)p, bytes);
+static inline hipError_t scs_dev_malloc(scs_ctx *ctx, T **p, size_t bytes) {
+    return scs_dev_malloc_impl(ctx, (void **)p, bytes);
 }
+// free bytes the arena of a device holds (beside what hipMemGetInfo reports as free)
+size_t scs_arena_free_bytes(int device);
 
 // ---- tile geometry of the accumulate kernel --------------------------------
 constexpr int SCS_TR = 64;    // rows of W per tile (one block record)
@@ -78,19 +83,11 @@ constexpr int SCS_LD_ALIGN = 512;  // leading dimension of W (doubles), see scs_
 // size cost 0.4 ms of every 21 ms step; the workspace of a memory-bound job, tens of GB, is not)
 constexpr size_t SCS_SCRATCH_KEEP = (size_t)1 << 30;
 constexpr size_t SCS_PINNED_KEEP = (size_t)2 << 30;  // free page-locked host blocks kept per context
-// free cached blocks kept per context (of 288 GB).  Round 6: 32 -> 64 GB -- the level forests of one subtree of
-// the recursion are ~20 GB and are all handed back at once when its walk is done; with 32 GB the cache overflowed
-// there every time and every release above the limit is a hipFree (5 657 forests freed at 0.9 ms each in the
-// configs[4] recursion, the next subtree's hipMallocs on top).  Allocations that fail drop the cache and retry
-// (scs_block_alloc, the W buffer, the image), and scs_ctx_trim hands it back behind the largest nodes.
-constexpr size_t SCS_BLOCK_KEEP = (size_t)64 << 30;
-// (round 6) a graph's W of at most this size comes from the block cache: the recursion builds thousands of
-// graphs of a few MB to a few hundred MB, and the one-buffer w_cache -- which keeps the LARGER of two buffers,
-// i.e. the root's, for ever -- served none of them: a hipMalloc and a hipFree (a device-wide synchronisation) each
-constexpr size_t SCS_W_BLOCK_MAX = (size_t)2 << 30;
+// (until round 6 a context kept free device blocks of its own, at most SCS_BLOCK_KEEP bytes, and one W buffer;
+// both are gone: blocks and W buffers of every size are chunks of the device's arena, scs_arena.h)
 
 struct scs_ctx;
-// cached device blocks of a context (scs_ctx.hip)
+// device blocks of a context, carved out of the device's arena (scs_ctx.hip)
 int scs_block_alloc(scs_ctx *ctx, size_t bytes, void **out);
 void scs_block_release(scs_ctx *ctx, void *p);
 // every free cached block back to the runtime (an allocation outside the cache has failed)
@@ -252,7 +249,7 @@ struct scs_graph {
     int32_t col0 = 0;
     bool upper = false;
     size_t w_bytes = 0;     // size of the d_w allocation (may exceed the need: reused buffer)
-    bool w_block = false;   // d_w comes from the context's block cache (graphs of at most SCS_W_BLOCK_MAX bytes)
+    bool w_block = false;   // d_w is a block of the arena (scs_block_alloc): always, since round 6
     // degree data for all V vertices (filled lazily by scs_graph_prepare_degrees)
     bool have_deg = false;
     void *deg_stage = nullptr;  // page-locked copy in flight (scs_graph_prepare_degrees_begin)

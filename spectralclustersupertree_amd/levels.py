@@ -615,8 +615,6 @@ class Engine:
                 maps, _ = scs._fiedler_checked(graph, None, scs.DEFAULT_TOL, scs.DEFAULT_MAX_ITER, 0)
             finally:
                 graph.free()
-            if n >= scs.TRIM_MIN_VERTICES:
-                dev.trim(scs.TRIM_KEEP_BYTES)  # (a W buffer of tens of GB: no later node is that large again)
             return maps
 
         return job

@@ -303,19 +303,13 @@ def _solve_node(dev, work, group_start, tol=DEFAULT_TOL, max_iter=DEFAULT_MAX_IT
         maps, stats = _fiedler_checked(graph, None, tol, max_iter, block)
         stats = dict(stats)
         stats["build"] = graph.build_stats
-        big = graph.shape[0] >= TRIM_MIN_VERTICES and span is None
     finally:
+        # (W, its image and the build's scratch go back to the device's arena here: the level forests and the
+        # other contexts on this GPU carve their blocks out of the same memory -- csrc/scs_arena.h.  Nothing is
+        # handed back to the driver during a recursion; Device.trim() does that)
         graph.free()
-    if big:
-        # (round 6) a node of tens of thousands of vertices leaves a W buffer of tens of GB cached in the
-        # context (and the block cache full of its build's scratch); no later node of this walk is that large
-        # again -- give it back to the level forests and the other contexts on this GPU
-        dev.trim(TRIM_KEEP_BYTES)
     return maps, stats
 
-
-TRIM_MIN_VERTICES = 16384
-TRIM_KEEP_BYTES = 4 << 30
 
 
 class _Begun:
