@@ -100,7 +100,7 @@ typedef struct scs_build_stats {
     int32_t reserved;
 } scs_build_stats;
 
-/* ABI version of this header: 105.  104 -> 105: scs_debug_arena_stats added; scs_ctx_trim's keep_bytes counts the
+/* ABI version of this header: 105.  104 -> 105: scs_debug_arena_stats and scs_ctx_reserve added; scs_ctx_trim's keep_bytes counts the
  * free bytes of the device's arena.  103 -> 104: scs_forest_split_level, scs_forest_analyze,
  * scs_forest_tables_download_range, scs_tables_from_forest_range, scs_small_solve_begin_level added;
  * scs_forest_upload checks the arrays.  102 -> 103: scs_stats ends with event_pair_ms.  101 -> 102: scs_stats is
@@ -144,6 +144,10 @@ int scs_ctx_synchronize(scs_ctx *ctx);
  * on the context's device (0: everything that is free), and with keep_bytes == 0 the context's free
  * page-locked host blocks.  No reference counterpart. */
 int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes);
+/* Make sure the arena of the context's device holds `bytes` of free memory in one piece, so that a request of
+ * that size is served without the driver (on this pool hipMalloc of memory another process has used before costs
+ * ~25 ms per GB: the driver clears it).  What a warm-up call leaves behind, without the call. */
+int scs_ctx_reserve(scs_ctx *ctx, int64_t bytes);
 /* The arena of a device, for tests and reports: out8 = {bytes of slabs held, bytes in use, slabs, chunks,
  * released chunks not yet safe for other contexts, driver allocations so far, driver releases so far,
  * requests served so far}. */

@@ -140,6 +140,7 @@ SIGNATURES = {
     "scs_ctx_synchronize": (C.c_int, [_P]),
     "scs_ctx_trim": (C.c_int, [_P, C.c_int64]),
     "scs_debug_arena_stats": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
+    "scs_ctx_reserve": (C.c_int, [_P, C.c_int64]),
     "scs_ctx_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "scs_forest_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP, C.c_int64, _PP]),
     "scs_forest_free": (C.c_int, [_P, _P]),

@@ -80,6 +80,10 @@ class Device:
         device and never shrinks by itself)."""
         nv.check(self._lib.scs_ctx_trim(self._ctx, int(keep_bytes)))
 
+    def reserve(self, n_bytes: int) -> None:
+        """``scs_ctx_reserve``: the device's arena holds ``n_bytes`` of free memory in one piece afterwards."""
+        nv.check(self._lib.scs_ctx_reserve(self._ctx, int(n_bytes)))
+
     def arena_stats(self) -> dict:
         """``scs_debug_arena_stats`` of this context's device."""
         out = (C.c_int64 * 8)()

@@ -820,6 +820,18 @@ extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
     return SCS_OK;
 }
 
+// Make sure the device's arena holds `bytes` of free memory in one piece (a request of that size will not go to
+// the driver): what a warm-up call of the same size would leave behind, without the call.
+extern "C" int scs_ctx_reserve(scs_ctx *ctx, int64_t bytes) {
+    SCS_REQUIRE(ctx != nullptr && bytes >= 0, "scs_ctx_reserve: bad argument");
+    SCS_HIP_CHECK(hipSetDevice(ctx->device));
+    if (bytes == 0) return SCS_OK;
+    void *p = nullptr;
+    SCS_TRY(scs_block_alloc(ctx, (size_t)bytes, &p));
+    scs_block_release(ctx, p);
+    return SCS_OK;
+}
+
 extern "C" int scs_ctx_synchronize(scs_ctx *ctx) {
     SCS_REQUIRE(ctx != nullptr, "scs_ctx_synchronize: null context");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));

@@ -45,13 +45,13 @@ MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 # diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
 stats = {"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
          "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
-         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": [], "redo_log": [], "split_log": []}
+         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": []}
 
 
 def reset_stats() -> None:
     stats.update({"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
                   "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
-                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "big_jobs": [], "redo_log": [], "split_log": []})
+                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": []})
 
 
 def max_taxa() -> int:
@@ -714,7 +714,9 @@ class Engine:
                 self._trace(lev, k, labels, maps)
             deferred = bool(lev.defer[k])
             if deferred:
-                pass  # (nothing was computed below this node: the labels of record decide now)
+                # (nothing was computed below this node: the labels of record decide now)
+                if np.array_equal(labels, prov) or np.array_equal(labels, 1 - prov):
+                    stats["deferred_agree"] += 1
             elif np.array_equal(labels, prov):
                 pass
             elif np.array_equal(labels, 1 - prov):

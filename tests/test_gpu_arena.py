@@ -1,0 +1,102 @@
+"""The device-memory arena on the device (csrc/scs_arena.h; its logic alone: tests/test_arena_cpu.py): blocks of
+every context of the process are carved out of slabs that stay with the process, a block one context released
+serves another context, ``trim`` hands whole free slabs back, ``reserve`` makes room ahead of a call -- and none
+of that changes a bit of the results."""
+import numpy as np
+import pytest
+
+from oracle import tables_oracle as to
+from spectralclustersupertree_amd import synthetic
+from spectralclustersupertree_amd.backend import Device
+
+pytestmark = pytest.mark.gpu
+
+
+def _build_and_solve(dev, tables, v0):
+    dtab = dev.upload(tables)
+    g = dtab.build()
+    w = g.download()
+    maps, _ = g.fiedler(v0)
+    g.free()
+    dtab.free()
+    return w, maps
+
+
+def test_a_second_context_is_served_from_what_the_first_released():
+    n, m = 3000, 40
+    tables = synthetic.make_tables(11, n, m, "branch")
+    w_ref, _ = to.pcg_dense(tables)
+    v0 = np.random.RandomState(1).uniform(-1, 1, n)
+    with Device(0) as a:
+        a.trim()  # (whatever earlier tests left free goes back first: the counts below are this test's)
+        w_a, maps_a = _build_and_solve(a, tables, v0)
+        after_a = a.arena_stats()
+        assert after_a["slab_bytes"] >= n * n * 8 and after_a["driver_allocations"] >= 1
+        with Device(0) as b:
+            w_b, maps_b = _build_and_solve(b, tables, v0)
+            after_b = b.arena_stats()
+        # the second context's W, tables and scratch came out of the slabs the first had filled: no driver call
+        assert after_b["driver_allocations"] == after_a["driver_allocations"]
+        assert after_b["slab_bytes"] == after_a["slab_bytes"]
+        assert after_b["requests"] > after_a["requests"]
+    assert np.array_equal(w_a, w_ref) and np.array_equal(w_b, w_ref)
+    assert np.array_equal(maps_a, maps_b)
+
+
+def test_trim_hands_free_slabs_back_and_reserve_takes_them_ahead_of_a_call():
+    with Device(0) as dev:
+        dev.trim()
+        base = dev.arena_stats()
+        dev.reserve(3 << 30)
+        held = dev.arena_stats()
+        assert held["slab_bytes"] >= base["slab_bytes"] + (3 << 30)
+        assert held["used_bytes"] == base["used_bytes"]  # (reserved, not in use)
+        # a graph whose W fits the reservation: the driver is not asked again for it
+        n = 15000
+        tables = synthetic.make_tables(5, n, 8, "one")
+        dtab = dev.upload(tables)
+        before = dev.arena_stats()["driver_allocations"]
+        g = dtab.build()
+        w_bytes = n * ((n + 511) // 512 * 512) * 8
+        assert w_bytes < (3 << 30)
+        during = dev.arena_stats()
+        assert during["used_bytes"] >= base["used_bytes"] + w_bytes
+        g.free()
+        dtab.free()
+        assert dev.arena_stats()["driver_allocations"] - before <= 2  # (small scratch slabs at most; not W)
+        dev.synchronize()
+        dev.trim()
+        after = dev.arena_stats()
+        assert after["slab_bytes"] < held["slab_bytes"] - (2 << 30)
+        assert after["driver_releases"] > held["driver_releases"]
+        dev.trim(keep_bytes=1 << 40)  # (keeps everything: nothing to do)
+        assert dev.arena_stats()["driver_releases"] == after["driver_releases"]
+
+
+def test_results_do_not_depend_on_where_the_arena_puts_a_block():
+    """The same build + solve with the arena empty, and with it fragmented by blocks of other sizes that are
+    alive or were released in between: bit-identical W and embedding (recycled memory is never assumed clean)."""
+    n, m = 2200, 30
+    tables = synthetic.make_tables(21, n, m, "depth", leaves_per_tree=1500)
+    v0 = np.random.RandomState(3).uniform(-1, 1, n)
+    w_ref, _ = to.pcg_dense(tables)
+    with Device(0) as dev:
+        dev.trim()
+        w0, maps0 = _build_and_solve(dev, tables, v0)
+        # fragment: graphs of other sizes, some kept alive across the second run
+        keep = []
+        for i, k in enumerate((700, 1900, 1200, 2600)):
+            t = synthetic.make_tables(30 + i, k, 6, "branch")
+            dt = dev.upload(t)
+            g = dt.build()
+            if i % 2 == 0:
+                keep.append((g, dt))
+            else:
+                g.free()
+                dt.free()
+        w1, maps1 = _build_and_solve(dev, tables, v0)
+        for g, dt in keep:
+            g.free()
+            dt.free()
+    assert np.array_equal(w0, w_ref) and np.array_equal(w1, w_ref)
+    assert np.array_equal(maps0, maps1)
