@@ -808,6 +808,15 @@ extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
         ctx->w32_cache_bytes = 0;
     }
     const size_t keep = keep_bytes > 0 ? (size_t)keep_bytes : 0;
+    if (keep == 0) {
+        // the build's scratch slots are kept between calls (up to SCS_SCRATCH_KEEP each); they were carved out of
+        // whatever slab had room -- and one live chunk keeps a whole slab from going back
+        for (auto &sl : ctx->scratch) {
+            if (sl.p) scs_dev_free(sl.p);
+            sl.p = nullptr;
+            sl.cap = 0;
+        }
+    }
     arena_trim(ctx->device, keep);
     for (size_t i = 0; i < ctx->pinned.size();) {
         if (!ctx->pinned[i].in_use && keep == 0) {
