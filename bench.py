@@ -868,6 +868,17 @@ def main() -> int:
             else:
                 result["recursion"] = {"skipped": f"{spent:.0f} s of the {budget_s:.0f} s for extra legs already used"}
 
+    if rank == 0:
+        try:
+            st = dev.arena_stats()
+            result["device_memory_arena"] = {
+                "what": "csrc/scs_arena.h (DESIGN.md 13): slabs the process keeps from the driver, every block of every "
+                        "context carved out of them; counts at the end of this run",
+                "slab_GB": round(st["slab_bytes"] / 2**30, 2), "slabs": st["slabs"],
+                "driver_allocations": st["driver_allocations"], "driver_releases": st["driver_releases"],
+                "requests_served": st["requests"]}
+        except Exception as exc:  # noqa: BLE001 - a report field, never fatal
+            result["device_memory_arena"] = {"error": str(exc)}
     dev.close()
     # N > 1: rank 0 also times the SAME workload alone on its GPU (one warm-up + one pass,
     # single-rank context, the other ranks wait), so that every multi-GPU line carries the

@@ -333,12 +333,12 @@ struct scs_arena_core {
         return true;
     }
 
-    // a context goes away (its streams are idle): its pending chunks become ready, what it still holds is released
+    // a context goes away (its streams are idle): its pending chunks become ready; what objects made on it still
+    // hold (a forest, a graph freed after its context) is ORPHANED, not released -- a later release of such a chunk
+    // is then the first and only one, instead of one that hits whoever was given the address in between
     void owner_gone(const void *owner) {
-        std::vector<char *> held;
         for (auto &kv : chunks)
-            if (!kv.second.free && kv.second.owner == owner) held.push_back(kv.first);
-        for (char *p : held) release(p);
+            if (!kv.second.free && kv.second.owner == owner) kv.second.owner = nullptr;
         auto os = owners.find(owner);
         if (os == owners.end()) return;
         for (auto &m : os->second.markers)

@@ -635,7 +635,7 @@ size_t scs_arena_free_bytes(int device) {
     return g_arena[device].core.free_bytes();
 }
 
-// a context's last act: what it still holds goes back, what it released is everybody's
+// a context's last act: what it released is everybody's, what objects made on it still hold is orphaned
 static void arena_ctx_gone(scs_ctx *ctx) {
     if (ctx->device < 0 || ctx->device >= ARENA_DEVICES || !g_arena[ctx->device].live.load()) return;
     std::lock_guard<std::mutex> lock(g_arena[ctx->device].mu);
@@ -755,12 +755,10 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
         hipStreamSynchronize(ctx->stream);
     }
     scs_comm_destroy(&ctx->comm);
-    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
-    if (ctx->small_stream) {
-        hipStreamSynchronize(ctx->small_stream);
-        hipStreamDestroy(ctx->small_stream);
-    }
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->small_stream) hipStreamSynchronize(ctx->small_stream);
+    // (the streams themselves go LAST: until the arena has forgotten this context -- arena_ctx_gone below --
+    // another context's request may ask whether they have passed a release)
     if (ctx->h_report) hipHostFree(ctx->h_report);
     for (auto &sl : ctx->scratch)
         if (sl.p) scs_dev_free(sl.p);
@@ -783,6 +781,9 @@ extern "C" int scs_ctx_destroy(scs_ctx *ctx) {
     ctx->small_slots.clear();
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     arena_ctx_gone(ctx);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    if (ctx->small_stream) hipStreamDestroy(ctx->small_stream);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return SCS_OK;
 }

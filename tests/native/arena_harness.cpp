@@ -195,10 +195,14 @@ void scenarios() {
         void *p = w.a.alloc(1 * GB, &a_ctx), *q = w.a.alloc(1 * GB, &a_ctx), *keep = w.a.alloc(1 * GB, &b_ctx);
         a_ctx.queued = 1;
         w.a.release(p);
-        (void)q;
         w.a.owner_gone(&a_ctx);
-        EXPECT(w.a.check() && w.a.used_bytes == 1 * GB && w.a.n_pending == 0, "what it held and what it had released is free");
-        EXPECT(w.a.holds(keep) && !w.a.holds(q), "the other context keeps its chunk");
+        EXPECT(w.a.check() && w.a.used_bytes == 2 * GB && w.a.n_pending == 0,
+               "what it had released is everybody's; what an object made on it still holds stays (orphaned)");
+        EXPECT(w.a.holds(keep) && w.a.holds(q), "held chunks survive their context");
+        void *r = w.a.alloc(1 * GB, &b_ctx);
+        EXPECT(r == p, "the released one serves the other context at once");
+        EXPECT(w.a.release(q) && w.a.n_pending == 0, "an orphan's release needs no stream: ready at once");
+        EXPECT(!w.a.release(q), "and happens once");
         printf("ok owner_gone\n");
     }
     (void)MB;

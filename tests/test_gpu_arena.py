@@ -100,3 +100,27 @@ def test_results_do_not_depend_on_where_the_arena_puts_a_block():
             dt.free()
     assert np.array_equal(w0, w_ref) and np.array_equal(w1, w_ref)
     assert np.array_equal(maps0, maps1)
+
+
+def test_an_object_freed_after_its_context_releases_its_own_memory_only():
+    """A graph that outlives its context (the documented order is the other way round; interpreter shutdown does
+    not always keep it): its blocks are orphaned when the context goes, NOT released -- so that its late release
+    cannot hit the memory another context has been given in between."""
+    n = 1800
+    tables = synthetic.make_tables(41, n, 12, "branch")
+    w_ref, _ = to.pcg_dense(tables)
+    a = Device(0)
+    dtab = a.upload(tables)
+    g = dtab.build()
+    dtab.free()
+    used_before = a.arena_stats()["used_bytes"]
+    a.close()  # (g still holds W)
+    with Device(0) as b:
+        assert b.arena_stats()["used_bytes"] >= n * n * 8  # W is still accounted for
+        # the other context allocates and computes while the orphan is alive ...
+        w_b, maps_b = _build_and_solve(b, tables, None)
+        g.free()  # ... and after it is gone
+        w_c, maps_c = _build_and_solve(b, tables, None)
+        assert b.arena_stats()["used_bytes"] < used_before
+    assert np.array_equal(w_b, w_ref) and np.array_equal(w_c, w_ref)
+    assert np.array_equal(maps_b, maps_c)
