@@ -994,18 +994,23 @@ __global__ void k_leaf_total(const int64_t *totals, int n_parts, int64_t *out) {
 // iff their sets are equal); the sum of a 2 x 64-bit mix of the side's first leaf slot over that set is equal
 // for equal sets -- so distinct sums PROVE that nothing is contracted, and equal sums send the node to the
 // exact host routine.
+// (measured and not kept, round 6: several leaves per thread with all their loads in flight, and "two leaves with
+// the same parent pointer are in one set" before any find -- 2.7 -> 2.5 ms a level at 20 000 taxa x 5 000 trees:
+// what this kernel waits for is the hooking of the first trees of every node, thousands of threads on a few roots)
+template <bool SIG>
 __global__ void k_analyze_leaves(const int32_t *__restrict__ leaf_taxon, const int32_t *__restrict__ adj_depth,
                                  const int32_t *__restrict__ side_excl, const int64_t *__restrict__ n_leaves,
                                  int32_t *parent, unsigned long long *sig) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= *n_leaves) return;
     const int32_t x = leaf_taxon[p];
-    const bool start = p == 0 || adj_depth[p - 1] == 0;
-    const unsigned long long side = (unsigned long long)(start ? (int32_t)p : side_excl[p]);
-    // (one 64-bit sum here, the second word stays 0: DISTINCT sums prove distinct sets whatever the width, and a
-    // false collision -- ~T^2 / 2^65 a level -- only sends a node to the exact routine for nothing; the second
-    // atomic per leaf was a third of this kernel's time at universes of tens of thousands of taxa)
-    atomicAdd(&sig[2 * x], mix64(side * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull));
+    if (SIG) {
+        const bool start = p == 0 || adj_depth[p - 1] == 0;
+        const unsigned long long side = (unsigned long long)(start ? (int32_t)p : side_excl[p]);
+        // (one 64-bit sum, the second word stays 0: DISTINCT sums prove distinct sets whatever the width, and a
+        // false collision -- ~T^2 / 2^65 a level -- only sends a node to the exact routine for nothing)
+        atomicAdd(&sig[2 * x], mix64(side * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull));
+    }
     if (adj_depth[p] == 0) return;  // a root gap, or the tree's last leaf
     int32_t u = x, v = leaf_taxon[p + 1];
     for (;;) {
@@ -1020,6 +1025,40 @@ __global__ void k_analyze_leaves(const int32_t *__restrict__ leaf_taxon, const i
         const int32_t old = atomicCAS(&parent[u], u, v);  // hook the larger root under the smaller
         if (old == u) break;
         u = old;
+    }
+}
+
+// The signatures of a universe above ANALYZE_LDS_TAXA ids: the global atomic per leaf was a quarter to a third of the
+// kernel above (3.96 ms a level with two 64-bit adds per leaf, 2.99 with one, 2.72 with none, at 20 000 taxa x
+// 5 000 trees).  Here a workgroup folds a long run of leaves into the partial sums of ONE tile
+// of SIG_TILE taxa in LDS (LDS atomics; the other tiles' leaves are skipped -- the run is read once per tile,
+// coalesced) and publishes one add per taxon it met: 50 x fewer global atomics.  Sums mod 2^64: any order.
+constexpr int SIG_TILE = 16384;  // x 8 bytes = 128 KB of the workgroup's LDS
+__global__ __launch_bounds__(1024) void k_analyze_sig_tiled(const int32_t *__restrict__ leaf_taxon,
+                                                            const int32_t *__restrict__ adj_depth,
+                                                            const int32_t *__restrict__ side_excl,
+                                                            const int64_t *__restrict__ n_leaves, int64_t chunk,
+                                                            int32_t n_taxa, unsigned long long *sig) {
+    extern __shared__ unsigned long long l_tile[];
+    const int64_t L = *n_leaves;
+    const int64_t p0 = (int64_t)blockIdx.x * chunk;
+    if (p0 >= L) return;
+    const int64_t p1 = p0 + chunk < L ? p0 + chunk : L;
+    const int32_t lo = (int32_t)blockIdx.y * SIG_TILE;
+    const int32_t n = n_taxa - lo < SIG_TILE ? n_taxa - lo : SIG_TILE;
+    for (int i = threadIdx.x; i < n; i += 1024) l_tile[i] = 0;
+    __syncthreads();
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 1024) {
+        const int32_t x = leaf_taxon[p] - lo;
+        if ((uint32_t)x >= (uint32_t)n) continue;
+        const bool start = p == 0 || adj_depth[p - 1] == 0;
+        const unsigned long long side = (unsigned long long)(start ? (int32_t)p : side_excl[p]);
+        atomicAdd(&l_tile[x], mix64(side * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const unsigned long long v = l_tile[i];
+        if (v) atomicAdd(&sig[2 * (lo + i)], v);
     }
 }
 
@@ -1093,7 +1132,8 @@ __global__ void k_uf_flatten(int32_t *parent, int32_t n, int32_t *root) {
 // outputs ([n_taxa] / [n_taxa][2]); scratch from `alloc`
 template <typename A>
 static int analyze_tables(A &alloc, const int32_t *leaf_taxon, const int32_t *adj_depth, const int64_t *d_n_leaves,
-                          int64_t leaf_cap, int32_t n_taxa, int32_t *comp_root, unsigned long long *sig, hipStream_t s) {
+                          int64_t leaf_cap, int32_t n_taxa, int32_t *comp_root, unsigned long long *sig, hipStream_t s,
+                          int max_lds_bytes) {
     int32_t *parent = nullptr, *side = nullptr, *block_sums = nullptr;
     SCS_TRY(alloc((size_t)n_taxa * 4, (void **)&parent));
     SCS_TRY(alloc((size_t)(leaf_cap + 1) * 4, (void **)&side));
@@ -1104,9 +1144,24 @@ static int analyze_tables(A &alloc, const int32_t *leaf_taxon, const int32_t *ad
     if (leaf_cap > 0 && n_taxa <= ANALYZE_LDS_TAXA)
         k_analyze_leaves_lds<<<(unsigned)((leaf_cap + ANALYZE_LEAVES_PER_BLOCK - 1) / ANALYZE_LEAVES_PER_BLOCK), 256, 0, s>>>(
             leaf_taxon, adj_depth, side, d_n_leaves, n_taxa, parent, sig);
-    else if (leaf_cap > 0)
-        k_analyze_leaves<<<(unsigned)((leaf_cap + 255) / 256), 256, 0, s>>>(leaf_taxon, adj_depth, side, d_n_leaves,
-                                                                            parent, sig);
+    else if (leaf_cap > 0 && max_lds_bytes >= SIG_TILE * 8 && !scs_dbg("SCS_ANALYZE_GLOBAL_SIG")) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SCS_HIP_CHECK(hipFuncSetAttribute((const void *)k_analyze_sig_tiled, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              SIG_TILE * 8));
+            attr_set = true;
+        }
+        k_analyze_leaves<false><<<(unsigned)((leaf_cap + 255) / 256), 256, 0, s>>>(leaf_taxon, adj_depth, side,
+                                                                                   d_n_leaves, parent, sig);
+        // runs of leaves: about two workgroups per CU and tile, at least 16 384 leaves each
+        int64_t chunk = (leaf_cap + 511) / 512;
+        chunk = (chunk + 1023) / 1024 * 1024;
+        if (chunk < 16384) chunk = 16384;
+        const dim3 grid((unsigned)((leaf_cap + chunk - 1) / chunk), (unsigned)((n_taxa + SIG_TILE - 1) / SIG_TILE));
+        k_analyze_sig_tiled<<<grid, 1024, SIG_TILE * 8, s>>>(leaf_taxon, adj_depth, side, d_n_leaves, chunk, n_taxa, sig);
+    } else if (leaf_cap > 0)
+        k_analyze_leaves<true><<<(unsigned)((leaf_cap + 255) / 256), 256, 0, s>>>(leaf_taxon, adj_depth, side,
+                                                                                  d_n_leaves, parent, sig);
     k_uf_flatten<<<(unsigned)((n_taxa + 255) / 256), 256, 0, s>>>(parent, n_taxa, comp_root);
     SCS_HIP_CHECK(hipGetLastError());
     return SCS_OK;
@@ -1505,7 +1560,8 @@ static int forest_split(scs_ctx *ctx, const scs_forest *f, const int32_t *part_o
         SCS_HIP_CHECK(hipGetLastError());
         auto sc_alloc = [&](size_t bytes, void **out) { return scratch.alloc(bytes, out); };
         SCS_TRY(analyze_tables(sc_alloc, p.c_leaf_taxon, p.c_adj_depth, d_leaf_total, L, TC,
-                               (int32_t *)(d_small + s_root), (unsigned long long *)(d_small + s_sig), s));
+                               (int32_t *)(d_small + s_root), (unsigned long long *)(d_small + s_sig), s,
+                               ctx->max_lds_bytes));
         SCS_HIP_CHECK(hipMemcpyAsync(d_small + s_flags, p.flags, 64, hipMemcpyDeviceToDevice, s));
         unsigned char *h_small = nullptr;
         SCS_TRY(scs_pinned_get(ctx, small_bytes, (void **)&h_small));
@@ -1721,7 +1777,7 @@ extern "C" int scs_forest_analyze(scs_ctx *ctx, const scs_forest *f, int32_t *co
     SCS_HIP_CHECK(hipMemcpyAsync(d + o_n, &L, 8, hipMemcpyHostToDevice, s));
     auto sc_alloc = [&](size_t b, void **out) { return scratch.alloc(b, out); };
     SCS_TRY(analyze_tables(sc_alloc, f->leaf_taxon, f->adj_depth, (const int64_t *)(d + o_n), L, T,
-                           (int32_t *)(d + o_root), (unsigned long long *)(d + o_sig), s));
+                           (int32_t *)(d + o_root), (unsigned long long *)(d + o_sig), s, ctx->max_lds_bytes));
     SCS_HIP_CHECK(hipMemcpyAsync(sig, d + o_sig, (size_t)T * 16, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipMemcpyAsync(comp_root, d + o_root, (size_t)T * 4, hipMemcpyDeviceToHost, s));
     SCS_HIP_CHECK(hipStreamSynchronize(s));

@@ -107,6 +107,28 @@ def test_engine_equals_the_node_by_node_walk(monkeypatch, n, m, leaves, strategy
     assert with_engine == node_by_node
 
 
+@pytest.mark.parametrize("global_sig", [False, True])
+def test_large_universes_with_twins_and_partial_coverage(monkeypatch, global_sig):
+    """Levels of more than 2 048 ids take the analysis kernels of large universes: the union-find with several
+    leaves per thread, and the signatures folded per tile of taxa in LDS (``global_sig``: the fall-back that adds
+    them with global atomics, forced).  300 twinned taxa must be contracted, partial coverage leaves components:
+    the engine's recursion equals the node-by-node walk, trace and stream position included."""
+    trees, weights = recursion_input(17, 2600, 14, 2000, 300, weighted=True)
+    names = sorted({tip for t in trees for tip in t.get_tip_names()})
+    arrays = TreeArrays.from_trees(trees, weights, names)
+    monkeypatch.setenv("SCS_SPEC_MIN_NODES", "0")
+    monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "1000000")
+    if global_sig:
+        monkeypatch.setenv("SCS_ANALYZE_GLOBAL_SIG", "1")
+    with_engine = _run(arrays, "branch", True, 9)
+    st = dict(levels.stats)
+    monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "0")
+    node_by_node = _run(arrays, "branch", True, 9)
+    assert st["roots"] >= 1 and st["exact_group_nodes"] >= 1  # (equal signatures found, the exact routine asked)
+    assert any(len(v) > 1 for v, _ in with_engine[2])  # contraction happened
+    assert with_engine == node_by_node
+
+
 def test_wrong_provisional_labels_are_all_repaired(monkeypatch, engine_everywhere):
     """Provisional labels that are wrong on purpose -- one vertex of every third node moved to the other part,
     every fifth node's labels reversed -- change nothing: the walk assigns every node's labels with the
