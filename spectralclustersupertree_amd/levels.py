@@ -243,7 +243,7 @@ class Engine:
         tpart = np.full(k, -1, dtype=np.int64)
         for b, ids in enumerate(parts):
             if len(ids):
-                ids = np.asarray(ids, dtype=np.int64)
+                ids = np.fromiter(ids, dtype=np.int64, count=len(ids))  # (a list or a set of ids)
                 tpart[ids] = b
                 l0.present[ids] = 1
         stats["t_first"] += time.perf_counter() - t0
