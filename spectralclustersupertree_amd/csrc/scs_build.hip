@@ -792,7 +792,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
     // 1 000 taxa x 5 000 trees 11.1 -> 9.5 ms, 3 000 x 5 000 15.5 -> 11.2, 3 000 x 300 1.03 -> 0.78;
     // up to 24 tiles the tree-parallel build below is faster still when the trees are many.)
     // (diagnostic switches are read on every call: tests and A/B tools set them in-process)
-    const size_t wide_min_tiles = scs_dbg("SCS_WIDE_MIN_TILES") ? (size_t)atoi(scs_dbg("SCS_WIDE_MIN_TILES")) : 13;
+    const size_t wide_min_tiles = 13;
     // Partial-coverage forests: when an average tree holds less than 1 / 64 of a tile's 64 + 256 rows
     // and columns' worth of the taxa -- less than about 1.5 % of them -- most (tile, tree) steps add
     // +0.0 everywhere; every tile then walks its own list of trees (k_tile_lists; the 4-wave kernel:
@@ -955,7 +955,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
         // prologue, its tile stores and the thin last round of its launch, and below ~100 trees
         // that costs more than the shorter steps save (measured at 10 000 leaves: 64 + 218 + 218
         // trees 6.93 ms either way, 218 + 218 with the 4-wave kernel in front 6.5).
-        const int wide_min_trees = wide_forced ? 1 : (scs_dbg("SCS_WIDE_MIN_TREES") ? atoi(scs_dbg("SCS_WIDE_MIN_TREES")) : 96);
+        const int wide_min_trees = wide_forced ? 1 : 96;
         // (with many rounds of workgroups per launch -- 50 000 leaves: 150 -- the prologue and the thin
         // last round are noise and the short first batch is the producer / consumer kernel's too:
         // 64 trees 25 -> 18 ms there)
@@ -1047,8 +1047,7 @@ extern "C" int scs_pcg_build(scs_ctx *ctx, const scs_tables *tb, int32_t row_beg
                 wide_params wp;
                 wp.m = mp;
                 wp.groups = (const int4 *)d_groups.p;
-                const int spec_prio = scs_dbg("SCS_SPEC_PRIO") ? atoi(scs_dbg("SCS_SPEC_PRIO")) : 2;
-                wp.producer_prio = spec_prio;
+                wp.producer_prio = 2;
                 const unsigned ng = (unsigned)groups.size();
                 dev_buf d_st8(ctx);
                 if (stamp) {

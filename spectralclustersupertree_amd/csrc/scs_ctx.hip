@@ -1176,11 +1176,10 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
             // an extra launch is cheaper than waiting for the other three quarters of a batch).
             // (Balancing the first batch's build against the copy of the rest -- a tree of L leaves
             // takes ~1.45e-13 L^2 s to accumulate and 16 L bytes at ~50 GB/s to arrive: F / M =
-            // 1 / (1 + L / 2200), ~90 trees at 10 000 x 500 -- was measured with SCS_FIRST_TREES:
+            // 1 / (1 + L / 2200), ~90 trees at 10 000 x 500 -- was measured (a switch since removed):
             // 64 / 80 / 96 / 112 trees first give 17.17 / 17.07 / 17.11 / 17.16 ms a step: within the
             // run-to-run spread, the rule stays.)
-            const int first_env = scs_dbg("SCS_FIRST_TREES") ? atoi(scs_dbg("SCS_FIRST_TREES")) : 0;
-            first = std::min(per, first_env > 0 ? first_env : 64);
+            first = std::min(per, 64);
             chunk = per;
         }
     }

@@ -1670,9 +1670,8 @@ extern "C" int scs_graph_matrix_free(scs_ctx *ctx, const scs_tables *tb, int32_t
     std::vector<int64_t> soff((size_t)M + 1, 0);
     for (int t = 0; t < M; ++t) soff[t + 1] = soff[t] + maxd[t] + 1;
     m->stack_total = soff[M];
-    // chunks per direction: pieces of a few hundred leaves, at most 16 (SCS_MF_CHUNKS overrides)
+    // chunks per direction: pieces of a few hundred leaves, at most 16
     m->chunks = std::max(1, std::min(16, tb->max_leaves / 256));
-    if (scs_dbg("SCS_MF_CHUNKS")) m->chunks = std::max(1, std::min(64, atoi(scs_dbg("SCS_MF_CHUNKS"))));
     const size_t strips = (size_t)2 * max_block * (size_t)m->chunks * (size_t)m->stack_total;
     const size_t slots = (size_t)2 * max_block * (size_t)m->chunks * (size_t)M;
     const size_t slab_bytes = (size_t)2 * M * (size_t)n * max_block * 8;
@@ -1926,8 +1925,7 @@ struct solver {
                                                                       tile_list, tri_pdir.d(), ptr_eff)
 #define TRI(B_, CT_, RPW_, D_) TRI_T(B_, CT_, RPW_, D_, double, w_eff)
         const int2 *tile_list = (const int2 *)tri_tiles.p + (use32 ? 2 * tri_ntiles : 0) + (tri_backwards ? ntiles : 0);
-        static const bool no_flip = scs_dbg("SCS_TRI_NO_FLIP") && atoi(scs_dbg("SCS_TRI_NO_FLIP"));
-        tri_backwards = !no_flip && !tri_backwards;
+        tri_backwards = !tri_backwards;
         if (use32) {
             // (b = 4, 128 x 512 tiles: 8 % faster than 256-column ones, tools/symm_tri_bench.hip)
             TRI_T(4, 2, 2, 3, float, g->d_w32);
@@ -2071,11 +2069,9 @@ struct solver {
         }
         // W is symmetric: with all of it on this device only the tiles on and above the
         // diagonal need streaming (small matrices keep k_symm, whose column segments fill the
-        // chip better).  SCS_NO_TRI=1 keeps the full stream.
-        static const bool no_tri = scs_dbg("SCS_NO_TRI") && atoi(scs_dbg("SCS_NO_TRI"));
-        tri = !g->mf && !no_tri && world == 1 && rows == n && g->row_begin == 0 && n >= 4096 && (b == 4 || b == 8);
+        // chip better).
+        tri = !g->mf && world == 1 && rows == n && g->row_begin == 0 && n >= 4096 && (b == 4 || b == 8);
         if (tri) {
-            if (scs_dbg("SCS_TRI_CT")) tri_ct = atoi(scs_dbg("SCS_TRI_CT"));
             const int tw = tri_ct * 128;
             const int n_rb = (n + TRI_TH - 1) / TRI_TH;
             tri_nct = (n + tw - 1) / tw;
@@ -2168,7 +2164,7 @@ struct solver {
 
     // ---- fused iteration (scs_panel.h), block widths 4 and 8 ----
     static int panel_cap() {
-        static const int cap = scs_dbg("SCS_PANEL_BLOCKS") ? std::max(1, std::min(512, atoi(scs_dbg("SCS_PANEL_BLOCKS")))) : PANEL_BLOCKS_MAX;
+        static const int cap = PANEL_BLOCKS_MAX;
         return cap;
     }
     int panel_blocks16() const { return std::max(1, std::min(panel_cap(), ((n + 15) / 16 + 3) / 4)); }
@@ -2445,9 +2441,8 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // 65 .. 96 vertices on one rank: the one-sided dense solve.  Its time grows with n^2 (n - 1
     // steps per sweep, each rewriting two columns per pair): measured 1.9 ms at 80 vertices
     // against 3.0 ms for LOBPCG, 4.5 against 3.5 ms at 120 -- the crossover is near 100.
-    // SCS_DENSE_MAX=n moves the limit (<= 128; 64 switches the path off); an asked-for block
-    // width keeps the iterative path too.
-    static const int dense_max = scs_dbg("SCS_DENSE_MAX") ? std::min(atoi(scs_dbg("SCS_DENSE_MAX")), DENSE2_MAX) : 96;
+    // An asked-for block width keeps the iterative path.
+    static const int dense_max = 96;
     if (n > MAXS && n <= dense_max && block == 0 && ctx->comm.world == 1 && !g->upper) {
         SCS_TRY(fiedler_dense_onesided(ctx, g, maps_out, st));
         SCS_HIP_CHECK(hipEventRecord(ev_b, s));
@@ -2472,13 +2467,12 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // not need S to sixteen digits: with the symmetric schedule at width 4 the SYMM streams a single-
     // precision image of W -- half the bytes, products and sums still in double precision -- that the
     // degree pass writes on its way through W.  What the image's rounding leaves in S X and S P is removed
-    // by renewing both through W itself (two applications) when the residual passes SCS_LOWP_TOL (1e-8), and
+    // by renewing both through W itself (two applications) when the residual passes 1e-8, and
     // once more should it stop halving; mode 1 goes on in double precision after the first renewal, mode 2
     // stays with the image.  The confirmation at the end always applies W, and a solve it sends back into the loop
     // continues without the image.
     const int lowp_mode = getenv("SCS_LOWP") ? atoi(getenv("SCS_LOWP")) : 2;
-    const double lowp_tol = scs_dbg("SCS_LOWP_TOL") ? atof(scs_dbg("SCS_LOWP_TOL")) : 1e-8;
-    const double lowp_tol2 = scs_dbg("SCS_LOWP_TOL2") ? atof(scs_dbg("SCS_LOWP_TOL2")) : 0.0;
+    const double lowp_tol = 1e-8, lowp_tol2 = 0.0;
     // (only the default loop hands its Rayleigh-Ritz solve the one-sided entries: small_rr_body)
     const bool loop_fused = !(scs_dbg("SCS_LEGACY_LOOP") && atoi(scs_dbg("SCS_LEGACY_LOOP"))) &&
                             !(scs_dbg("SCS_SPLIT_SMALL") && atoi(scs_dbg("SCS_SPLIT_SMALL"))) &&
@@ -2489,9 +2483,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
     // (round 6: a row-partitioned job -- whole rows on every rank, k_symm -- keeps the image of each rank's rows:
     // the first real multi-GPU run streams per rank what the one-GPU run streams, not twice that)
     const bool image_rows = ctx->comm.world > 1 && !g->upper;
-    const bool image_one = ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && g->row_end == n &&
-                           !(scs_dbg("SCS_NO_TRI") && atoi(scs_dbg("SCS_NO_TRI"))) &&
-                           !(scs_dbg("SCS_TRI_CT") && atoi(scs_dbg("SCS_TRI_CT")) != 2);
+    const bool image_one = ctx->comm.world == 1 && !g->upper && g->row_begin == 0 && g->row_end == n;
     const bool image_ok = !g->mf && lowp_mode > 0 && n >= 4096 && loop_fused && (image_one || image_rows) &&
                           (g->have_w32 || 4.0 * (double)(g->row_end - g->row_begin) * (double)g->ld <= lowp_max_bytes);
     // default width: 4 while the panel kernels and the 3b x 3b Rayleigh-Ritz solve weigh
@@ -2749,7 +2741,7 @@ extern "C" int scs_fiedler(scs_ctx *ctx, scs_graph *g, const double *x_init, dou
             // What the image adds to S X afterwards is its rounding (~1e-10 ||S||) times the steps still
             // to be taken, which are of the size of the residual over the spectral gap: one renewal clears
             // what the long early steps left (measured: without it 15 more iterations); a second one is
-            // made when the residual stops halving (four iterations) or passes SCS_LOWP_TOL2 (default: off).
+            // made when the residual stops halving (four iterations) (a second threshold on the residual itself exists and is off).
             // After the FIRST renewal a loop that has not halved its residual in eight iterations stops for the
             // confirmation (the image's rounding has become the floor); before it LOBPCG has plateaus of its own
             // -- ten iterations at 4e-5 on the `bootstrap` workload -- five orders above the image's rounding.
@@ -3545,8 +3537,8 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     const bool w_out = want_w != 0;
     SCS_REQUIRE(n_nodes >= 1, "scs_small_solve: need at least one node");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
-    // (a stream of its own: scs_internal.h; SCS_SMALL_STREAM=0 keeps the batch on the main stream)
-    const bool own_stream = !(scs_dbg("SCS_SMALL_STREAM") && !atoi(scs_dbg("SCS_SMALL_STREAM")));
+    // (a stream of its own: scs_internal.h)
+    const bool own_stream = true;
     if (own_stream && !ctx->small_stream)
         SCS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->small_stream, hipStreamNonBlocking));
     hipStream_t s = own_stream ? ctx->small_stream : ctx->stream;
