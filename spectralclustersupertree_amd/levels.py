@@ -24,6 +24,14 @@ one -- labels equal or swapped -- the children are already there.  Where it does
 decide), that node's forest comes back from the device and its subtree is redone on the node-by-node
 path with the true labels.  **Labels always come from the true draws**: the result is the reference's,
 bit for bit, whatever the provisional labels were.
+
+**Several ranks** (a ``partition.Team`` with the shared stream, one process per GPU): every rank walks the same
+engine -- the level splits, the small batches and the label assignments are cheap and done by all -- and the
+level's LARGER nodes, where the device time is, are dealt (``deal``): a node of ``team.shard_min`` vertices and more
+is solved by all ranks together on their job-wide contexts (row-partitioned W, all-gather of the Krylov block), the
+others go longest-first onto the least loaded rank, and one ``Team.allgather`` per level hands every embedding to
+every rank.  The embedding being a function of the forest alone, the labels drawn from it are the single device's
+whoever computed it: parity with a one-GPU run, which the "forked" streams of rounds 2-5 gave up.
 """
 
 from __future__ import annotations
@@ -45,13 +53,15 @@ MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 # diagnostics of the latest recursion (tests, tools/full_recursion_check.py)
 stats = {"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
          "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
-         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": []}
+         "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": [],
+         "team_dealt": 0, "team_received": 0, "team_collective": 0}
 
 
 def reset_stats() -> None:
     stats.update({"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
                   "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
-                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": []})
+                  "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": [],
+                  "team_dealt": 0, "team_received": 0, "team_collective": 0})
 
 
 def max_taxa() -> int:
@@ -94,7 +104,8 @@ def construct(sub, pcg_weighting, contract_edges, random_state, team=None, ahead
     try:
         engine.run()
     except nv.ScsError as exc:
-        if exc.code != nv.ENOMEM:
+        # (several ranks: a rank that left the engine alone would leave the others waiting in an exchange)
+        if exc.code != nv.ENOMEM or engine._spread():
             raise
         # not enough device memory for the levels of this subtree beside what else is resident: node by node
         engine.levels.clear()
@@ -131,7 +142,7 @@ def construct_parts(arrays, parts, pcg_weighting, contract_edges, random_state, 
     try:
         first = engine.run_parts(parts)
     except nv.ScsError as exc:
-        if exc.code != nv.ENOMEM:
+        if exc.code != nv.ENOMEM or engine._spread():
             raise
         engine.levels.clear()
         return None  # (the caller goes on node by node)
@@ -140,6 +151,32 @@ def construct_parts(arrays, parts, pcg_weighting, contract_edges, random_state, 
         return engine._children(0, list(range(int(first.node_seg[0]), int(first.node_seg[1]))), random_state)
     finally:
         stats["t_build"] += time.perf_counter() - t0
+
+
+def deal(large, n_pres, n_groups, n_trees, gs_patch, world: int, shard_min: int):
+    """The larger nodes of one level over the ranks of a team: ``(collective, owner)``.
+
+    ``collective``: ``[(node, splits)]`` -- nodes of ``shard_min`` vertices and more that split into group-aligned row
+    ranges for all ranks (``partition.row_splits``; a node that does not is dealt like the others), largest first: the
+    ONE order in which every rank enters them.  ``owner[node]``: the rank that embeds a dealt node -- longest job
+    first onto the least loaded rank (cost: vertices squared times trees, what the tile kernel does), ties to the lower
+    rank.  A pure function of its arguments: every rank computes the same deal."""
+    from spectralclustersupertree_amd.partition import row_splits
+
+    order = sorted((int(k) for k in large), key=lambda k: (-int(n_groups[k]), k))
+    collective, owner = [], {}
+    load = [0.0] * world
+    for k in order:
+        if int(n_groups[k]) >= shard_min:
+            try:
+                collective.append((k, row_splits(int(n_pres[k]), world, gs_patch.get(k))))
+                continue
+            except ValueError:
+                pass  # fewer groups (or 256-row blocks) than ranks
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[k] = r
+        load[r] += float(int(n_groups[k])) ** 2 * float(max(int(n_trees[k]), 1))
+    return collective, owner
 
 
 class Level:
@@ -313,27 +350,56 @@ class Engine:
         small = np.flatnonzero(spectral & (n_pres <= self.small_max))
         t1 = time.perf_counter()
         large = np.flatnonzero(spectral & (n_pres > self.small_max))
+        # several ranks walking this engine together (a team's shared stream): the level's larger nodes are DEALT --
+        # an embedding depends on the node's forest alone, so every rank may take it from whoever computed it
+        spread = self._spread() and len(large) > 0
+        collective: list = []
+        mine = [int(k) for k in large]
+        if spread:
+            collective, owner = deal(large, n_pres, n_groups, m, gs_patch, self.team.world, self.team.shard_min)
+            mine = [k for k in mine if owner.get(k) == self.team.rank]
+        got: dict[int, np.ndarray] = {}
+        failure = None
         jobs = []
-        if self.ahead is not None and len(large) > 1:
-            # the larger nodes of the level side by side on the look-ahead workers' contexts (largest first),
-            # while this thread batches the small ones -- and then takes whatever nobody has started
-            for k in sorted((int(k) for k in large), key=lambda k: -int(n_pres[k])):
-                jobs.append((k, self.ahead.submit(self._large_job(lev, k, relabel, gs_patch))))
+        try:
+            if self.ahead is not None and (len(mine) > 1 or (mine and (collective or len(small)) and spread)):
+                # the larger nodes of the level side by side on the look-ahead workers' contexts (largest first),
+                # while this thread batches the small ones -- and then takes whatever nobody has started
+                for k in sorted(mine, key=lambda k: -int(n_pres[k])):
+                    jobs.append((k, self.ahead.submit(self._large_job(lev, k, relabel, gs_patch))))
+        except Exception as exc:  # noqa: BLE001 - under a team the failure travels with the exchange below
+            if not spread:
+                raise
+            failure = f"rank {self.team.rank}: {type(exc).__name__}: {exc}"
         if len(small):
             self._solve_small(lev, small, m, relabel, nid, gs_patch)
         t2 = time.perf_counter()
-        if jobs:
-            for k, job in jobs:
-                try:
-                    got = self.ahead.result(job, self.dev)
-                except RuntimeError:
-                    # several nodes in flight need more device memory than one: what failed on a worker's context
-                    # is solved once more on this thread's own (a failure of the node itself just repeats)
-                    got = self._large_job(lev, k, relabel, gs_patch)(self.dev)
-                lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = got
-        else:
-            for k in large:
-                lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = self._large_job(lev, int(k), relabel, gs_patch)(self.dev)
+        # (nodes of team.shard_min vertices and more: every rank its rows, on the job-wide context, in ONE order)
+        for k, splits in collective:
+            got[k] = self._collective_job(lev, k, relabel, gs_patch, splits)
+            stats["team_collective"] += 1
+        try:
+            if failure is not None:
+                pass
+            elif jobs:
+                for k, job in jobs:
+                    try:
+                        got[k] = self.ahead.result(job, self.dev)
+                    except RuntimeError:
+                        # several nodes in flight need more device memory than one: what failed on a worker's context
+                        # is solved once more on this thread's own (a failure of the node itself just repeats)
+                        got[k] = self._large_job(lev, k, relabel, gs_patch)(self.dev)
+            else:
+                for k in mine:
+                    got[k] = self._large_job(lev, k, relabel, gs_patch)(self.dev)
+        except Exception as exc:  # noqa: BLE001
+            if not spread:
+                raise
+            failure = f"rank {self.team.rank}: {type(exc).__name__}: {exc}"
+        if spread:
+            got = self._exchange(got, failure, collective, mine)
+        for k, maps_k in got.items():
+            lev.maps[int(v_ptr[k]):int(v_ptr[k + 1])] = maps_k
         stats["n_large"] += len(large)
         t3 = time.perf_counter()
         # ---- provisional labels
@@ -495,6 +561,57 @@ class Engine:
         min_defer = int(_env.probe("SCS_SPEC_DEFER_MIN", "8"))
         defer[nodes[differ & (sizes[nodes] >= min_defer)]] = True
         return runs[0], defer
+
+    # ------------------------------------------------------------------ several ranks, one engine
+    def _spread(self) -> bool:
+        team = self.team
+        return team is not None and team.world > 1 and team.allgather is not None
+
+    def _exchange(self, got: dict, failure, collective, mine) -> dict:
+        """Every rank's share of the level's larger nodes to every rank (``Team.allgather``: plain data).  A failure
+        on one rank travels with the exchange, so that all ranks raise instead of waiting for one another."""
+        own = {int(k): np.ascontiguousarray(got[k]) for k in mine if k in got}
+        gathered = self.team.allgather(("levels.maps", own, failure))
+        if any(not (isinstance(g, tuple) and len(g) == 3 and g[0] == "levels.maps") for g in gathered):
+            msg = "levels: the ranks of the team are not walking the same recursion (an exchange out of step)"
+            raise RuntimeError(msg)
+        errors = [f for _, _, f in gathered if f is not None]
+        if errors:
+            msg = "a dealt node of the level failed -- " + "; ".join(errors)
+            raise RuntimeError(msg)
+        out = {int(k): got[k] for k, _ in collective}
+        for r, (_, part, _) in enumerate(gathered):
+            for k, maps_k in part.items():
+                out[int(k)] = got[k] if r == self.team.rank else np.asarray(maps_k, dtype=np.float64)
+            if r != self.team.rank:
+                stats["team_received"] += len(part)
+        stats["team_dealt"] += len(own)
+        return out
+
+    def _collective_job(self, lev, k, relabel, gs_patch, splits) -> np.ndarray:
+        """A node of ``team.shard_min`` vertices and more, by ALL ranks of the team on their job-wide contexts: this
+        rank's rows of W from the node's slice of the level's tables (each rank holds the level forest on its own
+        GPU), group-aligned splits, the row-partitioned LOBPCG with its all-gather of the Krylov block
+        (``scs.spectral_bipartition_device``'s sharded branch; reference: scs.py:210-258) -- returns the whole embedding."""
+        from spectralclustersupertree_amd import scs
+
+        team = self.team
+        lo, sz = int(lev.u_lo[k]), int(lev.u_sz[k])
+        rl = relabel[lo:lo + sz].copy()
+        n, gs = int(lev.n_pres[k]), gs_patch.get(k)
+        dtab = team.device.upload_range(lev.forest, int(lev.t_lo[k]), int(lev.t_hi[k]), lo, sz, rl, n,
+                                        self._monotone(lev))
+        try:
+            graph = dtab.build(int(splits[team.rank]), int(splits[team.rank + 1]), shared=True)
+        finally:
+            dtab.free()
+        try:
+            if gs is not None:
+                graph = graph.contract(gs)
+            maps, _ = scs._fiedler_checked(graph, None, scs.DEFAULT_TOL, scs.DEFAULT_MAX_ITER, 0)
+        finally:
+            graph.free()
+        return maps
 
     # ------------------------------------------------------------------ pieces of a level
     def _node_arrays(self, lev: Level, k: int) -> TreeArrays:
@@ -734,7 +851,7 @@ class Engine:
                 try:
                     again = self.redo(lev, k, labels)
                 except nv.ScsError as exc:
-                    if exc.code != nv.ENOMEM:
+                    if exc.code != nv.ENOMEM or self._spread():
                         raise
                     again = None
                 stats["t_redo"] += time.perf_counter() - t0

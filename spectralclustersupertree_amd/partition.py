@@ -136,11 +136,17 @@ class Team:
     allgather: object = None
     shard_min: int = field(default_factory=shard_min_vertices)
     # "shared": children are solved by every rank on its own device with the one shared
-    # RandomState stream (the reference's stream, scs.py:164) -- identical results, no
-    # speed-up below the threshold.  "forked": sibling sub-problems below the threshold are
+    # RandomState stream (the reference's stream, scs.py:164) -- identical results; the
+    # device work of the larger nodes below the threshold is dealt over the ranks by the level
+    # engine (``level_engine`` below), everything else is done by every rank.  "forked": sibling sub-problems below the threshold are
     # dealt to the ranks round-robin, each with a RandomState forked from the parent's
     # stream, and the subtrees are exchanged -- one sub-problem per device at a time.
     child_rng: str = "shared"
+    # "shared" teams: subtrees go through levels.Engine on every rank and the larger nodes of a level are dealt
+    # over the ranks (nodes of shard_min vertices and more: collectively), their embeddings exchanged through
+    # ``allgather`` -- the single-device labels, the device work of the mid-size nodes spread.  False: every rank
+    # walks every node by itself on the node-by-node path (rounds 2-5; kept for comparison).
+    level_engine: bool = True
 
     def close(self) -> None:
         for d in (self.device, self.solo):

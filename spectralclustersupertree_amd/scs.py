@@ -606,8 +606,19 @@ class _short_switch_interval:
         return False
 
 
+def _engine_for(team) -> bool:
+    """Whether a recursion walked by ``team`` goes through ``levels.Engine``: a single rank always; several ranks
+    when they share the one stream (every rank then makes the same calls in the same order, and the engine deals the
+    larger nodes of a level over them) and the team has not switched it off (``Team.level_engine``)."""
+    if team is None or team.world == 1:
+        return True
+    return team.child_rng == "shared" and bool(getattr(team, "level_engine", True))
+
+
 def _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipartition, team, pre):
-    single = team is None or team.world == 1
+    # (a team in "shared" mode walks the same recursion on every rank: each rank has look-ahead workers on its own
+    # GPU, and the level engine deals the larger nodes of a level over the ranks -- levels.Engine._process)
+    single = _engine_for(team)
     if bipartition is None and single and _small_path() and _ahead_enabled():
         from spectralclustersupertree_amd.ahead import Ahead
 
@@ -645,10 +656,13 @@ def _construct_node(arrays: TreeArrays, pcg_weighting, contract_edges, random_st
     and solved while the walk is busy with their left siblings' subtrees.
 
     ``team`` (several ranks walking together): nodes of at least ``team.shard_min`` vertices
-    are solved collectively.  Below it, ``team.child_rng == "shared"`` has every rank solve
-    every child on its own device with the shared stream (the reference's results, bit for
-    bit); ``"forked"`` deals sibling sub-problems to the ranks, one per device, each with a
-    RandomState forked from the parent's stream, and exchanges the subtrees.
+    are solved collectively.  Below it, ``team.child_rng == "shared"`` has every rank walk
+    every child with the shared stream (the reference's results, bit for bit): the subtrees go
+    through ``levels.Engine`` on every rank, which DEALS the larger nodes of a level over the
+    ranks -- an embedding depends on the node's forest alone, so whoever computes it, the labels
+    drawn from it are the single-device ones (``Engine._process``); ``"forked"`` deals sibling
+    sub-problems to the ranks, one per device, each with a RandomState forked from the parent's
+    stream, and exchanges the subtrees (no label parity with a single-device run).
     """
     given = bipartition  # a caller's own routine (tests) is handed down unchanged
     name = arrays.name
@@ -696,7 +710,7 @@ def _construct_children(arrays, parts, pcg_weighting, contract_edges, random_sta
     (ids of ``arrays``), the children's subtrees in the order of ``parts``, joined under a new root."""
     name = arrays.name
     forked = (team is not None and team.world > 1 and team.child_rng == "forked")
-    if given is None and not forked and _small_path() and (team is None or team.world == 1):
+    if given is None and not forked and _small_path() and _engine_for(team):
         # (round 6) all children as the first level of ONE level-synchronous engine, straight from this node's
         # forest: no download of the children's tables, their embeddings side by side (levels.construct_parts)
         from spectralclustersupertree_amd import levels
@@ -728,7 +742,7 @@ def _construct_children(arrays, parts, pcg_weighting, contract_edges, random_sta
             # an empty list and raises (reference: scs.py:63-65 reached from :158)
             msg = "There must be at least one tree to make a supertree."
             raise ValueError(msg)
-    speculate = given is None and not forked and _small_path() and (team is None or team.world == 1)
+    speculate = given is None and not forked and _small_path() and _engine_for(team)
     if speculate:
         # (round 6) a child of at most SCS_SPEC_MAX_TAXA taxa: its whole subtree level by level with provisional
         # labels (levels.Engine), verified against the true draws when the walk gets there

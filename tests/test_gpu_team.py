@@ -184,6 +184,54 @@ def test_construct_supertree_with_a_team_shared_stream():
         assert got.sorted().get_newick() == want.sorted().get_newick()
 
 
+@pytest.mark.parametrize("world, n, m, leaves, strategy, contract, shard_min", [
+    (2, 1500, 12, None, "branch", True, 300),
+    (3, 2000, 10, 1500, "bootstrap", True, 450),
+    (4, 1100, 16, None, "depth", False, 300),
+])
+def test_level_engine_under_a_team_deals_the_larger_nodes(world, n, m, leaves, strategy, contract, shard_min):
+    """Several ranks, ONE stream, the level engine on every rank: the larger nodes of every level are dealt over the
+    ranks (those of shard_min vertices and more solved by all of them together), the embeddings exchanged -- and the
+    tree, and the position the stream is left at, are the single device's (reference: scs.py:158-166, one RandomState
+    through every node).  Held against the same team walking every node by itself (rounds 2-5) as well."""
+    from spectralclustersupertree_amd import levels, scs
+
+    kw = {} if leaves is None else {"leaves_per_tree": leaves}
+    # (one copy of the input per rank: a rank keeps its own resident forest on the arrays it walks)
+    copies = [synthetic.tree_arrays(n + m, n, m, random_weights=True, **kw) for _ in range(world + 1)]
+
+    def run(team):
+        rs = np.random.RandomState(7)
+        arrays = copies[world if team is None else team.rank]
+        tree = scs._construct(arrays, strategy, contract, rs, team=team)
+        return tree.get_newick(), int(rs.randint(1 << 30))
+
+    want = run(None)
+    single = dict(levels.stats)
+    assert single["roots"] >= 1 and single["n_large"] >= 3  # the engine ran, with nodes to deal
+    assert single["team_dealt"] == 0 and single["team_collective"] == 0
+    teams = LocalTeams(world, shard_min=shard_min)
+    try:
+        out = teams.run(run)
+    finally:
+        teams.close()
+    st = dict(levels.stats)
+    for got in out:
+        assert got == want
+    assert st["roots"] >= 1 and st["team_dealt"] > 0 and st["team_received"] > 0 and st["team_collective"] > 0
+    copies = [synthetic.tree_arrays(n + m, n, m, random_weights=True, **kw) for _ in range(world + 1)]
+    teams = LocalTeams(world, shard_min=shard_min)
+    for t in teams.teams:
+        t.level_engine = False
+    try:
+        out = teams.run(run)
+    finally:
+        teams.close()
+    assert levels.stats["roots"] == 0  # (node by node on every rank)
+    for got in out:
+        assert got == want
+
+
 def test_construct_supertree_with_a_team_children_one_per_device():
     # "forked" streams: sibling sub-problems below the threshold are dealt to the ranks and the
     # subtrees exchanged; the reference's fixture has a seed-independent answer
