@@ -185,8 +185,8 @@ def test_construct_supertree_with_a_team_shared_stream():
 
 
 @pytest.mark.parametrize("world, n, m, leaves, strategy, contract, shard_min", [
-    (2, 1500, 12, None, "branch", True, 300),
-    (3, 2000, 10, 1500, "bootstrap", True, 450),
+    (2, 1500, 40, None, "branch", True, 300),  # (nothing contracts at the root: children of 672 / 828 vertices)
+    (3, 2000, 10, 1500, "bootstrap", True, 450),  # (1 662 groups of 2 000 taxa: group-aligned splits, 696 / 966)
     (4, 1100, 16, None, "depth", False, 300),
 ])
 def test_level_engine_under_a_team_deals_the_larger_nodes(world, n, m, leaves, strategy, contract, shard_min):
