@@ -37,6 +37,7 @@ whoever computed it: parity with a one-GPU run, which the "forked" streams of ro
 from __future__ import annotations
 
 import os
+import threading
 import time
 
 import numpy as np
@@ -54,14 +55,14 @@ MAX_PARTS = 8  # scs_forest_split_level: one mark bit per part
 stats = {"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [], "fallbacks": 0,
          "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0, "t_labels": 0.0,
          "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": [],
-         "team_dealt": 0, "team_received": 0, "team_collective": 0}
+         "team_dealt": 0, "team_received": 0, "team_collective": 0, "lazy_nodes": 0, "t_lazy_wait": 0.0}
 
 
 def reset_stats() -> None:
     stats.update({"roots": 0, "from_parts": 0, "levels": 0, "nodes": 0, "spectral": 0, "mismatches": 0, "mismatch_sizes": [],
                   "fallbacks": 0, "exact_group_nodes": 0, "t_first": 0.0, "t_host": 0.0, "t_small": 0.0, "t_large": 0.0,
                   "t_labels": 0.0, "t_split": 0.0, "t_build": 0.0, "t_redo": 0.0, "n_large": 0, "deferred": 0, "deferred_agree": 0, "big_jobs": [], "redo_log": [], "split_log": [],
-                  "team_dealt": 0, "team_received": 0, "team_collective": 0})
+                  "team_dealt": 0, "team_received": 0, "team_collective": 0, "lazy_nodes": 0, "t_lazy_wait": 0.0})
 
 
 def max_taxa() -> int:
@@ -179,13 +180,74 @@ def deal(large, n_pres, n_groups, n_trees, gs_patch, world: int, shard_min: int)
     return collective, owner
 
 
+class _Lazy:
+    """The embeddings of a level's nodes ABOVE the cap (``max_taxa()``: nothing is computed below them on a guess, so
+    the engine does not need them -- only the walk does, when it gets there), as ONE job of the look-ahead queue that
+    takes them one after the other in the order of the visit.
+
+    Before, the two children of a node above the cap were built side by side and the level waited for both: the
+    first one visited -- the only one the walk needs now -- finished when the pair did.  Now it has the chip to
+    itself, the walk goes on into its subtree as soon as it is there, and its sibling's build runs behind that
+    subtree's levels (whose small kernels leave most of the chip idle).  Same embeddings, same labels: only WHEN a
+    node is embedded changes."""
+
+    def __init__(self, engine, lev, nodes, relabel, gs_patch) -> None:
+        self.order = [int(k) for k in nodes]
+        self.fns = {k: engine._large_job(lev, k, relabel, gs_patch) for k in self.order}
+        self.done = {k: threading.Event() for k in self.order}
+        self.unfetched = set(self.order)
+        self.value: dict = {}
+        self.error: dict = {}
+        self.claimed: set = set()
+        self.lock = threading.Lock()
+        self.job = engine.ahead.submit(self._run)
+
+    def _compute(self, k: int, dev) -> None:
+        with self.lock:
+            if k in self.claimed:
+                return
+            self.claimed.add(k)
+        try:
+            self.value[k] = self.fns[k](dev)
+        except BaseException as exc:  # noqa: BLE001 -- handed to the walk when it asks
+            self.error[k] = exc
+        finally:
+            self.done[k].set()
+
+    def _run(self, dev) -> None:
+        for k in self.order:
+            self._compute(k, dev)
+
+    def pending(self, k: int) -> bool:
+        return k in self.unfetched
+
+    def fetch(self, k: int, own_device) -> np.ndarray:
+        """The embedding of node ``k`` (once).  A sequence no worker has picked up yet: this node here, now."""
+        from spectralclustersupertree_amd.ahead import _QUEUED
+
+        self.unfetched.discard(k)
+        done = self.done[k]
+        if not done.is_set() and self.job.state == _QUEUED:
+            self._compute(k, own_device)
+        done.wait()
+        fn = self.fns.pop(k)
+        exc = self.error.pop(k, None)
+        if exc is None:
+            return self.value.pop(k)
+        if isinstance(exc, RuntimeError):
+            # what failed beside other work on a worker's context is solved once more on the walk's own (two nodes in
+            # flight need more device memory than one; a failure of the node itself just repeats)
+            return fn(own_device)
+        raise exc
+
+
 class Level:
     """One level of a speculative subtree: K nodes as consecutive tree ranges of ``forest`` and consecutive
     id ranges of its taxon numbering (struct of arrays; see ``Engine``)."""
 
     __slots__ = ("forest", "K", "T", "t_lo", "t_hi", "n_leaves", "u_lo", "u_sz", "gid", "present", "comp_root",
                  "sig", "kind", "n_pres", "v_off", "n_groups", "maps", "prov", "members", "sorted_taxa", "seg_start",
-                 "seg_len", "seg_child", "node_seg", "graft", "monotone", "shift", "defer")
+                 "seg_len", "seg_child", "node_seg", "graft", "monotone", "shift", "defer", "lazy")
 
 
 class Engine:
@@ -358,6 +420,16 @@ class Engine:
         if spread:
             collective, owner = deal(large, n_pres, n_groups, m, gs_patch, self.team.world, self.team.shard_min)
             mine = [k for k in mine if owner.get(k) == self.team.rank]
+        # nodes above the cap are the walk's to label and nothing is computed below them on a guess: the level does
+        # not wait for them (``_Lazy``; a team's ranks enter them together instead, above)
+        lev.lazy = None
+        lazy_nodes: list[int] = []
+        if self.ahead is not None and not spread and max_taxa() > 0:
+            lazy_nodes = [k for k in mine if int(n_groups[k]) > max_taxa()]
+            if lazy_nodes:
+                mine = [k for k in mine if k not in lazy_nodes]
+                lev.lazy = _Lazy(self, lev, lazy_nodes, relabel, gs_patch)
+                stats["lazy_nodes"] += len(lazy_nodes)
         got: dict[int, np.ndarray] = {}
         failure = None
         jobs = []
@@ -406,13 +478,15 @@ class Engine:
         from spectralclustersupertree_amd import kmeans2
 
         # (a node whose batched solve failed has left the kind: its rows of maps are zero, its labels unused)
-        prov, defer = self._provisional(lev, v_ptr)
+        prov, defer = self._provisional(lev, v_ptr, lazy_nodes)
         lev.defer = defer if defer is not None else np.diff(v_ptr) > max_taxa()
         stats["deferred"] += int(lev.defer.sum())
         if prov is not None:
             lev.prov[:] = prov
         else:
             for k in np.flatnonzero(kind == SPECTRAL):
+                if int(k) in lazy_nodes:
+                    continue
                 v0, v1 = int(v_ptr[k]), int(v_ptr[k + 1])
                 lev.prov[v0:v1] = kmeans2.labels(lev.maps[v0:v1], self.prov_rs)
         t4 = time.perf_counter()
@@ -520,7 +594,7 @@ class Engine:
         stats["t_host"] += time.perf_counter() - t_begin - t_dev
         return nxt
 
-    def _provisional(self, lev: Level, v_ptr: np.ndarray):
+    def _provisional(self, lev: Level, v_ptr: np.ndarray, skip=()):
         """Provisional labels of all spectral nodes of the level, and which nodes to DEFER.
 
         Which partition the labels of record will be is a draw from a distribution (ten k-means++ starts, the best
@@ -538,10 +612,24 @@ class Engine:
         # computed in vain is computed later, one deferred subtree after the other, at the walk's pace.  Default: one.)
         votes = max(1, int(_env.probe("SCS_SPEC_VOTES", "1")))
         runs = []
+        maps, ptr, rows = lev.maps, v_ptr, None
+        if len(skip):
+            # (nodes whose embedding is not there yet -- ``_Lazy``, all above the cap -- take no part: empty ranges)
+            sizes = np.diff(v_ptr)
+            rows = np.ones(len(maps), dtype=bool)
+            for k in skip:
+                rows[int(v_ptr[k]):int(v_ptr[k + 1])] = False
+                sizes[k] = 0
+            maps = maps[rows]
+            ptr = np.concatenate(([0], np.cumsum(sizes, dtype=np.int64)))
         for _ in range(votes):
-            lab = kmeans2.provisional_labels(lev.maps, v_ptr, self.prov_rs)
+            lab = kmeans2.provisional_labels(maps, ptr, self.prov_rs)
             if lab is None:
                 return None, None
+            if rows is not None:
+                full = np.zeros(len(rows), dtype=lab.dtype)
+                full[rows] = lab
+                lab = full
             runs.append(lab)
         sizes = np.diff(v_ptr)
         # a node above the cap is never guessed: a lost bet there throws away a subtree of thousands of taxa
@@ -822,6 +910,12 @@ class Engine:
         segs = list(range(s0, s1))
         if kind == SPECTRAL:
             v0, v1 = int(lev.v_off[k]), int(lev.v_off[k + 1])
+            lazy = getattr(lev, "lazy", None)
+            was_lazy = lazy is not None and lazy.pending(k)
+            if was_lazy:
+                t0 = time.perf_counter()
+                lev.maps[v0:v1] = lazy.fetch(k, self.dev)
+                stats["t_lazy_wait"] += time.perf_counter() - t0
             maps = lev.maps[v0:v1]
             # the reference's draws: the ARPACK start vector (sklearn/utils/_arpack.py:31-33), then k-means
             random_state.uniform(-1, 1, v1 - v0)
@@ -832,7 +926,8 @@ class Engine:
             deferred = bool(lev.defer[k])
             if deferred:
                 # (nothing was computed below this node: the labels of record decide now)
-                if np.array_equal(labels, prov) or np.array_equal(labels, 1 - prov):
+                # (a node embedded behind the level -- ``_Lazy`` -- was given no provisional labels to agree with)
+                if not was_lazy and (np.array_equal(labels, prov) or np.array_equal(labels, 1 - prov)):
                     stats["deferred_agree"] += 1
             elif np.array_equal(labels, prov):
                 pass

@@ -121,3 +121,81 @@ def test_several_workers_take_jobs_side_by_side_each_on_a_device_of_its_own():
         assert [g[0] for g in got] == list(range(6))
         assert q.stats["by_worker"] + q.stats["by_walk"] == 6
     assert FakeDevice.made == made + 3
+
+
+# ---------------------------------------------------------------------------------------------------------
+# levels._Lazy: the nodes above the cap of one level, one after the other in the order of the visit
+# ---------------------------------------------------------------------------------------------------------
+class _FakeEngine:
+    """What levels._Lazy asks of an engine: the queue and a job per node."""
+
+    def __init__(self, queue, work):
+        self.ahead, self.work = queue, work
+
+    def _large_job(self, lev, k, relabel, gs_patch):
+        return lambda dev: self.work(k, dev)
+
+
+def test_lazy_nodes_are_embedded_one_after_the_other_in_the_order_of_the_visit():
+    from spectralclustersupertree_amd.levels import _Lazy
+
+    running, most, order = [0], [0], []
+    lock = threading.Lock()
+
+    def work(k, dev):
+        with lock:
+            running[0] += 1
+            most[0] = max(most[0], running[0])
+            order.append(k)
+        time.sleep(0.02)
+        with lock:
+            running[0] -= 1
+        return ("maps", k, dev.owner)
+
+    mine = FakeDevice()
+    with Ahead(FakeDevice, workers=3) as q:
+        lazy = _Lazy(_FakeEngine(q, work), None, [4, 7, 9], None, None)
+        assert lazy.pending(4) and lazy.pending(9) and not lazy.pending(5)
+        _until(lambda: lazy.job.state == 1)  # (a worker has the sequence: the walk only waits)
+        got = [lazy.fetch(k, mine) for k in (4, 7, 9)]
+    assert [g[1] for g in got] == [4, 7, 9]
+    assert order == [4, 7, 9] and most[0] == 1  # never two of them side by side
+    assert not lazy.pending(4) and not lazy.value and not lazy.fns  # handed over once, nothing kept
+
+
+def test_a_lazy_sequence_nobody_picked_up_is_computed_by_the_walk_node_by_node():
+    from spectralclustersupertree_amd.levels import _Lazy
+
+    gate = threading.Event()
+    mine = FakeDevice()
+    with Ahead(FakeDevice, workers=1) as q:
+        blocker = q.submit(lambda dev: gate.wait(5))  # the only worker is busy
+        _until(lambda: blocker.state == 1)
+        lazy = _Lazy(_FakeEngine(q, lambda k, dev: (k, dev.owner)), None, [1, 2], None, None)
+        assert lazy.fetch(1, mine) == (1, mine.owner)  # here, now -- and only this node
+        assert 2 not in lazy.claimed
+        gate.set()
+        q.result(blocker, mine)
+        _until(lambda: lazy.done[2].is_set())  # the worker, free again, takes the rest and skips node 1
+        assert lazy.fetch(2, mine) == (2, "scs-ahead-0")
+
+
+def test_a_lazy_node_that_failed_on_the_workers_context_is_solved_again_on_the_walks_own():
+    from spectralclustersupertree_amd.levels import _Lazy
+
+    mine = FakeDevice()
+
+    def work(k, dev):
+        if k == 2 and dev is not mine:
+            raise RuntimeError("out of device memory beside another node")
+        if k == 3:
+            raise ValueError("the node itself")
+        return (k, dev.owner)
+
+    with Ahead(FakeDevice, workers=2) as q:
+        lazy = _Lazy(_FakeEngine(q, work), None, [1, 2, 3], None, None)
+        _until(lambda: lazy.done[3].is_set())
+        assert lazy.fetch(1, mine)[0] == 1
+        assert lazy.fetch(2, mine) == (2, mine.owner)
+        with pytest.raises(ValueError, match="the node itself"):
+            lazy.fetch(3, mine)

@@ -107,6 +107,25 @@ def test_engine_equals_the_node_by_node_walk(monkeypatch, n, m, leaves, strategy
     assert with_engine == node_by_node
 
 
+@pytest.mark.parametrize("n, m, leaves, strategy, contract", [(700, 40, None, "one", False), (1200, 60, 800, "bootstrap", True),
+                                                              (2500, 30, None, "branch", True)])
+def test_nodes_above_the_cap_are_embedded_behind_the_walk(monkeypatch, n, m, leaves, strategy, contract):
+    """Nodes above the cap are deferred (nothing computed below them on a guess), so their level does not wait for
+    their embeddings: ONE job of the look-ahead queue takes them in the order of the visit and the walk picks each up
+    when it arrives (``levels._Lazy``).  Only WHEN a node is embedded changes -- the tree, the trace of every spectral
+    call and the stream position are those of the node-by-node walk."""
+    kw = {} if leaves is None else {"leaves_per_tree": leaves}
+    arrays = synthetic.tree_arrays(n + m, n, m, random_weights=True, **kw)
+    monkeypatch.setenv("SCS_SPEC_MIN_NODES", "0")
+    monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "150")
+    with_engine = _run(arrays, strategy, contract, 5)
+    st = dict(levels.stats)
+    monkeypatch.setenv("SCS_SPEC_MAX_TAXA", "0")
+    node_by_node = _run(arrays, strategy, contract, 5)
+    assert st["roots"] >= 1 and st["lazy_nodes"] >= 3 and st["deferred"] >= st["lazy_nodes"]
+    assert with_engine == node_by_node
+
+
 @pytest.mark.parametrize("global_sig", [False, True])
 def test_large_universes_with_twins_and_partial_coverage(monkeypatch, global_sig):
     """Levels of more than 2 048 ids take the analysis kernels of large universes: the union-find with several
