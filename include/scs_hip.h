@@ -100,7 +100,7 @@ typedef struct scs_build_stats {
     int32_t reserved;
 } scs_build_stats;
 
-/* ABI version of this header: 106.  105 -> 106: scs_ctx_set_background added.  104 -> 105: scs_debug_arena_stats and scs_ctx_reserve added; scs_ctx_trim's keep_bytes counts the
+/* ABI version of this header: 105.  104 -> 105: scs_debug_arena_stats and scs_ctx_reserve added; scs_ctx_trim's keep_bytes counts the
  * free bytes of the device's arena.  103 -> 104: scs_forest_split_level, scs_forest_analyze,
  * scs_forest_tables_download_range, scs_tables_from_forest_range, scs_small_solve_begin_level added;
  * scs_forest_upload checks the arrays.  102 -> 103: scs_stats ends with event_pair_ms.  101 -> 102: scs_stats is
@@ -137,12 +137,6 @@ int scs_ctx_create_local(int device, int rank, scs_local_group *group, scs_ctx *
 
 int scs_ctx_destroy(scs_ctx *ctx);
 int scs_ctx_synchronize(scs_ctx *ctx);
-/* A BACKGROUND context: its streams are made anew at the lowest priority the device offers, so that what it runs
- * yields to the other contexts' work on the same GPU (the look-ahead workers of the recursion, ahead.py: a node
- * built behind the walk must not take the chip from the node the walk is waiting for).  Call it on a context with
- * nothing in flight (right after creating it); on = 0 returns to the default priority.  Results do not depend on
- * it.  No reference counterpart (the reference has one thread and no device: scs.py:239 n_jobs=1). */
-int scs_ctx_set_background(scs_ctx *ctx, int on);
 /* Device memory: every block of the library is carved out of a per-device ARENA shared by all contexts of the
  * process (csrc/scs_arena.h) -- slabs taken from the driver stay with the process until they are handed back
  * here, or until the driver refuses a request (then whole free slabs go back and the request is tried again).

@@ -125,7 +125,7 @@ _I32 = C.c_int32
 # per argument (``data_as``) costs more than the call itself for the tiny nodes of a deep recursion;
 # dptr / iptr / lptr below check the dtype instead
 _DP = _IP = _LP = C.c_void_p
-ABI_VERSION = 106  # scs_version() of the header these bindings were written against
+ABI_VERSION = 105  # scs_version() of the header these bindings were written against
 
 SIGNATURES = {
     "scs_version": (C.c_int, []),
@@ -141,7 +141,6 @@ SIGNATURES = {
     "scs_ctx_trim": (C.c_int, [_P, C.c_int64]),
     "scs_debug_arena_stats": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
     "scs_ctx_reserve": (C.c_int, [_P, C.c_int64]),
-    "scs_ctx_set_background": (C.c_int, [_P, C.c_int]),
     "scs_ctx_comm_info": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "scs_forest_upload": (C.c_int, [_P, _I32, _I32, _LP, _IP, _IP, _DP, _DP, _DP, C.c_int64, _PP]),
     "scs_forest_free": (C.c_int, [_P, _P]),

@@ -46,12 +46,6 @@ class Device:
                 uid = C.create_string_buffer(bytes(unique_id), nv.UNIQUE_ID_BYTES)
             nv.check(self._lib.scs_ctx_create(device, rank, world, uid, C.byref(self._ctx)))
 
-    def set_background(self, on: bool = True) -> "Device":
-        """``scs_ctx_set_background``: this context's streams at the lowest priority of the device -- its work yields
-        to the other contexts' on the same GPU (the look-ahead workers).  On a context with nothing in flight."""
-        nv.check(self._lib.scs_ctx_set_background(self._ctx, 1 if on else 0))
-        return self
-
     @staticmethod
     def unique_id() -> bytes:
         """RCCL bootstrap id; rank 0 creates it and ships it to the other ranks."""

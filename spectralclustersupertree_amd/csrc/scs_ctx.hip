@@ -38,7 +38,7 @@ extern "C" const char *scs_last_error(void) { return g_last_error.c_str(); }
 // 101 (round 5): scs_build_stats grew by tree_parallel_batches / spec_batches (round 4), scs_tables_split added
 // 102 (round 5): scs_stats grew by the mixed-precision loop's fields
 // 103: ... and by event_pair_ms
-extern "C" int scs_version(void) { return 106; }
+extern "C" int scs_version(void) { return 105; }
 
 extern "C" int scs_device_count(void) {
     int n = 0;
@@ -471,31 +471,6 @@ static int ctx_common(int device, scs_ctx **out) {
         if (mb > 0) ctx->ws_limit = (size_t)mb << 20;
     }
     *out = ctx;
-    return SCS_OK;
-}
-
-// A context whose work yields to the other contexts' on the same GPU: its streams are made anew at the lowest
-// priority the device offers (the look-ahead workers of the recursion: what they build in the background must not
-// take the chip from the node the walk is waiting for).  Call it on a context that has nothing in flight -- right
-// after creating it; on = 0 goes back to the default priority.  Results do not depend on it.
-extern "C" int scs_ctx_set_background(scs_ctx *ctx, int on) {
-    SCS_REQUIRE(ctx != nullptr, "scs_ctx_set_background: null context");
-    SCS_HIP_CHECK(hipSetDevice(ctx->device));
-    for (hipStream_t s : {ctx->stream, ctx->small_stream, ctx->copy_stream})
-        if (s) SCS_HIP_CHECK(hipStreamSynchronize(s));
-    const bool want = on != 0;
-    if (want == ctx->background) return SCS_OK;
-    ctx->background = want;
-    hipStream_t fresh = nullptr;
-    SCS_HIP_CHECK(scs_stream_create(ctx, &fresh));
-    // (the arena asks a context for its streams when it needs them: nothing else holds the old handles)
-    hipStream_t old_main = ctx->stream, old_small = ctx->small_stream, old_copy = ctx->copy_stream;
-    ctx->stream = fresh;
-    ctx->small_stream = nullptr;  // (made again, at the new priority, on first use)
-    ctx->copy_stream = nullptr;
-    if (old_main) hipStreamDestroy(old_main);
-    if (old_small) hipStreamDestroy(old_small);
-    if (old_copy) hipStreamDestroy(old_copy);
     return SCS_OK;
 }
 
@@ -1223,7 +1198,7 @@ extern "C" int scs_tables_upload(scs_ctx *ctx, int32_t n_taxa, int32_t n_trees,
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_flags, d_flags, 4, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess && first < n_trees) {
-        if (!ctx->copy_stream) e = scs_stream_create(ctx, &ctx->copy_stream);
+        if (!ctx->copy_stream) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
         hipStream_t cs = ctx->copy_stream;
         for (int32_t a = first; a < n_trees && e == hipSuccess; a += chunk) {
             const int32_t b = std::min(n_trees, a + chunk);

@@ -3540,7 +3540,7 @@ static int small_solve_begin_impl(scs_ctx *ctx, int32_t n_nodes, const int32_t *
     // (a stream of its own: scs_internal.h)
     const bool own_stream = true;
     if (own_stream && !ctx->small_stream)
-        SCS_HIP_CHECK(scs_stream_create(ctx, &ctx->small_stream));
+        SCS_HIP_CHECK(hipStreamCreateWithFlags(&ctx->small_stream, hipStreamNonBlocking));
     hipStream_t s = own_stream ? ctx->small_stream : ctx->stream;
     const int K = n_nodes;
     // ---- layout of the one staging block: [pointers | tree_off | group_start | leaf arrays |

@@ -122,7 +122,6 @@ struct scs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;  // late chunks of a table upload (created on first use)
-    bool background = false;            // scs_ctx_set_background: every stream of this context at the lowest priority
     scs_comm comm;
     int n_cu = 256;
     int max_lds_bytes = 65536;  // dynamic LDS one workgroup may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock)
@@ -321,14 +320,3 @@ int scs_gather_row_splits(scs_ctx *ctx, int32_t row_begin, int32_t row_end, int3
 // eig.hip helpers used by debug entry points are declared in scs_hip.h
 
 static inline int64_t scs_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-
-// A stream of this context: non-blocking, at the lowest priority the device offers when the context is a
-// background one (scs_ctx_set_background), at the default priority otherwise.
-inline hipError_t scs_stream_create(const scs_ctx *ctx, hipStream_t *out) {
-    if (ctx->background) {
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-            return hipStreamCreateWithPriority(out, hipStreamNonBlocking, least);
-    }
-    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
-}

@@ -200,9 +200,6 @@ class _Lazy:
         self.error: dict = {}
         self.claimed: set = set()
         self.lock = threading.Lock()
-        # (SCS_SPEC_LAZY=2, a probe: the first node visited is left to the walk's own context -- at the default
-        # priority -- and the worker starts on the others at once, behind it)
-        self.first_own = _env.probe("SCS_SPEC_LAZY", "1") == "2"
         self.job = engine.ahead.submit(self._run)
 
     def _compute(self, k: int, dev) -> None:
@@ -218,7 +215,7 @@ class _Lazy:
             self.done[k].set()
 
     def _run(self, dev) -> None:
-        for k in (self.order[1:] + self.order[:1] if self.first_own else self.order):
+        for k in self.order:
             self._compute(k, dev)
 
     def pending(self, k: int) -> bool:
@@ -230,8 +227,8 @@ class _Lazy:
 
         self.unfetched.discard(k)
         done = self.done[k]
-        if not done.is_set() and (self.job.state == _QUEUED or self.first_own):
-            self._compute(k, own_device)  # (claimed by a worker meanwhile: returns at once, and the wait below is for it)
+        if not done.is_set() and self.job.state == _QUEUED:
+            self._compute(k, own_device)
         done.wait()
         fn = self.fns.pop(k)
         exc = self.error.pop(k, None)
@@ -427,7 +424,7 @@ class Engine:
         # not wait for them (``_Lazy``; a team's ranks enter them together instead, above)
         lev.lazy = None
         lazy_nodes: list[int] = []
-        if self.ahead is not None and not spread and max_taxa() > 0 and _env.probe("SCS_SPEC_LAZY", "1") != "0":
+        if self.ahead is not None and not spread and max_taxa() > 0:
             lazy_nodes = [k for k in mine if int(n_groups[k]) > max_taxa()]
             if lazy_nodes:
                 mine = [k for k in mine if k not in lazy_nodes]

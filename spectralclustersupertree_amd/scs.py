@@ -626,12 +626,7 @@ def _construct_tuned(arrays, pcg_weighting, contract_edges, random_state, bipart
             # (the worker's context is made when the first job arrives -- by then the walk has solved
             # the root on its own; a recursion that never reaches the spectral step touches no device)
             def second_context():
-                # (a worker's context yields to the walk's: what is built behind the walk must not take the chip
-                # from the node the walk is waiting for -- scs_ctx_set_background)
-                dev = Device((team.solo if team is not None else default_device()).index)
-                if _env.probe("SCS_AHEAD_PRIORITY", "low") != "default":
-                    dev.set_background(True)
-                return dev
+                return Device((team.solo if team is not None else default_device()).index)
 
             with Ahead(second_context, workers=int(os.environ.get("SCS_AHEAD_WORKERS", "3") or 1)) as queue:
                 global _last_ahead_stats
