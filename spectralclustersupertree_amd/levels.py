@@ -424,7 +424,7 @@ class Engine:
         # not wait for them (``_Lazy``; a team's ranks enter them together instead, above)
         lev.lazy = None
         lazy_nodes: list[int] = []
-        if self.ahead is not None and not spread and max_taxa() > 0:
+        if self.ahead is not None and not spread and max_taxa() > 0 and _env.probe("SCS_SPEC_LAZY", "1") != "0":
             lazy_nodes = [k for k in mine if int(n_groups[k]) > max_taxa()]
             if lazy_nodes:
                 mine = [k for k in mine if k not in lazy_nodes]
