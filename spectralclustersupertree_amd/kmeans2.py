@@ -268,6 +268,20 @@ def _whole_call(whole, x, x_sq, cdf, draws, tol, want_debug=False):
     return lab if rc == 0 else None
 
 
+def _centre_and_tolerance(x: np.ndarray):
+    """Centres the (n, 2) float64 C-ordered array ``x`` IN PLACE (``x -= x.mean(axis=0)``) and returns
+    ``np.mean(np.var(x_before, axis=0)) * 1e-4`` -- the same floating-point operations in the same order as the two
+    numpy calls (see ``_fast``), bit for bit."""
+    n = x.shape[0]
+    mean = np.add.reduce(x, axis=0)
+    mean /= n
+    x -= mean
+    dev = x * x
+    var = np.add.reduce(dev, axis=0)
+    var /= n
+    return (var[0] + var[1]) / 2 * 1e-4
+
+
 def _fast(maps, random_state, use_native=True):
     from sklearn.cluster import _k_means_common as kc
     from sklearn.cluster import _k_means_lloyd as kl
@@ -277,7 +291,12 @@ def _fast(maps, random_state, use_native=True):
     # fast path ends at 4 096 points x 2 coordinates -- an OpenMP team costs far more than it
     # computes: 6-12 ms per call on a 256-thread host against < 1 ms; the chunks are then reduced
     # in index order, which the team's order of arrival is not)
-    tol = np.mean(np.var(x, axis=0)) * 1e-4
+    # tol = np.mean(np.var(x, axis=0)) * 1e-4 and x -= x.mean(axis=0) (sklearn/cluster/_kmeans.py:_tolerance, :1485),
+    # operation for operation as numpy's _var / _mean carry them out (numpy/_core/_methods.py: the column sums over the
+    # rows, a true division by the count, the deviations squared in place, their column sums, a true division; the mean
+    # of the two variances is their sum halved) -- without the two calls' Python-level bookkeeping, and with the centred
+    # array, which both need, made once (``_centre_and_tolerance``; tests/test_kmeans2.py holds it against the calls)
+    tol = _centre_and_tolerance(x)
     per_size = _per_size.get(n)
     if per_size is None:
         weight = np.ones(n, dtype=np.float64)
@@ -287,7 +306,6 @@ def _fast(maps, random_state, use_native=True):
         if n <= 4096:
             _per_size[n] = per_size
     weight, weight_col, cdf = per_size
-    x -= x.mean(axis=0)
     x_sq = np.einsum("ij,ij->i", x, x)
     draws = random_state.random_sample(30)
     best_labels = None

@@ -218,3 +218,33 @@ def test_first_use_from_two_threads_at_once():
     res = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=240)
     assert res.returncode == 0, res.stderr[-2000:]
     assert res.stdout.split()[0] == "ok"
+
+
+def test_centre_and_tolerance_is_numpys_var_and_mean_bit_for_bit():
+    # kmeans2._centre_and_tolerance replaces np.mean(np.var(x, axis=0)) * 1e-4 and x -= x.mean(axis=0)
+    # (sklearn/cluster/_kmeans.py: _tolerance and the centring in fit) by the same operations without the calls'
+    # bookkeeping: the centred array and the tolerance must be the calls', bit for bit, at every size the fast path
+    # takes -- including constant columns, tiny and huge scales, ties and duplicated columns
+    from spectralclustersupertree_amd.kmeans2 import _centre_and_tolerance
+
+    rs = np.random.RandomState(11)
+    sizes = list(range(2, 140)) + [255, 256, 257, 511, 512, 513, 1000, 2047, 2048, 4095, 4096]
+    for n in sizes:
+        for kind in range(6):
+            x = rs.standard_normal((n, 2))
+            if kind == 1:
+                x[:, 0] = 1.0 / np.sqrt(n)  # (the embedding's first column: constant)
+            elif kind == 2:
+                x *= 1e-8
+            elif kind == 3:
+                x = np.round(x, 1)
+            elif kind == 4:
+                x[:, 1] = x[:, 0]
+            elif kind == 5:
+                x[:, 0] *= 1e150
+            a, b = np.array(x, copy=True), np.array(x, copy=True)
+            want_tol = np.mean(np.var(a, axis=0)) * 1e-4
+            a -= a.mean(axis=0)
+            got_tol = _centre_and_tolerance(b)
+            assert np.array_equal(a, b), (n, kind)
+            assert np.float64(want_tol).tobytes() == np.float64(got_tol).tobytes(), (n, kind)
