@@ -200,12 +200,6 @@ class _Lazy:
         self.error: dict = {}
         self.claimed: set = set()
         self.lock = threading.Lock()
-        self.stacked = _env.probe("SCS_SPEC_LAZY", "1") == "3"
-        if self.stacked:
-            # (a probe) only the node visited first starts now; the others wait on the queue's stack until the walk is
-            # busy with levels of small nodes (``kick``), most recent first, one at a time
-            stack = engine.ahead.__dict__.setdefault("lazy_stack", [])
-            stack.extend((self, k) for k in reversed(self.order[1:]))
         self.job = engine.ahead.submit(self._run)
 
     def _compute(self, k: int, dev) -> None:
@@ -221,26 +215,8 @@ class _Lazy:
             self.done[k].set()
 
     def _run(self, dev) -> None:
-        for k in (self.order[:1] if self.stacked else self.order):
+        for k in self.order:
             self._compute(k, dev)
-
-    @staticmethod
-    def kick(ahead) -> None:
-        """(``SCS_SPEC_LAZY=3``) The walk is in a level without nodes above the cap -- small kernels, most of the chip
-        idle: the most recent node still waiting on the stack (the one the walk will ask for soonest) is handed to a
-        worker, unless the one handed over before is still being built."""
-        stack = ahead.__dict__.get("lazy_stack")
-        if not stack:
-            return
-        running = ahead.__dict__.get("lazy_running")
-        if running is not None and not running[0].done[running[1]].is_set():
-            return
-        while stack:
-            lazy, k = stack.pop()
-            if k not in lazy.claimed:
-                ahead.__dict__["lazy_running"] = (lazy, k)
-                ahead.submit(lambda dev, lazy=lazy, k=k: lazy._compute(k, dev))
-                return
 
     def pending(self, k: int) -> bool:
         return k in self.unfetched
@@ -251,8 +227,8 @@ class _Lazy:
 
         self.unfetched.discard(k)
         done = self.done[k]
-        if not done.is_set() and (self.job.state == _QUEUED or self.stacked):
-            self._compute(k, own_device)  # (claimed by a worker meanwhile: returns at once, the wait below is for it)
+        if not done.is_set() and self.job.state == _QUEUED:
+            self._compute(k, own_device)
         done.wait()
         fn = self.fns.pop(k)
         exc = self.error.pop(k, None)
@@ -454,8 +430,6 @@ class Engine:
                 mine = [k for k in mine if k not in lazy_nodes]
                 lev.lazy = _Lazy(self, lev, lazy_nodes, relabel, gs_patch)
                 stats["lazy_nodes"] += len(lazy_nodes)
-            elif self.ahead is not None:
-                _Lazy.kick(self.ahead)
         got: dict[int, np.ndarray] = {}
         failure = None
         jobs = []

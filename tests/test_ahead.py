@@ -199,44 +199,3 @@ def test_a_lazy_node_that_failed_on_the_workers_context_is_solved_again_on_the_w
         assert lazy.fetch(2, mine) == (2, mine.owner)
         with pytest.raises(ValueError, match="the node itself"):
             lazy.fetch(3, mine)
-
-
-def test_stacked_lazy_nodes_wait_for_a_kick_and_go_most_recent_first(monkeypatch):
-    # (SCS_SPEC_LAZY=3, a probe) only the node visited first starts at once; its siblings wait on the queue's stack
-    # until the walk is in a level of small nodes, the most recent one first, never two at a time
-    from spectralclustersupertree_amd.levels import _Lazy
-
-    monkeypatch.setenv("SCS_SPEC_LAZY", "3")
-    gate = {k: threading.Event() for k in (12, 22)}
-    order = []
-
-    def work(k, dev):
-        order.append(k)
-        if k in gate:
-            gate[k].wait(5)
-        return (k, dev.owner)
-
-    mine = FakeDevice()
-    with Ahead(FakeDevice, workers=3) as q:
-        eng = _FakeEngine(q, work)
-        top = _Lazy(eng, None, [11, 12], None, None)      # a node above the cap and its sibling ...
-        assert top.fetch(11, mine)[0] == 11
-        deep = _Lazy(eng, None, [21, 22, 23], None, None)  # ... and, below the first, three more
-        assert deep.fetch(21, mine)[0] == 21
-        assert order == [11, 21]  # nothing else has started
-        _Lazy.kick(q)  # the walk reaches a level of small nodes
-        _until(lambda: order == [11, 21, 22])  # the one it will ask for soonest
-        _Lazy.kick(q)
-        _Lazy.kick(q)
-        time.sleep(0.05)
-        assert order == [11, 21, 22]  # one at a time
-        gate[22].set()
-        assert deep.fetch(22, mine)[0] == 22
-        # the walk arrives at 23 before anybody was asked to build it: here, now
-        assert deep.fetch(23, mine) == (23, mine.owner)
-        _Lazy.kick(q)
-        _until(lambda: order[-1] == 12)  # (23 was claimed by the walk: skipped on the stack)
-        gate[12].set()
-        assert top.fetch(12, mine)[0] == 12
-        _Lazy.kick(q)  # an empty stack
-    assert order == [11, 21, 22, 23, 12]
