@@ -142,7 +142,8 @@ int scs_ctx_synchronize(scs_ctx *ctx);
  * here, or until the driver refuses a request (then whole free slabs go back and the request is tried again).
  * scs_ctx_trim hands back whole free slabs, largest first, until at most keep_bytes of free arena memory remain
  * on the context's device (0: everything that is free), and with keep_bytes == 0 the context's free
- * page-locked host blocks.  No reference counterpart. */
+ * page-locked host blocks and the staging / scratch blocks of its small-solve slots that no ticket holds.
+ * No reference counterpart. */
 int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes);
 /* Make sure the arena of the context's device holds `bytes` of free memory in one piece, so that a request of
  * that size is served without the driver (on this pool hipMalloc of memory another process has used before costs

@@ -797,6 +797,7 @@ extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
     SCS_REQUIRE(ctx != nullptr, "scs_ctx_trim: null context");
     SCS_HIP_CHECK(hipSetDevice(ctx->device));
     SCS_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->small_stream) SCS_HIP_CHECK(hipStreamSynchronize(ctx->small_stream));
     std::lock_guard<std::mutex> lock(ctx->cache_mu);
     if (ctx->w_cache) {
         scs_dev_free(ctx->w_cache);
@@ -816,6 +817,19 @@ extern "C" int scs_ctx_trim(scs_ctx *ctx, int64_t keep_bytes) {
             if (sl.p) scs_dev_free(sl.p);
             sl.p = nullptr;
             sl.cap = 0;
+        }
+        // ... and so are the staging and scratch blocks of the small-solve slots no ticket holds (they used to stay
+        // until the context went away -- a level's batch of small nodes takes up to 8 GB of addends)
+        for (auto &sl : ctx->small_slots) {
+            if (sl.busy) continue;
+            if (sl.dev) scs_dev_free(sl.dev);
+            if (sl.host) hipHostFree(sl.host);
+            if (sl.scratch) scs_dev_free(sl.scratch);
+            sl.dev = nullptr;
+            sl.host = nullptr;
+            sl.cap = 0;
+            sl.scratch = nullptr;
+            sl.scratch_cap = 0;
         }
     }
     arena_trim(ctx->device, keep);

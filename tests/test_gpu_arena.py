@@ -124,3 +124,26 @@ def test_an_object_freed_after_its_context_releases_its_own_memory_only():
         assert b.arena_stats()["used_bytes"] < used_before
     assert np.array_equal(w_b, w_ref) and np.array_equal(w_c, w_ref)
     assert np.array_equal(maps_b, maps_c)
+
+
+def test_trim_releases_the_idle_small_solve_slots_too():
+    """The staging and scratch blocks of a batched small solve stay with their slot for the next batch -- and go back
+    with ``trim()`` (they used to stay until the context went away: ADVICE r05); the next batch makes them anew and
+    returns the same bits."""
+    nodes = [(synthetic.make_tables(90 + i, n, 40, "branch"), None) for i, n in enumerate((30, 64, 100, 128))]
+    with Device(0) as dev:
+        dev.trim()
+        base = dev.arena_stats()["used_bytes"]
+        want = dev.small_solve(nodes, want_w=True)
+        held = dev.arena_stats()["used_bytes"]
+        assert held > base  # (the slot keeps its blocks)
+        dev.trim()
+        assert dev.arena_stats()["used_bytes"] <= held - (2 << 20)  # (staging and scratch: a MiB each at least)
+        got = dev.small_solve(nodes, want_w=True)
+        for g, w in zip(got, want):
+            assert all(np.array_equal(a, b) for a, b in zip(g, w))
+        ticket = dev.small_solve_begin(nodes)  # a slot a ticket holds is left alone
+        dev.trim()
+        out = ticket.result()
+        for g, w in zip(out, want):
+            assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])

@@ -773,11 +773,13 @@ def test_spec_and_four_wave_kernels_agree_at_size(dev, monkeypatch):
 
 def test_small_node_that_fails_is_solved_again_on_the_general_path(dev, monkeypatch):
     # a node of 65 .. 128 taxa whose batched one-sided Jacobi reports NaN eigenvalues (forced here:
-    # SCS_DEBUG_SMALL_FAIL) goes through upload + build + LOBPCG instead of failing the whole batch;
+    # backend._FAIL_SMALL_FOR_TESTS) goes through upload + build + LOBPCG instead of failing the whole batch;
     # its neighbours in the batch keep their batched results
     nodes = [(synthetic.make_tables(70 + i, n, 12, "branch"), None) for i, n in enumerate((40, 90, 120))]
     want = dev.small_solve(nodes, want_w=True)
-    monkeypatch.setenv("SCS_DEBUG_SMALL_FAIL", "1")
+    from spectralclustersupertree_amd import backend
+
+    monkeypatch.setattr(backend, "_FAIL_SMALL_FOR_TESTS", True)
     got = dev.small_solve(nodes, want_w=True)
     assert np.array_equal(got[0][0], want[0][0]) and np.array_equal(got[0][1], want[0][1])
     for g, w in zip(got[1:], want[1:]):
